@@ -1,0 +1,76 @@
+"""ctypes binding of libdfmhip.so -- exactly the symbols include/dfm_hip.h declares.
+
+There is NO fallback: if the shared library is missing or a symbol is absent this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "lib", "libdfmhip.so")
+
+c_dp = ctypes.POINTER(ctypes.c_double)
+c_ip = ctypes.POINTER(ctypes.c_int)
+c_vp = ctypes.c_void_p
+c_int = ctypes.c_int
+c_uint = ctypes.c_uint
+
+DFM_F_MAY_HAVE_MISSING = 1
+DFM_MAX_R = 32
+ERRORS = {-1: "DFM_E_DIMS", -2: "DFM_E_R_UNSUPPORTED", -3: "DFM_E_NULL", -4: "DFM_E_MISSING",
+          -5: "DFM_E_NUMERIC", -6: "DFM_E_NO_DEVICE"}
+
+_PASS_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 10 + [c_uint]
+_EMSTEP_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 8 + [c_uint]
+_EM_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, ctypes.c_double] + [c_vp] * 4 + [c_uint]
+_PCA_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 8
+
+# name -> (restype, argtypes); every prototype of include/dfm_hip.h
+SYMBOLS = {
+    "dfm_create": (c_int, [ctypes.POINTER(c_vp), c_int, c_vp]),
+    "dfm_destroy": (c_int, [c_vp]),
+    "dfm_set_stream": (c_int, [c_vp, c_vp]),
+    "dfm_synchronize": (c_int, [c_vp]),
+    "dfm_last_error": (ctypes.c_char_p, [c_vp]),
+    "dfm_version": (ctypes.c_char_p, []),
+    "dfm_profile_enable": (c_int, [c_vp, c_int]),
+    "dfm_profile_read": (c_int, [c_vp, c_int, ctypes.c_char_p, c_int, c_dp, c_ip]),
+    "dfm_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_uint]),
+    "dfm_ks_pass_batch_dev": (c_int, _PASS_ARGS),
+    "dfm_ks_pass_batch": (c_int, _PASS_ARGS),
+    "dfm_em_step_batch_dev": (c_int, _EMSTEP_ARGS),
+    "dfm_em_batch_dev": (c_int, _EM_ARGS),
+    "dfm_em_batch": (c_int, _EM_ARGS),
+    "dfm_pca_init_batch_dev": (c_int, _PCA_ARGS),
+    "dfm_pca_init_batch": (c_int, _PCA_ARGS),
+    "dfm_synth_panels_dev": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_int64, c_int, c_int, c_int, c_int,
+                                     ctypes.c_double] + [c_vp] * 7),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load libdfmhip.so and bind every symbol.  Raises (never falls back) when it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} not found: build it with `python -m dynamic_factor_models_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for this path.")
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class DfmError(RuntimeError):
+    def __init__(self, code: int, text: str):
+        self.code = code
+        name = ERRORS.get(code, f"hipError_t {code}" if code > 0 else str(code))
+        super().__init__(f"libdfmhip: {name}: {text}")

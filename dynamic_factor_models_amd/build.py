@@ -1,0 +1,62 @@
+"""In-tree build of libdfmhip.so (hipcc, gfx950 only).  `python -m dynamic_factor_models_amd.build`."""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+SO = os.path.join(LIBDIR, "libdfmhip.so")
+SOURCES = ["collapse.hip", "recursion.hip", "mstep.hip", "pca.hip", "synth.hip", "capi.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libdfmhip.so (ROCm toolchain required)")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "dfm_hip.h"))
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
+            for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
+                if verbose or res.returncode:
+                    sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
+                if res.returncode:
+                    raise RuntimeError(f"hipcc failed: {' '.join(cmd)}")
+    if force or jobs or _stale(SO, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode:
+            sys.stderr.write(res.stdout + res.stderr)
+            raise RuntimeError("link of libdfmhip.so failed")
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,252 @@
+// collapse.hip -- streaming "collapse" of the N-dimensional observation rows onto the r factors.
+//
+// For replicate b and period t (Jungbacker & Koopman 2015), over observed cells:
+//     b_t = sum_i lam_i x_it / R_i   (r)        s_t = sum_i x_it^2 / R_i
+//     n_t = #observed                           ld_t = sum_i log R_i          C_t = sum_i lam_i lam_i' / R_i
+// This is the only kernel that touches the panel: one coalesced pass, HBM-bound (8 N T bytes per
+// replicate, ~2 (r+1) flops per 8 bytes).  The reference's analogue is the per-period complete-case
+// regression of x_t on Lambda (dfm_functions.ipynb:271-286 called from :364), which also first forms
+// the normal equations Lambda_t' x_t over the observed series of period t.
+//
+// Mapping (wave64): one workgroup (4 waves) per replicate; lane l owns panel columns
+// {2l, 2l+1} + 128 j (16-byte loads, a wave reads 1 KiB contiguous per instruction) and keeps
+// W[c][k] = lam_ck / R_c for its columns in registers for the whole replicate; each wave takes row
+// blocks of RB periods, accumulates RB (r+1) per-lane partial sums and folds them across the 64
+// lanes with the transpose-reduce of dfm_device.h (~1 shuffle per value instead of 6).
+// Rows with a NaN take a slow path that also emits n_t, ld_t and the packed C_t.
+#include "dfm_kernels.h"
+
+namespace dfm {
+
+__host__ __device__ constexpr int tri_row(int v) {
+    int k = 0;
+    while ((k + 1) * (k + 2) / 2 <= v) ++k;
+    return k;
+}
+
+// Partial (own-columns) sums of the packed lower triangle entries [V0, V0+CNT) of
+// sum_c m_c W[c][k] lam_c[k'], then wave reduction; canonical lanes store to out[V0 + idx].
+template <int R, int CPL2, int V0, int CNT, bool FULL>
+__device__ __forceinline__ void c_chunk(const double (&W)[CPL2][2][R], const double* __restrict__ L,
+                                        const bool (&m)[CPL2][2], int lane, double* out) {
+    double pc[CNT];
+#pragma unroll
+    for (int v = 0; v < CNT; ++v) pc[v] = 0.0;
+#pragma unroll
+    for (int j = 0; j < CPL2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (m[j][e]) {
+                const int c = 2 * lane + 128 * j + e;
+                const double* lc = L + (size_t)c * R;
+                double lam[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) lam[k] = lc[k];
+#pragma unroll
+                for (int v = 0; v < CNT; ++v) {
+                    const int k = tri_row(V0 + v);
+                    const int kp = V0 + v - k * (k + 1) / 2;
+                    pc[v] = fma(W[j][e][k], lam[kp], pc[v]);
+                }
+            }
+        }
+    wave_transpose_reduce<CNT>(pc, lane);
+    bool canon;
+    const int idx = reduce_index<CNT>(lane, canon);
+    if (canon) {
+        const int v = V0 + idx;
+        if constexpr (FULL) {  // full symmetric r x r output
+            const int k = tri_row(v), kp = v - k * (k + 1) / 2;
+            out[k * R + kp] = pc[0];
+            out[kp * R + k] = pc[0];
+        } else {
+            out[v] = pc[0];
+        }
+    }
+}
+
+template <int R, int CPL2, int V0, bool FULL>
+__device__ __forceinline__ void c_all(const double (&W)[CPL2][2][R], const double* __restrict__ L,
+                                      const bool (&m)[CPL2][2], int lane, double* out) {
+    constexpr int NP = R * (R + 1) / 2;
+    if constexpr (V0 < NP) {
+        constexpr int CNT = (NP - V0) < 64 ? (NP - V0) : 64;
+        c_chunk<R, CPL2, V0, CNT, FULL>(W, L, m, lane, out);
+        c_all<R, CPL2, V0 + CNT, FULL>(W, L, m, lane, out);
+    }
+}
+
+__device__ __forceinline__ double wave_allsum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+
+template <int R, int CPL2, int RB>
+__global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int N = a.N, T = a.T;
+    constexpr int NP = R * (R + 1) / 2;
+    const double* __restrict__ X = a.panel + (size_t)b * T * N;
+    const double* __restrict__ L = a.Lam + (size_t)b * N * R;
+    const double* __restrict__ Rv = a.Rv + (size_t)b * N;
+
+    double W[CPL2][2][R];
+    double Ri[CPL2][2];
+    bool own[CPL2][2];
+#pragma unroll
+    for (int j = 0; j < CPL2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = 2 * lane + 128 * j + e;
+            own[j][e] = c < N;
+            const double ri = own[j][e] ? 1.0 / Rv[c] : 0.0;
+            Ri[j][e] = ri;
+#pragma unroll
+            for (int k = 0; k < R; ++k) W[j][e][k] = own[j][e] ? L[(size_t)c * R + k] * ri : 0.0;
+        }
+
+    if (wave == 0) {  // per-replicate constants for the balanced rows
+        c_all<R, CPL2, 0, true>(W, L, own, lane, a.Cfull + (size_t)b * R * R);
+        double ld = 0.0;
+#pragma unroll
+        for (int j = 0; j < CPL2; ++j)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (own[j][e]) ld += log(Rv[2 * lane + 128 * j + e]);
+        ld = wave_allsum(ld);
+        if (lane == 0) a.ldfull[b] = ld;
+    }
+
+    constexpr int NV = RB * (R + 1);
+    bool canon;
+    const int myidx = reduce_index<NV>(lane, canon);
+    const int my_rr = myidx / (R + 1), my_k = myidx % (R + 1);
+    const bool vec2 = (N & 1) == 0;
+    const int nrb = (T + RB - 1) / RB;
+
+    for (int rb = wave; rb < nrb; rb += 4) {
+        const int t0 = rb * RB;
+        double acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+        bool nanrow[RB];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int t = (t0 + rr < T) ? t0 + rr : T - 1;
+            const double* xr = X + (size_t)t * N;
+            bool anynan = false;
+#pragma unroll
+            for (int j = 0; j < CPL2; ++j) {
+                const int c0 = 2 * lane + 128 * j;
+                double x0 = 0.0, x1 = 0.0;
+                if (vec2) {
+                    if (c0 < N) {
+                        const double2 xx = *reinterpret_cast<const double2*>(xr + c0);
+                        x0 = xx.x;
+                        x1 = xx.y;
+                    }
+                } else {
+                    if (c0 < N) x0 = xr[c0];
+                    if (c0 + 1 < N) x1 = xr[c0 + 1];
+                }
+                const bool n0 = x0 != x0, n1 = x1 != x1;
+                anynan = anynan || n0 || n1;
+                x0 = n0 ? 0.0 : x0;
+                x1 = n1 ? 0.0 : x1;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    acc[rr * (R + 1) + k] = fma(W[j][0][k], x0, acc[rr * (R + 1) + k]);
+                    acc[rr * (R + 1) + k] = fma(W[j][1][k], x1, acc[rr * (R + 1) + k]);
+                }
+                acc[rr * (R + 1) + R] = fma(x0 * Ri[j][0], x0, acc[rr * (R + 1) + R]);
+                acc[rr * (R + 1) + R] = fma(x1 * Ri[j][1], x1, acc[rr * (R + 1) + R]);
+            }
+            nanrow[rr] = anynan;
+        }
+        wave_transpose_reduce<NV>(acc, lane);
+        unsigned nanmask = 0;  // bit rr set: period t0+rr has a missing cell somewhere in the row
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) nanmask |= __any(nanrow[rr]) ? (1u << rr) : 0u;
+        {
+            const int t = t0 + my_rr;
+            if (canon && t < T) {
+                if (my_k < R) a.bcol[((size_t)b * T + t) * R + my_k] = acc[0];
+                else {
+                    a.scol[(size_t)b * T + t] = acc[0];
+                    if (((nanmask >> my_rr) & 1u) == 0) a.nobs[(size_t)b * T + t] = N;
+                }
+            }
+        }
+        // slow path: periods with missing cells also need n_t, ld_t, C_t
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            const int t = t0 + rr;
+            if (t < T && ((nanmask >> rr) & 1u)) {
+                if (a.Ct == nullptr) {
+                    if (lane == 0) atomicOr(a.status, 1);
+                    continue;
+                }
+                const double* xr = X + (size_t)t * N;
+                bool m[CPL2][2];
+                double cnt = 0.0, ld = 0.0;
+#pragma unroll
+                for (int j = 0; j < CPL2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int c = 2 * lane + 128 * j + e;
+                        bool ok = false;
+                        if (c < N) { const double x = xr[c]; ok = (x == x); }
+                        m[j][e] = ok;
+                        if (ok) { cnt += 1.0; ld += log(Rv[c]); }
+                    }
+                cnt = wave_allsum(cnt);
+                ld = wave_allsum(ld);
+                if (lane == 0) {
+                    a.nobs[(size_t)b * T + t] = (int)(cnt + 0.5);
+                    a.ldrow[(size_t)b * T + t] = ld;
+                }
+                c_all<R, CPL2, 0, false>(W, L, m, lane, a.Ct + ((size_t)b * T + t) * NP);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int R, int CPL2, int RB>
+static hipError_t launch_one(const CollapseArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((collapse_kernel<R, CPL2, RB>), dim3(a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int R>
+static hipError_t launch_r(const CollapseArgs& a, hipStream_t s) {
+    // register budget: CPL2*2*R doubles of W + RB*(R+1) accumulators
+    constexpr int RB = (R <= 4) ? 8 : (R <= 8) ? 4 : (R <= 16) ? 2 : 1;
+    if (a.N <= 128) return launch_one<R, 1, RB>(a, s);
+    if (a.N <= 256) return launch_one<R, 2, RB>(a, s);
+    if constexpr (R <= 16) {
+        if (a.N <= 512) return launch_one<R, 4, RB>(a, s);
+    }
+    if constexpr (R <= 8) {
+        if (a.N <= 1024) return launch_one<R, 8, RB>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s) {
+    switch (Rpad) {
+        case 2: return launch_r<2>(a, s);
+        case 4: return launch_r<4>(a, s);
+        case 8: return launch_r<8>(a, s);
+        case 16: return launch_r<16>(a, s);
+        case 32: return launch_r<32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+int collapse_max_n(int Rpad) { return Rpad <= 8 ? 1024 : Rpad <= 16 ? 512 : 256; }
+
+}  // namespace dfm

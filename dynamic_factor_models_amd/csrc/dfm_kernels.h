@@ -1,0 +1,53 @@
+// dfm_kernels.h -- host-visible launch interface of the gfx950 kernels (internal to libdfmhip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "dfm_device.h"
+
+namespace dfm {
+
+// All device arrays below use the PADDED factor dimension Rp (2,4,8,16,32 >= r): parameters are
+// embedded by pad_params_kernel (extra states: A = 0, Q = I, P0 = I, mu0 = 0, Lam = 0 -- independent
+// unit-variance noise states that no series loads on; every determinant / quadratic form they add
+// is exactly 0), so kernels are instantiated for a handful of sizes only.
+struct CollapseArgs {
+    int B, T, N;
+    const double* panel;  // [B][T][N]
+    const double* Lam;    // [B][N][Rp]
+    const double* Rv;     // [B][N]
+    double* bcol;         // [B][T][Rp]
+    double* scol;         // [B][T]
+    int* nobs;            // [B][T]
+    double* ldrow;        // [B][T]      (written only where nobs < N)
+    double* Ct;           // [B][T][Rp(Rp+1)/2] packed, or nullptr (written only where nobs < N)
+    double* Cfull;        // [B][Rp][Rp]
+    double* ldfull;       // [B]
+    int* status;          // bit0: NaN met while Ct == nullptr
+};
+
+struct RecursionArgs {
+    int B, T, N, r;       // r = caller's factor count (<= Rp) for the outputs
+    const double* A;      // [B][Rp][Rp]
+    const double* Q;      // [B][Rp][Rp]
+    const double* mu0;    // [B][Rp]
+    const double* P0;     // [B][Rp][Rp]
+    const double* bcol; const double* scol; const int* nobs; const double* ldrow;
+    const double* Ct; const double* Cfull; const double* ldfull;
+    // scratch
+    double* ZJtab;        // [B][T+1][2][Rp][Rp]   Z_e, J_e of every distinct covariance step
+    double* wtab;         // [B][T][Rp]
+    int* eidx;            // [B][T]
+    // outputs (caller's r): f_smooth [B][T][r], P_smooth [B][T][r(r+1)/2] or null, loglik [B]
+    double* f_smooth; double* P_smooth; double* loglik;
+    // EM sufficient statistics (null for a plain pass): S11,S10,S00 [B][Rp][Rp]; f0s [B][Rp]; P0s [B][Rp][Rp]
+    double* S11; double* S10; double* S00; double* f0s; double* P0s;
+    int* ncov;            // [B] number of distinct covariance steps (diagnostic), or null
+};
+
+hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
+int collapse_max_n(int Rpad);
+hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
+
+}  // namespace dfm

@@ -1,0 +1,503 @@
+// recursion.hip -- the sequential part of one Kalman-smoother pass, batched over replicates.
+//
+// Algebra (pinned in oracle/info_form.py against the covariance-form oracle): information-form
+// filter + "Z-smoother"; ONE r x r SPD inversion per period serves filter and smoother.
+//   constants   Qi = Q^-1, Psi = A' Qi, Phi = A' Qi A;  Om_f,0 = P0^-1, xi_0 = P0^-1 mu0
+//   forward t = 0..T-1 (step t consumes panel row t = period t+1):
+//       Z = (Om_f + Phi)^-1,  J = Z Psi,  Om_p = Qi - Psi' J,  w = Z xi,
+//       xi <- Psi' w + b_t,   Om_f <- Om_p + C_t
+//   terminal    P_T = Om_f^-1,  f_T = P_T xi
+//   backward    P_s <- Z + J (P_s J')',  f_s <- w + J f_s      (P_s J' = Cov(f_t+1, f_t | X))
+//   log-lik     telescoped sums of log det Z_t and xi_t' w_t (see oracle/info_form.py)
+// The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only); its
+// state-space notation is dfm_functions.ipynb:30-34.
+//
+// Mapping (wave64): a group of R lanes owns one replicate, lane i keeps ROW i of every r x r
+// matrix in registers; 64/R replicates per wave, one wave per workgroup.  Rows that other lanes need
+// (pivot row of a Gauss-Jordan sweep, operand of a product, a state vector) are exchanged through a
+// per-group LDS slot and read back with same-address (broadcast) ds_read_b128.
+// Covariance steps are memoised: when Om_f repeats (balanced stretch of the panel: Riccati fixed
+// point reached in a handful of periods) Z, J, Om_p are reused and only the O(r^2) mean recursion
+// runs; same for P_s going backward.  Distinct (Z, J) pairs go to a scratch table in HBM; an LDS
+// bitmask remembers at which periods a new pair was made.
+#include "dfm_kernels.h"
+
+namespace dfm {
+
+constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+constexpr int CH = 8;                 // periods per prefetch chunk
+constexpr double kSteadyTol = 4.5e-16;  // ~2 ulp: successive Om_f / P_s this close are "equal"
+
+template <int R>
+struct RecLayout {
+    static constexpr int GPW = 64 / R;                       // replicates per wave
+    // per-group doubles: X (exchange), PSI, JS, V0, V1, ring[2][CH][R+3]
+    static constexpr int kRing = 2 * CH * (R + 3);
+    static constexpr int kRaw = 3 * R * R + 2 * R + kRing;
+    static constexpr int S = ((kRaw + 3) / 4) * 4 + 2;       // S/2 odd: groups land on distinct 16-B bank slots
+    static __host__ __device__ size_t lds_bytes(int T) {
+        return (size_t)GPW * S * sizeof(double) + (size_t)((T + 31) / 32 + 1) * sizeof(unsigned);
+    }
+};
+
+template <int R>
+__device__ __forceinline__ void store_row(double* M, int i, const double (&row)[R]) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) M[i * R + j] = row[j];
+}
+// out[j] = sum_k own[k] * M[k][j]
+template <int R>
+__device__ __forceinline__ void mm_rows(double (&out)[R], const double (&own)[R], const double* M) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) out[j] = 0.0;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const double a = own[k];
+#pragma unroll
+        for (int j = 0; j < R; ++j) out[j] = fma(a, M[k * R + j], out[j]);
+    }
+}
+// out[j] = sum_k own[k] * M[j][k]
+template <int R>
+__device__ __forceinline__ void mm_rowsT(double (&out)[R], const double (&own)[R], const double* M) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) s = fma(own[k], M[j * R + k], s);
+        out[j] = s;
+    }
+}
+template <int R>
+__device__ __forceinline__ double dot_vec(const double (&own)[R], const double* v) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int k = 0; k + 1 < R; k += 2) {
+        s0 = fma(own[k], v[k], s0);
+        s1 = fma(own[k + 1], v[k + 1], s1);
+    }
+    return s0 + s1;
+}
+
+// In-place Gauss-Jordan inverse (no pivoting; SPD input).  Lane i holds row i in m; sweep k broadcasts
+// row k through the two R-double LDS rows at X (double-buffered: one barrier per sweep).
+// Returns det(input) = product of pivots.  Every lane of the group gets the same value.
+template <int R>
+__device__ __forceinline__ double gj_inverse(double (&m)[R], double* X, int i) {
+    double det = 1.0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        double* buf = X + (k & 1) * R;
+        if (i == k) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) buf[j] = m[j];
+        }
+        __syncthreads();
+        double q[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) q[j] = buf[j];
+        const double piv = q[k];
+        const double d = 1.0 / piv;
+        det *= piv;
+        const double c = m[k];
+        const bool me = (i == k);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (j == k) {
+                m[j] = me ? d : -c * d;
+            } else {
+                const double qj = q[j] * d;
+                m[j] = me ? qj : fma(-c, qj, m[j]);
+            }
+        }
+    }
+    return det;
+}
+
+__device__ __forceinline__ bool close_enough(double a, double b) {
+    return fabs(a - b) <= kSteadyTol * fabs(b);
+}
+
+template <int R>
+__global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
+    using LY = RecLayout<R>;
+    constexpr int GPW = LY::GPW;
+    constexpr int NPp = R * (R + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int g = lane / R, i = lane % R;
+    const int T = a.T, N = a.N, r = a.r;
+    int b = blockIdx.x * GPW + g;
+    const bool live = b < a.B;
+    if (!live) b = a.B - 1;
+
+    double* X = smem + (size_t)g * LY::S;
+    double* PSI = X + R * R;
+    double* JS = PSI + R * R;
+    double* V0 = JS + R * R;
+    double* V1 = V0 + R;
+    double* RING = V1 + R;  // [2][CH][R+3]: b[0..R), s, n, ld
+    unsigned* cmask = reinterpret_cast<unsigned*>(smem + (size_t)GPW * LY::S);
+    const int nwords = (T + 31) / 32 + 1;
+    for (int w = lane; w < nwords; w += 64) cmask[w] = 0u;
+
+    const double* Ab = a.A + (size_t)b * R * R;
+    const double* Qb = a.Q + (size_t)b * R * R;
+    const double* P0b = a.P0 + (size_t)b * R * R;
+    const double* bcol = a.bcol + (size_t)b * T * R;
+    const double* scol = a.scol + (size_t)b * T;
+    const int* nobs = a.nobs + (size_t)b * T;
+    const double* ldrow = a.ldrow + (size_t)b * T;
+    const double ldfull = a.ldfull[b];
+    double* ZJ = a.ZJtab + (size_t)b * (T + 1) * 2 * R * R;
+    double* wtab = a.wtab + (size_t)b * T * R;
+
+    // ---------------- prologue: constants --------------------------------------------------------
+    double Arow[R], Qi[R], PsiT[R], Phi[R], Cf[R], Omf[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        Arow[j] = Ab[i * R + j];
+        Qi[j] = Qb[i * R + j];
+        Cf[j] = a.Cfull[(size_t)b * R * R + i * R + j];
+        Omf[j] = P0b[i * R + j];
+    }
+    const double mu0i = a.mu0[(size_t)b * R + i];
+    const double detQ = gj_inverse<R>(Qi, X, i);
+    const double detP0 = gj_inverse<R>(Omf, X, i);       // Omf = P0^-1 = Om_f,0
+    __syncthreads();
+    store_row<R>(X, i, Arow);                              // X = A rows
+    __syncthreads();
+    mm_rows<R>(PsiT, Qi, X);                               // Psi' = Qi A   (row i)
+#pragma unroll
+    for (int j = 0; j < R; ++j) PSI[j * R + i] = PsiT[j];  // PSI = Psi rows (transpose of Psi')
+    __syncthreads();
+    {
+        double prow[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) prow[k] = PSI[i * R + k];
+        mm_rows<R>(Phi, prow, X);                          // Phi = Psi A
+    }
+    V0[i] = mu0i;
+    __syncthreads();
+    double xi = dot_vec<R>(Omf, V0);                       // xi_0 = P0^-1 mu0
+    const double q0_part = mu0i * xi;
+
+    // ---------------- forward sweep --------------------------------------------------------------
+    const int nchunks = (T + CH - 1) / CH;
+    constexpr int SPL = (CH + R - 1) / R;                  // scalar-loading steps per lane
+    double pb[CH], ps[SPL], pl[SPL];
+    int pn[SPL];
+    auto issue_fwd = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            int t = c * CH + s;
+            t = t < T ? t : T - 1;
+            pb[s] = bcol[(size_t)t * R + i];
+        }
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+            const int s = i + q * R;
+            int t = c * CH + s;
+            t = t < T ? t : T - 1;
+            if (s < CH) { ps[q] = scol[t]; pn[q] = nobs[t]; pl[q] = ldrow[t]; }
+        }
+    };
+    auto commit_fwd = [&](int slot) {
+        double* ring = RING + slot * CH * (R + 3);
+#pragma unroll
+        for (int s = 0; s < CH; ++s) ring[s * (R + 3) + i] = pb[s];
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+            const int s = i + q * R;
+            if (s < CH) {
+                ring[s * (R + 3) + R] = ps[q];
+                ring[s * (R + 3) + R + 1] = (double)pn[q];
+                ring[s * (R + 3) + R + 2] = (pn[q] == N) ? ldfull : pl[q];   // ldrow is only written for rows with NaN
+            }
+        }
+    };
+
+    double Z[R], Jr[R], Omp[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { Z[j] = 0.0; Jr[j] = 0.0; Omp[j] = 0.0; }
+    double ldz_cur = 0.0, sum_ldz = 0.0, sum_xw = 0.0, ssum = 0.0, nsum = 0.0, ldsum = 0.0;
+    int e = -1;
+    bool need_cov = true;
+
+    issue_fwd(0);
+    __syncthreads();
+    commit_fwd(0);
+    if (nchunks > 1) issue_fwd(1);
+    __syncthreads();
+
+    for (int c = 0; c < nchunks; ++c) {
+        const double* ring = RING + (c & 1) * CH * (R + 3);
+        const int smax = (T - c * CH) < CH ? (T - c * CH) : CH;
+        for (int s = 0; s < smax; ++s) {
+            const int t = c * CH + s;
+            const bool computed = need_cov;
+            double Omf_used[R];
+            if (need_cov) {  // wave-uniform
+#pragma unroll
+                for (int j = 0; j < R; ++j) { Omf_used[j] = Omf[j]; Z[j] = Omf[j] + Phi[j]; }
+                const double detM = gj_inverse<R>(Z, X, i);
+                ldz_cur = -log(detM);                      // log det Z
+                mm_rows<R>(Jr, Z, PSI);                    // J = Z Psi
+                __syncthreads();
+                store_row<R>(X, i, Jr);
+                __syncthreads();
+                double tmp[R];
+                mm_rows<R>(tmp, PsiT, X);                  // Psi' J
+#pragma unroll
+                for (int j = 0; j < R; ++j) Omp[j] = Qi[j] - tmp[j];
+                ++e;
+                {   // (groups past the end of the batch duplicate replicate B-1: same values, same address)
+                    double* zt = ZJ + ((size_t)e * 2 + 0) * R * R + i * R;
+                    double* jt = ZJ + ((size_t)e * 2 + 1) * R * R + i * R;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) { zt[j] = Z[j]; jt[j] = Jr[j]; }
+                }
+                if (lane == 0) cmask[t >> 5] |= 1u << (t & 31);
+            }
+            // mean recursion
+            V0[i] = xi;
+            __syncthreads();
+            const double w = dot_vec<R>(Z, V0);
+            sum_xw = fma(xi, w, sum_xw);
+            sum_ldz += ldz_cur;
+            wtab[(size_t)t * R + i] = w;
+            V1[i] = w;
+            __syncthreads();
+            const double xip = dot_vec<R>(PsiT, V1);
+            const double* rs = ring + s * (R + 3);
+            xi = xip + rs[i];
+            ssum += rs[R];
+            const double nt = rs[R + 1];
+            nsum += nt;
+            ldsum += rs[R + 2];
+            const bool full = (nt == (double)N);
+            double Omf_new[R];
+            if (full) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) Omf_new[j] = Omp[j] + Cf[j];
+            } else {  // row i of the packed C_t of this period
+                const double* ct = a.Ct + ((size_t)b * T + t) * NPp;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int hi = i > j ? i : j, lo = i > j ? j : i;
+                    Omf_new[j] = Omp[j] + ct[hi * (hi + 1) / 2 + lo];
+                }
+            }
+            if (computed) {
+                bool same = full;
+#pragma unroll
+                for (int j = 0; j < R; ++j) same = same && close_enough(Omf_new[j], Omf_used[j]);
+                need_cov = !__all(same);
+            } else {
+                need_cov = __any(!full);
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) Omf[j] = Omf_new[j];
+        }
+        __syncthreads();
+        if (c + 1 < nchunks) commit_fwd((c + 1) & 1);
+        if (c + 2 < nchunks) issue_fwd(c + 2);
+        __syncthreads();
+    }
+
+    // ---------------- terminal: P_T = Om_f^-1, f_T = P_T xi, log-likelihood ------------------------
+    double Ps[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) Ps[j] = Omf[j];
+    const double detOmT = gj_inverse<R>(Ps, X, i);
+    __syncthreads();
+    V0[i] = xi;
+    __syncthreads();
+    double fs = dot_vec<R>(Ps, V0);
+    {
+        const double part = q0_part - xi * fs - sum_xw;    // lane part of mu0'P0^-1mu0 - xi_T'f_T - sum xi'w
+        V1[i] = part;
+        __syncthreads();
+        double qd = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) qd += V1[k];
+        const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) - sum_ldz;
+        const double ll = -0.5 * (nsum * kLog2Pi + ldsum + LD + ssum + qd);
+        if (live && i == 0) {
+            a.loglik[b] = ll;
+            if (a.ncov) a.ncov[b] = e + 1;
+        }
+    }
+
+    // ---------------- backward sweep -------------------------------------------------------------
+    const int npr = r * (r + 1) / 2;
+    auto emit = [&](int trow, const double (&P)[R], double f) {   // smoothed moments of period trow+1
+        if (!live || i >= r) return;
+        a.f_smooth[((size_t)b * T + trow) * r + i] = f;
+        if (a.P_smooth) {
+            double* po = a.P_smooth + ((size_t)b * T + trow) * npr + i * (i + 1) / 2;
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                if (j <= i) po[j] = P[j];
+        }
+    };
+    emit(T - 1, Ps, fs);
+
+    // gathered f_s (period t+1) for the products below
+    double fvec[R];
+    __syncthreads();
+    V0[i] = fs;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < R; ++k) fvec[k] = V0[k];
+
+    const bool em = a.S11 != nullptr;
+    double S11[R], S10[R], termT[R], U[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        termT[j] = fma(fs, fvec[j], Ps[j]);                // E[f_T f_T'] row i
+        S11[j] = termT[j];
+        S10[j] = 0.0;
+        U[j] = 0.0;
+    }
+
+    double pw[CH];
+    auto issue_bwd = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            int t = c * CH + s;
+            t = t < T ? t : T - 1;
+            pw[s] = wtab[(size_t)t * R + i];
+        }
+    };
+    auto commit_bwd = [&](int slot) {
+        double* ring = RING + slot * CH * (R + 3);
+#pragma unroll
+        for (int s = 0; s < CH; ++s) ring[s * (R + 3) + i] = pw[s];
+    };
+    // Z/J of the current entry; the next older entry is prefetched into Zn/Jn
+    double Zn[R], Jn[R];
+    auto load_entry = [&](int ee, double (&zz)[R], double (&jj)[R]) {
+        const int ec = ee < 0 ? 0 : ee;
+        const double* zt = ZJ + ((size_t)ec * 2 + 0) * R * R + i * R;
+        const double* jt = ZJ + ((size_t)ec * 2 + 1) * R * R + i * R;
+#pragma unroll
+        for (int j = 0; j < R; ++j) { zz[j] = zt[j]; jj[j] = jt[j]; }
+    };
+    // after the forward sweep Z, Jr hold entry e (the last one made) -- still in registers
+    int e_cur = e;
+    load_entry(e_cur - 1, Zn, Jn);
+    __syncthreads();
+    store_row<R>(JS, i, Jr);
+    bool need_b = true;
+
+    issue_bwd(nchunks - 1);
+    __syncthreads();
+    commit_bwd((nchunks - 1) & 1);
+    if (nchunks > 1) issue_bwd(nchunks - 2);
+    __syncthreads();
+
+    for (int c = nchunks - 1; c >= 0; --c) {
+        const double* ring = RING + (c & 1) * CH * (R + 3);
+        const int smax = (T - c * CH) < CH ? (T - c * CH) : CH;
+        for (int s = smax - 1; s >= 0; --s) {
+            const int t = c * CH + s;          // step t: from period t+1 to period t (t = 0: initial state)
+            // entry of step t: e_cur is the entry of the step processed before (t+1); it changes iff a
+            // new pair was made at step t+1
+            bool changed = false;
+            if (t + 1 < T && ((cmask[(t + 1) >> 5] >> ((t + 1) & 31)) & 1u)) {
+                --e_cur;
+#pragma unroll
+                for (int j = 0; j < R; ++j) { Z[j] = Zn[j]; Jr[j] = Jn[j]; }
+                load_entry(e_cur - 1, Zn, Jn);
+                __syncthreads();
+                store_row<R>(JS, i, Jr);
+                __syncthreads();
+                changed = true;
+            }
+            if (need_b || changed) {  // wave-uniform
+                __syncthreads();
+                mm_rowsT<R>(U, Ps, JS);                    // U = P_s J'  = Cov(f_{t+1}, f_t | X)
+                store_row<R>(X, i, U);
+                __syncthreads();
+                double tmp[R];
+                mm_rows<R>(tmp, Jr, X);                    // J U
+                bool same = true;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const double pn_ = Z[j] + tmp[j];
+                    same = same && close_enough(pn_, Ps[j]);
+                    Ps[j] = pn_;
+                }
+                need_b = !__all(same);
+            }
+            const double fnew = ring[s * (R + 3) + i] + dot_vec<R>(Jr, fvec);   // w_t + J f_{t+1}
+            if (em) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) S10[j] += U[j];          // + f_{t+1} f_t' added below
+            }
+            const double fprev_i = fs;                     // f_{t+1}[i]
+            fs = fnew;
+            __syncthreads();
+            V0[i] = fs;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < R; ++k) fvec[k] = V0[k];
+            if (em) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    S10[j] = fma(fprev_i, fvec[j], S10[j]);
+                    if (t > 0) S11[j] += fma(fs, fvec[j], Ps[j]);
+                }
+            }
+            if (t > 0) emit(t - 1, Ps, fs);
+        }
+        __syncthreads();
+        if (c - 1 >= 0) commit_bwd((c - 1) & 1);
+        if (c - 2 >= 0) issue_bwd(c - 2);
+        __syncthreads();
+    }
+    // now fs / Ps / fvec are the smoothed moments of the initial state f_0
+    if (em && live) {
+        const size_t o = (size_t)b * R * R + (size_t)i * R;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            a.S11[o + j] = S11[j];
+            a.S10[o + j] = S10[j];
+            a.S00[o + j] = S11[j] - termT[j] + fma(fs, fvec[j], Ps[j]);
+            a.P0s[o + j] = Ps[j];
+        }
+        a.f0s[(size_t)b * R + i] = fs;
+    }
+}
+
+template <int R>
+static hipError_t launch_rec(const RecursionArgs& a, hipStream_t s) {
+    using LY = RecLayout<R>;
+    const int grid = (a.B + LY::GPW - 1) / LY::GPW;
+    const size_t lds = LY::lds_bytes(a.T);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&recursion_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((recursion_kernel<R>), dim3(grid), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s) {
+    switch (Rpad) {
+        case 2: return launch_rec<2>(a, s);
+        case 4: return launch_rec<4>(a, s);
+        case 8: return launch_rec<8>(a, s);
+        case 16: return launch_rec<16>(a, s);
+        case 32: return launch_rec<32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dfm

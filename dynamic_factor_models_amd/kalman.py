@@ -1,0 +1,133 @@
+"""Host-side wrappers of the C-ABI (include/dfm_hip.h) over torch device tensors / NumPy arrays.
+
+torch is plumbing only (device memory, the current HIP stream, torch.distributed); every number is
+produced by the hand-written gfx950 kernels inside libdfmhip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+def _check(h, rc: int):
+    if rc != 0:
+        raise _lib.DfmError(rc, _lib.load().dfm_last_error(h).decode())
+
+
+class DfmContext:
+    """One libdfmhip handle bound to a HIP device and (by default) torch's current stream."""
+
+    def __init__(self, device: Optional[int] = None, use_torch_stream: bool = True):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("DfmContext needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback for this path")
+        self._lib = _lib.load()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self._torch = torch
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
+        h = ctypes.c_void_p()
+        rc = self._lib.dfm_create(ctypes.byref(h), self.device, ctypes.c_void_p(stream))
+        if rc != 0:
+            raise _lib.DfmError(rc, "dfm_create failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dfm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, t, name, shape=None):
+        torch = self._torch
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous():
+            raise TypeError(f"{name}: expected a contiguous float64 tensor on the HIP device")
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def _sync_stream(self):
+        s = self._torch.cuda.current_stream(self.device).cuda_stream
+        self._lib.dfm_set_stream(self._h, ctypes.c_void_p(s))
+
+    def synchronize(self):
+        _check(self._h, self._lib.dfm_synchronize(self._h))
+
+    def profile_enable(self, on: bool = True):
+        self._sync_stream()
+        _check(self._h, self._lib.dfm_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """{kernel name: (total ms, launches)} since profile_enable(True)."""
+        out = {}
+        idx = 0
+        while True:
+            name = ctypes.create_string_buffer(64)
+            ms = ctypes.c_double(); n = ctypes.c_int()
+            rc = self._lib.dfm_profile_read(self._h, idx, name, 64, ctypes.byref(ms), ctypes.byref(n))
+            if rc != 0:
+                break
+            if n.value:
+                out[name.value.decode()] = (ms.value, n.value)
+            idx += 1
+        return out
+
+    @staticmethod
+    def _flags(panel, may_have_missing):
+        import torch
+        if may_have_missing is None:
+            may_have_missing = bool(torch.isnan(panel).any().item())
+        return _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+
+    # ------------------------------------------------------------------ smoother pass
+    def ks_pass_batch(self, panel, Lam, R, A, Q, mu0, P0, want_P: bool = True,
+                      may_have_missing: Optional[bool] = None, out=None):
+        """One Kalman-smoother pass per replicate (device tensors in, device tensors out).
+        Returns (f_smooth [B,T,r], P_smooth [B,T,r(r+1)/2] or None, loglik [B]).  Asynchronous on
+        torch's current stream."""
+        torch = self._torch
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        flags = self._flags(panel, may_have_missing)
+        if out is None:
+            f = torch.empty((B, T, r), dtype=torch.float64, device=panel.device)
+            P = torch.empty((B, T, r * (r + 1) // 2), dtype=torch.float64, device=panel.device) if want_P else None
+            ll = torch.empty((B,), dtype=torch.float64, device=panel.device)
+        else:
+            f, P, ll = out
+        self._sync_stream()
+        rc = self._lib.dfm_ks_pass_batch_dev(
+            self._h, B, T, N, r, self._dev(panel, "panel"), self._dev(Lam, "Lam", (B, N, r)),
+            self._dev(R, "R", (B, N)), self._dev(A, "A", (B, r, r)), self._dev(Q, "Q", (B, r, r)),
+            self._dev(mu0, "mu0", (B, r)), self._dev(P0, "P0", (B, r, r)), self._dev(f, "f_smooth"),
+            self._dev(P, "P_smooth") if P is not None else None, self._dev(ll, "loglik"), flags)
+        _check(self._h, rc)
+        return f, P, ll
+
+    def ks_pass_batch_host(self, panel, Lam, R, A, Q, mu0, P0, want_P: bool = True,
+                           may_have_missing: Optional[bool] = None):
+        """Same through the HOST-pointer entry point (what Julia's ccall binds): NumPy in/out."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        panel, Lam, R, A, Q, mu0, P0 = map(c, (panel, Lam, R, A, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2)) if want_P else None
+        ll = np.empty(B)
+        p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_ks_pass_batch(self._h, B, T, N, r, p(panel), p(Lam), p(R), p(A), p(Q), p(mu0),
+                                         p(P0), p(f), p(P), p(ll), flags)
+        _check(self._h, rc)
+        return f, P, ll

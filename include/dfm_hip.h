@@ -1,0 +1,130 @@
+/* include/dfm_hip.h -- C-ABI of libdfmhip.so: MI355X (gfx950) batched Kalman filter / RTS smoother /
+ * EM for the dynamic factor model of QuantEcon/dynamic_factor_models.
+ *
+ * What it replaces in the reference.  The reference has NO FFI and NO parametric estimator: it
+ * declares the dispatch tag `struct Parametric <: EstimationMethod end` (dfm_functions.ipynb:21-23),
+ * writes the state-space form y_t = Q z_t, z_t = M z_{t-1} + G u_t (dfm_functions.ipynb:30-34,
+ * matrices filled at :477-492) and implements only `estimate!(m, ::NonParametric)` (:530-543).
+ * The entry points below are what a new method `estimate!(m::DFMModel, ::Parametric; ...)` binds
+ * with `ccall` (binding shown in INTEGRATION.md / julia/dfm_hip.jl).  Each entry point cites the
+ * reference object whose role it fills.
+ *
+ * Conventions
+ *   - all arithmetic and storage: IEEE fp64; integers only for sizes / indices
+ *   - panel[b][t][i]  (i fastest; the reference stores T x ns column-major per model,
+ *                      dfm_functions.ipynb:89-111 `data`; the Julia shim permutes once)
+ *     NaN = missing cell (the reference's `missing`, dfm_functions.ipynb:155-158)
+ *   - Lam[b][i][k] (= `lambda`, ns x r, dfm_functions.ipynb:104), R[b][i] (idiosyncratic variance;
+ *     the reference keeps `uar_ser`, :106), A[b][r][r] row-major (= VAR(1) block of `M`, :477-492),
+ *     Q[b][r][r] (= `seps`, :57 / G G'), mu0[b][r], P0[b][r][r]
+ *   - packed symmetric outputs: lower triangle, row-major: idx(i,j) = i(i+1)/2 + j, j <= i
+ *   - every function returns an int status: 0 ok; <0 argument error (DFM_E_*); >0 = hipError_t.
+ *     No C++ exception or exit() crosses the boundary; dfm_last_error() gives the text.
+ *   - "_dev" entry points take DEVICE pointers and only enqueue work on the handle's stream
+ *     (asynchronous; inputs must stay valid until the stream is synchronised).  The plain entry
+ *     points take HOST pointers, copy in, run, copy out and synchronise (what Julia's ccall binds).
+ *   - the caller owns every buffer passed in; the library owns its workspace inside the handle.
+ *   - requires Q and P0 positive definite (information-form recursion), 1 <= r <= DFM_MAX_R.
+ */
+#ifndef DFM_HIP_H
+#define DFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFM_MAX_R 32
+
+enum {
+    DFM_OK = 0,
+    DFM_E_DIMS = -1,          /* B,T,N,r out of range */
+    DFM_E_R_UNSUPPORTED = -2, /* r > DFM_MAX_R */
+    DFM_E_NULL = -3,          /* required pointer is NULL */
+    DFM_E_MISSING = -4,       /* NaN found in the panel but DFM_F_MAY_HAVE_MISSING not set */
+    DFM_E_NUMERIC = -5,       /* non-finite log-likelihood in some replicate (non-PD Q/P0/...) */
+    DFM_E_NO_DEVICE = -6      /* no HIP device / extension not usable */
+};
+
+/* flags */
+#define DFM_F_MAY_HAVE_MISSING 1u /* panel may contain NaN: allocate the per-period C_t workspace */
+
+typedef struct dfm_handle dfm_handle;
+
+/* Create a context bound to HIP device `device_id`.  `stream` is a hipStream_t the caller owns
+ * (e.g. torch's current stream) or NULL for a stream created and owned by the handle. */
+int dfm_create(dfm_handle** h, int device_id, void* stream);
+int dfm_destroy(dfm_handle* h);
+int dfm_set_stream(dfm_handle* h, void* stream);
+int dfm_synchronize(dfm_handle* h);
+const char* dfm_last_error(const dfm_handle* h);
+const char* dfm_version(void);
+
+/* Per-kernel timing with HIP events recorded on the handle's stream around every kernel launch
+ * (bench.py's roofline leg; no reference counterpart).  dfm_profile_enable(h, 1) clears and starts,
+ * dfm_profile_read synchronises and returns the summed duration and launch count of kernel
+ * `kernel_index` (0 .. until it returns DFM_E_DIMS) together with its name. */
+int dfm_profile_enable(dfm_handle* h, int on);
+int dfm_profile_read(dfm_handle* h, int kernel_index, char* name_out, int name_cap, double* total_ms,
+                     int* launches);
+
+/* Bytes of device workspace the handle will hold for a (B,T,N,r) problem (for capacity planning). */
+size_t dfm_workspace_bytes(int B, int T, int N, int r, unsigned flags);
+
+/* --- one full Kalman-smoother pass per replicate (SURVEY.md §8(d) "pass") ---------------------
+ * Fills the slot of the reference's unused `Parametric` estimator: E-step at fixed parameters.
+ * Outputs: f_smooth[b][t][k] = E[f_t | X] (what the reference stores in `factor`,
+ * dfm_functions.ipynb:103), P_smooth[b][t][r(r+1)/2] = Var[f_t | X] packed (may be NULL),
+ * loglik[b] = Gaussian log-likelihood of the replicate's observed cells. */
+int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel,
+                          const double* Lam, const double* R, const double* A, const double* Q,
+                          const double* mu0, const double* P0, double* f_smooth, double* P_smooth,
+                          double* loglik, unsigned flags);
+int dfm_ks_pass_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
+                      const double* Lam, const double* R, const double* A, const double* Q,
+                      const double* mu0, const double* P0, double* f_smooth, double* P_smooth,
+                      double* loglik, unsigned flags);
+
+/* --- EM (Shumway-Stoffer / Banbura-Modugno) ------------------------------------------------------
+ * One EM iteration per replicate, parameters updated IN PLACE (device pointers); loglik[b] is the
+ * log-likelihood at the parameters passed in.  The role of the reference's per-series OLS
+ * (dfm_functions.ipynb:391-415) and factor VAR OLS (:444-468) in the non-parametric path. */
+int dfm_em_step_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel,
+                          double* Lam, double* R, double* A, double* Q, double* mu0, double* P0,
+                          double* loglik, unsigned flags);
+/* max_iter EM iterations; loglik_path[b][k] = log-likelihood at the parameters entering iteration
+ * k (NaN for k >= iters[b]); a replicate stops after iteration k >= 1 when
+ * (ll_k - ll_{k-1}) / (0.5 (|ll_k| + |ll_{k-1}|)) < tol (tol <= 0: run all iterations); iters[b] =
+ * iterations run.  Afterwards f_smooth/P_smooth (may be NULL) hold the smoother output at the
+ * final parameters.  Host-pointer variant copies parameters in and out. */
+int dfm_em_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam,
+                     double* R, double* A, double* Q, double* mu0, double* P0, int max_iter,
+                     double tol, double* loglik_path, int* iters, double* f_smooth,
+                     double* P_smooth, unsigned flags);
+int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam,
+                 double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol,
+                 double* loglik_path, int* iters, double* f_smooth, double* P_smooth,
+                 unsigned flags);
+
+/* --- PCA initialisation (reference: pca_score, dfm_functions.ipynb:179-183, on the standardised
+ * balanced panel, :339-348) followed by the OLS start of EM: Lam = OLS(x on F), R = residual
+ * variance, A/Q = VAR(1) OLS of F, mu0 = 0, P0 = F'F/T.  Balanced panels only (no NaN). */
+int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel,
+                           double* Lam, double* R, double* A, double* Q, double* mu0, double* P0,
+                           double* factors /* [B][T][r] PCA scores, may be NULL */);
+int dfm_pca_init_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam,
+                       double* R, double* A, double* Q, double* mu0, double* P0, double* factors);
+
+/* --- synthetic replicates generated on the device (SURVEY.md §8(d) DGP; no reference
+ * counterpart -- the reference has no RNG).  Writes the standardised panel and the DGP parameters
+ * rescaled to it.  Counter-based generator keyed by (seed, first_replicate + b). */
+int dfm_synth_panels_dev(dfm_handle* h, uint64_t seed, int64_t first_replicate, int B, int T, int N,
+                         int r, double missing_prob, double* panel, double* Lam, double* R,
+                         double* A, double* Q, double* mu0, double* P0);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFM_HIP_H */

@@ -1,0 +1,148 @@
+"""GPU parity tests of the hot path proper: HIP Kalman-smoother pass (through the C-ABI) vs the
+CPU oracle on the same seeded inputs.  fp64: tolerance 1e-9 relative (north_star asks 1e-6)."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import kalman_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def _batch(B, N, T, r, missing=0.0, seed=ko.SEED0, blank_rows=()):
+    reps = [ko.synth_replicate(b, N, T, r, seed=seed, missing=missing) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    for t in blank_rows:
+        panel[:, t, :] = np.nan
+    st = {k: np.stack([p[k] for _, p in reps]) for k in reps[0][1]}
+    return panel, st
+
+
+def _oracle(panel, st):
+    return co.ks_pass_batch(panel, st["Lam"], st["R"], st["A"], st["Q"], st["mu0"], st["P0"])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from dynamic_factor_models_amd import DfmContext
+    c = DfmContext()
+    yield c
+    c.close()
+
+
+def _run_dev(ctx, panel, st, **kw):
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_batch(t(panel), t(st["Lam"]), t(st["R"]), t(st["A"]), t(st["Q"]), t(st["mu0"]),
+                                 t(st["P0"]), **kw)
+    torch.cuda.synchronize()
+    return f.cpu().numpy(), None if P is None else P.cpu().numpy(), ll.cpu().numpy()
+
+
+def _compare(got, ref, tag=""):
+    f, P, ll = got
+    fo, Po, llo = ref
+    assert np.all(np.isfinite(ll)), tag
+    np.testing.assert_allclose(ll, llo, rtol=RTOL, err_msg=f"loglik {tag}")
+    scale_f = np.abs(fo).max()
+    assert np.abs(f - fo).max() <= RTOL * scale_f, f"f_smooth {tag}: {np.abs(f - fo).max()}"
+    if P is not None:
+        assert np.abs(P - Po).max() <= RTOL * np.abs(Po).max(), f"P_smooth {tag}: {np.abs(P - Po).max()}"
+
+
+@pytest.mark.parametrize("B,N,T,r,missing", [
+    (16, 200, 500, 8, 0.0),      # BASELINE config 2 shape, host-checked subset
+    (13, 200, 500, 8, 0.1),      # 10 %-missing variant; B not a multiple of the 8 replicates per wave
+    (5, 30, 60, 4, 0.15),
+    (3, 139, 222, 4, 0.05),      # Stock-Watson "All" panel shape (config 1)
+    (4, 31, 41, 3, 0.0),         # odd N (8-byte loads), r padded 3 -> 4
+    (4, 31, 41, 3, 0.2),
+    (3, 20, 25, 1, 0.1),         # r = 1 (padded to 2)
+    (3, 50, 40, 5, 0.1),         # r padded 5 -> 8
+    (2, 64, 48, 12, 0.1),        # r padded 12 -> 16
+    (2, 100, 40, 20, 0.05),      # config 4's r = 20 (padded to 32)
+    (2, 256, 30, 8, 0.0),        # widest N of the 2-chunk tiling
+    (2, 300, 20, 8, 0.1),        # 4-chunk tiling
+])
+def test_pass_matches_oracle(ctx, B, N, T, r, missing):
+    panel, st = _batch(B, N, T, r, missing)
+    got = _run_dev(ctx, panel, st)
+    _compare(got, _oracle(panel, st), f"B={B} N={N} T={T} r={r} miss={missing}")
+
+
+def test_rows_with_every_cell_missing(ctx):
+    panel, st = _batch(4, 40, 50, 4, 0.1, blank_rows=(0, 7, 8, 49))
+    _compare(_run_dev(ctx, panel, st), _oracle(panel, st), "blank rows")
+
+
+def test_missing_only_at_the_edges(ctx):
+    # unbalanced like the Stock-Watson panel: series that start late / end early; long balanced middle
+    panel, st = _batch(9, 60, 120, 4, 0.0)
+    panel[:, :10, 50:] = np.nan
+    panel[:, -5:, :7] = np.nan
+    _compare(_run_dev(ctx, panel, st), _oracle(panel, st), "ragged edges")
+
+
+def test_nondiagonal_dynamics_from_em(ctx):
+    # parameters after a few oracle EM steps: full A, full Q, nonzero mu0, general P0
+    B, N, T, r = 3, 40, 80, 3
+    panel, st = _batch(B, N, T, r, 0.1)
+    for b in range(B):
+        p0, _ = ko.pca_init(np.nan_to_num(panel[b]), r)
+        p, _, _ = ko.em(panel[b], p0, 4)
+        for k in st:
+            st[k][b] = p[k]
+    _compare(_run_dev(ctx, panel, st), _oracle(panel, st), "EM params")
+
+
+def test_host_pointer_entry_and_no_P(ctx):
+    panel, st = _batch(3, 30, 40, 4, 0.1)
+    ref = _oracle(panel, st)
+    f, P, ll = ctx.ks_pass_batch_host(panel, st["Lam"], st["R"], st["A"], st["Q"], st["mu0"], st["P0"])
+    _compare((f, P, ll), ref, "host entry")
+    f2, P2, ll2 = _run_dev(ctx, panel, st, want_P=False)
+    assert P2 is None
+    _compare((f2, None, ll2), ref, "no P")
+
+
+def test_nan_without_flag_is_an_error(ctx):
+    from dynamic_factor_models_amd import DfmError
+    panel, st = _batch(2, 20, 30, 2, 0.1)
+    with pytest.raises(DfmError) as ei:
+        ctx.ks_pass_batch_host(panel, st["Lam"], st["R"], st["A"], st["Q"], st["mu0"], st["P0"],
+                               may_have_missing=False)
+    assert ei.value.code == -4
+
+
+def test_deterministic(ctx):
+    panel, st = _batch(8, 64, 100, 8, 0.05)
+    a = _run_dev(ctx, panel, st)
+    b = _run_dev(ctx, panel, st)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_linearity_in_the_data_full_size(ctx):
+    """Size-independent property at BASELINE config-2 size: with mu0 = 0 the smoothed mean is linear
+    in the panel and the smoothed covariance does not depend on it."""
+    import torch
+    B, N, T, r = 64, 200, 500, 8
+    g = torch.Generator(device="cuda").manual_seed(1)
+    dev = torch.device("cuda", ctx.device)
+    panel = torch.randn((B, T, N), dtype=torch.float64, device=dev, generator=g)
+    _, st = _batch(1, N, T, r)
+    rep = lambda a: torch.from_numpy(a).to(dev).expand(B, *a.shape[1:]).contiguous()
+    args = [rep(st[k]) for k in ("Lam", "R", "A", "Q", "mu0", "P0")]
+    f1, P1, _ = ctx.ks_pass_batch(panel, *args, may_have_missing=False)
+    f2, P2, _ = ctx.ks_pass_batch(2.5 * panel, *args, may_have_missing=False)
+    f3, _, _ = ctx.ks_pass_batch(panel + panel.flip(0), *args, may_have_missing=False)
+    torch.cuda.synchronize()
+    assert torch.allclose(f2, 2.5 * f1, rtol=1e-10, atol=1e-12)
+    assert torch.allclose(f3, f1 + f1.flip(0), rtol=1e-10, atol=1e-12)
+    assert torch.equal(P1, P2)
+    assert torch.allclose(P1[0], P1[-1], rtol=0, atol=0)
