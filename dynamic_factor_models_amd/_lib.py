@@ -56,6 +56,13 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  The HIP runtime that is
+    # loaded FIRST becomes the process-wide one, and device pointers / streams are only meaningful
+    # inside one runtime -- so torch must be imported before libdfmhip.so pulls in a runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(SO_PATH):
         raise RuntimeError(
             f"{SO_PATH} not found: build it with `python -m dynamic_factor_models_amd.build` "

@@ -105,10 +105,12 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em) {
         p.S00 = take(off, B * rr * d);
         p.P0s = take(off, B * rr * d);
         p.f0s = take(off, (size_t)B * Rp * d);
-        p.fsm = take(off, (size_t)B * T * r * d);
-        p.Psm = take(off, (size_t)B * T * ((size_t)r * (r + 1) / 2) * d);
+        p.fsm = take(off, (size_t)B * T * Rp * d);
+        p.Psm = take(off, (size_t)B * T * np * d);
+        p.Sxf = take(off, B * rr * d);                       // S11^-1
         p.llbuf = take(off, (size_t)B * d);
         p.active = take(off, (size_t)B * sizeof(int));
+        if (mstep_needs_dmiss(Rp, N)) p.Dmiss = take(off, (size_t)B * N * np * d);
     }
     p.total = off;
     return p;
@@ -190,10 +192,17 @@ int pad_params(dfm_handle* h, const Plan& p, int B, int N, int r, const double* 
     return 0;
 }
 
-// Enqueue collapse + recursion for already-planned workspace.
-int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int r, const double* panel,
+struct EmOpts {          // all-null for a plain pass
+    double *A_out = nullptr, *Q_out = nullptr, *mu0_out = nullptr, *P0_out = nullptr;
+    int* active = nullptr; int* iters = nullptr; double* ll_path = nullptr;
+    int k = 0, max_iter = 1; double tol = 0.0;
+};
+
+// Enqueue collapse + recursion for already-planned workspace.  out_r = factor dimension of the
+// f_smooth / P_smooth layout (caller's r for a plain pass, Rp for EM-internal buffers).
+int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, const double* panel,
                  const PaddedParams& pp, const double* Rv, double* f_smooth, double* P_smooth, double* loglik,
-                 bool em) {
+                 const EmOpts* em) {
     CollapseArgs ca;
     ca.B = B; ca.T = T; ca.N = N;
     ca.panel = panel; ca.Lam = pp.Lam; ca.Rv = Rv;
@@ -202,16 +211,122 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int r, const
     ca.ldfull = at<double>(h, p.ldfull); ca.status = at<int>(h, p.status);
     { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(p.Rp, ca, h->stream)); }
     RecursionArgs ra;
-    ra.B = B; ra.T = T; ra.N = N; ra.r = r;
+    memset(&ra, 0, sizeof(ra));
+    ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
     ra.A = pp.A; ra.Q = pp.Q; ra.mu0 = pp.mu0; ra.P0 = pp.P0;
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
     ra.ZJtab = at<double>(h, p.ZJ); ra.wtab = at<double>(h, p.wtab); ra.eidx = nullptr;
     ra.f_smooth = f_smooth; ra.P_smooth = P_smooth; ra.loglik = loglik;
-    ra.S11 = em ? at<double>(h, p.S11) : nullptr; ra.S10 = at<double>(h, p.S10); ra.S00 = at<double>(h, p.S00);
-    ra.f0s = at<double>(h, p.f0s); ra.P0s = at<double>(h, p.P0s);
     ra.ncov = at<int>(h, p.ncov);
+    if (em) {
+        ra.S11 = at<double>(h, p.S11); ra.S10 = at<double>(h, p.S10); ra.S00 = at<double>(h, p.S00);
+        ra.f0s = at<double>(h, p.f0s); ra.P0s = at<double>(h, p.P0s); ra.S11inv = at<double>(h, p.Sxf);
+        ra.A_out = em->A_out; ra.Q_out = em->Q_out; ra.mu0_out = em->mu0_out; ra.P0_out = em->P0_out;
+        ra.active = em->active; ra.iters = em->iters; ra.ll_path = em->ll_path;
+        ra.k = em->k; ra.max_iter = em->max_iter; ra.tol = em->tol;
+    }
     { ProfScope ps(h, K_RECURSION); HIP_TRY(h, launch_recursion(p.Rp, ra, h->stream)); }
+    return 0;
+}
+
+// dst[b][i][j] = src[b][i][j], i < rd, j < cd (un-padding of parameters / smoother outputs)
+__global__ void copy_block_kernel(size_t nb, int rs, int cs, int rd, int cd, const double* src, double* dst) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = nb * rd * cd;
+    if (tid >= n) return;
+    const int j = tid % cd;
+    const int i = (tid / cd) % rd;
+    const size_t b = tid / ((size_t)cd * rd);
+    dst[tid] = src[(b * rs + i) * cs + j];
+}
+int copy_block(dfm_handle* h, size_t nb, int rs, int cs, int rd, int cd, const double* src, double* dst) {
+    const size_t n = nb * rd * cd;
+    hipLaunchKernelGGL(copy_block_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, nb, rs, cs,
+                       rd, cd, src, dst);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
+// One EM iteration on PADDED, writable device parameters (Lam [B][N][Rp], A/Q/P0 [B][Rp][Rp], mu0 [B][Rp]).
+int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double* panel, double* LamP,
+                 double* Rv, double* AP, double* QP, double* mu0P, double* P0P, double* fsm, double* Psm,
+                 double* loglik, EmOpts eo) {
+    const int Rp = p.Rp;
+    PaddedParams pp{LamP, AP, QP, mu0P, P0P};
+    eo.A_out = AP; eo.Q_out = QP; eo.mu0_out = mu0P; eo.P0_out = P0P;
+    if (int rc = enqueue_pass(h, p, B, T, N, Rp, panel, pp, Rv, fsm, Psm, loglik, &eo)) return rc;
+    MstepArgs ma;
+    ma.B = B; ma.T = T; ma.N = N; ma.r = Rp;
+    ma.panel = panel; ma.fsm = fsm; ma.Psm = Psm;
+    ma.S11 = at<double>(h, p.S11); ma.S11inv = at<double>(h, p.Sxf);
+    ma.Dmiss = at<double>(h, p.Dmiss);
+    ma.active = eo.active; ma.Lam_out = LamP; ma.R_out = Rv; ma.lam_stride = Rp;
+    if (ma.Dmiss)
+        HIP_TRY(h, hipMemsetAsync(ma.Dmiss, 0, (size_t)B * N * (Rp * (Rp + 1) / 2) * sizeof(double), h->stream));
+    { ProfScope ps(h, K_MSTEP_STATS); HIP_TRY(h, launch_mstep_lam(Rp, ma, h->stream)); }
+    return 0;
+}
+
+// Shared driver of dfm_em_step_batch_dev (max_iter = 1, no bookkeeping) and dfm_em_batch_dev.
+int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R, double* A,
+           double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path, int* iters,
+           double* loglik_single, double* f_smooth, double* P_smooth, unsigned flags) {
+    if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const Plan p = make_plan(B, T, N, r, flags, true);
+    if (int rc = ensure_ws(h, p.total)) return rc;
+    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
+    const int Rp = p.Rp;
+    const size_t np = (size_t)r * (r + 1) / 2, npp = (size_t)Rp * (Rp + 1) / 2;
+    const bool padded = (r != Rp);
+    double *LamP = Lam, *AP = A, *QP = Q, *mu0P = mu0, *P0P = P0;
+    if (padded) {
+        PaddedParams pp;
+        if (int rc = pad_params(h, p, B, N, r, Lam, A, Q, mu0, P0, &pp)) return rc;
+        LamP = at<double>(h, p.LamP); AP = at<double>(h, p.AP); QP = at<double>(h, p.QP);
+        mu0P = at<double>(h, p.mu0P); P0P = at<double>(h, p.P0P);
+    }
+    // smoother outputs of the E-steps: straight into the caller's buffers when layouts coincide
+    double* fsm = (!padded && f_smooth) ? f_smooth : at<double>(h, p.fsm);
+    double* Psm = (!padded && P_smooth) ? P_smooth : at<double>(h, p.Psm);
+    double* llbuf = loglik_single ? loglik_single : at<double>(h, p.llbuf);
+    const bool book = loglik_path != nullptr;
+    int* active = book ? at<int>(h, p.active) : nullptr;
+    if (book) {
+        HIP_TRY(h, hipMemsetAsync(loglik_path, 0xFF, (size_t)B * max_iter * sizeof(double), h->stream));  // NaN
+        HIP_TRY(h, hipMemsetAsync(iters, 0, (size_t)B * sizeof(int), h->stream));
+    }
+    std::vector<int> act_host;
+    for (int k = 0; k < max_iter; ++k) {
+        EmOpts eo;
+        eo.active = active; eo.iters = iters; eo.ll_path = loglik_path; eo.k = k; eo.max_iter = max_iter; eo.tol = tol;
+        if (int rc = em_iteration(h, p, B, T, N, panel, LamP, R, AP, QP, mu0P, P0P, fsm, Psm, llbuf, eo)) return rc;
+        if (book && tol > 0.0 && k + 1 < max_iter) {   // stop launching once every replicate has converged
+            act_host.resize(B);
+            HIP_TRY(h, hipMemcpyAsync(act_host.data(), active, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            bool any = false;
+            for (int b = 0; b < B; ++b) any = any || act_host[b] != 0;
+            if (!any) break;
+        }
+    }
+    if (padded) {
+        if (int rc = copy_block(h, (size_t)B * N, 1, Rp, 1, r, LamP, Lam)) return rc;
+        if (int rc = copy_block(h, B, Rp, Rp, r, r, AP, A)) return rc;
+        if (int rc = copy_block(h, B, Rp, Rp, r, r, QP, Q)) return rc;
+        if (int rc = copy_block(h, B, Rp, Rp, r, r, P0P, P0)) return rc;
+        if (int rc = copy_block(h, B, 1, Rp, 1, r, mu0P, mu0)) return rc;
+        if (f_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, Rp, 1, r, fsm, f_smooth)) return rc;
+        if (P_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, (int)npp, 1, (int)np, Psm, P_smooth)) return rc;
+    } else {
+        if (f_smooth && fsm != f_smooth)
+            HIP_TRY(h, hipMemcpyAsync(f_smooth, fsm, (size_t)B * T * r * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        if (P_smooth && Psm != P_smooth)
+            HIP_TRY(h, hipMemcpyAsync(P_smooth, Psm, (size_t)B * T * np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
     return 0;
 }
 
@@ -320,7 +435,7 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     PaddedParams pp;
     if (int rc = pad_params(h, p, B, N, r, Lam, A, Q, mu0, P0, &pp)) return rc;
-    return enqueue_pass(h, p, B, T, N, r, panel, pp, R, f_smooth, P_smooth, loglik, false);
+    return enqueue_pass(h, p, B, T, N, r, panel, pp, R, f_smooth, P_smooth, loglik, nullptr);
 }
 
 // status word / log-likelihood sanity after a synchronising call
@@ -373,12 +488,70 @@ int dfm_ks_pass_batch(dfm_handle* h, int B, int T, int N, int r, const double* p
 
 
 // ---- TEMPORARY bring-up stubs (replaced as the kernels land) ----------------------------------
-int dfm_em_step_batch_dev(dfm_handle* h, int, int, int, int, const double*, double*, double*, double*, double*,
-                          double*, double*, double*, unsigned) { return fail(h, DFM_E_DIMS, "not implemented yet%s"); }
-int dfm_em_batch_dev(dfm_handle* h, int, int, int, int, const double*, double*, double*, double*, double*, double*,
-                     double*, int, double, double*, int*, double*, double*, unsigned) { return fail(h, DFM_E_DIMS, "not implemented yet%s"); }
-int dfm_em_batch(dfm_handle* h, int, int, int, int, const double*, double*, double*, double*, double*, double*,
-                 double*, int, double, double*, int*, double*, double*, unsigned) { return fail(h, DFM_E_DIMS, "not implemented yet%s"); }
+int dfm_em_step_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,
+                          double* A, double* Q, double* mu0, double* P0, double* loglik, unsigned flags) {
+    if (!h) return DFM_E_NULL;
+    if (!loglik) return fail(h, DFM_E_NULL, "loglik is NULL%s");
+    return em_run(h, B, T, N, r, panel, Lam, R, A, Q, mu0, P0, 1, 0.0, nullptr, nullptr, loglik, nullptr, nullptr, flags);
+}
+
+int dfm_em_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,
+                     double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                     int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
+    if (!h) return DFM_E_NULL;
+    if (!loglik_path || !iters) return fail(h, DFM_E_NULL, "loglik_path / iters is NULL%s");
+    return em_run(h, B, T, N, r, panel, Lam, R, A, Q, mu0, P0, max_iter, tol, loglik_path, iters, nullptr, f_smooth,
+                  P_smooth, flags);
+}
+
+int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R, double* A,
+                 double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path, int* iters,
+                 double* f_smooth, double* P_smooth, unsigned flags) {
+    if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double), np = (size_t)r * (r + 1) / 2;
+    const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_m = (size_t)B * r * r,
+                 n_v = (size_t)B * r, n_f = (size_t)B * T * r, n_P = (size_t)B * T * np, n_ll = (size_t)B * max_iter;
+    const size_t total = (n_panel + n_lam + n_R + 3 * n_m + n_v + n_f + n_P + n_ll) * d + (size_t)B * sizeof(int);
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), total));
+    double* dp = buf;
+    auto up = [&](const double* src, size_t n) -> double* {
+        double* dst = dp; dp += n;
+        (void)hipMemcpyAsync(dst, src, n * d, hipMemcpyHostToDevice, h->stream);
+        return dst;
+    };
+    double *x_d = up(panel, n_panel), *lam_d = up(Lam, n_lam), *R_d = up(R, n_R), *A_d = up(A, n_m), *Q_d = up(Q, n_m),
+           *mu_d = up(mu0, n_v), *P0_d = up(P0, n_m);
+    double* f_d = dp; dp += n_f;
+    double* P_d = dp; dp += n_P;
+    double* ll_d = dp; dp += n_ll;
+    int* it_d = reinterpret_cast<int*>(dp);
+    int rc = dfm_em_batch_dev(h, B, T, N, r, x_d, lam_d, R_d, A_d, Q_d, mu_d, P0_d, max_iter, tol, ll_d, it_d,
+                              f_smooth ? f_d : nullptr, P_smooth ? P_d : nullptr, flags);
+    if (rc == 0) {
+        auto down = [&](void* dst, const void* src, size_t bytes) { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream); };
+        down(Lam, lam_d, n_lam * d); down(R, R_d, n_R * d); down(A, A_d, n_m * d); down(Q, Q_d, n_m * d);
+        down(mu0, mu_d, n_v * d); down(P0, P0_d, n_m * d); down(loglik_path, ll_d, n_ll * d);
+        down(iters, it_d, (size_t)B * sizeof(int));
+        if (f_smooth) down(f_smooth, f_d, n_f * d);
+        if (P_smooth) down(P_smooth, P_d, n_P * d);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    if (rc == 0) {
+        int st = 0;
+        (void)hipMemcpy(&st, at<int>(h, make_plan(B, T, N, r, flags, true).status), sizeof(int), hipMemcpyDeviceToHost);
+        if (st & 1) rc = fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
+        for (int b = 0; rc == 0 && b < B; ++b)
+            if (!isfinite(loglik_path[(size_t)b * max_iter])) rc = fail(h, DFM_E_NUMERIC, "non-finite log-likelihood%s");
+    }
+    (void)hipFree(buf);
+    return rc;
+}
 int dfm_pca_init_batch_dev(dfm_handle* h, int, int, int, int, const double*, double*, double*, double*, double*,
                            double*, double*, double*) { return fail(h, DFM_E_DIMS, "not implemented yet%s"); }
 int dfm_pca_init_batch(dfm_handle* h, int, int, int, int, const double*, double*, double*, double*, double*,

@@ -185,8 +185,11 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
         for (int rr = 0; rr < RB; ++rr) {
             const int t = t0 + rr;
             if (t < T && ((nanmask >> rr) & 1u)) {
-                if (a.Ct == nullptr) {
-                    if (lane == 0) atomicOr(a.status, 1);
+                if (a.Ct == nullptr) {   // caller promised a balanced panel: flag the error, keep the
+                    if (lane == 0) {     // recursion on valid memory (results of this call are void)
+                        atomicOr(a.status, 1);
+                        a.nobs[(size_t)b * T + t] = N;
+                    }
                     continue;
                 }
                 const double* xr = X + (size_t)t * N;

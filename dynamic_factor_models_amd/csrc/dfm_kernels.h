@@ -44,10 +44,35 @@ struct RecursionArgs {
     // EM sufficient statistics (null for a plain pass): S11,S10,S00 [B][Rp][Rp]; f0s [B][Rp]; P0s [B][Rp][Rp]
     double* S11; double* S10; double* S00; double* f0s; double* P0s;
     int* ncov;            // [B] number of distinct covariance steps (diagnostic), or null
+    // EM epilogue (all null / 0 for a plain pass): new transition parameters written IN PLACE
+    // (each replicate's A, Q, mu0, P0 are read only in the kernel prologue of the same group)
+    double* A_out; double* Q_out; double* mu0_out; double* P0_out;   // padded [B][Rp][Rp] / [B][Rp]
+    double* S11inv;       // [B][Rp][Rp]  (S11)^-1 for the loadings step
+    int* active;          // [B] or null: replicate still iterating (read, then updated by the kernel)
+    int* iters;           // [B] or null
+    double* ll_path;      // [B][max_iter] or null
+    int k, max_iter;      // current EM iteration
+    double tol;
+};
+
+struct MstepArgs {
+    int B, T, N, r;
+    const double* panel;  // [B][T][N]
+    const double* fsm;    // [B][T][Rp]            smoothed means (padded layout)
+    const double* Psm;    // [B][T][Rp(Rp+1)/2]    smoothed covariances, packed
+    const double* S11;    // [B][Rp][Rp]
+    const double* S11inv; // [B][Rp][Rp]
+    double* Dmiss;        // [B][N][Rp(Rp+1)/2] zeroed scratch, or null (register accumulators)
+    const int* active;    // [B] or null
+    double* Lam_out;      // [B][N][lam_stride]
+    double* R_out;        // [B][N]
+    int lam_stride;
 };
 
 hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
 int collapse_max_n(int Rpad);
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
+hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
+bool mstep_needs_dmiss(int Rpad, int N);
 
 }  // namespace dfm

@@ -1,0 +1,265 @@
+// mstep.hip -- EM M-step for the observation equation: new loadings Lam and idiosyncratic
+// variances R from the smoothed moments (Banbura & Modugno 2014 for missing
+// cells).  Second (and last) streaming read of the panel in an EM iteration.
+//
+//   per series i over its observed periods T_i:
+//     Sff_i = sum_t E[f_t f_t' | X]          (= S11 - sum over the periods where x_ti is missing)
+//     Sxf_i = sum_t x_ti E[f_t | X],  Sxx_i = sum_t x_ti^2
+//     lam_i = Sff_i^-1 Sxf_i,   R_i = (Sxx_i - 2 lam_i'Sxf_i + lam_i'Sff_i lam_i) / |T_i|
+// The reference's counterpart of this step is the per-series OLS of x_i on the factors over the
+// series' complete cases (dfm_functions.ipynb:355-362 and :391-404).
+//
+// Mapping: one workgroup (256 lanes) per replicate, LANE = SERIES (column i = tid + 256 j): a row of
+// the panel is read by the 4 waves as 4 x 512 contiguous bytes, E[f_t] / Var[f_t] are wave-uniform
+// loads, and every per-series sum lives in the registers of the lane that owns the series -- no
+// cross-lane reduction, no atomics, bit-reproducible.  The (A, Q, mu0, P0) half of the M-step is the
+// epilogue of recursion_kernel, which also leaves S11 and S11^-1 for this kernel.
+#include "dfm_kernels.h"
+
+namespace dfm {
+
+// Solve the SPD system S x = rhs (S packed lower, row-major) by Cholesky.  R <= 8: fully unrolled
+// (compile-time indices, everything in registers).  Larger R: plain loops over a private array
+// (only series with missing cells take this path).
+template <int R>
+__device__ __forceinline__ void chol_solve_packed(const double (&S)[R * (R + 1) / 2], const double (&rhs)[R],
+                                                  double (&x)[R]) {
+    double L[R * (R + 1) / 2];
+    double y[R];
+    if constexpr (R <= 8) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double s = S[i * (i + 1) / 2 + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) s = fma(-L[i * (i + 1) / 2 + k], L[j * (j + 1) / 2 + k], s);
+                if (j == i) L[i * (i + 1) / 2 + j] = sqrt(s);
+                else L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            double s = rhs[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) s = fma(-L[i * (i + 1) / 2 + k], y[k], s);
+            y[i] = s / L[i * (i + 1) / 2 + i];
+        }
+#pragma unroll
+        for (int i = R - 1; i >= 0; --i) {
+            double s = y[i];
+#pragma unroll
+            for (int k = i + 1; k < R; ++k) s = fma(-L[k * (k + 1) / 2 + i], x[k], s);
+            x[i] = s / L[i * (i + 1) / 2 + i];
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < R; ++i) {
+#pragma unroll 1
+            for (int j = 0; j <= i; ++j) {
+                double s = S[i * (i + 1) / 2 + j];
+#pragma unroll 1
+                for (int k = 0; k < j; ++k) s = fma(-L[i * (i + 1) / 2 + k], L[j * (j + 1) / 2 + k], s);
+                if (j == i) L[i * (i + 1) / 2 + j] = sqrt(s);
+                else L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
+            }
+        }
+#pragma unroll 1
+        for (int i = 0; i < R; ++i) {
+            double s = rhs[i];
+#pragma unroll 1
+            for (int k = 0; k < i; ++k) s = fma(-L[i * (i + 1) / 2 + k], y[k], s);
+            y[i] = s / L[i * (i + 1) / 2 + i];
+        }
+#pragma unroll 1
+        for (int i = R - 1; i >= 0; --i) {
+            double s = y[i];
+#pragma unroll 1
+            for (int k = i + 1; k < R; ++k) s = fma(-L[k * (k + 1) / 2 + i], x[k], s);
+            x[i] = s / L[i * (i + 1) / 2 + i];
+        }
+    }
+}
+
+template <int R, int CPL, bool REGD>
+__global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
+    constexpr int NP = R * (R + 1) / 2;
+    const int b = blockIdx.x;
+    if (a.active && !a.active[b]) return;
+    const int tid = threadIdx.x;
+    const int T = a.T, N = a.N, r = a.r;
+    const double* __restrict__ X = a.panel + (size_t)b * T * N;
+    const double* __restrict__ F = a.fsm + (size_t)b * T * R;
+    const double* __restrict__ PS = a.Psm + (size_t)b * T * NP;
+
+    double sxf[CPL][R], sxx[CPL];
+    int ti[CPL];
+    double dm[REGD ? CPL : 1][REGD ? NP : 1];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        sxx[j] = 0.0;
+        ti[j] = 0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) sxf[j][k] = 0.0;
+        if constexpr (REGD) {
+#pragma unroll
+            for (int v = 0; v < NP; ++v) dm[j][v] = 0.0;
+        }
+    }
+    double* dmg = a.Dmiss ? a.Dmiss + (size_t)b * N * NP : nullptr;   // global accumulators (zeroed by the host)
+
+    constexpr int UN = 4;
+    for (int t0 = 0; t0 < T; t0 += UN) {
+        double xv[UN][CPL];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int t = (t0 + u < T) ? t0 + u : T - 1;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int col = tid + 256 * j;
+                xv[u][j] = (col < N) ? X[(size_t)t * N + col] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int t = t0 + u;
+            if (t >= T) break;
+            double f[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) f[k] = F[(size_t)t * R + k];
+            bool miss_any = false;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const int col = tid + 256 * j;
+                const double x = xv[u][j];
+                const bool ok = (x == x);
+                const double xz = ok ? x : 0.0;
+                if (col < N) {
+                    ti[j] += ok ? 1 : 0;
+                    miss_any = miss_any || !ok;
+                }
+                sxx[j] = fma(xz, xz, sxx[j]);
+#pragma unroll
+                for (int k = 0; k < R; ++k) sxf[j][k] = fma(xz, f[k], sxf[j][k]);
+            }
+            if (__any(miss_any)) {   // wave-uniform: somebody in this wave lacks period t
+                double ef[NP];
+#pragma unroll
+                for (int i = 0; i < R; ++i)
+#pragma unroll
+                    for (int jj = 0; jj <= i; ++jj)
+                        ef[i * (i + 1) / 2 + jj] = fma(f[i], f[jj], PS[(size_t)t * NP + i * (i + 1) / 2 + jj]);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const int col = tid + 256 * j;
+                    const double x = xv[u][j];
+                    if (col < N && x != x) {
+                        if constexpr (REGD) {
+#pragma unroll
+                            for (int v = 0; v < NP; ++v) dm[j][v] += ef[v];
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < NP; ++v) dmg[(size_t)col * NP + v] += ef[v];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // per-series solve
+    const double* S11 = a.S11 + (size_t)b * R * R;
+    const double* S11inv = a.S11inv + (size_t)b * R * R;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int col = tid + 256 * j;
+        if (col >= N) continue;
+        double lam[R];
+        double quad;   // lam' Sff lam
+        if (ti[j] == T) {   // fully observed series: shared inverse
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) s = fma(S11inv[i * R + k], sxf[j][k], s);
+                lam[i] = s;
+            }
+            quad = 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) s = fma(S11[i * R + k], lam[k], s);
+                quad = fma(lam[i], s, quad);
+            }
+        } else {
+            double Sff[NP];
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int jj = 0; jj <= i; ++jj) {
+                    const int v = i * (i + 1) / 2 + jj;
+                    double d;
+                    if constexpr (REGD) d = dm[j][v];
+                    else d = dmg[(size_t)col * NP + v];
+                    Sff[v] = 0.5 * (S11[i * R + jj] + S11[jj * R + i]) - d;
+                }
+            chol_solve_packed<R>(Sff, sxf[j], lam);
+            quad = 0.0;
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int hi = i > k ? i : k, lo = i > k ? k : i;
+                    s = fma(Sff[hi * (hi + 1) / 2 + lo], lam[k], s);
+                }
+                quad = fma(lam[i], s, quad);
+            }
+        }
+        double cross = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) cross = fma(lam[k], sxf[j][k], cross);
+        const double Rn = (sxx[j] - 2.0 * cross + quad) / (double)ti[j];
+        a.R_out[(size_t)b * N + col] = Rn;
+        double* lo = a.Lam_out + ((size_t)b * N + col) * R;
+#pragma unroll
+        for (int k = 0; k < R; ++k) lo[k] = lam[k];
+    }
+    (void)r;
+}
+
+template <int R>
+static hipError_t launch_m(const MstepArgs& a, hipStream_t s) {
+    constexpr bool small = (R <= 8);
+    if (a.N <= 256) {
+        if (a.Dmiss) hipLaunchKernelGGL((mstep_lam_kernel<R, 1, false>), dim3(a.B), dim3(256), 0, s, a);
+        else if constexpr (small) hipLaunchKernelGGL((mstep_lam_kernel<R, 1, true>), dim3(a.B), dim3(256), 0, s, a);
+        else return hipErrorInvalidValue;
+    } else if (a.N <= 512) {
+        if (!a.Dmiss) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((mstep_lam_kernel<R, 2, false>), dim3(a.B), dim3(256), 0, s, a);
+    } else if (a.N <= 1024) {
+        if (!a.Dmiss) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((mstep_lam_kernel<R, 4, false>), dim3(a.B), dim3(256), 0, s, a);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// Dmiss (global per-series accumulators, zeroed by the caller) is required unless R <= 8 and N <= 256.
+bool mstep_needs_dmiss(int Rpad, int N) { return !(Rpad <= 8 && N <= 256); }
+
+hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s) {
+    switch (Rpad) {
+        case 2: return launch_m<2>(a, s);
+        case 4: return launch_m<4>(a, s);
+        case 8: return launch_m<8>(a, s);
+        case 16: return launch_m<16>(a, s);
+        case 32: return launch_m<32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dfm

@@ -307,6 +307,7 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
     }
 
     // ---------------- terminal: P_T = Om_f^-1, f_T = P_T xi, log-likelihood ------------------------
+    bool em_apply = true;
     double Ps[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) Ps[j] = Omf[j];
@@ -327,6 +328,21 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
         if (live && i == 0) {
             a.loglik[b] = ll;
             if (a.ncov) a.ncov[b] = e + 1;
+        }
+        // EM bookkeeping (oracle/kalman_oracle.py em()): record ll_k; stop WITHOUT applying this
+        // M-step when the relative improvement over ll_{k-1} is below tol.
+        if (a.active) {
+            const bool was = a.k == 0 ? true : (a.active[b] != 0);
+            bool go = was;
+            if (was && a.k >= 1 && a.tol > 0.0) {
+                const double llp = a.ll_path[(size_t)b * a.max_iter + a.k - 1];
+                go = !((ll - llp) / (0.5 * (fabs(ll) + fabs(llp))) < a.tol);
+            }
+            em_apply = go;
+            if (live && i == 0) {
+                if (was) { a.ll_path[(size_t)b * a.max_iter + a.k] = ll; a.iters[b] = a.k + 1; }
+                a.active[b] = go ? 1 : 0;
+            }
         }
     }
 
@@ -459,16 +475,64 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
         __syncthreads();
     }
     // now fs / Ps / fvec are the smoothed moments of the initial state f_0
-    if (em && live) {
+    if (em) {
         const size_t o = (size_t)b * R * R + (size_t)i * R;
+        double S00[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            a.S11[o + j] = S11[j];
-            a.S10[o + j] = S10[j];
-            a.S00[o + j] = S11[j] - termT[j] + fma(fs, fvec[j], Ps[j]);
-            a.P0s[o + j] = Ps[j];
+        for (int j = 0; j < R; ++j) S00[j] = S11[j] - termT[j] + fma(fs, fvec[j], Ps[j]);
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                a.S11[o + j] = S11[j];
+                a.S10[o + j] = S10[j];
+                a.S00[o + j] = S00[j];
+                a.P0s[o + j] = Ps[j];
+            }
+            a.f0s[(size_t)b * R + i] = fs;
         }
-        a.f0s[(size_t)b * R + i] = fs;
+        if (a.A_out) {
+            // A = S10 S00^-1 ;  Q = sym(S11 - A S10') / T ;  mu0 = f_0|T ;  P0 = sym(P_0|T) ;  S11^-1
+            double inv[R], An[R], tmp[R], Qn[R], P0n[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) inv[j] = S00[j];
+            (void)gj_inverse<R>(inv, X, i);
+            __syncthreads();
+            store_row<R>(X, i, inv);
+            __syncthreads();
+            mm_rows<R>(An, S10, X);                        // A row i
+            __syncthreads();
+            store_row<R>(X, i, S10);
+            __syncthreads();
+            mm_rowsT<R>(tmp, An, X);                       // (A S10')[i][:]
+#pragma unroll
+            for (int j = 0; j < R; ++j) Qn[j] = (S11[j] - tmp[j]) / (double)T;
+            __syncthreads();
+            store_row<R>(X, i, Qn);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < R; ++j) Qn[j] = 0.5 * (Qn[j] + X[j * R + i]);
+            __syncthreads();
+            store_row<R>(X, i, Ps);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < R; ++j) P0n[j] = 0.5 * (Ps[j] + X[j * R + i]);
+#pragma unroll
+            for (int j = 0; j < R; ++j) inv[j] = S11[j];
+            (void)gj_inverse<R>(inv, X, i);
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) a.S11inv[o + j] = inv[j];
+                if (em_apply) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        a.A_out[o + j] = An[j];
+                        a.Q_out[o + j] = Qn[j];
+                        a.P0_out[o + j] = P0n[j];
+                    }
+                    a.mu0_out[(size_t)b * R + i] = fs;
+                }
+            }
+        }
     }
 }
 

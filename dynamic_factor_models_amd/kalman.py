@@ -131,3 +131,64 @@ class DfmContext:
                                          p(P0), p(f), p(P), p(ll), flags)
         _check(self._h, rc)
         return f, P, ll
+
+    # ------------------------------------------------------------------ EM
+    def em_step_batch(self, panel, Lam, R, A, Q, mu0, P0, may_have_missing: Optional[bool] = None):
+        """One EM iteration per replicate; parameters (device tensors) are updated IN PLACE.
+        Returns loglik [B] at the parameters passed in."""
+        torch = self._torch
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        flags = self._flags(panel, may_have_missing)
+        ll = torch.empty((B,), dtype=torch.float64, device=panel.device)
+        self._sync_stream()
+        rc = self._lib.dfm_em_step_batch_dev(
+            self._h, B, T, N, r, self._dev(panel, "panel"), self._dev(Lam, "Lam", (B, N, r)),
+            self._dev(R, "R", (B, N)), self._dev(A, "A", (B, r, r)), self._dev(Q, "Q", (B, r, r)),
+            self._dev(mu0, "mu0", (B, r)), self._dev(P0, "P0", (B, r, r)), self._dev(ll, "loglik"), flags)
+        _check(self._h, rc)
+        return ll
+
+    def em_batch(self, panel, Lam, R, A, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
+                 want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None):
+        """max_iter EM iterations (parameters updated in place).  Returns
+        (loglik_path [B,max_iter] (NaN past iters[b]), iters [B] int32, f_smooth, P_smooth)."""
+        torch = self._torch
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        flags = self._flags(panel, may_have_missing)
+        dev = panel.device
+        path = torch.empty((B, max_iter), dtype=torch.float64, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        f = torch.empty((B, T, r), dtype=torch.float64, device=dev) if want_smooth else None
+        P = torch.empty((B, T, r * (r + 1) // 2), dtype=torch.float64, device=dev) if (want_smooth and want_P) else None
+        self._sync_stream()
+        rc = self._lib.dfm_em_batch_dev(
+            self._h, B, T, N, r, self._dev(panel, "panel"), self._dev(Lam, "Lam", (B, N, r)),
+            self._dev(R, "R", (B, N)), self._dev(A, "A", (B, r, r)), self._dev(Q, "Q", (B, r, r)),
+            self._dev(mu0, "mu0", (B, r)), self._dev(P0, "P0", (B, r, r)), int(max_iter), float(tol),
+            self._dev(path, "loglik_path"), ctypes.c_void_p(iters.data_ptr()),
+            self._dev(f, "f_smooth") if f is not None else None,
+            self._dev(P, "P_smooth") if P is not None else None, flags)
+        _check(self._h, rc)
+        return path, iters, f, P
+
+    def em_batch_host(self, panel, Lam, R, A, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
+                      may_have_missing: Optional[bool] = None):
+        """Host-pointer EM entry (what Julia's ccall binds).  Returns (params dict, loglik_path, iters,
+        f_smooth, P_smooth); inputs are not modified."""
+        c = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
+        panel = np.ascontiguousarray(panel, dtype=np.float64)
+        Lam, R, A, Q, mu0, P0 = map(c, (Lam, R, A, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
+        f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2))
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_em_batch(self._h, B, T, N, r, p(panel), p(Lam), p(R), p(A), p(Q), p(mu0), p(P0),
+                                    int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags)
+        _check(self._h, rc)
+        return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), path, iters, f, P

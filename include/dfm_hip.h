@@ -97,8 +97,10 @@ int dfm_em_step_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
 /* max_iter EM iterations; loglik_path[b][k] = log-likelihood at the parameters entering iteration
  * k (NaN for k >= iters[b]); a replicate stops after iteration k >= 1 when
  * (ll_k - ll_{k-1}) / (0.5 (|ll_k| + |ll_{k-1}|)) < tol (tol <= 0: run all iterations); iters[b] =
- * iterations run.  Afterwards f_smooth/P_smooth (may be NULL) hold the smoother output at the
- * final parameters.  Host-pointer variant copies parameters in and out. */
+ * iterations run.  A replicate that stops this way keeps the parameters that ENTERED its last
+ * iteration (that M-step is discarded), exactly as oracle/kalman_oracle.py em().  Afterwards
+ * f_smooth/P_smooth (may be NULL) hold the smoother output of the last E-step that was run.
+ * Host-pointer variant copies parameters in and out. */
 int dfm_em_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam,
                      double* R, double* A, double* Q, double* mu0, double* P0, int max_iter,
                      double tol, double* loglik_path, int* iters, double* f_smooth,
