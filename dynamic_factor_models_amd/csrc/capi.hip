@@ -3,6 +3,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -16,6 +17,12 @@ struct dfm_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t side = nullptr;            // data-independent kernels (gram, cov) run beside the collapse
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool force_general = false;            // DFM_FORCE_GENERAL=1: never take the balanced fast path
+    int collapse_variant = 0;              // DFM_COLLAPSE_VARIANT: ring/row-block tuning of collapse_dma
+    int scan_abl = 0;
+    bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
     void* ws = nullptr;
     size_t ws_bytes = 0;
     char err[512] = {0};
@@ -25,10 +32,12 @@ struct dfm_handle {
     std::vector<Ev> events;
 };
 
-enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD, K_COUNT };
-static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_stats_kernel",
+enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_COUNT };
+static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
                                                   "mstep_solve_kernel", "pca_kernels", "synth_kernel",
-                                                  "pad_params_kernel"};
+                                                  "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
+                                                  "cov_kernel", "meanscan_kernel"};
 
 namespace {
 
@@ -47,16 +56,16 @@ int hip_fail(dfm_handle* h, hipError_t e, const char* where) {
     } while (0)
 
 struct ProfScope {  // records an event pair around one kernel launch when profiling is on
-    dfm_handle* h; int idx = -1;
-    ProfScope(dfm_handle* h_, int kid) : h(h_) {
+    dfm_handle* h; int idx = -1; hipStream_t st;
+    ProfScope(dfm_handle* h_, int kid, hipStream_t st_ = nullptr) : h(h_), st(st_ ? st_ : h_->stream) {
         if (!h->profiling) return;
         dfm_handle::Ev ev; ev.kid = kid;
         if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
-        (void)hipEventRecord(ev.a, h->stream);
+        (void)hipEventRecord(ev.a, st);
         h->events.push_back(ev);
         idx = (int)h->events.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(h->events[idx].b, h->stream); }
+    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(h->events[idx].b, st); }
 };
 
 int pad_r(int r) { return pow2_ge(r) < 2 ? 2 : pow2_ge(r); }
@@ -67,6 +76,9 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t bcol, scol, ldrow, nobs, Ct, Cfull, ldfull;
     size_t ZJ, wtab, status, ncov;
     size_t S11, S10, S00, P0s, f0s, fsm, Psm, Sxf, Sxx, Dmiss, llbuf, active;
+    // balanced fast path (fastpath.hip); (size_t)-1 when the plan is for the general path
+    size_t f_tab, f_E, f_stead, f_xi0, f_PT, f_llc, f_fill, f_PsInf, f_ssum;
+    bool fast;
     size_t total;
 };
 
@@ -76,10 +88,11 @@ size_t take(size_t& off, size_t bytes) {
     return at;
 }
 
-Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em) {
+Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = false) {
     Plan p;
     const int Rp = pad_r(r);
     p.Rp = Rp;
+    p.fast = fast;
     const size_t d = sizeof(double), rr = (size_t)Rp * Rp, np = (size_t)Rp * (Rp + 1) / 2;
     size_t off = 0;
     p.LamP = take(off, (size_t)B * N * Rp * d);
@@ -94,7 +107,21 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em) {
     p.Ct = (flags & DFM_F_MAY_HAVE_MISSING) ? take(off, (size_t)B * T * np * d) : (size_t)-1;
     p.Cfull = take(off, B * rr * d);
     p.ldfull = take(off, (size_t)B * d);
-    p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
+    p.f_tab = p.f_E = p.f_stead = p.f_xi0 = p.f_PT = p.f_llc = p.f_fill = p.f_PsInf = p.f_ssum = (size_t)-1;
+    p.ZJ = (size_t)-1;
+    if (fast) {
+        p.f_tab = take(off, (size_t)B * T * 3 * rr * d);
+        p.f_E = take(off, (size_t)B * sizeof(int));
+        p.f_stead = take(off, (size_t)B * fast_stead_mats(Rp) * rr * d);
+        p.f_xi0 = take(off, (size_t)B * Rp * d);
+        p.f_PT = take(off, B * rr * d);
+        p.f_llc = take(off, (size_t)B * d);
+        p.f_fill = take(off, (size_t)B * 2 * sizeof(int));
+        p.f_PsInf = take(off, B * rr * d);
+        p.f_ssum = take(off, (size_t)B * 4 * d);
+    } else {
+        p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
+    }
     p.wtab = take(off, (size_t)B * T * Rp * d);
     p.status = take(off, 256);
     p.ncov = take(off, (size_t)B * sizeof(int));
@@ -198,11 +225,56 @@ struct EmOpts {          // all-null for a plain pass
     int k = 0, max_iter = 1; double tol = 0.0;
 };
 
+// Balanced panel, even N, plain pass: may this call take the fast path (fastpath.hip)?
+bool fast_eligible(const dfm_handle* h, int N, int r, unsigned flags) {
+    return !h->force_general && !(flags & DFM_F_MAY_HAVE_MISSING) && collapse_dma_supported(pad_r(r), N);
+}
+
+// gram + cov on the side stream, beside the streaming collapse on the main stream; then meanscan.
+int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, const double* panel,
+                      const PaddedParams& pp, const double* Rv, double* f_smooth, double* P_smooth,
+                      double* loglik) {
+    CollapseArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.B = B; ca.T = T; ca.N = N;
+    ca.panel = panel; ca.Lam = pp.Lam; ca.Rv = Rv;
+    ca.bcol = at<double>(h, p.bcol); ca.scol = at<double>(h, p.scol); ca.ssum = at<double>(h, p.f_ssum);
+    ca.Cfull = at<double>(h, p.Cfull); ca.ldfull = at<double>(h, p.ldfull); ca.status = at<int>(h, p.status);
+    FastArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.B = B; fa.T = T; fa.N = N; fa.r = out_r; fa.L = fast_chunk_len(p.Rp, T);
+    fa.A = pp.A; fa.Q = pp.Q; fa.mu0 = pp.mu0; fa.P0 = pp.P0;
+    fa.Cfull = ca.Cfull; fa.ldfull = ca.ldfull;
+    fa.tab = at<double>(h, p.f_tab); fa.E = at<int>(h, p.f_E); fa.stead = at<double>(h, p.f_stead);
+    fa.xi0 = at<double>(h, p.f_xi0); fa.PT = at<double>(h, p.f_PT); fa.llc = at<double>(h, p.f_llc);
+    fa.fill = at<int>(h, p.f_fill); fa.PsInf = at<double>(h, p.f_PsInf);
+    fa.bcol = ca.bcol; fa.ssum = ca.ssum; fa.wtab = at<double>(h, p.wtab);
+    fa.f_smooth = f_smooth; fa.P_smooth = P_smooth; fa.loglik = loglik;
+    fa.abl = h->scan_abl;
+    // fork: the side stream starts after everything already enqueued on the main stream (parameters)
+    hipStream_t side = h->no_side ? h->stream : h->side;
+    if (!h->no_side) {
+        HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    }
+    { ProfScope ps(h, K_GRAM, side); HIP_TRY(h, launch_gram(p.Rp, ca, side)); }
+    { ProfScope ps(h, K_COV, side); HIP_TRY(h, launch_cov(p.Rp, fa, side)); }
+    if (!h->no_side) HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
+    { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, h->collapse_variant)); }
+    if (!h->no_side) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
+    return 0;
+}
+
 // Enqueue collapse + recursion for already-planned workspace.  out_r = factor dimension of the
 // f_smooth / P_smooth layout (caller's r for a plain pass, Rp for EM-internal buffers).
 int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, const double* panel,
                  const PaddedParams& pp, const double* Rv, double* f_smooth, double* P_smooth, double* loglik,
                  const EmOpts* em) {
+    if (p.fast) {
+        if (em) return fail(h, DFM_E_DIMS, "internal: fast plan used for an EM pass%s");
+        return enqueue_pass_fast(h, p, B, T, N, out_r, panel, pp, Rv, f_smooth, P_smooth, loglik);
+    }
     CollapseArgs ca;
     ca.B = B; ca.T = T; ca.N = N;
     ca.panel = panel; ca.Lam = pp.Lam; ca.Rv = Rv;
@@ -354,10 +426,17 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
             h->own_stream = true;
         }
     }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
         delete h;
         return (int)e;
     }
+    if (const char* v = getenv("DFM_FORCE_GENERAL")) h->force_general = atoi(v) != 0;
+    if (const char* v = getenv("DFM_COLLAPSE_VARIANT")) h->collapse_variant = atoi(v);
+    if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
+    if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
     *out = h;
     return 0;
 }
@@ -366,6 +445,9 @@ int dfm_destroy(dfm_handle* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ws) hipFree(h->ws);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -430,7 +512,7 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0 || !f_smooth || !loglik)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     HIP_TRY(h, hipSetDevice(h->device));
-    const Plan p = make_plan(B, T, N, r, flags, false);
+    const Plan p = make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags));
     if (int rc = ensure_ws(h, p.total)) return rc;
     HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     PaddedParams pp;
@@ -481,7 +563,7 @@ int dfm_ks_pass_batch(dfm_handle* h, int B, int T, int N, int r, const double* p
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }
-    if (rc == 0) rc = post_check(h, make_plan(B, T, N, r, flags, false), loglik, B);
+    if (rc == 0) rc = post_check(h, make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags)), loglik, B);
     hipFree(buf);
     return rc;
 }

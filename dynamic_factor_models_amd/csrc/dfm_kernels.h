@@ -25,6 +25,7 @@ struct CollapseArgs {
     double* Cfull;        // [B][Rp][Rp]
     double* ldfull;       // [B]
     int* status;          // bit0: NaN met while Ct == nullptr
+    double* ssum;         // [B][4]  collapse_dma only: sum_t s_t of each wave's periods
 };
 
 struct RecursionArgs {
@@ -71,8 +72,41 @@ struct MstepArgs {
 
 hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
 int collapse_max_n(int Rpad);
+// balanced panels (no NaN), even N: LDS-DMA streaming collapse (writes bcol, scol only) + Gram kernel
+bool collapse_dma_supported(int Rpad, int N);
+hipError_t launch_collapse_dma(int Rpad, const CollapseArgs& a, hipStream_t s, int variant);
+hipError_t launch_gram(int Rpad, const CollapseArgs& a, hipStream_t s);
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
 hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
 bool mstep_needs_dmiss(int Rpad, int N);
+
+// Balanced-panel fast path (fastpath.hip): data-independent covariance steps (cov_kernel) and the
+// time-parallel mean recursion (meanscan_kernel).  All matrices in the padded dimension Rp.
+struct FastArgs {
+    int B, T, N, r, L;          // r = caller's factor count for the outputs; L = chunk length (power of 2)
+    const double* A; const double* Q; const double* mu0; const double* P0;   // [B][Rp][Rp] / [B][Rp]
+    const double* Cfull; const double* ldfull;                               // gram_kernel outputs
+    // cov_kernel -> meanscan_kernel
+    double* tab;                // [B][T][3][Rp][Rp]  Z_e, J_e, G_e of the distinct covariance steps
+    int* E;                     // [B]  number of distinct steps; step t uses entry min(t, E-1)
+    double* stead;              // [B][fast_stead_mats][Rp][Rp]  steady Z, J, G, G^(L 2^k), J^(L 2^k)
+    double* xi0;                // [B][Rp]
+    double* PT;                 // [B][Rp][Rp]   P_T|T
+    double* llc;                // [B]  data-independent part of -2 loglik
+    int* fill;                  // [B][2]  rows [lo, hi) of P_smooth equal to PsInf
+    double* PsInf;              // [B][Rp][Rp]
+    double* SP11; double* SU; double* P0s;   // EM covariance sums (or null)
+    // collapse -> meanscan
+    const double* bcol; const double* ssum;                                  // ssum [B][4]
+    double* wtab;               // [B][T][Rp] scratch
+    // outputs
+    double* f_smooth; double* P_smooth; double* loglik;
+    double* f0s;                // [B][Rp] E[f_0 | X] (EM) or null
+    int abl;                    // diagnostics (DFM_SCAN_ABL): bit0 skip the P_smooth fill, bit1 skip the scans
+};
+hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
+hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);
+int fast_chunk_len(int Rpad, int T);
+int fast_stead_mats(int Rpad);
 
 }  // namespace dfm

@@ -1,0 +1,708 @@
+// fastpath.hip -- Kalman-smoother recursion for BALANCED panels, parallel in time.
+//
+// With no missing cell C_t = Lam' R^-1 Lam is the same every period, so the covariance half of the
+// information-form recursion (recursion.hip header; oracle/info_form.py) does not depend on the
+// data and reaches its Riccati fixed point after E steps (a handful when the cross-section is
+// informative).  The pass is split accordingly:
+//
+//   cov_kernel       (data-independent, sequential, O(E) steps; runs beside the streaming collapse)
+//       forward   Z_e, J_e, G_e = Psi' Z_e  for the E distinct steps; step t uses entry min(t, E-1)
+//       terminal  P_T, log-determinants
+//       backward  P_s,t = Z_t + J_t P_s,t+1 J_t' : distinct near t = T and for t < E-1, one fixed
+//                 point P_s,inf in between (rows of P_smooth in that range are filled by meanscan)
+//       powers    G^L, J^L of the steady matrices for the chunk carries of meanscan
+//   meanscan_kernel  (the means; one workgroup per replicate, 256/R lane groups = time chunks)
+//       xi_{t+1} = G_t xi_t + b_t,  w_t = Z_t xi_t           forward  (t < E-1 sequential, then
+//       f_t      = w_t + J_t f_{t+1}                         backward  a 3-phase chunked scan)
+//     Steady steps form a linear time-invariant recurrence: every chunk of L steps first runs from a
+//     zero state (phase 1), the chunk carries are chained with G^L / J^L (phase 2), and the chunk is
+//     re-run from its true start state (phase 3) -- sequential depth 2L + T/L instead of T.
+//
+// r x r matrix-vector products inside a lane group use no LDS: lane i holds M[i][i^s], s = 0..R-1,
+// and fetches x[i^s] with DPP row operations (xor_lane in dfm_device.h).
+// The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
+#include "dfm_kernels.h"
+#include "dfm_smallmat.h"
+
+namespace dfm {
+
+constexpr double kLog2PiF = 1.8378770664093454835606594728112;
+constexpr int kScanThreads = 256;   // meanscan workgroup: 256 / R lane groups = time chunks
+// levels of the carry scan over the 256 / R chunks, and matrices kept per replicate in `stead`:
+// Z, J, G, then G^(L 2^k) and J^(L 2^k), k = 0 .. levels-1
+__host__ __device__ constexpr int scan_levels(int R) { int n = 0; while ((1 << n) < kScanThreads / R) ++n; return n; }
+__host__ __device__ constexpr int stead_mats(int R) { return 3 + 2 * scan_levels(R); }
+
+// ================================================================================================
+// cov_kernel
+// ================================================================================================
+template <int R>
+struct CovLayout {
+    static constexpr int GPW = 64 / R;
+    // per group: X, PSI, JS (exchange / operands), K0..K2 (forward: Q^-1, Phi, C; backward: sum P_s, sum U), V0
+    static constexpr int kRaw = 6 * R * R + R;
+    static constexpr int S = ((kRaw + 3) / 4) * 4 + 2;
+    static constexpr size_t lds_bytes() { return (size_t)GPW * S * sizeof(double); }
+};
+
+template <int R>
+__global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
+    using LY = CovLayout<R>;
+    constexpr int GPW = LY::GPW;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int g = lane / R, i = lane % R;
+    const int T = a.T, r = a.r;
+    int b = blockIdx.x * GPW + g;
+    const bool live = b < a.B;
+    if (!live) b = a.B - 1;
+
+    double* X = smem + (size_t)g * LY::S;
+    double* PSI = X + R * R;
+    double* JS = PSI + R * R;
+    double* K0 = JS + R * R;       // rows owned by lane i: K0[i*R + j]
+    double* K1 = K0 + R * R;
+    double* K2 = K1 + R * R;
+    double* V0 = K2 + R * R;
+
+    const size_t mo = (size_t)b * R * R + (size_t)i * R;     // row i of a [B][R][R] array
+    double* tab = a.tab + (size_t)b * T * 3 * R * R;
+    double detQ, detP0, q0;
+    double PsiT[R], Omf[R];
+    {
+        double Arow[R], Qi[R], Phi[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            Arow[j] = a.A[mo + j];
+            Qi[j] = a.Q[mo + j];
+            Omf[j] = a.P0[mo + j];
+            K2[i * R + j] = a.Cfull[mo + j];
+        }
+        const double mu0i = a.mu0[(size_t)b * R + i];
+        detQ = gj_inverse<R>(Qi, X, i);
+        detP0 = gj_inverse<R>(Omf, X, i);                    // Omf = P0^-1
+        __syncthreads();
+        store_row<R>(X, i, Arow);
+        __syncthreads();
+        mm_rows<R>(PsiT, Qi, X);                             // Psi' = Qi A (row i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) PSI[j * R + i] = PsiT[j];  // PSI = Psi (rows)
+        __syncthreads();
+        {
+            double prow[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) prow[k] = PSI[i * R + k];
+            mm_rows<R>(Phi, prow, X);                        // Phi = Psi A
+        }
+        store_row<R>(K0, i, Qi);
+        store_row<R>(K1, i, Phi);
+        V0[i] = mu0i;
+        __syncthreads();
+        const double xi0 = dot_vec<R>(Omf, V0);              // xi_0 = P0^-1 mu0
+        q0 = mu0i * xi0;                                     // lane part of mu0' P0^-1 mu0
+        if (live) a.xi0[(size_t)b * R + i] = xi0;
+        __syncthreads();
+    }
+
+    // ---------------- forward covariance steps until the fixed point ----------------------------
+    double sum_ldz = 0.0, ldz_last = 0.0;
+    int E = 0;
+    {
+        bool done = false;
+        for (int e = 0;; ++e) {
+            double Z[R], Jr[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) Z[j] = Omf[j] + K1[i * R + j];
+            const double detM = gj_inverse<R>(Z, X, i);
+            const double ldz = -log(detM);
+            mm_rows<R>(Jr, Z, PSI);                          // J = Z Psi
+            __syncthreads();
+            store_row<R>(X, i, Jr);
+            __syncthreads();
+            double Omf_new[R];
+            {
+                double tmp[R];
+                mm_rows<R>(tmp, PsiT, X);                    // Psi' J
+#pragma unroll
+                for (int j = 0; j < R; ++j) Omf_new[j] = (K0[i * R + j] - tmp[j]) + K2[i * R + j];   // Om_p + C
+            }
+            bool same = true;
+#pragma unroll
+            for (int j = 0; j < R; ++j) same = same && close_enough(Omf_new[j], Omf[j]);
+            V0[i] = same ? 1.0 : 0.0;
+            __syncthreads();
+            bool gsame = true;
+#pragma unroll
+            for (int k = 0; k < R; ++k) gsame = gsame && (V0[k] != 0.0);
+            store_row<R>(X, i, Z);
+            __syncthreads();
+            if (!done) {
+                double G[R];
+                mm_rows<R>(G, PsiT, X);                      // G = Psi' Z
+                if (live) {
+                    double* te = tab + (size_t)e * 3 * R * R + (size_t)i * R;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) { te[j] = Z[j]; te[R * R + j] = Jr[j]; te[2 * R * R + j] = G[j]; }
+                }
+                E = e + 1;
+                sum_ldz += ldz;
+                ldz_last = ldz;
+#pragma unroll
+                for (int j = 0; j < R; ++j) Omf[j] = Omf_new[j];
+                if (gsame || e + 1 >= T) done = true;
+            }
+            if (__all(done)) break;
+        }
+    }
+    sum_ldz += (double)(T - E) * ldz_last;
+    const int ts = E - 1;                                     // first steady step
+
+    // ---------------- terminal ---------------------------------------------------------------------
+    double Ps[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) Ps[j] = Omf[j];
+    const double detOmT = gj_inverse<R>(Ps, X, i);           // P_T
+    __syncthreads();
+    V0[i] = q0;
+    __syncthreads();
+    {
+        double qs = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) qs += V0[k];
+        q0 = qs;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) a.PT[mo + j] = Ps[j];
+        if (i == 0) {
+            const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) - sum_ldz;
+            a.llc[b] = (double)a.N * (double)T * kLog2PiF + (double)T * a.ldfull[b] + LD + q0;
+            a.E[b] = E;
+        }
+    }
+
+    // ---------------- backward covariance steps ----------------------------------------------------
+    const int npr = r * (r + 1) / 2;
+    auto emit = [&](int trow, const double (&P)[R]) {
+        if (!live || i >= r || a.P_smooth == nullptr) return;
+        double* po = a.P_smooth + ((size_t)b * T + trow) * npr + i * (i + 1) / 2;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (j <= i) po[j] = P[j];
+    };
+    emit(T - 1, Ps);
+    double* SPl = K0;   // sum over periods 1..T of P_s   (row i owned by lane i)
+    double* SUl = K1;   // sum over steps 0..T-1 of U_t = Cov(f_{t+1}, f_t | X)
+#pragma unroll
+    for (int j = 0; j < R; ++j) { SPl[i * R + j] = Ps[j]; SUl[i * R + j] = 0.0; }
+    int fill_lo = 0, fill_hi = 0;
+    int t = T - 1;
+    int cur_e = -2;                                           // entry whose Z, J are loaded
+    double Zc[R], Jc[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { Zc[j] = 0.0; Jc[j] = 0.0; }
+    while (true) {
+        const bool act = t >= 0;
+        const int e = act ? (t < ts ? t : ts) : ts;
+        if (e != cur_e) {                                     // (group-uniform: t, ts are per group)
+            const double* te = tab + (size_t)e * 3 * R * R + (size_t)i * R;
+#pragma unroll
+            for (int j = 0; j < R; ++j) { Zc[j] = te[j]; Jc[j] = te[R * R + j]; }
+            cur_e = e;
+        }
+        __syncthreads();
+        store_row<R>(JS, i, Jc);
+        __syncthreads();
+        double U[R], Psn[R];
+        mm_rowsT<R>(U, Ps, JS);                              // U = P_s J' = Cov(f_{t+1}, f_t | X)
+        store_row<R>(X, i, U);
+        __syncthreads();
+        {
+            double tmp[R];
+            mm_rows<R>(tmp, Jc, X);                          // J U
+#pragma unroll
+            for (int j = 0; j < R; ++j) Psn[j] = Zc[j] + tmp[j];
+        }
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < R; ++j) same = same && close_enough(Psn[j], Ps[j]);
+        V0[i] = same ? 1.0 : 0.0;
+        __syncthreads();
+        bool gsame = true;
+#pragma unroll
+        for (int k = 0; k < R; ++k) gsame = gsame && (V0[k] != 0.0);
+        if (act) {
+            const bool skip = (e == ts && t > ts && gsame);   // steps t-1 .. ts repeat this (U, P_s)
+            const int plo = ts >= 1 ? ts : 1;                // periods plo .. t-1 carry P_s,inf
+            const double cu = skip ? (double)(t - ts + 1) : 1.0;
+            const double cp = (t >= 1 ? 1.0 : 0.0) + (skip ? (double)(t - plo) : 0.0);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                SUl[i * R + j] = fma(cu, U[j], SUl[i * R + j]);
+                SPl[i * R + j] = fma(cp, Psn[j], SPl[i * R + j]);
+            }
+            if (t >= 1) emit(t - 1, Psn);
+            if (live && (t == 0 || (skip && ts == 0)) && a.P0s) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) a.P0s[mo + j] = Psn[j];
+            }
+            if (skip) {
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) a.PsInf[mo + j] = Psn[j];
+                }
+                fill_lo = plo - 1;
+                fill_hi = t - 1;
+                t = ts - 1;
+            } else {
+                t -= 1;
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) Ps[j] = Psn[j];
+        }
+        if (__all(t < 0)) break;
+    }
+    if (live) {
+        if (i == 0) { a.fill[2 * b] = fill_lo; a.fill[2 * b + 1] = fill_hi; }
+        if (a.SP11) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) { a.SP11[mo + j] = SPl[i * R + j]; a.SU[mo + j] = SUl[i * R + j]; }
+        }
+    }
+
+    // ---------------- steady Z, J, G and the powers G^(L 2^k), J^(L 2^k) for the chunk carries --------
+    {
+        constexpr int NLEV = scan_levels(R);
+        const double* te = tab + (size_t)ts * 3 * R * R + (size_t)i * R;
+        double* st = a.stead + (size_t)b * stead_mats(R) * R * R + (size_t)i * R;
+        double M[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) M[j] = te[j];
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) st[j] = M[j];
+        }
+#pragma unroll 1
+        for (int which = 0; which < 2; ++which) {            // 0: G -> slot 2, powers 3..;  1: J -> slot 1, powers 3+NLEV..
+            const int src = which == 0 ? 2 : 1, dst = which == 0 ? 3 : 3 + NLEV;
+#pragma unroll
+            for (int j = 0; j < R; ++j) M[j] = te[src * R * R + j];
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) st[src * R * R + j] = M[j];
+            }
+            auto square = [&]() {
+                double tmp[R];
+                __syncthreads();
+                store_row<R>(X, i, M);
+                __syncthreads();
+                mm_rows<R>(tmp, M, X);
+#pragma unroll
+                for (int j = 0; j < R; ++j) M[j] = tmp[j];
+            };
+            for (int l = 1; l < a.L; l <<= 1) square();       // M^L
+#pragma unroll 1
+            for (int k = 0; k < NLEV; ++k) {
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) st[(dst + k) * R * R + j] = M[j];
+                }
+                if (k + 1 < NLEV) square();
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// meanscan_kernel
+// ================================================================================================
+// sum_s Mp[s] * x[lane ^ s]  with Mp[s] = M[i][i ^ s]
+template <int R, int S>
+struct MatVecX {
+    static __device__ __forceinline__ void run(const double (&Mp)[R], double x, double& a0, double& a1) {
+        if constexpr (S < R) {
+            const double xs = xor_lane<S>(x);
+            if constexpr ((S & 1) != 0) a1 = fma(Mp[S], xs, a1);
+            else a0 = fma(Mp[S], xs, a0);
+            MatVecX<R, S + 1>::run(Mp, x, a0, a1);
+        }
+    }
+};
+template <int R>
+__device__ __forceinline__ double matvec_x(const double (&Mp)[R], double x, double add = 0.0) {
+    double a0 = add, a1 = 0.0;
+    MatVecX<R, 0>::run(Mp, x, a0, a1);
+    return a0 + a1;
+}
+template <int R>
+__device__ __forceinline__ void load_xperm(double (&Mp)[R], const double* M, int i) {
+#pragma unroll
+    for (int s = 0; s < R; ++s) Mp[s] = M[i * R + (i ^ s)];
+}
+
+constexpr int kPF = 8;    // chain steps per prefetch block
+// transient covariance steps staged in LDS (later ones are read from global memory)
+__host__ __device__ constexpr int ecap(int R) { return R <= 8 ? 8 : R <= 16 ? 4 : 2; }
+
+// First prefetch block of a chunk: operands u_t, t = t0 + dir * j, j < kPF.
+template <int R, bool FULL>
+__device__ __forceinline__ void chunk_prefetch(double (&cur)[kPF], const double* src, int t0, int dir, int L, int tlo,
+                                               int thi, int i) {
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) {
+        const int t = t0 + dir * u;
+        const bool ok = FULL ? (u < L) : (u < L && t >= tlo && t < thi);
+        cur[u] = ok ? src[(size_t)t * R + i] : 0.0;
+    }
+}
+
+// One chunk of a linear recurrence v <- M v + u_t over L steps (t = t0 + dir * j), operands u_t from
+// `src` ([t][R] doubles; first block already in `cur`, later ones prefetched kPF steps ahead).
+// FULL: every step of every lane group in this wave is valid (no predicates).  EMIT = 0: nothing;
+// 1: forward phase 3 (also w_t = Z v -> wout, dot += v.w); 2: backward phase 3 (f of period t -> f_smooth
+// row t-1).
+template <int R, bool FULL, int EMIT>
+__device__ __forceinline__ double chunk_run(const double (&Mp)[R], const double (&Zp)[R], double v, double (&cur)[kPF],
+                                            const double* src, int t0, int dir, int L, int tlo, int thi, int i,
+                                            double* wout, double& dot, double* fout, int r) {
+    auto valid = [&](int j) { const int t = t0 + dir * j; return j < L && t >= tlo && t < thi; };
+    double nxt[kPF];
+    for (int j0 = 0; j0 < L; j0 += kPF) {
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) {
+            const int j = j0 + kPF + u;
+            const int t = t0 + dir * j;
+            nxt[u] = (FULL ? (j < L) : valid(j)) ? src[(size_t)t * R + i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) {
+            const int j = j0 + u;
+            const int t = t0 + dir * j;
+            if (j < L) {                                     // wave-uniform (L is a kernel argument)
+                const bool ok = FULL ? true : valid(j);
+                if constexpr (EMIT == 1) {
+                    const double w = matvec_x<R>(Zp, v);
+                    const double vn = matvec_x<R>(Mp, v, cur[u]);
+                    if (ok) {
+                        dot = fma(v, w, dot);
+                        wout[(size_t)t * R + i] = w;
+                    }
+                    v = ok ? vn : v;
+                } else {
+                    const double vn = matvec_x<R>(Mp, v, cur[u]);
+                    v = ok ? vn : v;
+                    if constexpr (EMIT == 2) {
+                        if (ok && t >= 1 && i < r) fout[(size_t)(t - 1) * r + i] = v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) cur[u] = nxt[u];
+    }
+    return v;
+}
+
+// Start state of every chunk from the chunk-local end states e_c (zero-state runs): an inclusive
+// Kogge-Stone scan of the affine maps x -> M^L x + e_c over the NG chunks, level k using M^(L 2^k)
+// (pw: the NLEV power matrices, in LDS).  `head` (the true state entering chunk 0) is folded into e_0.
+// Returns the state entering chunk c.
+template <int R, int NG>
+__device__ __forceinline__ double carry_scan(double e, double head, const double* pw, int c, int i, double* sA,
+                                             double* sB) {
+    constexpr int NLEV = scan_levels(R);
+    double Mp[R];
+    load_xperm<R>(Mp, pw, i);                                // M^L
+    const double h = matvec_x<R>(Mp, head);
+    double v = (c == 0) ? e + h : e;
+    double* cur = sA;
+    double* oth = sB;
+    __syncthreads();                                          // previous users of sA / sB are done
+#pragma unroll 1
+    for (int k = 0; k < NLEV; ++k) {
+        cur[c * R + i] = v;
+        __syncthreads();
+        const int d = 1 << k;
+        const double left = (c >= d) ? cur[(c - d) * R + i] : 0.0;
+        if (k > 0) load_xperm<R>(Mp, pw + (size_t)k * R * R, i);
+        v = matvec_x<R>(Mp, left, v);                         // lanes with c < d add M * 0
+        double* t_ = cur; cur = oth; oth = t_;
+    }
+    cur[c * R + i] = v;
+    __syncthreads();
+    return (c == 0) ? head : cur[(c - 1) * R + i];
+}
+
+template <int R>
+struct ScanLds {   // dynamic LDS of meanscan_kernel, in doubles
+    static constexpr int NG = kScanThreads / R;
+    static constexpr int NM = stead_mats(R) + 1;                  // steady matrices + P_T
+    static constexpr int oMat = 0;
+    static constexpr int oTab = oMat + NM * R * R;                // ecap(R) x (Z, J, G)
+    static constexpr int oB0 = oTab + ecap(R) * 3 * R * R;        // b_t, then w_t, of the staged transient steps
+    static constexpr int oA = oB0 + ecap(R) * R;
+    static constexpr int oB = oA + NG * R;
+    static constexpr int oVec = oB + NG * R;
+    static constexpr int oPs = oVec + 2 * R;
+    static constexpr int oRed = oPs + R * (R + 1) / 2;
+    static constexpr int total = oRed + kScanThreads / 64;
+    static constexpr size_t bytes() { return (size_t)total * sizeof(double); }
+};
+
+template <int R>
+__global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
+    using LY = ScanLds<R>;
+    constexpr int NG = LY::NG;
+    constexpr int NLEV = scan_levels(R);
+    constexpr int NST = stead_mats(R);
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    double* s_mat = dsm + LY::oMat;      // Z, J, G, G-powers, J-powers, P_T   (row-major R x R each)
+    double* s_tab = dsm + LY::oTab;
+    double* s_b0 = dsm + LY::oB0;
+    double* s_a = dsm + LY::oA;
+    double* s_b = dsm + LY::oB;
+    double* s_vec = dsm + LY::oVec;      // xi_T | f at the steady/transient boundary
+    double* s_ps = dsm + LY::oPs;
+    double* s_red = dsm + LY::oRed;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int c = tid / R, i = tid % R;
+    const int T = a.T, r = a.r, L = a.L;
+    const int E = a.E[b];
+    const int ts = E - 1;
+    const int nst = ts < ecap(R) ? ts : ecap(R);              // transient steps staged in LDS
+    const double* bcol = a.bcol + (size_t)b * T * R;
+    double* wtab = a.wtab + (size_t)b * T * R;
+    const double* tab = a.tab + (size_t)b * T * 3 * R * R;
+    const double* stead = a.stead + (size_t)b * NST * R * R;
+    double* fout = a.f_smooth + (size_t)b * T * r;
+    const int npr = r * (r + 1) / 2;
+
+    // ---- one round trip to global memory for everything the sequential parts will touch ------------
+    for (int k = tid; k < NST * R * R; k += kScanThreads) s_mat[k] = stead[k];
+    for (int k = tid; k < R * R; k += kScanThreads) s_mat[NST * R * R + k] = a.PT[(size_t)b * R * R + k];
+    {   // a fixed count, so these loads do not wait for E (entries past E are never used)
+        const int nfix = ecap(R) < T ? ecap(R) : T;
+        for (int k = tid; k < nfix * 3 * R * R; k += kScanThreads) s_tab[k] = tab[k];
+        for (int k = tid; k < nfix * R; k += kScanThreads) s_b0[k] = bcol[k];
+    }
+    if (a.P_smooth) {
+        for (int v = tid; v < npr; v += kScanThreads) {       // packed (caller's r) copy of P_s,inf
+            int ri = 0;
+            while ((ri + 1) * (ri + 2) / 2 <= v) ++ri;
+            s_ps[v] = a.PsInf[(size_t)b * R * R + ri * R + (v - ri * (ri + 1) / 2)];
+        }
+    }
+    double xi = a.xi0[(size_t)b * R + i];
+    const int clast = (T - 1 - ts) / L;                       // chunk that holds step T-1 (fwd) / step ts (bwd)
+    const int cmax = c | (64 / R - 1);                        // last chunk handled by this wave
+    const int t0f = ts + c * L;                               // forward chunk: steps t0f + j
+    const int t0b = T - 1 - c * L;                            // backward chunk: steps t0b - j
+    const bool fullf = (ts + (cmax + 1) * L) <= T;            // wave-uniform: no partial chunk in this wave
+    const bool fullb = (T - (cmax + 1) * L) >= ts;
+    double cur[kPF];
+    if (fullf) chunk_prefetch<R, true>(cur, bcol, t0f, 1, L, ts, T, i);
+    else chunk_prefetch<R, false>(cur, bcol, t0f, 1, L, ts, T, i);
+    __syncthreads();
+
+    // ---- P_smooth rows inside the fixed-point range: fire-and-forget stores --------------------------
+    if (a.P_smooth && !(a.abl & 1)) {
+        const int lo = a.fill[2 * b], hi = a.fill[2 * b + 1];
+        if (hi > lo) {
+            double* base = a.P_smooth + ((size_t)b * T + lo) * npr;   // element k of the range is s_ps[k % npr]
+            const unsigned n = (unsigned)(hi - lo) * (unsigned)npr;
+            const unsigned peel = ((reinterpret_cast<size_t>(base) & 15) != 0) ? 1u : 0u;   // to 16-byte alignment
+            if (peel && tid == 0) base[0] = s_ps[0];
+            const unsigned npair = (n - peel) / 2;
+            const unsigned step = (2u * kScanThreads) % (unsigned)npr;
+            unsigned k = peel + 2u * tid;
+            unsigned v = k % (unsigned)npr;
+            for (unsigned p = tid; p < npair; p += kScanThreads) {
+                const unsigned v1 = (v + 1 == (unsigned)npr) ? 0u : v + 1;
+                *reinterpret_cast<double2*>(base + k) = make_double2(s_ps[v], s_ps[v1]);
+                k += 2u * kScanThreads;
+                v += step;
+                if (v >= (unsigned)npr) v -= (unsigned)npr;
+            }
+            if (((n - peel) & 1u) != 0 && tid == 0) base[n - 1] = s_ps[(n - 1) % (unsigned)npr];
+        }
+    }
+    if (a.abl & 2) return;
+    if (a.abl & 4) return;
+
+    // ---- forward transient: steps 0 .. ts-1 on wave 0 only (its lane groups redundantly); the other
+    // waves wait at the barrier, leaving their SIMDs to the co-resident workgroups
+    double dot = 0.0;                     // lane part of sum_t xi_t' w_t
+    if (ts > 0) {
+        if (tid < 64) {
+            for (int t = 0; t < ts; ++t) {
+                double Zp[R], Gp[R];
+                const bool st = t < nst;
+                const double* ent = st ? s_tab + (size_t)t * 3 * R * R : tab + (size_t)t * 3 * R * R;
+                load_xperm<R>(Zp, ent, i);
+                load_xperm<R>(Gp, ent + 2 * R * R, i);
+                const double bt = st ? s_b0[t * R + i] : bcol[(size_t)t * R + i];
+                const double w = matvec_x<R>(Zp, xi);
+                if (c == 0) {
+                    dot = fma(xi, w, dot);
+                    if (st) s_b0[t * R + i] = w;              // b_t is consumed; the slot now holds w_t
+                    else wtab[(size_t)t * R + i] = w;
+                }
+                xi = matvec_x<R>(Gp, xi, bt);
+            }
+            if (c == 0) s_vec[i] = xi;
+        }
+        __syncthreads();
+        xi = s_vec[i];
+        __syncthreads();                  // s_vec is reused for xi_T
+    }
+    // xi = xi_ts in every group.
+    if (a.abl & 8) { if (xi == 1.2345e300) fout[0] = xi; return; }
+
+    // ---- steady forward scan: steps ts .. T-1; group c owns steps ts + c L + j ---------------------
+    {
+        double Gp[R], Zp[R];
+        load_xperm<R>(Gp, s_mat + 2 * R * R, i);
+        double dummy = 0.0;
+        // phase 1: chunk from a zero state
+        const double e = fullf ? chunk_run<R, true, 0>(Gp, Gp, 0.0, cur, bcol, t0f, 1, L, ts, T, i, nullptr, dummy, nullptr, r)
+                               : chunk_run<R, false, 0>(Gp, Gp, 0.0, cur, bcol, t0f, 1, L, ts, T, i, nullptr, dummy, nullptr, r);
+        if (a.abl & 16) { if (e == 1.2345e300) fout[0] = e; return; }
+        if (fullf) chunk_prefetch<R, true>(cur, bcol, t0f, 1, L, ts, T, i);     // operands of phase 3, in flight during phase 2
+        else chunk_prefetch<R, false>(cur, bcol, t0f, 1, L, ts, T, i);
+        // phase 2: true start state of chunk c
+        const double s = carry_scan<R, NG>(e, xi, s_mat + 3 * R * R, c, i, s_a, s_b);
+        if (a.abl & 32) { if (s == 1.2345e300) fout[0] = s; return; }
+        // phase 3: re-run from the true start; emit w_t, accumulate xi_t' w_t
+        load_xperm<R>(Zp, s_mat, i);
+        const double v = fullf ? chunk_run<R, true, 1>(Gp, Zp, s, cur, bcol, t0f, 1, L, ts, T, i, wtab, dot, nullptr, r)
+                               : chunk_run<R, false, 1>(Gp, Zp, s, cur, bcol, t0f, 1, L, ts, T, i, wtab, dot, nullptr, r);
+        if (c == clast) s_vec[i] = v;                         // xi_T
+    }
+    if (a.abl & 64) { if (dot == 1.2345e300) fout[0] = dot; return; }
+    __syncthreads();   // xi_T in LDS; every w_t of this replicate is written (workgroup-visible)
+    if (fullb) chunk_prefetch<R, true>(cur, wtab, t0b, -1, L, ts, T, i);
+    else chunk_prefetch<R, false>(cur, wtab, t0b, -1, L, ts, T, i);
+
+    // ---- terminal ------------------------------------------------------------------------------
+    const double xiT = s_vec[i];
+    double fT;
+    {
+        double PTp[R];
+        load_xperm<R>(PTp, s_mat + NST * R * R, i);
+        fT = matvec_x<R>(PTp, xiT);
+    }
+    if (c == 0) {
+        dot = fma(xiT, fT, dot);          // the log-likelihood needs sum xi'w + xi_T' f_T
+        if (i < r) fout[(size_t)(T - 1) * r + i] = fT;
+    }
+
+    // ---- steady backward scan: steps T-1 .. ts; group c owns steps T-1 - c L - j -------------------
+    double fb;   // smoothed mean at the steady/transient boundary (period ts)
+    {
+        double Jp[R];
+        load_xperm<R>(Jp, s_mat + R * R, i);
+        double dummy = 0.0;
+        const double e = fullb ? chunk_run<R, true, 0>(Jp, Jp, 0.0, cur, wtab, t0b, -1, L, ts, T, i, nullptr, dummy, nullptr, r)
+                               : chunk_run<R, false, 0>(Jp, Jp, 0.0, cur, wtab, t0b, -1, L, ts, T, i, nullptr, dummy, nullptr, r);
+        if (fullb) chunk_prefetch<R, true>(cur, wtab, t0b, -1, L, ts, T, i);
+        else chunk_prefetch<R, false>(cur, wtab, t0b, -1, L, ts, T, i);
+        const double s = carry_scan<R, NG>(e, fT, s_mat + (size_t)(3 + NLEV) * R * R, c, i, s_a, s_b);
+        const double v = fullb ? chunk_run<R, true, 2>(Jp, Jp, s, cur, wtab, t0b, -1, L, ts, T, i, nullptr, dummy, fout, r)
+                               : chunk_run<R, false, 2>(Jp, Jp, s, cur, wtab, t0b, -1, L, ts, T, i, nullptr, dummy, fout, r);
+        if (c == clast) s_vec[R + i] = v;
+        __syncthreads();
+        fb = s_vec[R + i];
+    }
+
+    // ---- backward transient: steps ts-1 .. 0 (wave 0 only) -----------------------------------------
+    if (tid < 64) {
+        double v = fb;
+        for (int t = ts - 1; t >= 0; --t) {
+            double Jp[R];
+            const bool st = t < nst;
+            load_xperm<R>(Jp, (st ? s_tab + (size_t)t * 3 * R * R : tab + (size_t)t * 3 * R * R) + R * R, i);
+            const double wt = st ? s_b0[t * R + i] : wtab[(size_t)t * R + i];
+            v = matvec_x<R>(Jp, v, wt);
+            if (c == 0 && t >= 1 && i < r) fout[(size_t)(t - 1) * r + i] = v;
+        }
+        if (a.f0s && c == 0) a.f0s[(size_t)b * R + i] = v;   // E[f_0 | X] (EM)
+    }
+
+    // ---- log-likelihood ----------------------------------------------------------------------------
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, kWave);
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) s_red[wave] = dot;
+    __syncthreads();
+    if (tid == 0) {
+        double d = 0.0, sq = 0.0;
+#pragma unroll
+        for (int w = 0; w < kScanThreads / 64; ++w) d += s_red[w];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sq += a.ssum[(size_t)b * 4 + w];
+        a.loglik[b] = -0.5 * (a.llc[b] + sq - d);
+    }
+}
+
+// ================================================================================================
+template <int R>
+static hipError_t launch_cov_r(const FastArgs& a, hipStream_t s) {
+    using LY = CovLayout<R>;
+    const int grid = (a.B + LY::GPW - 1) / LY::GPW;
+    static bool attr_done = false;
+    if (!attr_done && LY::lds_bytes() > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cov_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((cov_kernel<R>), dim3(grid), dim3(64), LY::lds_bytes(), s, a);
+    return hipGetLastError();
+}
+template <int R>
+static hipError_t launch_scan_r(const FastArgs& a, hipStream_t s) {
+    const size_t lds = ScanLds<R>::bytes();
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&meanscan_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((meanscan_kernel<R>), dim3(a.B), dim3(kScanThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+int fast_stead_mats(int Rpad) { return stead_mats(Rpad); }
+
+int fast_chunk_len(int Rpad, int T) {
+    const int ng = kScanThreads / Rpad;
+    int L = 1;
+    while (L * ng < T) L <<= 1;
+    return L;
+}
+
+hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s) {
+    switch (Rpad) {
+        case 2: return launch_cov_r<2>(a, s);
+        case 4: return launch_cov_r<4>(a, s);
+        case 8: return launch_cov_r<8>(a, s);
+        case 16: return launch_cov_r<16>(a, s);
+        case 32: return launch_cov_r<32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s) {
+    switch (Rpad) {
+        case 2: return launch_scan_r<2>(a, s);
+        case 4: return launch_scan_r<4>(a, s);
+        case 8: return launch_scan_r<8>(a, s);
+        case 16: return launch_scan_r<16>(a, s);
+        case 32: return launch_scan_r<32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace dfm
