@@ -18,7 +18,10 @@ struct dfm_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t side = nullptr;            // data-independent kernels (gram, cov) run beside the collapse
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t post = nullptr;            // meanscan of sub-batch s runs here, beside the collapse of sub-batch s+1
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_post = nullptr;
+    std::vector<hipEvent_t> ev_sub;        // collapse of sub-batch s done
+    int subbatch = 0;                      // DFM_SUBBATCH: sub-batches per fast pass (0 = automatic)
     bool force_general = false;            // DFM_FORCE_GENERAL=1: never take the balanced fast path
     int collapse_variant = 0;              // DFM_COLLAPSE_VARIANT: ring/row-block tuning of collapse_dma
     int scan_abl = 0;
@@ -230,7 +233,9 @@ bool fast_eligible(const dfm_handle* h, int N, int r, unsigned flags) {
     return !h->force_general && !(flags & DFM_F_MAY_HAVE_MISSING) && collapse_dma_supported(pad_r(r), N);
 }
 
-// gram + cov on the side stream, beside the streaming collapse on the main stream; then meanscan.
+// gram + cov on the side stream, beside the streaming collapse on the main stream; the batch is cut
+// into sub-batches so that the (latency-bound) meanscan of sub-batch s runs on a third stream beside the
+// (bandwidth-bound) collapse of sub-batch s+1.
 int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, const double* panel,
                       const PaddedParams& pp, const double* Rv, double* f_smooth, double* P_smooth,
                       double* loglik) {
@@ -251,18 +256,54 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     fa.bcol = ca.bcol; fa.ssum = ca.ssum; fa.wtab = at<double>(h, p.wtab);
     fa.f_smooth = f_smooth; fa.P_smooth = P_smooth; fa.loglik = loglik;
     fa.abl = h->scan_abl;
-    // fork: the side stream starts after everything already enqueued on the main stream (parameters)
-    hipStream_t side = h->no_side ? h->stream : h->side;
-    if (!h->no_side) {
+    if (h->no_side) {   // diagnostics: everything in order on the main stream
+        { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }
+        { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
+        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, h->collapse_variant)); }
+        { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
+        return 0;
+    }
+    // Measured on MI355X (profiles/r01): every cross-stream event edge costs 7-25 us, more than the
+    // overlap buys at B = 1024, so the default is one sub-batch; DFM_SUBBATCH keeps the knob for big batches.
+    int S = h->subbatch > 0 ? h->subbatch : 1;
+    if (S > B) S = B;
+    if (S == 1) {
         HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, launch_gram(p.Rp, ca, h->side)); }
+        { ProfScope ps(h, K_COV, h->side); HIP_TRY(h, launch_cov(p.Rp, fa, h->side)); }
+        HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
+        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, h->collapse_variant)); }
+        HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+        { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
+        return 0;
     }
-    { ProfScope ps(h, K_GRAM, side); HIP_TRY(h, launch_gram(p.Rp, ca, side)); }
-    { ProfScope ps(h, K_COV, side); HIP_TRY(h, launch_cov(p.Rp, fa, side)); }
-    if (!h->no_side) HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
-    { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, h->collapse_variant)); }
-    if (!h->no_side) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
+    while ((int)h->ev_sub.size() < S) {
+        hipEvent_t e;
+        HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->ev_sub.push_back(e);
+    }
+    // fork: side and post start after everything already enqueued on the main stream (parameters, memsets)
+    HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_fork, 0));
+    { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, launch_gram(p.Rp, ca, h->side)); }
+    { ProfScope ps(h, K_COV, h->side); HIP_TRY(h, launch_cov(p.Rp, fa, h->side)); }
+    HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
+    HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));
+    for (int s = 0; s < S; ++s) {
+        const int b0 = (int)((long long)B * s / S), b1 = (int)((long long)B * (s + 1) / S);
+        CollapseArgs cs = ca;
+        cs.b0 = b0; cs.B = b1 - b0;
+        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, cs, h->stream, h->collapse_variant)); }
+        HIP_TRY(h, hipEventRecord(h->ev_sub[s], h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_sub[s], 0));
+        FastArgs fs = fa;
+        fs.b0 = b0; fs.B = b1 - b0;
+        { ProfScope ps(h, K_MEANSCAN, h->post); HIP_TRY(h, launch_meanscan(p.Rp, fs, h->post)); }
+    }
+    HIP_TRY(h, hipEventRecord(h->ev_post, h->post));
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_post, 0));   // join
     return 0;
 }
 
@@ -427,6 +468,8 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
         }
     }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->post, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_post, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -436,6 +479,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_FORCE_GENERAL")) h->force_general = atoi(v) != 0;
     if (const char* v = getenv("DFM_COLLAPSE_VARIANT")) h->collapse_variant = atoi(v);
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
+    if (const char* v = getenv("DFM_SUBBATCH")) h->subbatch = atoi(v);
     if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
     *out = h;
     return 0;
@@ -446,6 +490,9 @@ int dfm_destroy(dfm_handle* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->side) { hipStreamSynchronize(h->side); hipStreamDestroy(h->side); }
+    if (h->post) { hipStreamSynchronize(h->post); hipStreamDestroy(h->post); }
+    if (h->ev_post) hipEventDestroy(h->ev_post);
+    for (auto e : h->ev_sub) hipEventDestroy(e);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ws) hipFree(h->ws);

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void collapse_dma_kernel(CollapseArgs a) {
     constexpr int KWAIT = NP - RB * CPL2 - 1;   // pieces that may still be in flight when a row block is read
     static_assert(KWAIT >= 1 && KWAIT <= 63, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x + a.b0;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = a.N, T = a.T;

@@ -14,6 +14,7 @@ namespace dfm {
 // is exactly 0), so kernels are instantiated for a handful of sizes only.
 struct CollapseArgs {
     int B, T, N;
+    int b0;               // collapse_dma only: first replicate of this launch (sub-batch pipelining)
     const double* panel;  // [B][T][N]
     const double* Lam;    // [B][N][Rp]
     const double* Rv;     // [B][N]
@@ -102,6 +103,7 @@ struct FastArgs {
     // outputs
     double* f_smooth; double* P_smooth; double* loglik;
     double* f0s;                // [B][Rp] E[f_0 | X] (EM) or null
+    int b0;                     // meanscan: first replicate of this launch (sub-batch pipelining)
     int abl;                    // diagnostics (DFM_SCAN_ABL): bit0 skip the P_smooth fill, bit1 skip the scans
 };
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
     double* s_vec = dsm + LY::oVec;      // xi_T | f at the steady/transient boundary
     double* s_ps = dsm + LY::oPs;
     double* s_red = dsm + LY::oRed;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x + a.b0;
     const int tid = threadIdx.x;
     const int c = tid / R, i = tid % R;
     const int T = a.T, r = a.r, L = a.L;

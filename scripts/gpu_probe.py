@@ -56,6 +56,7 @@ ap.add_argument("--skip-parity", action="store_true")
 ap.add_argument("--variants", default="0,1,2,3,4")
 ap.add_argument("--no-side", default="0")
 ap.add_argument("--scan-abl", default="0")
+ap.add_argument("--sub", default="0")
 cli = ap.parse_args()
 
 cases = [(16, 200, 500, 8, False), (5, 40, 50, 4, False), (3, 64, 48, 12, False), (2, 100, 40, 20, False),
@@ -91,7 +92,8 @@ ll = torch.empty((B,), dtype=torch.float64, device=dev)
 runs = [("general", dict(DFM_FORCE_GENERAL=1))]
 for ns in cli.no_side.split(","):
     for ab in cli.scan_abl.split(","):
-        runs += [(f"fast_v{v}_noside{ns}_abl{ab}", dict(DFM_COLLAPSE_VARIANT=v, DFM_NO_SIDE=ns, DFM_SCAN_ABL=ab)) for v in cli.variants.split(",")]
+        for sb in cli.sub.split(","):
+            runs += [(f"fast_v{v}_noside{ns}_abl{ab}_sub{sb}", dict(DFM_COLLAPSE_VARIANT=v, DFM_NO_SIDE=ns, DFM_SCAN_ABL=ab, DFM_SUBBATCH=sb)) for v in cli.variants.split(",")]
 for tag, env in runs:
     c = ctx_with(**env)
     for _ in range(5):
