@@ -616,7 +616,7 @@ int dfm_ks_pass_batch(dfm_handle* h, int B, int T, int N, int r, const double* p
 }
 
 
-// ---- TEMPORARY bring-up stubs (replaced as the kernels land) ----------------------------------
+// ---- EM --------------------------------------------------------------------------------------------
 int dfm_em_step_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,
                           double* A, double* Q, double* mu0, double* P0, double* loglik, unsigned flags) {
     if (!h) return DFM_E_NULL;
@@ -681,11 +681,76 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
     (void)hipFree(buf);
     return rc;
 }
-int dfm_pca_init_batch_dev(dfm_handle* h, int, int, int, int, const double*, double*, double*, double*, double*,
-                           double*, double*, double*) { return fail(h, DFM_E_DIMS, "not implemented yet%s"); }
-int dfm_pca_init_batch(dfm_handle* h, int, int, int, int, const double*, double*, double*, double*, double*,
-                       double*, double*, double*) { return fail(h, DFM_E_DIMS, "not implemented yet%s"); }
-int dfm_synth_panels_dev(dfm_handle* h, uint64_t, int64_t, int, int, int, int, double, double*, double*, double*,
-                         double*, double*, double*, double*) { return fail(h, DFM_E_DIMS, "not implemented yet%s"); }
+int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,
+                           double* A, double* Q, double* mu0, double* P0, double* factors) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || T < 2 || N < 1 || r < 1) return fail(h, DFM_E_DIMS, "B, N, r must be >= 1 and T >= 2%s");
+    if (r > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r > DFM_MAX_R (32)%s");
+    if (r > N || r > T - 1) return fail(h, DFM_E_DIMS, "r must not exceed N or T - 1%s");
+    if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int Rp = pad_r(r);
+    const size_t d = sizeof(double);
+    size_t off = 0;
+    const size_t oS = take(off, (size_t)B * N * N * d), oV = take(off, (size_t)B * N * Rp * d),
+                 oY = take(off, (size_t)B * N * Rp * d), oF = take(off, (size_t)B * T * Rp * d);
+    if (int rc = ensure_ws(h, off)) return rc;
+    PcaArgs pa;
+    pa.B = B; pa.T = T; pa.N = N; pa.r = r; pa.max_iter = 4000;
+    pa.panel = panel;
+    pa.S = at<double>(h, oS); pa.V = at<double>(h, oV); pa.Y = at<double>(h, oY); pa.F = at<double>(h, oF);
+    pa.Lam = Lam; pa.Rv = R; pa.A = A; pa.Q = Q; pa.mu0 = mu0; pa.P0 = P0; pa.factors = factors;
+    { ProfScope ps(h, K_PCA); HIP_TRY(h, launch_gram_xx(pa, h->stream)); HIP_TRY(h, launch_pca(Rp, pa, h->stream)); }
+    return 0;
+}
+
+int dfm_pca_init_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,
+                       double* A, double* Q, double* mu0, double* P0, double* factors) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || T < 2 || N < 1 || r < 1 || r > DFM_MAX_R) return fail(h, DFM_E_DIMS, "bad dimensions%s");
+    if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double);
+    const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_m = (size_t)B * r * r,
+                 n_v = (size_t)B * r, n_f = (size_t)B * T * r;
+    for (size_t k = 0; k < n_panel; ++k)
+        if (panel[k] != panel[k]) return fail(h, DFM_E_MISSING, "PCA initialisation needs a balanced panel (NaN found)%s");
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), (n_panel + n_lam + n_R + 3 * n_m + n_v + n_f) * d));
+    double* x_d = buf; double* lam_d = x_d + n_panel; double* R_d = lam_d + n_lam; double* A_d = R_d + n_R;
+    double* Q_d = A_d + n_m; double* P0_d = Q_d + n_m; double* mu_d = P0_d + n_m; double* f_d = mu_d + n_v;
+    (void)hipMemcpyAsync(x_d, panel, n_panel * d, hipMemcpyHostToDevice, h->stream);
+    int rc = dfm_pca_init_batch_dev(h, B, T, N, r, x_d, lam_d, R_d, A_d, Q_d, mu_d, P0_d, factors ? f_d : nullptr);
+    if (rc == 0) {
+        auto down = [&](void* dst, const void* src, size_t bytes) { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream); };
+        down(Lam, lam_d, n_lam * d); down(R, R_d, n_R * d); down(A, A_d, n_m * d); down(Q, Q_d, n_m * d);
+        down(mu0, mu_d, n_v * d); down(P0, P0_d, n_m * d);
+        if (factors) down(factors, f_d, n_f * d);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    (void)hipFree(buf);
+    return rc;
+}
+int dfm_synth_panels_dev(dfm_handle* h, uint64_t seed, int64_t first_replicate, int B, int T, int N, int r,
+                         double missing_prob, double* panel, double* Lam, double* R, double* A, double* Q,
+                         double* mu0, double* P0) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || T < 2 || N < 1 || r < 1) return fail(h, DFM_E_DIMS, "B, N, r must be >= 1 and T >= 2%s");
+    if (r > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r > DFM_MAX_R (32)%s");
+    if (!(missing_prob >= 0.0 && missing_prob < 1.0)) return fail(h, DFM_E_DIMS, "missing_prob must be in [0, 1)%s");
+    if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t off = 0;
+    const size_t oF = take(off, (size_t)B * (T + 1) * r * sizeof(double));
+    if (int rc = ensure_ws(h, off)) return rc;
+    SynthArgs sa;
+    sa.B = B; sa.T = T; sa.N = N; sa.r = r; sa.seed = seed; sa.first_replicate = first_replicate;
+    sa.missing_prob = missing_prob;
+    sa.panel = panel; sa.Lam = Lam; sa.R = R; sa.A = A; sa.Q = Q; sa.mu0 = mu0; sa.P0 = P0;
+    sa.fscratch = at<double>(h, oF);
+    { ProfScope ps(h, K_SYNTH); HIP_TRY(h, launch_synth(sa, h->stream)); }
+    return 0;
+}
 
 }  // extern "C"

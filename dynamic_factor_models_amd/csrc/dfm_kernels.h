@@ -111,4 +111,26 @@ hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);
 int fast_chunk_len(int Rpad, int T);
 int fast_stead_mats(int Rpad);
 
+// PCA initialisation (pca.hip).  Scratch arrays use the padded factor dimension Rp; outputs the caller's r.
+struct PcaArgs {
+    int B, T, N, r, max_iter;
+    const double* panel;        // [B][T][N], no NaN
+    double* S;                  // [B][N][N]   X'X
+    double* V; double* Y;       // [B][N][Rp]  basis / S V
+    double* F;                  // [B][T][Rp]  scores
+    double* Lam; double* Rv; double* A; double* Q; double* mu0; double* P0;   // caller's layout (r)
+    double* factors;            // [B][T][r] or null
+};
+hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s);
+hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s);
+
+// Device-side synthetic replicates (synth.hip); all arrays in the caller's layout (r).
+struct SynthArgs {
+    int B, T, N, r;
+    uint64_t seed; int64_t first_replicate; double missing_prob;
+    double* panel; double* Lam; double* R; double* A; double* Q; double* mu0; double* P0;
+    double* fscratch;           // [B][T+1][r]
+};
+hipError_t launch_synth(const SynthArgs& a, hipStream_t s);
+
 }  // namespace dfm

@@ -1,0 +1,418 @@
+// pca.hip -- PCA initialisation of the EM loop, batched over replicates.
+//
+// Reference: pca_score (dfm_functions.ipynb:179-183): `_, _, V = svd(X); score = (X*V)[:, 1:nfac_u]` on
+// the standardised balanced panel (:339-348), followed here by the closed-form OLS start of EM used by
+// the oracle (oracle/kalman_oracle.py pca_init; Doz, Giannone & Reichlin two-step start):
+//     Lam = OLS(x on F) = V_r,  R_i = mean squared residual,  A, Q = VAR(1) OLS of F (no constant,
+//     divisor T-1),  mu0 = 0,  P0 = F'F / T.
+// The right singular vectors of X are the eigenvectors of S = X'X, so per replicate:
+//   gram_xx_kernel   S = X'X           (N x N, the one dense contraction on the path; 4x4 register tiles)
+//   pca_kernel       top-r eigenpairs of S by orthogonal (subspace) iteration with a Rayleigh-Ritz
+//                    projection (r x r cyclic Jacobi) -- iterated to the fp64 floor, then sign-fixed as
+//                    the oracle does (largest-|.| entry of each vector positive); F = X V; the r x r
+//                    moment matrices of F; the OLS / VAR solves.
+// One workgroup (256 threads) per replicate in both kernels.
+#include "dfm_kernels.h"
+
+namespace dfm {
+
+constexpr int kPcaThreads = 256;
+
+// ---------------------------------------------------------------------------------------------
+// S = X'X.  Thread tile 4 x 4 over the upper triangle of 4 x 4 blocks; mirrored on store.
+__global__ __launch_bounds__(kPcaThreads) void gram_xx_kernel(PcaArgs a) {
+    const int b = blockIdx.x;
+    const int N = a.N, T = a.T;
+    const double* __restrict__ X = a.panel + (size_t)b * T * N;
+    double* S = a.S + (size_t)b * N * N;
+    const int nb = (N + 3) / 4;                     // 4-wide blocks per side
+    const int ntile = nb * (nb + 1) / 2;
+    for (int tile = threadIdx.x; tile < ntile; tile += kPcaThreads) {
+        // tile -> (bi <= bj) in the upper triangle, row-major over bi
+        int bi = 0, rem = tile;
+        while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+        const int bj = bi + rem;
+        const int i0 = 4 * bi, j0 = 4 * bj;
+        double acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+        for (int t = 0; t < T; ++t) {
+            const double* xr = X + (size_t)t * N;
+            double xi[4], xj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xi[u] = (i0 + u < N) ? xr[i0 + u] : 0.0;
+                xj[u] = (j0 + u < N) ? xr[j0 + u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fma(xi[u], xj[v], acc[u][v]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = i0 + u, j = j0 + v;
+                if (i < N && j < N) {
+                    S[(size_t)i * N + j] = acc[u][v];
+                    S[(size_t)j * N + i] = acc[u][v];
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide sum of NV values per thread -> every thread gets the totals (through LDS)
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* red /* [4][NV] */) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off, kWave);
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[wave * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = red[k] + red[NV + k] + red[2 * NV + k] + red[3 * NV + k];
+}
+
+// M (r x r, row-major in LDS, leading dimension R) = A' B for tall A, B ([n][R] in global memory)
+template <int R>
+__device__ __forceinline__ void tall_gram(double* M, const double* A, const double* Bm, int n, int r, double* red) {
+    for (int p = 0; p < r; ++p) {
+        double acc[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q] = 0.0;
+        for (int i = threadIdx.x; i < n; i += kPcaThreads) {
+            const double ap = A[(size_t)i * R + p];
+#pragma unroll
+            for (int q = 0; q < R; ++q) acc[q] = fma(ap, Bm[(size_t)i * R + q], acc[q]);
+        }
+        block_sum<R>(acc, red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) M[p * R + q] = acc[q];
+        }
+    }
+    __syncthreads();
+}
+
+// In-place Cholesky of the leading r x r block of G (LDS, ld R): lower factor L; thread 0.
+template <int R>
+__device__ __forceinline__ void chol_lds(double* G, int r) {
+    for (int j = 0; j < r; ++j) {
+        double d = G[j * R + j];
+        for (int k = 0; k < j; ++k) d -= G[j * R + k] * G[j * R + k];
+        d = sqrt(d);
+        G[j * R + j] = d;
+        for (int i = j + 1; i < r; ++i) {
+            double s = G[i * R + j];
+            for (int k = 0; k < j; ++k) s -= G[i * R + k] * G[j * R + k];
+            G[i * R + j] = s / d;
+        }
+    }
+}
+
+// Cyclic Jacobi on the symmetric r x r H (LDS, ld R); W receives the eigenvectors (columns), sorted by
+// decreasing eigenvalue; ev[k] the eigenvalues.  Thread 0.
+template <int R>
+__device__ __forceinline__ void jacobi_lds(double* H, double* W, double* ev, int r) {
+    for (int i = 0; i < r; ++i)
+        for (int j = 0; j < r; ++j) W[i * R + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0, dia = 0.0;
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < r; ++j) {
+                if (i == j) dia += H[i * R + j] * H[i * R + j];
+                else off += H[i * R + j] * H[i * R + j];
+            }
+        if (off <= 1e-32 * dia) break;
+        for (int p = 0; p < r - 1; ++p)
+            for (int q = p + 1; q < r; ++q) {
+                const double hpq = H[p * R + q];
+                if (hpq == 0.0) continue;
+                const double theta = (H[q * R + q] - H[p * R + p]) / (2.0 * hpq);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < r; ++k) {            // H <- H J
+                    const double hkp = H[k * R + p], hkq = H[k * R + q];
+                    H[k * R + p] = c * hkp - s * hkq;
+                    H[k * R + q] = s * hkp + c * hkq;
+                }
+                for (int k = 0; k < r; ++k) {            // H <- J' H
+                    const double hpk = H[p * R + k], hqk = H[q * R + k];
+                    H[p * R + k] = c * hpk - s * hqk;
+                    H[q * R + k] = s * hpk + c * hqk;
+                }
+                for (int k = 0; k < r; ++k) {            // W <- W J
+                    const double wkp = W[k * R + p], wkq = W[k * R + q];
+                    W[k * R + p] = c * wkp - s * wkq;
+                    W[k * R + q] = s * wkp + c * wkq;
+                }
+            }
+    }
+    for (int k = 0; k < r; ++k) ev[k] = H[k * R + k];
+    for (int a_ = 0; a_ < r - 1; ++a_) {                   // selection sort, descending
+        int m = a_;
+        for (int k = a_ + 1; k < r; ++k)
+            if (ev[k] > ev[m]) m = k;
+        if (m != a_) {
+            const double t = ev[a_]; ev[a_] = ev[m]; ev[m] = t;
+            for (int k = 0; k < r; ++k) { const double w = W[k * R + a_]; W[k * R + a_] = W[k * R + m]; W[k * R + m] = w; }
+        }
+    }
+}
+
+// Solve (leading r x r of) M Xs = Bs for Xs, M SPD, nb right-hand sides as columns of Bs; all LDS ld R;
+// M is destroyed (Cholesky).  Thread 0.
+template <int R>
+__device__ __forceinline__ void spd_solve_lds(double* M, double* Bs, int r, int nb) {
+    chol_lds<R>(M, r);
+    for (int c = 0; c < nb; ++c) {
+        for (int i = 0; i < r; ++i) {
+            double s = Bs[i * R + c];
+            for (int k = 0; k < i; ++k) s -= M[i * R + k] * Bs[k * R + c];
+            Bs[i * R + c] = s / M[i * R + i];
+        }
+        for (int i = r - 1; i >= 0; --i) {
+            double s = Bs[i * R + c];
+            for (int k = i + 1; k < r; ++k) s -= M[k * R + i] * Bs[k * R + c];
+            Bs[i * R + c] = s / M[i * R + i];
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
+    __shared__ double sH[R * R], sW[R * R], sG[R * R], sM[R * R], sev[R], sred[4 * R], sflag[2];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int N = a.N, T = a.T, r = a.r;
+    const double* __restrict__ X = a.panel + (size_t)b * T * N;
+    const double* __restrict__ S = a.S + (size_t)b * N * N;
+    double* V = a.V + (size_t)b * N * R;           // [N][R] current basis (columns >= r are zero)
+    double* Y = a.Y + (size_t)b * N * R;
+    double* F = a.F + (size_t)b * T * R;           // [T][R] scores
+
+    // deterministic, replicate-independent start: a fixed hash of (i, k), columns >= r zero
+    for (int idx = tid; idx < N * R; idx += kPcaThreads) {
+        const int i = idx / R, k = idx % R;
+        unsigned hsh = (unsigned)(i * 73856093u) ^ (unsigned)((k + 1) * 19349663u);
+        hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
+        Y[idx] = (k < r) ? ((double)(hsh & 0xFFFFu) / 65536.0 - 0.5) : 0.0;
+    }
+    __syncthreads();
+
+    auto orthonormalise = [&]() {                   // V <- Y L^-T  with  Y'Y = L L'  (Cholesky QR)
+        tall_gram<R>(sG, Y, Y, N, r, sred);
+        if (tid == 0) chol_lds<R>(sG, r);
+        __syncthreads();
+        for (int i = tid; i < N; i += kPcaThreads) {
+            double y[R], v[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { y[k] = Y[(size_t)i * R + k]; v[k] = 0.0; }
+            for (int k = 0; k < r; ++k) {           // forward substitution on the row: v L' = y
+                double s = y[k];
+                for (int m = 0; m < k; ++m) s -= v[m] * sG[k * R + m];
+                v[k] = s / sG[k * R + k];
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) V[(size_t)i * R + k] = v[k];
+        }
+        __syncthreads();
+    };
+    auto apply_S = [&]() {                          // Y <- S V   (S symmetric: column reads are row reads)
+        for (int i = tid; i < N; i += kPcaThreads) {
+            double y[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) y[k] = 0.0;
+            for (int j = 0; j < N; ++j) {
+                const double s = S[(size_t)j * N + i];
+#pragma unroll
+                for (int k = 0; k < R; ++k) y[k] = fma(s, V[(size_t)j * R + k], y[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) Y[(size_t)i * R + k] = y[k];
+        }
+        __syncthreads();
+    };
+
+    orthonormalise();
+    // iterate until the invariant-subspace residual ||S V - V (V'S V)||_F / ||S V||_F reaches the fp64
+    // floor (or stops improving): the Ritz vectors taken afterwards are then exact to roundoff / gap
+    double best = 1e300;
+    int stall = 0;
+    for (int it = 0; it < a.max_iter; ++it) {
+        apply_S();
+        tall_gram<R>(sH, V, Y, N, r, sred);              // H = V'S V
+        double part[2] = {0.0, 0.0};
+        for (int i = tid; i < N; i += kPcaThreads) {
+            for (int k = 0; k < r; ++k) {
+                double vh = 0.0;
+                for (int m = 0; m < r; ++m) vh = fma(V[(size_t)i * R + m], sH[m * R + k], vh);
+                const double y = Y[(size_t)i * R + k], d = y - vh;
+                part[0] = fma(d, d, part[0]);
+                part[1] = fma(y, y, part[1]);
+            }
+        }
+        block_sum<2>(part, sred);
+        const double rel = sqrt(part[0] / part[1]);
+        orthonormalise();
+        if (rel <= 1e-14) break;
+        if (rel < 0.5 * best) { best = rel; stall = 0; }
+        else if (++stall >= 8 && best < 1e-10) break;
+    }
+    // Rayleigh-Ritz: H = V'SV, H = W Theta W', V <- V W (descending), sign rule of the oracle
+    apply_S();
+    tall_gram<R>(sH, V, Y, N, r, sred);
+    if (tid == 0) {
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < i; ++j) { const double h = 0.5 * (sH[i * R + j] + sH[j * R + i]); sH[i * R + j] = h; sH[j * R + i] = h; }
+        jacobi_lds<R>(sH, sW, sev, r);
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += kPcaThreads) {
+        double v[R], w[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) { v[k] = V[(size_t)i * R + k]; w[k] = 0.0; }
+        for (int k = 0; k < r; ++k) {
+            double s = 0.0;
+            for (int m = 0; m < r; ++m) s = fma(v[m], sW[m * R + k], s);
+            w[k] = s;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) Y[(size_t)i * R + k] = w[k];    // rotated basis in Y
+    }
+    __syncthreads();
+    // sign: largest-|.| entry of each eigenvector positive (first such entry on ties, as numpy argmax)
+    for (int k = 0; k < r; ++k) {
+        double best = -1.0; int bi = N;
+        for (int i = tid; i < N; i += kPcaThreads) {
+            const double av = fabs(Y[(size_t)i * R + k]);
+            if (av > best) { best = av; bi = i; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ob = __shfl_xor(best, off, kWave);
+            const int oi = __shfl_xor(bi, off, kWave);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { sred[2 * (tid >> 6)] = best; sred[2 * (tid >> 6) + 1] = (double)bi; }
+        __syncthreads();
+        if (tid == 0) {
+            double bb = sred[0]; int ii = (int)sred[1];
+            for (int w = 1; w < 4; ++w)
+                if (sred[2 * w] > bb || (sred[2 * w] == bb && (int)sred[2 * w + 1] < ii)) { bb = sred[2 * w]; ii = (int)sred[2 * w + 1]; }
+            sflag[0] = (Y[(size_t)ii * R + k] < 0.0) ? -1.0 : 1.0;
+        }
+        __syncthreads();
+        const double sg = sflag[0];
+        for (int i = tid; i < N; i += kPcaThreads) V[(size_t)i * R + k] = sg * Y[(size_t)i * R + k];
+        __syncthreads();
+    }
+    for (int idx = tid; idx < N * R; idx += kPcaThreads)
+        if (idx % R >= r) V[idx] = 0.0;
+    __syncthreads();
+
+    // scores F = X V  (one wave per period, lanes over series)
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int t = wave; t < T; t += kPcaThreads / 64) {
+            double f[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) f[k] = 0.0;
+            for (int i = lane; i < N; i += 64) {
+                const double x = X[(size_t)t * N + i];
+#pragma unroll
+                for (int k = 0; k < R; ++k) f[k] = fma(x, V[(size_t)i * R + k], f[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) f[k] += __shfl_xor(f[k], off, kWave);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) F[(size_t)t * R + k] = f[k];
+            }
+        }
+    }
+    __syncthreads();
+    if (a.factors) {
+        for (int idx = tid; idx < T * r; idx += kPcaThreads) {
+            const int t = idx / r, k = idx % r;
+            a.factors[((size_t)b * T + t) * r + k] = F[(size_t)t * R + k];
+        }
+    }
+    // Lam = V_r;  R_i = (S_ii - sum_k theta_k V_ik^2) / T, with theta_k = ||F_k||^2 (= Ritz value)
+    tall_gram<R>(sG, F, F, T, r, sred);                   // F'F
+    for (int i = tid; i < N; i += kPcaThreads) {
+        double q = 0.0;
+        for (int k = 0; k < r; ++k) {
+            const double v = V[(size_t)i * R + k];
+            a.Lam[((size_t)b * N + i) * r + k] = v;
+            // residual of series i: ||x_i||^2 - 2 x_i'F lam_i + lam_i'F'F lam_i, with F'x_i = (F'F) lam_i
+            double s = 0.0;
+            for (int m = 0; m < r; ++m) s = fma(sG[k * R + m], V[(size_t)i * R + m], s);
+            q = fma(v, s, q);
+        }
+        a.Rv[(size_t)b * N + i] = (S[(size_t)i * N + i] - q) / (double)T;
+    }
+    // VAR(1) of F without constant: A = (F0'F0)^-1 F0'F1 (transposed), Q = e'e / (T-1)
+    tall_gram<R>(sH, F, F, T - 1, r, sred);                       // F0'F0
+    tall_gram<R>(sW, F, F + R, T - 1, r, sred);                   // F0'F1   ([p][q] = sum_t F[t][p] F[t+1][q])
+    tall_gram<R>(sM, F + R, F + R, T - 1, r, sred);               // F1'F1
+    if (tid == 0) {
+        double* Ao = a.A + (size_t)b * r * r;
+        double* Qo = a.Q + (size_t)b * r * r;
+        double* P0o = a.P0 + (size_t)b * r * r;
+        for (int i = 0; i < r; ++i) {
+            a.mu0[(size_t)b * r + i] = 0.0;
+            for (int j = 0; j < r; ++j) P0o[i * r + j] = 0.5 * (sG[i * R + j] + sG[j * R + i]) / (double)T;
+        }
+        // keep F0'F1 in sev-free storage: copy to sG (F'F no longer needed)
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < r; ++j) sG[i * R + j] = sW[i * R + j];
+        spd_solve_lds<R>(sH, sW, r, r);                           // sW <- (F0'F0)^-1 F0'F1 = A'   ([p][q]: A[q][p])
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < r; ++j) Ao[i * r + j] = sW[j * R + i];
+        // e'e = F1'F1 - A (F0'F1) - (F0'F1)' A' + A (F0'F0) A' = F1'F1 - A (F0'F1)   at the OLS solution
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < r; ++j) {
+                double s = sM[i * R + j];
+                for (int k = 0; k < r; ++k) s -= sW[k * R + i] * sG[k * R + j];   // A[i][k] (F0'F1)[k][j]
+                sH[i * R + j] = s / (double)(T - 1);
+            }
+        for (int i = 0; i < r; ++i)
+            for (int j = 0; j < r; ++j) Qo[i * r + j] = 0.5 * (sH[i * R + j] + sH[j * R + i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(gram_xx_kernel, dim3(a.B), dim3(kPcaThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s) {
+    switch (Rpad) {
+        case 2: hipLaunchKernelGGL((pca_kernel<2>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pca_kernel<4>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((pca_kernel<8>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((pca_kernel<16>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((pca_kernel<32>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace dfm

@@ -192,3 +192,53 @@ class DfmContext:
                                     int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags)
         _check(self._h, rc)
         return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
+
+    # ------------------------------------------------------------------ PCA initialisation / synthetic panels
+    def pca_init_batch(self, panel, r: int, want_factors: bool = True):
+        """PCA + OLS start of EM on balanced standardised panels (device tensor [B,T,N], no NaN).
+        Returns (Lam, R, A, Q, mu0, P0, factors or None) as device tensors.  Asynchronous."""
+        torch = self._torch
+        B, T, N = panel.shape
+        f64 = dict(dtype=torch.float64, device=panel.device)
+        Lam = torch.empty((B, N, r), **f64); R = torch.empty((B, N), **f64)
+        A = torch.empty((B, r, r), **f64); Q = torch.empty((B, r, r), **f64)
+        mu0 = torch.empty((B, r), **f64); P0 = torch.empty((B, r, r), **f64)
+        F = torch.empty((B, T, r), **f64) if want_factors else None
+        self._sync_stream()
+        rc = self._lib.dfm_pca_init_batch_dev(
+            self._h, B, T, N, int(r), self._dev(panel, "panel"), self._dev(Lam, "Lam"), self._dev(R, "R"),
+            self._dev(A, "A"), self._dev(Q, "Q"), self._dev(mu0, "mu0"), self._dev(P0, "P0"),
+            self._dev(F, "factors") if F is not None else None)
+        _check(self._h, rc)
+        return Lam, R, A, Q, mu0, P0, F
+
+    def pca_init_batch_host(self, panel, r: int):
+        """Host-pointer PCA entry (what Julia's ccall binds): NumPy in / out."""
+        panel = np.ascontiguousarray(panel, dtype=np.float64)
+        B, T, N = panel.shape
+        Lam = np.empty((B, N, r)); R = np.empty((B, N)); A = np.empty((B, r, r)); Q = np.empty((B, r, r))
+        mu0 = np.empty((B, r)); P0 = np.empty((B, r, r)); F = np.empty((B, T, r))
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_pca_init_batch(self._h, B, T, N, int(r), p(panel), p(Lam), p(R), p(A), p(Q), p(mu0),
+                                          p(P0), p(F))
+        _check(self._h, rc)
+        return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), F
+
+    def synth_panels(self, seed: int, first_replicate: int, B: int, T: int, N: int, r: int,
+                     missing_prob: float = 0.0):
+        """Synthetic replicates of the SURVEY §8(d) DGP generated on the device.  Returns
+        (panel [B,T,N], (Lam, R, A, Q, mu0, P0)) -- the DGP parameters rescaled to the standardised panel."""
+        torch = self._torch
+        dev = torch.device("cuda", self.device)
+        f64 = dict(dtype=torch.float64, device=dev)
+        panel = torch.empty((B, T, N), **f64)
+        Lam = torch.empty((B, N, r), **f64); R = torch.empty((B, N), **f64)
+        A = torch.empty((B, r, r), **f64); Q = torch.empty((B, r, r), **f64)
+        mu0 = torch.empty((B, r), **f64); P0 = torch.empty((B, r, r), **f64)
+        self._sync_stream()
+        rc = self._lib.dfm_synth_panels_dev(
+            self._h, ctypes.c_uint64(seed), ctypes.c_int64(first_replicate), B, T, N, r,
+            ctypes.c_double(missing_prob), self._dev(panel, "panel"), self._dev(Lam, "Lam"), self._dev(R, "R"),
+            self._dev(A, "A"), self._dev(Q, "Q"), self._dev(mu0, "mu0"), self._dev(P0, "P0"))
+        _check(self._h, rc)
+        return panel, (Lam, R, A, Q, mu0, P0)
