@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference's Julia interface for the parametric path.
+
+The reference (QuantEcon/dynamic_factor_models, dfm_functions.ipynb) is Julia; Julia is not installed in
+the build image, so the layer that a Julia user would call -- `DFMModel(...)`, `estimate!(m, Parametric())`
+-- is mirrored here in Python with the same names, argument meaning and error behaviour, on top of the
+same C-ABI (include/dfm_hip.h) the Julia shim (julia/dfm_hip.jl) binds with `ccall`.  Index arguments
+(`initperiod`, `lastperiod`) are 1-based and inclusive exactly as in the reference.
+
+What runs where: everything O(B T N) -- PCA initialisation, Kalman filter, RTS smoother, EM -- runs in the
+hand-written HIP kernels of libdfmhip.so.  The host does what the reference's Julia host code does around
+its numerical kernels: slicing the estimation window, `standardize_data`, the complete-case column filter,
+and copying results into the model object.  There is no CPU implementation of the hot path in this
+package: without a HIP device `estimate` raises.
+
+Reference objects mirrored (file:line of dfm_functions.ipynb):
+  EstimationMethod / NonParametric / Parametric   :21-23
+  VARModel                                         :43-57, ctor :424-435
+  FactorEstimateStats                              :66-73
+  DFMModel                                         :89-111, ctor and its three `error(...)` checks :120-146
+  standardize_data                                 :501-509
+  drop_missing_col                                 :167-170
+  estimate!(m, ::NonParametric)                    :530-543  (the only method the reference implements;
+                                                              `Parametric` is the declared-but-empty slot)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- dispatch tags (:21-23)
+class EstimationMethod:
+    pass
+
+
+class NonParametric(EstimationMethod):
+    pass
+
+
+class Parametric(EstimationMethod):
+    pass
+
+
+# ----------------------------------------------------------------------------- containers
+@dataclass
+class FactorEstimateStats:          # dfm_functions.ipynb:66-73
+    T: int
+    ns: int
+    nobs: Optional[int] = None
+    tss: Optional[float] = None
+    ssr: Optional[float] = None
+    R2: np.ndarray = field(default_factory=lambda: np.empty(0))
+
+
+@dataclass
+class VARModel:                     # dfm_functions.ipynb:43-57 (y_t = Q z_t, z_t = M z_{t-1} + G u_t, :30-34)
+    y: np.ndarray
+    nlag: int
+    withconst: bool
+    initperiod: int
+    lastperiod: int
+    T: int
+    ns: int
+    resid: np.ndarray
+    betahat: np.ndarray
+    M: np.ndarray
+    Q: np.ndarray
+    G: np.ndarray
+    seps: np.ndarray
+
+
+def _var_model(y: np.ndarray, nlag: int = 1, withconst: bool = True, initperiod: int = 1,
+               lastperiod: Optional[int] = None) -> VARModel:
+    """VARModel(y, nlag; withconst, initperiod, lastperiod) -- dfm_functions.ipynb:424-435."""
+    T, ns = y.shape
+    lastperiod = T if lastperiod is None else lastperiod
+    k = ns * nlag
+    return VARModel(y=y, nlag=nlag, withconst=withconst, initperiod=initperiod, lastperiod=lastperiod, T=T, ns=ns,
+                    resid=np.full((T, ns), np.nan), betahat=np.full((k + (1 if withconst else 0), ns), np.nan),
+                    M=np.zeros((k, k)), Q=np.zeros((ns, k)), G=np.zeros((k, ns)), seps=np.full((ns, ns), np.nan))
+
+
+class DFMModel:
+    """DFMModel(data, inclcode, nt_min_factor_estimation, nt_min_factorloading_estimation, initperiod,
+    lastperiod, nfac_o, nfac_u, tol, n_uarlag, n_factorlag) -- dfm_functions.ipynb:89-146.
+
+    `data` is T x ns with NaN for the reference's `missing`.  `factor` and `factor_var_model.y` alias the
+    same array, as in the reference (:80, :138).  The reference's field `lambda` is `lambda_` here."""
+
+    def __init__(self, data, inclcode, nt_min_factor_estimation: int, nt_min_factorloading_estimation: int,
+                 initperiod: int, lastperiod: int, nfac_o: int, nfac_u: int, tol: float, n_uarlag: int,
+                 n_factorlag: int):
+        data = np.asarray(data, dtype=np.float64)
+        inclcode = np.asarray(inclcode).astype(int).ravel()
+        if data.ndim != 2 or data.shape[1] != inclcode.shape[0]:
+            raise ValueError("length of inclcode must equal to number of data series")          # :124
+        if not (initperiod < lastperiod):
+            raise ValueError("initperiod must be smaller than lastperiod")                      # :125
+        if not (n_uarlag > 0 and n_factorlag > 0):
+            raise ValueError("n_uarlag and n_factorlag must be positive")                       # :126
+        T, ns = data.shape
+        if not (1 <= initperiod and lastperiod <= T):
+            raise ValueError("estimation window must lie inside the data (1 <= initperiod, lastperiod <= T)")
+        self.data = data
+        self.inclcode = inclcode
+        self.T, self.ns = T, ns
+        self.nt_min_factor_estimation = int(nt_min_factor_estimation)
+        self.nt_min_factorloading_estimation = int(nt_min_factorloading_estimation)
+        self.initperiod, self.lastperiod = int(initperiod), int(lastperiod)
+        self.nfac_o, self.nfac_u = int(nfac_o), int(nfac_u)
+        self.nfac_t = self.nfac_o + self.nfac_u
+        self.tol = float(tol)
+        n_incl = int(np.count_nonzero(inclcode == 1))
+        self.fes = FactorEstimateStats(self.lastperiod - self.initperiod + 1, n_incl, None, None, None,
+                                       np.full(n_incl, np.nan))
+        self.factor = np.full((T, self.nfac_t), np.nan)
+        self.lambda_ = np.full((ns, self.nfac_t), np.nan)
+        self.uar_coef = np.full((ns, n_uarlag), np.nan)
+        self.uar_ser = np.full(ns, np.nan)
+        self.n_uarlag, self.n_factorlag = int(n_uarlag), int(n_factorlag)
+        self.factor_var_model = _var_model(self.factor, self.n_factorlag, True, self.initperiod, self.lastperiod)
+        self.r2 = np.full(ns, np.nan)
+        # results of the parametric path that have no field in the reference struct
+        self.loglik_path: Optional[np.ndarray] = None
+        self.em_iters: Optional[int] = None
+        self.em_params: Optional[dict] = None
+
+
+# ----------------------------------------------------------------------------- host helpers
+def standardize_data(x: np.ndarray):
+    """dfm_functions.ipynb:501-509: per-series mean and *population* s.d. over the observed cells;
+    returns ((x - mean) / sd, sd [1 x ns])."""
+    x = np.asarray(x, dtype=np.float64)
+    n = np.count_nonzero(~np.isnan(x), axis=0)
+    mu = np.nansum(x, axis=0) / n
+    d = np.where(np.isnan(x), 0.0, x - mu)
+    sd = np.sqrt((d * d).sum(axis=0) / n)
+    return (x - mu) / sd, sd[None, :]
+
+
+def drop_missing_col(A: np.ndarray):
+    """dfm_functions.ipynb:167-170: keep the columns with no missing cell; returns (sub-matrix, mask)."""
+    keep = ~np.isnan(A).any(axis=0)
+    return A[:, keep], keep
+
+
+def _ols_rows(y: np.ndarray, X: np.ndarray):
+    """Complete-case least squares of one series on the factors (the reference's `ols_skipmissing(...,
+    Balanced())`, dfm_functions.ipynb:242-252, no intercept): returns (b, residual variance, #rows)."""
+    ok = ~np.isnan(y)
+    Xo, yo = X[ok], y[ok]
+    b = np.linalg.lstsq(Xo, yo, rcond=None)[0]
+    e = yo - Xo @ b
+    return b, float(e @ e) / max(int(ok.sum()), 1), int(ok.sum())
+
+
+# ----------------------------------------------------------------------------- estimate!(m, ::Parametric)
+def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int = 50, tol_em: float = 1e-6,
+             ctx=None, lam_constr_f=None, lam_constr_fl=None):
+    """`estimate!(m::DFMModel, ::Parametric; max_em_iter, tol_em)`: PCA-initialised EM for the exact
+    Gaussian state-space DFM  x_t = Lam f_t + e_t,  f_t = A f_{t-1} + eta_t  on the standardised
+    estimation window (rows initperiod..lastperiod, series with inclcode == 1), fitted with the HIP
+    library.  Mutates `m` in place like the reference's `estimate!` and returns the per-iteration
+    log-likelihood vector (the reference's own methods return `nothing`).
+
+      m.factor[initperiod:lastperiod, :]  <- smoothed factors E[f_t | X]
+      m.lambda_[incl, :]                  <- loadings in data units (Lam_i * sd_i)
+      m.uar_ser[incl]                     <- idiosyncratic s.d. in data units; m.uar_coef[incl, :] = 0
+      m.factor_var_model.M / G / seps     <- A (companion block), chol(Q) lower, Q      (cf. :477-492)
+      m.fes.tss / nobs / ssr / R2         <- as estimate_factor! defines them (:342-343, :366, :372-380),
+                                             with the common component Lam f_t|T in place of the ALS fit
+    `NonParametric()` is the reference's own pure-Julia path and is not re-implemented here."""
+    method = Parametric() if method is None else method
+    if isinstance(method, NonParametric):
+        raise NotImplementedError(
+            "estimate(m, NonParametric()) is the reference's own ALS path (dfm_functions.ipynb:530-543); this "
+            "package accelerates the Parametric() slot only")
+    if not isinstance(method, Parametric):
+        raise TypeError("method must be Parametric() or NonParametric()")
+    if lam_constr_f is not None or lam_constr_fl is not None:
+        raise NotImplementedError("loading constraints are not supported on the parametric path")
+    if m.nfac_o != 0:
+        raise NotImplementedError("observed factors (nfac_o > 0) are not supported (non-functional in the reference too)")
+    r = m.nfac_u
+    incl = m.inclcode == 1
+    xdata = m.data[m.initperiod - 1:m.lastperiod, :][:, incl]           # :335-336
+    z, sd = standardize_data(xdata)                                     # :339
+    obs = ~np.isnan(z)
+    m.fes.tss = float(np.nansum(z * z))                                 # :342
+    m.fes.nobs = int(obs.sum())                                         # :343
+    enough = obs.sum(axis=0) >= m.nt_min_factor_estimation              # :357 (series too short are left out)
+    if not enough.all():
+        z = z[:, enough]
+    xbal, balmask = drop_missing_col(z)                                 # :345
+    T, N = z.shape
+    if xbal.shape[1] < r:
+        raise ValueError("fewer fully observed series than factors: cannot initialise by PCA")
+
+    own_ctx = ctx is None
+    if own_ctx:
+        from .kalman import DfmContext
+        ctx = DfmContext()                                              # raises without a HIP device
+    try:
+        p0, F0 = ctx.pca_init_batch_host(xbal[None, :, :], r)          # pca_score (:179-183) + OLS start, on the GPU
+        F0 = F0[0]
+        Lam = np.empty((N, r)); R = np.empty(N)
+        Lam[balmask] = p0["Lam"][0]; R[balmask] = p0["R"][0]
+        for i in np.nonzero(~balmask)[0]:                               # series with gaps: complete-case OLS on F0
+            Lam[i], R[i], _ = _ols_rows(z[:, i], F0)
+        start = dict(Lam=Lam[None], R=R[None], A=p0["A"], Q=p0["Q"], mu0=p0["mu0"], P0=p0["P0"])
+        params, path, iters, f, P = ctx.em_batch_host(z[None], start["Lam"], start["R"], start["A"], start["Q"],
+                                                      start["mu0"], start["P0"], max_iter=max_em_iter, tol=tol_em,
+                                                      may_have_missing=bool((~obs).any()))
+    finally:
+        if own_ctx:
+            ctx.close()
+    k = int(iters[0])
+    f = f[0]
+    Lam, R, A, Q = params["Lam"][0], params["R"][0], params["A"][0], params["Q"][0]
+    m.loglik_path = path[0, :k].copy()
+    m.em_iters = k
+    m.em_params = {kk: v[0].copy() for kk, v in params.items()}
+    m.factor[m.initperiod - 1:m.lastperiod, :] = f                      # in place: aliases factor_var_model.y (:371, :80)
+    cols = np.nonzero(incl)[0][enough] if not enough.all() else np.nonzero(incl)[0]
+    sdv = sd[0][enough] if not enough.all() else sd[0]
+    m.lambda_[cols, :] = Lam * sdv[:, None]
+    m.uar_ser[cols] = np.sqrt(R) * sdv
+    m.uar_coef[cols, :] = 0.0
+    common = f @ Lam.T
+    e = np.where(np.isnan(z), 0.0, z - common)
+    m.fes.ssr = float((e * e).sum())                                    # :366
+    zc = z - np.nanmean(z, axis=0)
+    R2 = 1.0 - (e * e).sum(axis=0) / np.nansum(zc * zc, axis=0)         # compute_r2 (:565-569)
+    m.fes.R2 = np.full(m.fes.ns, np.nan)
+    m.fes.R2[np.nonzero(enough)[0]] = R2
+    m.r2[cols] = R2
+    var = m.factor_var_model                                            # fill_matrices! (:477-492) for VAR(1)
+    var.M[:] = 0.0; var.Q[:] = 0.0; var.G[:] = 0.0
+    var.M[:r, :r] = A
+    if var.nlag > 1:
+        var.M[r:, :-r] = np.eye(r * (var.nlag - 1))
+    var.Q[:, :r] = np.eye(r)
+    var.seps[:] = Q
+    var.G[:r, :r] = np.linalg.cholesky(Q)
+    var.betahat[:] = 0.0
+    var.betahat[(1 if var.withconst else 0):(1 if var.withconst else 0) + r, :] = A.T
+    return m.loglik_path

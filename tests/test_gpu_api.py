@@ -1,0 +1,51 @@
+"""GPU test of the reference-interface mirror: estimate(m, Parametric()) on an unbalanced panel against the
+same pipeline assembled from the CPU oracle (PCA start -> complete-case OLS for gappy series -> EM)."""
+import numpy as np
+import pytest
+
+from oracle import kalman_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def test_estimate_parametric_matches_oracle_pipeline():
+    from dynamic_factor_models_amd import api
+    rng = np.random.default_rng(5)
+    T_all, ns, r = 120, 30, 3
+    x, _ = ko.synth_replicate(11, ns, T_all, r)
+    raw = 3.0 + x * rng.uniform(0.5, 2.0, ns)                 # un-standardised data with level and scale
+    raw[rng.random(raw.shape) < 0.04] = np.nan
+    raw[:, :18][np.isnan(raw[:, :18])] = 1.0                  # 18 fully observed series
+    inclcode = np.ones(ns, dtype=int); inclcode[[4, 9]] = 0
+    init, last = 3, 118
+    m = api.DFMModel(raw, inclcode, 20, 40, init, last, 0, r, 1e-8, 4, 4)
+    path = api.estimate(m, api.Parametric(), max_em_iter=8, tol_em=0.0)
+
+    # oracle pipeline
+    z, sd = api.standardize_data(raw[init - 1:last][:, inclcode == 1])
+    xbal, bal = api.drop_missing_col(z)
+    p0, F0 = ko.pca_init(xbal, r)
+    N = z.shape[1]
+    Lam = np.empty((N, r)); R = np.empty(N)
+    Lam[bal] = p0["Lam"]; R[bal] = p0["R"]
+    for i in np.nonzero(~bal)[0]:
+        ok = ~np.isnan(z[:, i])
+        b = np.linalg.lstsq(F0[ok], z[ok, i], rcond=None)[0]
+        e = z[ok, i] - F0[ok] @ b
+        Lam[i] = b; R[i] = e @ e / ok.sum()
+    start = dict(Lam=Lam, R=R, A=p0["A"], Q=p0["Q"], mu0=p0["mu0"], P0=p0["P0"])
+    pe, pathe, out = ko.em(z, start, max_iter=8, tol=0.0)
+
+    np.testing.assert_allclose(path, pathe, rtol=1e-7)
+    f = m.factor[init - 1:last]
+    assert np.isnan(m.factor[:init - 1]).all() and np.isnan(m.factor[last:]).all()
+    np.testing.assert_allclose(f, out["f_smooth"], atol=1e-6 * np.abs(out["f_smooth"]).max())
+    cols = np.nonzero(inclcode == 1)[0]
+    # the path returns the parameters entering the last E-step run (oracle em(): `p` after max_iter-1 M-steps ...)
+    assert m.em_iters == 8
+    np.testing.assert_allclose(m.lambda_[cols] / sd[0][:, None], m.em_params["Lam"], rtol=1e-12)
+    assert np.isnan(m.lambda_[[4, 9]]).all()
+    np.testing.assert_allclose(m.factor_var_model.seps, m.em_params["Q"])
+    np.testing.assert_allclose(m.factor_var_model.G[:r, :r] @ m.factor_var_model.G[:r, :r].T, m.em_params["Q"], rtol=1e-10)
+    assert 0 < m.fes.ssr < m.fes.tss and m.fes.nobs == int((~np.isnan(z)).sum())
+    assert np.all(np.diff(path) > -1e-8 * np.abs(path[:-1]))   # EM monotone
