@@ -1,0 +1,281 @@
+"""CPU fp64 oracle for the reference's NON-parametric estimator (PCA start + alternating least squares,
+loadings, factor VAR, information criteria, impulse responses).
+
+TEST INFRASTRUCTURE ONLY (see oracle/kalman_oracle.py header): nothing under
+dynamic_factor_models_amd/ may import it.
+
+PARITY PINNED.  Unlike the Kalman/EM oracle, every function here restates code that exists in the
+reference (`dfm_functions.ipynb`, raw-line citations per function) and the whole chain
+readin -> standardise -> PCA -> ALS -> loadings -> VAR is pinned by the outputs saved in the reference's
+driver notebook (`Stock_Watson.ipynb:572-576, 619-628, 673-682, 991-1017, 1250-1261`): see
+tests/test_oracle_sw.py, which asserts every printed digit.
+
+Conventions: NaN = `missing`; `init`/`last` are the reference's 1-based inclusive row numbers
+(`initperiod`, `lastperiod`), so the estimation window is rows init-1 .. last-1 in 0-based terms.
+Least squares: the reference solves `X\\y` (Householder QR, `dfm_functions.ipynb:205-210`); here
+`solver="qr"` calls LAPACK least squares per regression (the faithful restatement) and
+`solver="normal"` solves the same problems through batched normal equations (fast; agrees with "qr" to
+~1e-12 on these well-conditioned problems - asserted in the tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------- helpers
+def standardize_data(x: np.ndarray):
+    """dfm_functions.ipynb:501-509: per-column mean and POPULATION sd over observed cells."""
+    obs = ~np.isnan(x)
+    n = obs.sum(axis=0)
+    with np.errstate(invalid="ignore", divide="ignore"):      # an all-missing column stays all-NaN
+        mean = np.nansum(x, axis=0) / n
+        d = np.where(obs, x - mean, 0.0)
+        sd_sample = np.sqrt((d * d).sum(axis=0) / (n - 1))
+        std = sd_sample * np.sqrt((n - 1) / n)
+        return (x - mean) / std, std
+
+
+def pca_score(xbal: np.ndarray, r: int) -> np.ndarray:
+    """dfm_functions.ipynb:179-183: `_,_,V = svd(X); (X*V)[:, 1:r]` (scores = U S, LAPACK's signs)."""
+    _, _, Vt = np.linalg.svd(xbal, full_matrices=False)
+    return (xbal @ Vt.T)[:, :r]
+
+
+def _ols(y: np.ndarray, X: np.ndarray):
+    """dfm_functions.ipynb:205-210."""
+    b = np.linalg.lstsq(X, y, rcond=None)[0]
+    return b, y - X @ b
+
+
+def compute_r2(y: np.ndarray, e: np.ndarray) -> float:
+    """dfm_functions.ipynb:565-569."""
+    d = y - y.mean()
+    return 1.0 - float(e @ e) / float(d @ d)
+
+
+def lagmat(X: np.ndarray, lags) -> np.ndarray:
+    """dfm_functions.ipynb:295-303."""
+    X = X.reshape(X.shape[0], -1)
+    T, nc = X.shape
+    lags = list(lags)
+    out = np.full((T, nc * len(lags)), np.nan)
+    for i, lag in enumerate(lags):
+        out[lag:, nc * i: nc * (i + 1)] = X[: T - lag]
+    return out
+
+
+# ----------------------------------------------------------------------------- ALS sweeps
+def _lambda_step(z, obs, f, nt_min, solver):
+    """Loadings given factors, one complete-case regression per series (dfm_functions.ipynb:355-362).
+    Series with fewer than nt_min usable rows keep NaN loadings (the reference leaves them `missing`,
+    which removes them from the next per-period regression)."""
+    T, ns = z.shape
+    r = f.shape[1]
+    lam = np.full((ns, r), np.nan)
+    cnt = obs.sum(axis=0)
+    if solver == "normal":
+        ff = (f[:, :, None] * f[:, None, :]).reshape(T, r * r)
+        G = (obs.T.astype(float) @ ff).reshape(ns, r, r)
+        h = np.where(obs, z, 0.0).T @ f
+        ok = cnt >= nt_min
+        lam[ok] = np.linalg.solve(G[ok], h[ok][..., None])[..., 0]
+        return lam
+    for i in range(ns):
+        if cnt[i] >= nt_min:
+            w = obs[:, i]
+            lam[i] = _ols(z[w, i], f[w])[0]
+    return lam
+
+
+def _factor_step(z, obs, lam, solver):
+    """Factors given loadings, one regression per period over the series observed in that period with
+    defined loadings (dfm_functions.ipynb:364-366 -> :271-286).  Returns f (T x r) and the SSR."""
+    T, ns = z.shape
+    r = lam.shape[1]
+    good = ~np.isnan(lam).any(axis=1)
+    use = obs & good[None, :]
+    lam0 = np.where(good[:, None], lam, 0.0)
+    if solver == "normal":
+        ll = (lam0[:, :, None] * lam0[:, None, :]).reshape(ns, r * r)
+        G = (use.astype(float) @ ll).reshape(T, r, r)
+        h = np.where(use, z, 0.0) @ lam0
+        f = np.linalg.solve(G, h[..., None])[..., 0]
+        e = np.where(use, z - f @ lam0.T, 0.0)
+        return f, float((e * e).sum())
+    f = np.empty((T, r))
+    ssr = 0.0
+    for t in range(T):
+        w = use[t]
+        b, e = _ols(z[t, w], lam0[w])
+        f[t] = b
+        ssr += float(e @ e)
+    return f, ssr
+
+
+def estimate_factor(data, inclcode, init, last, r, tol=1e-8, nt_min=20, max_iter=10 ** 8,
+                    compute_r2_flag=True, solver="qr"):
+    """`estimate_factor!` (dfm_functions.ipynb:328-382) with nfac_o = 0 and no loading constraint.
+
+    Returns dict: factor (T_all x r, NaN outside the window), f (T x r), lam (ns x r, standardised units),
+    z (standardised window), std, tss, nobs, ssr, ssr_path (SSR after every sweep), iters, R2 (ns,)."""
+    data = np.asarray(data, float)
+    inclcode = np.asarray(inclcode).ravel()
+    x = data[init - 1: last][:, inclcode == 1]                    # :335-336
+    z, std = standardize_data(x)                                  # :339
+    obs = ~np.isnan(z)
+    tss = float(np.nansum(z * z))                                 # :342
+    nobs = int(obs.sum())                                         # :343
+    xbal = z[:, obs.all(axis=0)]                                  # :345
+    f = pca_score(xbal, r)                                        # :348
+    T, ns = z.shape
+    ssr, path = 0.0, []
+    lam = np.full((ns, r), np.nan)
+    it = 0
+    for it in range(1, max_iter + 1):                             # :352
+        ssr_old = ssr
+        lam = _lambda_step(z, obs, f, nt_min, solver)
+        f, ssr = _factor_step(z, obs, lam, solver)
+        path.append(ssr)
+        if not abs(ssr_old - ssr) >= tol * T * ns:                # :367-368
+            break
+    factor = np.full((data.shape[0], r), np.nan)
+    factor[init - 1: last] = f                                    # :371
+    R2 = np.full(ns, np.nan)
+    if compute_r2_flag:                                           # :372-380
+        for i in range(ns):
+            w = obs[:, i]
+            if w.sum() >= nt_min:
+                _, e = _ols(z[w, i], f[w])
+                R2[i] = compute_r2(z[w, i], e)
+    return dict(factor=factor, f=f, lam=lam, z=z, std=std, tss=tss, nobs=nobs, ssr=ssr,
+                ssr_path=np.array(path), iters=it, R2=R2, T=T, ns=ns)
+
+
+# ----------------------------------------------------------------------------- loadings, AR, VAR
+def uar(y: np.ndarray, n_lags: int):
+    """dfm_functions.ipynb:305-311: AR(n) without intercept; ser = sqrt(ssr / (len(y) - n))."""
+    x = lagmat(y, range(1, n_lags + 1))
+    ok = ~np.isnan(x).any(axis=1) & ~np.isnan(y)
+    b, e = _ols(y[ok], x[ok])
+    return b, float(np.sqrt(e @ e / (x.shape[0] - x.shape[1])))
+
+
+def estimate_factor_loading(data, factor, init, last, nt_min=40, n_uarlag=4):
+    """`estimate_factor_loading!` (dfm_functions.ipynb:391-415): every column of `data` (raw units) on
+    [F 1] over complete cases of the window; AR(n_uarlag) of the residuals.  Series with too few rows
+    are returned as NaN (the reference leaves stale values there - SURVEY App. D.5)."""
+    data = np.asarray(data, float)
+    ns_all, r = data.shape[1], factor.shape[1]
+    lam = np.full((ns_all, r), np.nan)
+    r2 = np.full(ns_all, np.nan)
+    uar_coef = np.full((ns_all, n_uarlag), np.nan)
+    uar_ser = np.full(ns_all, np.nan)
+    F = factor[init - 1: last]
+    for i in range(ns_all):
+        y = data[init - 1: last, i]
+        ok = ~np.isnan(y) & ~np.isnan(F).any(axis=1)
+        if ok.sum() >= nt_min:
+            X = np.column_stack([F[ok], np.ones(ok.sum())])
+            b, u = _ols(y[ok], X)
+            lam[i] = b[:-1]
+            r2[i] = compute_r2(y[ok], u)
+            if r2[i] < 0.9999:
+                uar_coef[i], uar_ser[i] = uar(u, n_uarlag)
+            else:
+                uar_coef[i], uar_ser[i] = 0.0, 0.0
+    return lam, r2, uar_coef, uar_ser
+
+
+def estimate_var(y, nlag, init, last, withconst=True):
+    """`estimate_var!` + `fill_matrices!` (dfm_functions.ipynb:444-492)."""
+    y = np.asarray(y, float)
+    yr = y[init - 1: last]
+    ns = yr.shape[1]
+    x = lagmat(yr, range(1, nlag + 1))
+    if withconst:
+        x = np.column_stack([np.ones(yr.shape[0]), x])
+    ok = ~np.isnan(x).any(axis=1) & ~np.isnan(yr).any(axis=1)
+    beta, e = _ols(yr[ok], x[ok])
+    T_used, K = int(ok.sum()), x.shape[1]
+    seps = e.T @ e / (T_used - K)
+    resid = np.full(y.shape, np.nan)
+    resid[init - 1 + np.flatnonzero(ok)] = e
+    b = beta[1:].T if withconst else beta.T                       # (:481 always drops row 1; App. D.6)
+    M = np.zeros((ns * nlag, ns * nlag))
+    M[:ns] = b
+    M[ns:, :-ns] = np.eye(ns * nlag - ns)
+    Q = np.zeros((ns, ns * nlag))
+    Q[:, :ns] = np.eye(ns)
+    G = np.zeros((ns * nlag, ns))
+    G[:ns] = np.linalg.cholesky(seps)                             # cholesky(seps).U' = lower factor
+    return dict(betahat=beta, seps=seps, resid=resid, M=M, Q=Q, G=G, T_used=T_used)
+
+
+def impulse_response(M, Q, G, shock_ids, H):
+    """dfm_functions.ipynb:793-816: irf[:, t, k] = Q M^t G[:, shock_k]."""
+    out = np.empty((Q.shape[0], H, len(shock_ids)))
+    for k, s in enumerate(shock_ids):
+        x = G[:, s].copy()
+        for t in range(H):
+            out[:, t, k] = Q @ x
+            x = M @ x
+    return out
+
+
+# ----------------------------------------------------------------------------- number of factors
+def bai_ng_criterion(ssr, nobs, T, r):
+    """dfm_functions.ipynb:648-654 (ICp2 with nbar = nobs / T)."""
+    nbar = nobs / T
+    g = np.log(min(nbar, T)) * (nbar + T) / nobs
+    return float(np.log(ssr / nobs) + r * g)
+
+
+def amengual_watson_test(data, inclcode, factor, init, last, nlag=4, tol=1e-8, nt_min=20, solver="normal"):
+    """dfm_functions.ipynb:734-768: residuals of each included series on [1, lags 1..nlag of the static
+    factors] (all rows of the data), then ALS with k = 1..r dynamic factors on the residual panel over
+    rows init+4..last."""
+    data = np.asarray(data, float)
+    est = data[:, np.asarray(inclcode).ravel() == 1]
+    T_all, ns = est.shape
+    r = factor.shape[1]
+    x = np.column_stack([np.ones(T_all), lagmat(factor, range(1, nlag + 1))])
+    okx = ~np.isnan(x).any(axis=1)
+    res = np.full((T_all, ns), np.nan)
+    for i in range(ns):
+        ok = okx & ~np.isnan(est[:, i])
+        if ok.sum() - x.shape[1] >= nt_min:
+            _, e = _ols(est[ok, i], x[ok])
+            res[ok, i] = e
+    aw, ssr = np.empty(r), np.empty(r)
+    for k in range(1, r + 1):
+        o = estimate_factor(res, np.ones(ns, int), init + 4, last, k, tol, nt_min, solver=solver,
+                            compute_r2_flag=False)
+        aw[k - 1] = bai_ng_criterion(o["ssr"], o["nobs"], o["T"], k)
+        ssr[k - 1] = o["ssr"]
+    return aw, ssr
+
+
+def estimate_factor_numbers(data, inclcode, init, last, max_nfac, tol=1e-8, nt_min=20, nlag=4,
+                            solver="normal", with_aw=True):
+    """dfm_functions.ipynb:698-725."""
+    bn = np.empty(max_nfac)
+    ssr = np.empty(max_nfac)
+    aw = np.full((max_nfac, max_nfac), np.nan)
+    tss = nobs = T = None
+    for r in range(1, max_nfac + 1):
+        o = estimate_factor(data, inclcode, init, last, r, tol, nt_min, solver=solver, compute_r2_flag=False)
+        bn[r - 1] = bai_ng_criterion(o["ssr"], o["nobs"], o["T"], r)
+        ssr[r - 1] = o["ssr"]
+        tss, nobs, T = o["tss"], o["nobs"], o["T"]
+        if with_aw:
+            aw[:r, r - 1], _ = amengual_watson_test(data, inclcode, o["factor"], init, last, nlag, tol, nt_min,
+                                                    solver)
+    return dict(bn_icp=bn, ssr_static=ssr, aw_icp=aw, tss=tss, nobs=nobs, T=T)
+
+
+def canonical_correlations(X: np.ndarray, Y: np.ndarray) -> np.ndarray:
+    """Canonical correlations of two column-variable data sets (observations in rows), centred - what
+    `correlations(fit(CCA, X', Y'; method=:svd))` returns in the driver (Stock_Watson.ipynb:1300-1309)."""
+    qx, _ = np.linalg.qr(X - X.mean(axis=0))
+    qy, _ = np.linalg.qr(Y - Y.mean(axis=0))
+    return np.linalg.svd(qx.T @ qy, compute_uv=False)
