@@ -23,9 +23,11 @@ struct dfm_handle {
     std::vector<hipEvent_t> ev_sub;        // collapse of sub-batch s done
     int subbatch = 0;                      // DFM_SUBBATCH: sub-batches per fast pass (0 = automatic)
     bool force_general = false;            // DFM_FORCE_GENERAL=1: never take the balanced fast path
-    int collapse_variant = 0;              // DFM_COLLAPSE_VARIANT: ring/row-block tuning of collapse_dma
+    int collapse_variant = 0;              // DFM_COLLAPSE_VARIANT: 0 = automatic; 1..199 VALU kernel tunings; 200 = MFMA kernel
+    int collapse_split = 1;                // DFM_COLLAPSE_SPLIT: workgroups per replicate of the MFMA collapse (1..4)
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
+    bool no_fuse_gram = false;             // DFM_NO_FUSE_GRAM=1: separate gram_kernel launch (diagnostics)
     void* ws = nullptr;
     size_t ws_bytes = 0;
     char err[512] = {0};
@@ -121,7 +123,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.f_llc = take(off, (size_t)B * d);
         p.f_fill = take(off, (size_t)B * 2 * sizeof(int));
         p.f_PsInf = take(off, B * rr * d);
-        p.f_ssum = take(off, (size_t)B * 4 * d);
+        p.f_ssum = take(off, (size_t)B * kSsumSlots * d);
     } else {
         p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
     }
@@ -254,12 +256,21 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     fa.xi0 = at<double>(h, p.f_xi0); fa.PT = at<double>(h, p.f_PT); fa.llc = at<double>(h, p.f_llc);
     fa.fill = at<int>(h, p.f_fill); fa.PsInf = at<double>(h, p.f_PsInf);
     fa.bcol = ca.bcol; fa.ssum = ca.ssum; fa.wtab = at<double>(h, p.wtab);
+    // collapse kernel of the balanced path: contraction on the matrix pipe where the shape allows it
+    // (collapse_mfma.hip), else the VALU kernel (collapse_dma.hip); DFM_COLLAPSE_VARIANT < 200 forces the latter
+    const bool use_mfma = collapse_mfma_supported(p.Rp, N) && (h->collapse_variant == 0 || h->collapse_variant >= 200);
+    const int cvariant = use_mfma ? (h->collapse_variant >= 200 ? h->collapse_variant : 200)
+                                  : (h->collapse_variant == 199 ? 0 : h->collapse_variant);   // 199: the VALU kernel's default
+    ca.split = use_mfma ? h->collapse_split : 1;
+    fa.nseg = 4 * (ca.split > 0 ? ca.split : 1);
+    const bool fuse_gram = cov_fuses_gram(p.Rp, N) && !h->no_fuse_gram;
+    if (fuse_gram) { fa.Lam = pp.Lam; fa.Rv = Rv; }
     fa.f_smooth = f_smooth; fa.P_smooth = P_smooth; fa.loglik = loglik;
     fa.abl = h->scan_abl;
     if (h->no_side) {   // diagnostics: everything in order on the main stream
-        { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }
+        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }
         { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
-        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, h->collapse_variant)); }
+        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
         return 0;
     }
@@ -268,12 +279,15 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     int S = h->subbatch > 0 ? h->subbatch : 1;
     if (S > B) S = B;
     if (S == 1) {
+        // The covariance kernel (128 waves, 224 VGPRs each) must be resident BEFORE the streaming collapse fills
+        // every CU, or it waits for the collapse to drain (measured: 285 us instead of 90).  It therefore goes
+        // first on the caller's stream, and the collapse is the forked work: its queue starts ~6 us later.
         HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, launch_gram(p.Rp, ca, h->side)); }
-        { ProfScope ps(h, K_COV, h->side); HIP_TRY(h, launch_cov(p.Rp, fa, h->side)); }
+        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }
+        { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
+        { ProfScope ps(h, K_COLLAPSE_DMA, h->side); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->side, cvariant)); }
         HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
-        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, h->collapse_variant)); }
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
         return 0;
@@ -287,7 +301,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_fork, 0));
-    { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, launch_gram(p.Rp, ca, h->side)); }
+    if (!fuse_gram) { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, launch_gram(p.Rp, ca, h->side)); }
     { ProfScope ps(h, K_COV, h->side); HIP_TRY(h, launch_cov(p.Rp, fa, h->side)); }
     HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
     HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));
@@ -295,7 +309,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         const int b0 = (int)((long long)B * s / S), b1 = (int)((long long)B * (s + 1) / S);
         CollapseArgs cs = ca;
         cs.b0 = b0; cs.B = b1 - b0;
-        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, cs, h->stream, h->collapse_variant)); }
+        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, cs, h->stream, cvariant)); }
         HIP_TRY(h, hipEventRecord(h->ev_sub[s], h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_sub[s], 0));
         FastArgs fs = fa;
@@ -467,7 +481,11 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
             h->own_stream = true;
         }
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+    if (e == hipSuccess) {   // the side stream carries the short latency-bound kernels (gram, cov) the scan waits for:
+        int lo = 0, hi = 0;      // highest priority, so that their workgroups are placed ahead of the streaming collapse
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, hi);
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->post, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_post, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
@@ -478,7 +496,9 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     }
     if (const char* v = getenv("DFM_FORCE_GENERAL")) h->force_general = atoi(v) != 0;
     if (const char* v = getenv("DFM_COLLAPSE_VARIANT")) h->collapse_variant = atoi(v);
+    if (const char* v = getenv("DFM_COLLAPSE_SPLIT")) { h->collapse_split = atoi(v); if (h->collapse_split < 1 || h->collapse_split > 4) h->collapse_split = 1; }
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
+    if (const char* v = getenv("DFM_NO_FUSE_GRAM")) h->no_fuse_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_SUBBATCH")) h->subbatch = atoi(v);
     if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
     *out = h;

@@ -50,7 +50,11 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 __device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <int R, int CPL2, int RB, int NP, int ABL = 0>
+// OPT bits (tuning, measured with scripts/microbench/colbw.hip): 1 = wave segments start on 128-byte
+// boundaries (rows per wave rounded to a multiple of 128 / gcd(8N, 128)); 2 = the first ring fill is
+// issued before the loading weights are fetched; 4 = no filler DMAs past the end of the segment (the
+// last row blocks drain with vmcnt(0) instead).
+template <int R, int CPL2, int RB, int NP, int ABL = 0, int OPT = 0>
 __global__ __launch_bounds__(256) void collapse_dma_kernel(CollapseArgs a) {
     // ring of NP 1-KiB pieces per wave; a row block spans at most RB * CPL2 + 1 pieces
     static_assert((NP & (NP - 1)) == 0 && NP >= 2 * RB * CPL2, "ring: power of two, two row blocks deep");
@@ -65,29 +69,16 @@ __global__ __launch_bounds__(256) void collapse_dma_kernel(CollapseArgs a) {
     const double* __restrict__ L = a.Lam + (size_t)b * N * R;
     const double* __restrict__ Rv = a.Rv + (size_t)b * N;
 
-    double W[CPL2][2][R];
-    double Ri[CPL2][2];
-#pragma unroll
-    for (int j = 0; j < CPL2; ++j)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int c = 2 * lane + 128 * j + e;
-            const bool own = c < N;
-            const int cc = own ? c : N - 1;       // clamped: unconditional loads, no branch per element
-            const double ri = own ? 1.0 / Rv[cc] : 0.0;
-            Ri[j][e] = ri;
-#pragma unroll
-            for (int k = 0; k < R; ++k) W[j][e][k] = L[(size_t)cc * R + k] * ri;
-        }
-
     // this wave's periods [ta, tb): one contiguous byte stream of the panel
-    const int tq = (T + 3) / 4;
-    const int ta = wave * tq;
-    const int tb = (ta + tq < T) ? ta + tq : T;
-    if (ta >= tb) {
-        if (lane == 0) a.ssum[(size_t)b * 4 + wave] = 0.0;
-        return;
+    int tq = (T + 3) / 4;
+    if constexpr ((OPT & 1) != 0) {            // segment starts on 128-byte boundaries
+        unsigned g = rowB & 127u;              // gcd(rowB, 128) for rowB a multiple of 16
+        g = g == 0 ? 128u : (g & (~g + 1u));
+        const int m = (int)(128u / g);
+        tq = ((tq + m - 1) / m) * m;
     }
+    const int ta = (wave * tq < T) ? wave * tq : T;
+    const int tb = (ta + tq < T) ? ta + tq : T;
     const int nrows = tb - ta;
     const int nblk = (nrows + RB - 1) / RB;
     const unsigned segB = (unsigned)nrows * rowB;
@@ -103,16 +94,51 @@ __global__ __launch_bounds__(256) void collapse_dma_kernel(CollapseArgs a) {
 #pragma unroll
     for (int j = 0; j < CPL2; ++j) act[j] = (128 * j + 2 * lane) < N;
 
-    // piece p -> ring slot p mod NP.  Pieces past the end of the segment re-load the last piece: they only
-    // keep the number of in-flight DMAs constant so that one fixed vmcnt threshold is valid to the end.
+    // piece p -> ring slot p mod NP.  Without OPT&4, pieces past the end of the segment re-load the last
+    // piece: they only keep the number of in-flight DMAs constant so that one fixed vmcnt threshold is valid
+    // to the end.  With OPT&4 nothing is issued past the end and the tail blocks drain with vmcnt(0).
     auto issue_piece = [&](int p) {
+        if constexpr ((OPT & 4) != 0) {
+            if (p >= npiece) return;
+        }
         const int pc = p < npiece ? p : npiece - 1;
         const unsigned off = (unsigned)pc * 1024u + lane16;
         if (off < segB) dma16(seg + off, __builtin_amdgcn_readfirstlane(ring_lds + ((unsigned)p & (NP - 1)) * 1024u));
     };
     int issued = 0;
+    if constexpr ((OPT & 2) != 0) {
+        if (nrows > 0) {
 #pragma unroll
-    for (int s = 0; s < NP; ++s) issue_piece(issued++);
+            for (int s = 0; s < NP; ++s) issue_piece(issued++);
+        }
+    }
+
+    double W[CPL2][2][R];
+    double Ri[CPL2][2];
+#pragma unroll
+    for (int j = 0; j < CPL2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = 2 * lane + 128 * j + e;
+            const bool own = c < N;
+            const int cc = own ? c : N - 1;       // clamped: unconditional loads, no branch per element
+            const double ri = own ? 1.0 / Rv[cc] : 0.0;
+            Ri[j][e] = ri;
+#pragma unroll
+            for (int k = 0; k < R; ++k) W[j][e][k] = L[(size_t)cc * R + k] * ri;
+        }
+    // (OPT & 2: the weights were fetched behind the first ring fill; loads return in order, so the counted
+    // wait of the first row block -- at most KWAIT of the YOUNGEST operations outstanding -- still implies
+    // that every piece of the first fill has landed)
+
+    if (nrows <= 0) {
+        if (lane == 0) a.ssum[(size_t)b * kSsumSlots + wave] = 0.0;
+        return;
+    }
+    if constexpr ((OPT & 2) == 0) {
+#pragma unroll
+        for (int s = 0; s < NP; ++s) issue_piece(issued++);
+    }
 
     constexpr int NV = RB * R;
     bool canon;
@@ -126,7 +152,24 @@ __global__ __launch_bounds__(256) void collapse_dma_kernel(CollapseArgs a) {
         const int r0 = blk * RB;
         // all pieces below ceil((r0 + RB) rowB / 1024) have landed once at most KWAIT younger DMAs are
         // outstanding (loads complete in order; outstanding stores only make this wait longer)
-        wait_vmcnt<KWAIT>();
+        // The row-block store of b_t is a VMEM operation too and sits between the re-arm DMAs of successive
+        // blocks: with OPT&8 the counted wait allows for the (at most two) stores younger than the pieces this
+        // block needs -- gfx9 returns loads and stores of one wave in issue order on the single vmcnt counter.
+        auto counted_wait = [&]() {
+            if constexpr ((OPT & 8) != 0 && KWAIT + 2 <= 63) {
+                if (blk >= 2) wait_vmcnt<KWAIT + 2>();
+                else if (blk == 1) wait_vmcnt<KWAIT + 1>();
+                else wait_vmcnt<KWAIT>();
+            } else {
+                wait_vmcnt<KWAIT>();
+            }
+        };
+        if constexpr ((OPT & 4) != 0) {
+            if (issued >= npiece) wait_vmcnt<0>();        // wave-uniform: every real piece is issued, drain
+            else counted_wait();
+        } else {
+            counted_wait();
+        }
         double2 xs[RB][CPL2];
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
@@ -185,6 +228,10 @@ __global__ __launch_bounds__(256) void collapse_dma_kernel(CollapseArgs a) {
         }
         wave_transpose_reduce<NV>(acc, lane);
         const int t = ta + r0 + my_rr;
+        if constexpr (ABL == 3) {          // ablation: everything but the store
+            if (acc[0] == 1.2345e300) a.bcol[(size_t)b * T + ta + blk] = acc[0];
+            continue;
+        }
         if (canon && t < tb) a.bcol[((size_t)b * T + t) * R + my_k] = acc[0];
     }
     wait_vmcnt<0>();   // drain the trailing DMAs before the LDS is released
@@ -194,7 +241,7 @@ __global__ __launch_bounds__(256) void collapse_dma_kernel(CollapseArgs a) {
     for (int j = 0; j < CPL2; ++j) sp = fma(q[j][0], Ri[j][0], fma(q[j][1], Ri[j][1], sp));
     sp = wave_allsum(sp);
     if (lane == 0) {
-        a.ssum[(size_t)b * 4 + wave] = sp;
+        a.ssum[(size_t)b * kSsumSlots + wave] = sp;
         if (sp != sp) atomicOr(a.status, 1);   // NaN in the panel on the balanced path
     }
 }
@@ -230,18 +277,18 @@ __global__ __launch_bounds__(64) void gram_kernel(CollapseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int R, int CPL2, int RB, int NP, int ABL = 0>
+template <int R, int CPL2, int RB, int NP, int ABL = 0, int OPT = 0>
 static hipError_t launch_dma_one(const CollapseArgs& a, hipStream_t s) {
     const size_t lds = (size_t)4 * NP * 1024;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_dma_kernel<R, CPL2, RB, NP, ABL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_dma_kernel<R, CPL2, RB, NP, ABL, OPT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((collapse_dma_kernel<R, CPL2, RB, NP, ABL>), dim3(a.B), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((collapse_dma_kernel<R, CPL2, RB, NP, ABL, OPT>), dim3(a.B), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -254,7 +301,8 @@ constexpr int ring_pieces(int rb, int cpl2) {   // smallest power of two >= 2 * 
 template <int R>
 static hipError_t launch_dma_r(const CollapseArgs& a, hipStream_t s, int variant) {
     constexpr int RB = (R <= 4) ? 8 : (R <= 8) ? 4 : (R <= 16) ? 2 : 1;
-    if (a.N <= 128) return launch_dma_one<R, 1, RB, ring_pieces(RB, 1)>(a, s);
+    // defaults carry OPT = 7 (aligned segments, fill before weights, no filler DMAs): -6 % at the headline shape
+    if (a.N <= 128) return launch_dma_one<R, 1, RB, ring_pieces(RB, 1), 0, 7>(a, s);
     if (a.N <= 256) {
         if constexpr (R == 8) {   // tuning variants of the headline shape (DFM_COLLAPSE_VARIANT)
             if (variant == 1) return launch_dma_one<8, 2, 4, 32>(a, s);
@@ -264,14 +312,31 @@ static hipError_t launch_dma_r(const CollapseArgs& a, hipStream_t s, int variant
             if (variant == 11) return launch_dma_one<8, 2, 4, 16, 2>(a, s);
             if (variant == 12) return launch_dma_one<8, 2, 2, 8, 1>(a, s);
             if (variant == 13) return launch_dma_one<8, 2, 2, 8, 2>(a, s);
+#ifdef DFM_MFMA_BENCH_ONLY
+            if (variant >= 100 && variant < 116) {   // 100 + OPT: <8,2,4,16> with tuning bits
+                switch (variant - 100) {
+#define DFM_V(o) case o: return launch_dma_one<8, 2, 4, 16, 0, o>(a, s);
+                    DFM_V(0) DFM_V(1) DFM_V(2) DFM_V(3) DFM_V(4) DFM_V(5) DFM_V(6) DFM_V(7)
+                    DFM_V(8) DFM_V(9) DFM_V(10) DFM_V(11) DFM_V(12) DFM_V(13) DFM_V(14) DFM_V(15)
+#undef DFM_V
+                    default: break;
+                }
+            }
+            if (variant == 20) return launch_dma_one<8, 2, 4, 16, 3, 7>(a, s);    // no store
+            if (variant == 21) return launch_dma_one<8, 2, 4, 16, 2, 7>(a, s);    // no reduce, no store
+            if (variant == 22) return launch_dma_one<8, 2, 4, 16, 1, 7>(a, s);    // DMA + LDS read only
+            if (variant == 23) return launch_dma_one<8, 2, 2, 16, 0, 15>(a, s);
+            if (variant == 24) return launch_dma_one<8, 2, 2, 8, 0, 15>(a, s);
+            if (variant == 25) return launch_dma_one<8, 2, 4, 32, 0, 15>(a, s);
+#endif
         }
-        return launch_dma_one<R, 2, RB, ring_pieces(RB, 2)>(a, s);
+        return launch_dma_one<R, 2, RB, ring_pieces(RB, 2), 0, 7>(a, s);
     }
     if constexpr (R <= 16) {
-        if (a.N <= 512) return launch_dma_one<R, 4, RB, ring_pieces(RB, 4)>(a, s);
+        if (a.N <= 512) return launch_dma_one<R, 4, RB, ring_pieces(RB, 4), 0, 7>(a, s);
     }
     if constexpr (R <= 8) {
-        if (a.N <= 1024) return launch_dma_one<R, 8, RB / 2, ring_pieces(RB / 2, 8)>(a, s);
+        if (a.N <= 1024) return launch_dma_one<R, 8, RB / 2, ring_pieces(RB / 2, 8), 0, 7>(a, s);
     }
     return hipErrorInvalidValue;
 }
@@ -279,6 +344,7 @@ static hipError_t launch_dma_r(const CollapseArgs& a, hipStream_t s, int variant
 bool collapse_dma_supported(int Rpad, int N) { return (N % 2 == 0) && N <= collapse_max_n(Rpad); }
 
 hipError_t launch_collapse_dma(int Rpad, const CollapseArgs& a, hipStream_t s, int variant) {
+    if (variant >= 200 && variant < 300 && collapse_mfma_supported(Rpad, a.N)) return launch_collapse_mfma(Rpad, a, s, variant - 200);
     switch (Rpad) {
         case 2: return launch_dma_r<2>(a, s, variant);
         case 4: return launch_dma_r<4>(a, s, variant);

@@ -12,6 +12,8 @@ namespace dfm {
 // embedded by pad_params_kernel (extra states: A = 0, Q = I, P0 = I, mu0 = 0, Lam = 0 -- independent
 // unit-variance noise states that no series loads on; every determinant / quadratic form they add
 // is exactly 0), so kernels are instantiated for a handful of sizes only.
+constexpr int kSsumSlots = 16;
+
 struct CollapseArgs {
     int B, T, N;
     int b0;               // collapse_dma only: first replicate of this launch (sub-batch pipelining)
@@ -26,7 +28,8 @@ struct CollapseArgs {
     double* Cfull;        // [B][Rp][Rp]
     double* ldfull;       // [B]
     int* status;          // bit0: NaN met while Ct == nullptr
-    double* ssum;         // [B][4]  collapse_dma only: sum_t s_t of each wave's periods
+    double* ssum;         // [B][kSsumSlots]  balanced path only: sum_t s_t of each wave's periods (slots 0 .. nseg-1)
+    int split;            // collapse_mfma only: workgroups per replicate (0 = 1); nseg = 4 * split <= kSsumSlots
 };
 
 struct RecursionArgs {
@@ -77,6 +80,9 @@ int collapse_max_n(int Rpad);
 bool collapse_dma_supported(int Rpad, int N);
 hipError_t launch_collapse_dma(int Rpad, const CollapseArgs& a, hipStream_t s, int variant);
 hipError_t launch_gram(int Rpad, const CollapseArgs& a, hipStream_t s);
+// same contract as launch_collapse_dma, contraction on the fp64 matrix pipe (collapse_mfma.hip)
+bool collapse_mfma_supported(int Rpad, int N);
+hipError_t launch_collapse_mfma(int Rpad, const CollapseArgs& a, hipStream_t s, int variant);
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
 hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
 bool mstep_needs_dmiss(int Rpad, int N);
@@ -86,7 +92,8 @@ bool mstep_needs_dmiss(int Rpad, int N);
 struct FastArgs {
     int B, T, N, r, L;          // r = caller's factor count for the outputs; L = chunk length (power of 2)
     const double* A; const double* Q; const double* mu0; const double* P0;   // [B][Rp][Rp] / [B][Rp]
-    const double* Cfull; const double* ldfull;                               // gram_kernel outputs
+    const double* Cfull; const double* ldfull;                               // gram_kernel outputs (Lam == nullptr)
+    const double* Lam; const double* Rv;                                     // or: cov_kernel computes them itself
     // cov_kernel -> meanscan_kernel
     double* tab;                // [B][T][3][Rp][Rp]  Z_e, J_e, G_e of the distinct covariance steps
     int* E;                     // [B]  number of distinct steps; step t uses entry min(t, E-1)
@@ -98,7 +105,8 @@ struct FastArgs {
     double* PsInf;              // [B][Rp][Rp]
     double* SP11; double* SU; double* P0s;   // EM covariance sums (or null)
     // collapse -> meanscan
-    const double* bcol; const double* ssum;                                  // ssum [B][4]
+    const double* bcol; const double* ssum;                                  // ssum [B][kSsumSlots]
+    int nseg;                   // slots of ssum that were written
     double* wtab;               // [B][T][Rp] scratch
     // outputs
     double* f_smooth; double* P_smooth; double* loglik;
@@ -107,6 +115,7 @@ struct FastArgs {
     int abl;                    // diagnostics (DFM_SCAN_ABL): bit0 skip the P_smooth fill, bit1 skip the scans
 };
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
+bool cov_fuses_gram(int Rpad, int N);   // launch_cov with a.Lam != nullptr is supported for this shape
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);
 int fast_chunk_len(int Rpad, int T);
 int fast_stead_mats(int Rpad);

@@ -21,6 +21,7 @@
 // r x r matrix-vector products inside a lane group use no LDS: lane i holds M[i][i^s], s = 0..R-1,
 // and fetches x[i^s] with DPP row operations (xor_lane in dfm_device.h).
 // The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
+#include "dfm_gram.h"
 #include "dfm_kernels.h"
 #include "dfm_smallmat.h"
 
@@ -45,7 +46,11 @@ struct CovLayout {
     static constexpr size_t lds_bytes() { return (size_t)GPW * S * sizeof(double); }
 };
 
-template <int R>
+// CPL2 > 0: the Gram matrices C = Lam' R^-1 Lam and sum log R of the wave's replicates are computed here first,
+// one after the other by the whole wave (lane l owns series {2l, 2l+1} + 128 j, j < CPL2), instead of by a
+// separate gram_kernel launch: beside the streaming collapse, which fills every CU, a second dependent launch
+// on the side stream waits ~150 us for free registers.
+template <int R, int CPL2>
 __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
     using LY = CovLayout<R>;
     constexpr int GPW = LY::GPW;
@@ -67,6 +72,37 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
 
     const size_t mo = (size_t)b * R * R + (size_t)i * R;     // row i of a [B][R][R] array
     double* tab = a.tab + (size_t)b * T * 3 * R * R;
+    double ldfull_b = 0.0;
+    if constexpr (CPL2 > 0) {
+        const int N = a.N;
+        for (int rep = 0; rep < GPW; ++rep) {
+            int bb = blockIdx.x * GPW + rep;
+            if (bb >= a.B) bb = a.B - 1;
+            const double* __restrict__ L = a.Lam + (size_t)bb * N * R;
+            const double* __restrict__ Rv = a.Rv + (size_t)bb * N;
+            double W[CPL2][2][R];
+            bool own[CPL2][2];
+            double ld = 0.0;
+#pragma unroll
+            for (int j = 0; j < CPL2; ++j)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int c = 2 * lane + 128 * j + e;
+                    own[j][e] = c < N;
+                    const int cc = own[j][e] ? c : N - 1;
+                    const double rv = own[j][e] ? Rv[cc] : 1.0;
+                    const double ri = own[j][e] ? 1.0 / rv : 0.0;
+                    ld += log(rv);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) W[j][e][k] = L[(size_t)cc * R + k] * ri;
+                }
+            double* Cdst = smem + (size_t)rep * LY::S + 5 * R * R;     // K2 of lane group `rep`
+            c_all<R, CPL2, 0, true>(W, L, own, lane, Cdst);
+            ld = wave_allsum(ld);
+            if (g == rep) ldfull_b = ld;
+        }
+        __syncthreads();
+    }
     double detQ, detP0, q0;
     double PsiT[R], Omf[R];
     {
@@ -76,7 +112,7 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
             Arow[j] = a.A[mo + j];
             Qi[j] = a.Q[mo + j];
             Omf[j] = a.P0[mo + j];
-            K2[i * R + j] = a.Cfull[mo + j];
+            if constexpr (CPL2 == 0) K2[i * R + j] = a.Cfull[mo + j];
         }
         const double mu0i = a.mu0[(size_t)b * R + i];
         detQ = gj_inverse<R>(Qi, X, i);
@@ -177,7 +213,7 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
         for (int j = 0; j < R; ++j) a.PT[mo + j] = Ps[j];
         if (i == 0) {
             const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) - sum_ldz;
-            a.llc[b] = (double)a.N * (double)T * kLog2PiF + (double)T * a.ldfull[b] + LD + q0;
+            a.llc[b] = (double)a.N * (double)T * kLog2PiF + (double)T * (CPL2 > 0 ? ldfull_b : a.ldfull[b]) + LD + q0;
             a.E[b] = E;
         }
     }
@@ -640,27 +676,40 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
         double d = 0.0, sq = 0.0;
 #pragma unroll
         for (int w = 0; w < kScanThreads / 64; ++w) d += s_red[w];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) sq += a.ssum[(size_t)b * 4 + w];
+        for (int w = 0; w < a.nseg; ++w) sq += a.ssum[(size_t)b * kSsumSlots + w];
         a.loglik[b] = -0.5 * (a.llc[b] + sq - d);
     }
 }
 
 // ================================================================================================
-template <int R>
-static hipError_t launch_cov_r(const FastArgs& a, hipStream_t s) {
+template <int R, int CPL2>
+static hipError_t launch_cov_rc(const FastArgs& a, hipStream_t s) {
     using LY = CovLayout<R>;
     const int grid = (a.B + LY::GPW - 1) / LY::GPW;
     static bool attr_done = false;
     if (!attr_done && LY::lds_bytes() > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cov_kernel<R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cov_kernel<R, CPL2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((cov_kernel<R>), dim3(grid), dim3(64), LY::lds_bytes(), s, a);
+    hipLaunchKernelGGL((cov_kernel<R, CPL2>), dim3(grid), dim3(64), LY::lds_bytes(), s, a);
     return hipGetLastError();
 }
+// fused Gram (a.Lam != nullptr) for the series tilings whose weights fit the register file next to the
+// covariance state; otherwise Cfull / ldfull come from gram_kernel
+template <int R>
+static hipError_t launch_cov_r(const FastArgs& a, hipStream_t s) {
+    if (a.Lam != nullptr) {
+        if (a.N <= 128) return launch_cov_rc<R, 1>(a, s);
+        if constexpr (R <= 16) {
+            if (a.N <= 256) return launch_cov_rc<R, 2>(a, s);
+        }
+        return hipErrorInvalidValue;
+    }
+    return launch_cov_rc<R, 0>(a, s);
+}
+bool cov_fuses_gram(int Rpad, int N) { return N <= 128 || (Rpad <= 16 && N <= 256); }
 template <int R>
 static hipError_t launch_scan_r(const FastArgs& a, hipStream_t s) {
     const size_t lds = ScanLds<R>::bytes();

@@ -146,3 +146,53 @@ def test_linearity_in_the_data_full_size(ctx):
     assert torch.allclose(f3, f1 + f1.flip(0), rtol=1e-10, atol=1e-12)
     assert torch.equal(P1, P2)
     assert torch.allclose(P1[0], P1[-1], rtol=0, atol=0)
+
+
+# ---- balanced panels: the fast path (collapse on the matrix pipe / VALU LDS-DMA kernel, time-parallel scan) ------
+BALANCED_SHAPES = [
+    (5, 40, 50, 4), (3, 64, 48, 12), (4, 30, 41, 3), (3, 20, 25, 1), (3, 50, 7, 2), (2, 20, 3, 2), (2, 20, 2, 4),
+    (9, 200, 222, 8),          # Stock-Watson window length, headline cross-section
+    (3, 38, 33, 8),            # N not a multiple of the 8 series of an MFMA step (clamped last step)
+    (2, 130, 37, 5),           # two DMAs per period, r padded 5 -> 8, T = 1 mod 4
+    (2, 512, 19, 3),           # four DMAs per period, 16 series per step, 32 steps
+    (3, 6, 9, 2), (2, 4, 3, 1),
+    (2, 400, 50, 16),          # too many MFMA steps for the register file: VALU kernel
+    (2, 1000, 64, 8),          # 8N > 4 KiB rows: VALU kernel, 8-chunk tiling
+    (2, 100, 40, 20),          # r padded to 32: VALU kernel
+]
+
+
+def _ctx_with_env(**env):
+    import os
+    from dynamic_factor_models_amd import DfmContext
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return DfmContext()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("B,N,T,r", BALANCED_SHAPES)
+def test_balanced_fast_path_matches_oracle(ctx, B, N, T, r):
+    panel, st = _batch(B, N, T, r, 0.0)
+    ref = _oracle(panel, st)
+    _compare(_run_dev(ctx, panel, st, may_have_missing=False), ref, f"fast B={B} N={N} T={T} r={r}")
+
+
+@pytest.mark.parametrize("env", [dict(DFM_COLLAPSE_VARIANT=199), dict(DFM_COLLAPSE_SPLIT=3), dict(DFM_COLLAPSE_SPLIT=4),
+                                 dict(DFM_FORCE_GENERAL=1)])
+def test_balanced_kernel_choices_agree(env):
+    """The VALU collapse, the MFMA collapse with 1/3/4 workgroups per replicate and the general
+    (sequential) path are the same function of the inputs."""
+    c = _ctx_with_env(**env)
+    try:
+        for (B, N, T, r) in [(5, 200, 500, 8), (3, 64, 48, 12), (4, 30, 41, 3), (3, 50, 7, 2), (2, 130, 37, 5)]:
+            panel, st = _batch(B, N, T, r, 0.0)
+            _compare(_run_dev(c, panel, st, may_have_missing=False), _oracle(panel, st), f"{env} N={N} T={T} r={r}")
+    finally:
+        c.close()
