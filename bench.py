@@ -166,16 +166,19 @@ def main():
         b_in, b_out = algorithmic_bytes(N, T, r)
         panel_b = 8 * (N * T + N * r + N)                      # panel + loadings + idiosyncratic variances
         # algorithmic bytes per launch (DESIGN.md "Kernels"): compulsory inputs read once + outputs written once
-        kern_bytes = {"collapse_dma_kernel": B * panel_b, "collapse_kernel": B * panel_b,
+        npack = r * (r + 1) // 2
+        kern_bytes = {"collapse_mfma_kernel": B * panel_b, "collapse_dma_kernel": B * panel_b,
+                      "collapse_kernel": B * panel_b,
                       "recursion_kernel": B * (b_in - panel_b + b_out),
-                      "meanscan_kernel": B * (b_in - panel_b + b_out),
+                      "meanscan_kernel": B * (b_in - panel_b + 8 * (T * r + 1)),
+                      "pfill_kernel": B * 8 * T * npack,
                       "gram_kernel": B * 8 * (N * r + N), "cov_kernel": B * 8 * (3 * r * r + r)}
         avg = {k: v[0] / v[1] for k, v in prof.items()}
-        dom = max((k for k in avg if k in ("collapse_dma_kernel", "collapse_kernel", "recursion_kernel",
-                                            "meanscan_kernel")), key=avg.get)
+        dom = max((k for k in avg if k in ("collapse_mfma_kernel", "collapse_dma_kernel", "collapse_kernel",
+                                            "recursion_kernel", "meanscan_kernel")), key=avg.get)
         achieved = kern_bytes.get(dom, 0) / (avg[dom] * 1e-3) / 1e9
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")   # rocprofv3 --pmc passes (scripts/gpu_pmc.sh)
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")   # rocprofv3 --pmc passes (scripts/gpu_profile.sh)
         if os.path.exists(pmc_file) and (B, N, T, r, may_missing) == (1024, 200, 500, 8, False):
             try:
                 with open(pmc_file) as fh:
@@ -186,7 +189,8 @@ def main():
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         avg_launch_ms=avg[dom], bytes_per_launch=kern_bytes.get(dom, 0),
                         kernels_ms={k: round(v, 4) for k, v in avg.items()},
-                        note="gram/cov run on a side stream beside the collapse; their durations overlap it",
+                        note="cov_kernel and pfill_kernel run beside the streaming collapse (forked stream); their "
+                             "durations overlap it and each other's memory traffic",
                         whole_pass=dict(bytes_per_pass=b_in + b_out,
                                         achieved=B * (b_in + b_out) / (ms_per_step * 1e-3) / 1e9,
                                         frac=B * (b_in + b_out) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -24,10 +24,13 @@ struct dfm_handle {
     int subbatch = 0;                      // DFM_SUBBATCH: sub-batches per fast pass (0 = automatic)
     bool force_general = false;            // DFM_FORCE_GENERAL=1: never take the balanced fast path
     int collapse_variant = 0;              // DFM_COLLAPSE_VARIANT: 0 = automatic; 1..199 VALU kernel tunings; 200 = MFMA kernel
-    int collapse_split = 1;                // DFM_COLLAPSE_SPLIT: workgroups per replicate of the MFMA collapse (1..4)
+    int collapse_wpr = 0;                  // DFM_COLLAPSE_WPR: period segments (waves) per replicate of the MFMA collapse; 0 = automatic
+    int num_cu = 256;
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
-    bool no_fuse_gram = false;             // DFM_NO_FUSE_GRAM=1: separate gram_kernel launch (diagnostics)
+    bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
+    bool fuse_gram = false;                // DFM_FUSE_GRAM=1: Gram matrices inside cov_kernel instead of gram_kernel (slower: its
+                                           // per-series loads are dependent round trips, ~5 us each beside the collapse)
     void* ws = nullptr;
     size_t ws_bytes = 0;
     char err[512] = {0};
@@ -38,11 +41,11 @@ struct dfm_handle {
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
-                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_COUNT };
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
                                                   "mstep_solve_kernel", "pca_kernels", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
-                                                  "cov_kernel", "meanscan_kernel"};
+                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel"};
 
 namespace {
 
@@ -261,16 +264,25 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     const bool use_mfma = collapse_mfma_supported(p.Rp, N) && (h->collapse_variant == 0 || h->collapse_variant >= 200);
     const int cvariant = use_mfma ? (h->collapse_variant >= 200 ? h->collapse_variant : 200)
                                   : (h->collapse_variant == 199 ? 0 : h->collapse_variant);   // 199: the VALU kernel's default
-    ca.split = use_mfma ? h->collapse_split : 1;
-    fa.nseg = 4 * (ca.split > 0 ? ca.split : 1);
-    const bool fuse_gram = cov_fuses_gram(p.Rp, N) && !h->no_fuse_gram;
+    // MFMA collapse: as many period segments per replicate as the chip has resident wave slots for this batch
+    // (3 workgroups x 4 waves on each CU), so that the launch is one balanced round
+    int wpr = 4;
+    if (use_mfma) {
+        wpr = h->collapse_wpr > 0 ? h->collapse_wpr : (h->num_cu * 12) / B;
+        if (wpr < 1) wpr = 1;
+        if (wpr > 8) wpr = 8;
+        while (wpr > 1 && T / wpr < 8) --wpr;     // keep segments a few row blocks long
+    }
+    ca.wpr = wpr;
+    fa.nseg = use_mfma ? wpr : 4;
+    const bool fuse_gram = cov_fuses_gram(p.Rp, N) && h->fuse_gram;
     if (fuse_gram) { fa.Lam = pp.Lam; fa.Rv = Rv; }
     fa.f_smooth = f_smooth; fa.P_smooth = P_smooth; fa.loglik = loglik;
     fa.abl = h->scan_abl;
     if (h->no_side) {   // diagnostics: everything in order on the main stream
         if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }
         { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
-        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
+        { ProfScope ps(h, use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
         return 0;
     }
@@ -282,12 +294,17 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         // The covariance kernel (128 waves, 224 VGPRs each) must be resident BEFORE the streaming collapse fills
         // every CU, or it waits for the collapse to drain (measured: 285 us instead of 90).  It therefore goes
         // first on the caller's stream, and the collapse is the forked work: its queue starts ~6 us later.
+        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }   // 12 us, alone
         HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }
         { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
-        { ProfScope ps(h, K_COLLAPSE_DMA, h->side); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->side, cvariant)); }
+        { ProfScope ps(h, use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA, h->side); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->side, cvariant)); }
         HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
+        if (!h->no_pfill && P_smooth) {   // the data-independent rows of P_smooth, beside the collapse
+            ProfScope ps(h, K_PFILL);
+            HIP_TRY(h, launch_pfill(p.Rp, fa, h->stream));
+            fa.abl |= 1;
+        }
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
         return 0;
@@ -309,7 +326,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         const int b0 = (int)((long long)B * s / S), b1 = (int)((long long)B * (s + 1) / S);
         CollapseArgs cs = ca;
         cs.b0 = b0; cs.B = b1 - b0;
-        { ProfScope ps(h, K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, cs, h->stream, cvariant)); }
+        { ProfScope ps(h, use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, cs, h->stream, cvariant)); }
         HIP_TRY(h, hipEventRecord(h->ev_sub[s], h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_sub[s], 0));
         FastArgs fs = fa;
@@ -496,9 +513,11 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     }
     if (const char* v = getenv("DFM_FORCE_GENERAL")) h->force_general = atoi(v) != 0;
     if (const char* v = getenv("DFM_COLLAPSE_VARIANT")) h->collapse_variant = atoi(v);
-    if (const char* v = getenv("DFM_COLLAPSE_SPLIT")) { h->collapse_split = atoi(v); if (h->collapse_split < 1 || h->collapse_split > 4) h->collapse_split = 1; }
+    if (const char* v = getenv("DFM_COLLAPSE_WPR")) { h->collapse_wpr = atoi(v); if (h->collapse_wpr < 0 || h->collapse_wpr > kSsumSlots) h->collapse_wpr = 0; }
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
-    if (const char* v = getenv("DFM_NO_FUSE_GRAM")) h->no_fuse_gram = atoi(v) != 0;
+    if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
+    if (const char* v = getenv("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_SUBBATCH")) h->subbatch = atoi(v);
     if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
     *out = h;

@@ -83,11 +83,16 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned long long t_entry = ABL == 2 ? __builtin_amdgcn_s_memtime() : 0ull;
     const unsigned long long rt_entry = ABL == 2 ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    const int split = a.split > 0 ? a.split : 1;             // workgroups per replicate
-    const int b = (int)(blockIdx.x / split) + a.b0;
-    const int part = (int)(blockIdx.x % split);
+    // Waves are the unit of work: wave gw of the grid takes segment gw % wpr of replicate gw / wpr, so a
+    // workgroup's four waves may serve different replicates (each has its own ring and weights).  With
+    // wpr = (resident waves of the chip) / B every wave slot gets one equal share and the grid is one round.
+    const int wpr = a.wpr > 0 ? a.wpr : 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = (int)blockIdx.x * 4 + wave;
+    if (gw >= a.B * wpr) return;
+    const int b = gw / wpr + a.b0;
+    const int segi = gw % wpr;
     const int N = a.N, T = a.T;
     const unsigned rowB = (unsigned)N * 8u;
     const double* __restrict__ L = a.Lam + (size_t)b * N * R;
@@ -97,16 +102,15 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
     const int K = lane >> 4, blk = (lane >> 2) & 3, q = lane & 3;
     const int g = blk / G::FPI, h = blk % G::FPI;
 
-    // this wave's periods [ta, tb): segment 4 part + wave of the 4 split equal segments of [0, T), each
-    // starting on a 128-byte boundary
-    int tq = (T + 4 * split - 1) / (4 * split);
+    // this wave's periods [ta, tb): segment segi of the wpr equal segments of [0, T), each starting on a
+    // 128-byte boundary
+    int tq = (T + wpr - 1) / wpr;
     {
         unsigned gg = rowB & 127u;
         gg = gg == 0 ? 128u : (gg & (~gg + 1u));
         const int m = (int)(128u / gg);
         tq = ((tq + m - 1) / m) * m;
     }
-    const int segi = 4 * part + wave;
     const int ta = (segi * tq < T) ? segi * tq : T;
     const int tb = (ta + tq < T) ? ta + tq : T;
     const int nrows = tb - ta;
@@ -363,9 +367,9 @@ static hipError_t launch_mfma_one(const CollapseArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int split = a.split > 0 ? a.split : 1;
-    if (4 * split > kSsumSlots) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>), dim3(a.B * split), dim3(256), lds, s, a, SB);
+    const int wpr = a.wpr > 0 ? a.wpr : 4;
+    if (wpr > kSsumSlots) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>), dim3((a.B * wpr + 3) / 4), dim3(256), lds, s, a, SB);
     return hipGetLastError();
 }
 

@@ -29,7 +29,7 @@ struct CollapseArgs {
     double* ldfull;       // [B]
     int* status;          // bit0: NaN met while Ct == nullptr
     double* ssum;         // [B][kSsumSlots]  balanced path only: sum_t s_t of each wave's periods (slots 0 .. nseg-1)
-    int split;            // collapse_mfma only: workgroups per replicate (0 = 1); nseg = 4 * split <= kSsumSlots
+    int wpr;              // collapse_mfma only: waves (period segments) per replicate (0 = 4); nseg = wpr <= kSsumSlots
 };
 
 struct RecursionArgs {
@@ -117,6 +117,7 @@ struct FastArgs {
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
 bool cov_fuses_gram(int Rpad, int N);   // launch_cov with a.Lam != nullptr is supported for this shape
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);
+hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s);   // the P_smooth fill of meanscan (then run it with abl bit 0)
 int fast_chunk_len(int Rpad, int T);
 int fast_stead_mats(int Rpad);
 

@@ -50,10 +50,23 @@ __device__ __forceinline__ double dot_vec(const double (&own)[R], const double* 
 // In-place Gauss-Jordan inverse (no pivoting; SPD input).  Lane i holds row i in m; sweep k broadcasts
 // row k through the two R-double LDS rows at X (double-buffered: one barrier per sweep).
 // Returns det(input) = product of pivots.  Every lane of the group gets the same value.
-template <int R>
+// Exchange fence for LDS traffic between the lanes of ONE wave (no s_barrier): a wave's DS operations are
+// processed in issue order, so only the compiler has to be kept from moving loads above stores.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <bool WAVE>
+__device__ __forceinline__ void group_sync() {
+    if constexpr (WAVE) wave_lds_sync(); else __syncthreads();
+}
+
+// WAVE = true: the lane groups exchanging through X all live in one wave of a multi-wave workgroup
+template <int R, bool WAVE = false>
 __device__ __forceinline__ double gj_inverse(double (&m)[R], double* X, int i) {
     double det = 1.0;
-    __syncthreads();
+    group_sync<WAVE>();
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         double* buf = X + (k & 1) * R;
@@ -61,7 +74,7 @@ __device__ __forceinline__ double gj_inverse(double (&m)[R], double* X, int i) {
 #pragma unroll
             for (int j = 0; j < R; ++j) buf[j] = m[j];
         }
-        __syncthreads();
+        group_sync<WAVE>();
         double q[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) q[j] = buf[j];

@@ -29,6 +29,9 @@ namespace dfm {
 
 constexpr double kLog2PiF = 1.8378770664093454835606594728112;
 constexpr int kScanThreads = 256;   // meanscan workgroup: 256 / R lane groups = time chunks
+// cov workgroup: 4 independent waves.  Four-wave workgroups put the 224-VGPR covariance waves on a quarter of
+// the CUs a one-wave workgroup would touch, which is what the streaming collapse beside them loses.
+__host__ __device__ constexpr int cov_threads(int R) { (void)R; return 64; }
 // levels of the carry scan over the 256 / R chunks, and matrices kept per replicate in `stead`:
 // Z, J, G, then G^(L 2^k) and J^(L 2^k), k = 0 .. levels-1
 __host__ __device__ constexpr int scan_levels(int R) { int n = 0; while ((1 << n) < kScanThreads / R) ++n; return n; }
@@ -41,9 +44,12 @@ template <int R>
 struct CovLayout {
     static constexpr int GPW = 64 / R;
     // per group: X, PSI, JS (exchange / operands), K0..K2 (forward: Q^-1, Phi, C; backward: sum P_s, sum U), V0
-    static constexpr int kRaw = 6 * R * R + R;
+    // + TB: Z_e, J_e of the first ECL covariance steps (the backward pass re-reads them; beside the streaming
+    // collapse a global round trip costs ~5 us)
+    static constexpr int ECL = R <= 8 ? 8 : R <= 16 ? 2 : 0;
+    static constexpr int kRaw = 6 * R * R + R + ECL * 2 * R * R;
     static constexpr int S = ((kRaw + 3) / 4) * 4 + 2;
-    static constexpr size_t lds_bytes() { return (size_t)GPW * S * sizeof(double); }
+    static constexpr size_t lds_bytes() { return (size_t)(cov_threads(R) / 64) * GPW * S * sizeof(double); }
 };
 
 // CPL2 > 0: the Gram matrices C = Lam' R^-1 Lam and sum log R of the wave's replicates are computed here first,
@@ -51,57 +57,68 @@ struct CovLayout {
 // separate gram_kernel launch: beside the streaming collapse, which fills every CU, a second dependent launch
 // on the side stream waits ~150 us for free registers.
 template <int R, int CPL2>
-__global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
+__global__ __launch_bounds__(cov_threads(R)) void cov_kernel(FastArgs a) {
+    constexpr int kCovThreads = cov_threads(R);
     using LY = CovLayout<R>;
     constexpr int GPW = LY::GPW;
+    __builtin_amdgcn_s_setprio(3);   // a latency chain everything waits for, beside the streaming collapse
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;                          // waves of a workgroup work independently
     const int g = lane / R, i = lane % R;
     const int T = a.T, r = a.r;
-    int b = blockIdx.x * GPW + g;
+    const int wave_first = (blockIdx.x * (kCovThreads / 64) + wv) * GPW;   // first replicate of this wave
+    int b = wave_first + g;
     const bool live = b < a.B;
     if (!live) b = a.B - 1;
 
-    double* X = smem + (size_t)g * LY::S;
+    double* wsm = smem + (size_t)wv * GPW * LY::S;           // this wave's LDS
+    double* X = wsm + (size_t)g * LY::S;
     double* PSI = X + R * R;
     double* JS = PSI + R * R;
     double* K0 = JS + R * R;       // rows owned by lane i: K0[i*R + j]
     double* K1 = K0 + R * R;
     double* K2 = K1 + R * R;
     double* V0 = K2 + R * R;
+    double* TB = V0 + R;           // [ECL][2][R][R]: rows i of Z_e, J_e (lane i reads back only what it wrote)
 
     const size_t mo = (size_t)b * R * R + (size_t)i * R;     // row i of a [B][R][R] array
     double* tab = a.tab + (size_t)b * T * 3 * R * R;
     double ldfull_b = 0.0;
     if constexpr (CPL2 > 0) {
+        // C = Lam' R^-1 Lam, row i in lane i of the replicate's lane group: every series is read by the whole
+        // group (same address: one request), lane i accumulates (lam_ci / R_c) lam_c.  All loads independent.
         const int N = a.N;
-        for (int rep = 0; rep < GPW; ++rep) {
-            int bb = blockIdx.x * GPW + rep;
-            if (bb >= a.B) bb = a.B - 1;
-            const double* __restrict__ L = a.Lam + (size_t)bb * N * R;
-            const double* __restrict__ Rv = a.Rv + (size_t)bb * N;
-            double W[CPL2][2][R];
-            bool own[CPL2][2];
-            double ld = 0.0;
+        const double* __restrict__ L = a.Lam + (size_t)b * N * R;
+        const double* __restrict__ Rv = a.Rv + (size_t)b * N;
+        double crow[R];
 #pragma unroll
-            for (int j = 0; j < CPL2; ++j)
+        for (int j = 0; j < R; ++j) crow[j] = 0.0;
+        constexpr int UN = 4;
+        for (int c0 = 0; c0 < N; c0 += UN) {
+            double lam[UN][R], rvv[UN], li[UN];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int c = 2 * lane + 128 * j + e;
-                    own[j][e] = c < N;
-                    const int cc = own[j][e] ? c : N - 1;
-                    const double rv = own[j][e] ? Rv[cc] : 1.0;
-                    const double ri = own[j][e] ? 1.0 / rv : 0.0;
-                    ld += log(rv);
+            for (int u = 0; u < UN; ++u) {
+                const int c = (c0 + u < N) ? c0 + u : N - 1;
+                rvv[u] = Rv[c];
+                li[u] = L[(size_t)c * R + i];
 #pragma unroll
-                    for (int k = 0; k < R; ++k) W[j][e][k] = L[(size_t)cc * R + k] * ri;
-                }
-            double* Cdst = smem + (size_t)rep * LY::S + 5 * R * R;     // K2 of lane group `rep`
-            c_all<R, CPL2, 0, true>(W, L, own, lane, Cdst);
-            ld = wave_allsum(ld);
-            if (g == rep) ldfull_b = ld;
+                for (int j = 0; j < R; ++j) lam[u][j] = L[(size_t)c * R + j];
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const double wi = (c0 + u < N) ? li[u] / rvv[u] : 0.0;
+#pragma unroll
+                for (int j = 0; j < R; ++j) crow[j] = fma(wi, lam[u][j], crow[j]);
+            }
         }
-        __syncthreads();
+        double ld = 0.0;                                     // sum log R: series i, i + R, ... then over the group
+        for (int c = i; c < N; c += R) ld += log(Rv[c]);
+#pragma unroll
+        for (int off = 1; off < R; off <<= 1) ld += __shfl_xor(ld, off, kWave);
+        ldfull_b = ld;
+#pragma unroll
+        for (int j = 0; j < R; ++j) K2[i * R + j] = crow[j];
     }
     double detQ, detP0, q0;
     double PsiT[R], Omf[R];
@@ -115,15 +132,15 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
             if constexpr (CPL2 == 0) K2[i * R + j] = a.Cfull[mo + j];
         }
         const double mu0i = a.mu0[(size_t)b * R + i];
-        detQ = gj_inverse<R>(Qi, X, i);
-        detP0 = gj_inverse<R>(Omf, X, i);                    // Omf = P0^-1
-        __syncthreads();
+        detQ = gj_inverse<R, true>(Qi, X, i);
+        detP0 = gj_inverse<R, true>(Omf, X, i);                    // Omf = P0^-1
+        wave_lds_sync();
         store_row<R>(X, i, Arow);
-        __syncthreads();
+        wave_lds_sync();
         mm_rows<R>(PsiT, Qi, X);                             // Psi' = Qi A (row i)
 #pragma unroll
         for (int j = 0; j < R; ++j) PSI[j * R + i] = PsiT[j];  // PSI = Psi (rows)
-        __syncthreads();
+        wave_lds_sync();
         {
             double prow[R];
 #pragma unroll
@@ -133,11 +150,11 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
         store_row<R>(K0, i, Qi);
         store_row<R>(K1, i, Phi);
         V0[i] = mu0i;
-        __syncthreads();
+        wave_lds_sync();
         const double xi0 = dot_vec<R>(Omf, V0);              // xi_0 = P0^-1 mu0
         q0 = mu0i * xi0;                                     // lane part of mu0' P0^-1 mu0
         if (live) a.xi0[(size_t)b * R + i] = xi0;
-        __syncthreads();
+        wave_lds_sync();
     }
 
     // ---------------- forward covariance steps until the fixed point ----------------------------
@@ -149,12 +166,12 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
             double Z[R], Jr[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) Z[j] = Omf[j] + K1[i * R + j];
-            const double detM = gj_inverse<R>(Z, X, i);
+            const double detM = gj_inverse<R, true>(Z, X, i);
             const double ldz = -log(detM);
             mm_rows<R>(Jr, Z, PSI);                          // J = Z Psi
-            __syncthreads();
+            wave_lds_sync();
             store_row<R>(X, i, Jr);
-            __syncthreads();
+            wave_lds_sync();
             double Omf_new[R];
             {
                 double tmp[R];
@@ -166,12 +183,12 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
 #pragma unroll
             for (int j = 0; j < R; ++j) same = same && close_enough(Omf_new[j], Omf[j]);
             V0[i] = same ? 1.0 : 0.0;
-            __syncthreads();
+            wave_lds_sync();
             bool gsame = true;
 #pragma unroll
             for (int k = 0; k < R; ++k) gsame = gsame && (V0[k] != 0.0);
             store_row<R>(X, i, Z);
-            __syncthreads();
+            wave_lds_sync();
             if (!done) {
                 double G[R];
                 mm_rows<R>(G, PsiT, X);                      // G = Psi' Z
@@ -179,6 +196,10 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
                     double* te = tab + (size_t)e * 3 * R * R + (size_t)i * R;
 #pragma unroll
                     for (int j = 0; j < R; ++j) { te[j] = Z[j]; te[R * R + j] = Jr[j]; te[2 * R * R + j] = G[j]; }
+                }
+                if (e < LY::ECL) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) { TB[(e * 2) * R * R + i * R + j] = Z[j]; TB[(e * 2 + 1) * R * R + i * R + j] = Jr[j]; }
                 }
                 E = e + 1;
                 sum_ldz += ldz;
@@ -197,17 +218,17 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
     double Ps[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) Ps[j] = Omf[j];
-    const double detOmT = gj_inverse<R>(Ps, X, i);           // P_T
-    __syncthreads();
+    const double detOmT = gj_inverse<R, true>(Ps, X, i);           // P_T
+    wave_lds_sync();
     V0[i] = q0;
-    __syncthreads();
+    wave_lds_sync();
     {
         double qs = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) qs += V0[k];
         q0 = qs;
     }
-    __syncthreads();
+    wave_lds_sync();
     if (live) {
 #pragma unroll
         for (int j = 0; j < R; ++j) a.PT[mo + j] = Ps[j];
@@ -242,18 +263,23 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
         const bool act = t >= 0;
         const int e = act ? (t < ts ? t : ts) : ts;
         if (e != cur_e) {                                     // (group-uniform: t, ts are per group)
-            const double* te = tab + (size_t)e * 3 * R * R + (size_t)i * R;
+            if (e < LY::ECL) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) { Zc[j] = te[j]; Jc[j] = te[R * R + j]; }
+                for (int j = 0; j < R; ++j) { Zc[j] = TB[(e * 2) * R * R + i * R + j]; Jc[j] = TB[(e * 2 + 1) * R * R + i * R + j]; }
+            } else {
+                const double* te = tab + (size_t)e * 3 * R * R + (size_t)i * R;
+#pragma unroll
+                for (int j = 0; j < R; ++j) { Zc[j] = te[j]; Jc[j] = te[R * R + j]; }
+            }
             cur_e = e;
         }
-        __syncthreads();
+        wave_lds_sync();
         store_row<R>(JS, i, Jc);
-        __syncthreads();
+        wave_lds_sync();
         double U[R], Psn[R];
         mm_rowsT<R>(U, Ps, JS);                              // U = P_s J' = Cov(f_{t+1}, f_t | X)
         store_row<R>(X, i, U);
-        __syncthreads();
+        wave_lds_sync();
         {
             double tmp[R];
             mm_rows<R>(tmp, Jc, X);                          // J U
@@ -264,7 +290,7 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
 #pragma unroll
         for (int j = 0; j < R; ++j) same = same && close_enough(Psn[j], Ps[j]);
         V0[i] = same ? 1.0 : 0.0;
-        __syncthreads();
+        wave_lds_sync();
         bool gsame = true;
 #pragma unroll
         for (int k = 0; k < R; ++k) gsame = gsame && (V0[k] != 0.0);
@@ -312,27 +338,27 @@ __global__ __launch_bounds__(64) void cov_kernel(FastArgs a) {
         constexpr int NLEV = scan_levels(R);
         const double* te = tab + (size_t)ts * 3 * R * R + (size_t)i * R;
         double* st = a.stead + (size_t)b * stead_mats(R) * R * R + (size_t)i * R;
-        double M[R];
+        double M[R], Ms[2][R];                               // one batch of loads: a single round trip
 #pragma unroll
-        for (int j = 0; j < R; ++j) M[j] = te[j];
+        for (int j = 0; j < R; ++j) { M[j] = te[j]; Ms[0][j] = te[2 * R * R + j]; Ms[1][j] = te[R * R + j]; }
         if (live) {
 #pragma unroll
             for (int j = 0; j < R; ++j) st[j] = M[j];
         }
-#pragma unroll 1
+#pragma unroll
         for (int which = 0; which < 2; ++which) {            // 0: G -> slot 2, powers 3..;  1: J -> slot 1, powers 3+NLEV..
             const int src = which == 0 ? 2 : 1, dst = which == 0 ? 3 : 3 + NLEV;
 #pragma unroll
-            for (int j = 0; j < R; ++j) M[j] = te[src * R * R + j];
+            for (int j = 0; j < R; ++j) M[j] = Ms[which][j];
             if (live) {
 #pragma unroll
                 for (int j = 0; j < R; ++j) st[src * R * R + j] = M[j];
             }
             auto square = [&]() {
                 double tmp[R];
-                __syncthreads();
+                wave_lds_sync();
                 store_row<R>(X, i, M);
-                __syncthreads();
+                wave_lds_sync();
                 mm_rows<R>(tmp, M, X);
 #pragma unroll
                 for (int j = 0; j < R; ++j) M[j] = tmp[j];
@@ -375,6 +401,47 @@ template <int R>
 __device__ __forceinline__ void load_xperm(double (&Mp)[R], const double* M, int i) {
 #pragma unroll
     for (int s = 0; s < R; ++s) Mp[s] = M[i * R + (i ^ s)];
+}
+
+// Rows [lo, hi) of P_smooth equal the backward fixed point P_s,inf: element k of the range is s_ps[k % npr]
+// (packed lower triangle in the caller's r).  Plain 16-byte stores, nothing waits for them.
+__device__ __forceinline__ void fill_psmooth_rows(const FastArgs& a, int b, int tid, int nthreads, const double* s_ps) {
+    const int npr = a.r * (a.r + 1) / 2;
+    const int lo = a.fill[2 * b], hi = a.fill[2 * b + 1];
+    if (hi <= lo) return;
+    double* base = a.P_smooth + ((size_t)b * a.T + lo) * npr;
+    const unsigned n = (unsigned)(hi - lo) * (unsigned)npr;
+    const unsigned peel = ((reinterpret_cast<size_t>(base) & 15) != 0) ? 1u : 0u;   // to 16-byte alignment
+    if (peel && tid == 0) base[0] = s_ps[0];
+    const unsigned npair = (n - peel) / 2;
+    const unsigned step = (2u * nthreads) % (unsigned)npr;
+    unsigned k = peel + 2u * tid;
+    unsigned v = k % (unsigned)npr;
+    for (unsigned p = tid; p < npair; p += nthreads) {
+        const unsigned v1 = (v + 1 == (unsigned)npr) ? 0u : v + 1;
+        *reinterpret_cast<double2*>(base + k) = make_double2(s_ps[v], s_ps[v1]);
+        k += 2u * nthreads;
+        v += step;
+        if (v >= (unsigned)npr) v -= (unsigned)npr;
+    }
+    if (((n - peel) & 1u) != 0 && tid == 0) base[n - 1] = s_ps[(n - 1) % (unsigned)npr];
+}
+
+// The same fill as its own launch: it only needs cov_kernel's outputs, so it can run behind cov_kernel beside
+// the streaming collapse instead of inside the scan that everything waits for.
+template <int R>
+__global__ __launch_bounds__(256) void pfill_kernel(FastArgs a) {
+    __shared__ double s_ps[R * (R + 1) / 2];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int npr = a.r * (a.r + 1) / 2;
+    for (int v = tid; v < npr; v += 256) {
+        int ri = 0;
+        while ((ri + 1) * (ri + 2) / 2 <= v) ++ri;
+        s_ps[v] = a.PsInf[(size_t)b * R * R + ri * R + (v - ri * (ri + 1) / 2)];
+    }
+    __syncthreads();
+    fill_psmooth_rows(a, b, tid, 256, s_ps);
 }
 
 constexpr int kPF = 8;    // chain steps per prefetch block
@@ -542,28 +609,8 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
     else chunk_prefetch<R, false>(cur, bcol, t0f, 1, L, ts, T, i);
     __syncthreads();
 
-    // ---- P_smooth rows inside the fixed-point range: fire-and-forget stores --------------------------
-    if (a.P_smooth && !(a.abl & 1)) {
-        const int lo = a.fill[2 * b], hi = a.fill[2 * b + 1];
-        if (hi > lo) {
-            double* base = a.P_smooth + ((size_t)b * T + lo) * npr;   // element k of the range is s_ps[k % npr]
-            const unsigned n = (unsigned)(hi - lo) * (unsigned)npr;
-            const unsigned peel = ((reinterpret_cast<size_t>(base) & 15) != 0) ? 1u : 0u;   // to 16-byte alignment
-            if (peel && tid == 0) base[0] = s_ps[0];
-            const unsigned npair = (n - peel) / 2;
-            const unsigned step = (2u * kScanThreads) % (unsigned)npr;
-            unsigned k = peel + 2u * tid;
-            unsigned v = k % (unsigned)npr;
-            for (unsigned p = tid; p < npair; p += kScanThreads) {
-                const unsigned v1 = (v + 1 == (unsigned)npr) ? 0u : v + 1;
-                *reinterpret_cast<double2*>(base + k) = make_double2(s_ps[v], s_ps[v1]);
-                k += 2u * kScanThreads;
-                v += step;
-                if (v >= (unsigned)npr) v -= (unsigned)npr;
-            }
-            if (((n - peel) & 1u) != 0 && tid == 0) base[n - 1] = s_ps[(n - 1) % (unsigned)npr];
-        }
-    }
+    // ---- P_smooth rows inside the fixed-point range: fire-and-forget stores (unless pfill_kernel wrote them)
+    if (a.P_smooth && !(a.abl & 1)) fill_psmooth_rows(a, b, tid, kScanThreads, s_ps);
     if (a.abl & 2) return;
     if (a.abl & 4) return;
 
@@ -685,7 +732,9 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
 template <int R, int CPL2>
 static hipError_t launch_cov_rc(const FastArgs& a, hipStream_t s) {
     using LY = CovLayout<R>;
-    const int grid = (a.B + LY::GPW - 1) / LY::GPW;
+    constexpr int kCovThreads = cov_threads(R);
+    constexpr int per_wg = LY::GPW * (kCovThreads / 64);
+    const int grid = (a.B + per_wg - 1) / per_wg;
     static bool attr_done = false;
     if (!attr_done && LY::lds_bytes() > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cov_kernel<R, CPL2>),
@@ -693,7 +742,7 @@ static hipError_t launch_cov_rc(const FastArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((cov_kernel<R, CPL2>), dim3(grid), dim3(64), LY::lds_bytes(), s, a);
+    hipLaunchKernelGGL((cov_kernel<R, CPL2>), dim3(grid), dim3(kCovThreads), LY::lds_bytes(), s, a);
     return hipGetLastError();
 }
 // fused Gram (a.Lam != nullptr) for the series tilings whose weights fit the register file next to the
@@ -742,6 +791,18 @@ hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s) {
         case 32: return launch_cov_r<32>(a, s);
         default: return hipErrorInvalidValue;
     }
+}
+hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s) {
+    if (!a.P_smooth) return hipSuccess;
+    switch (Rpad) {
+        case 2: hipLaunchKernelGGL((pfill_kernel<2>), dim3(a.B), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pfill_kernel<4>), dim3(a.B), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((pfill_kernel<8>), dim3(a.B), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((pfill_kernel<16>), dim3(a.B), dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((pfill_kernel<32>), dim3(a.B), dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s) {
     switch (Rpad) {

@@ -46,10 +46,10 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<int> vars;
     for (int i = 1; i < argc; ++i) vars.push_back(atoi(argv[i]));
-    if (vars.empty()) vars = {107, 200, 201, 202};
+    if (vars.empty()) vars = {200, 3200, 3202, 6200, 3201};
     std::vector<double> ref((size_t)B * T * R), got((size_t)B * T * R);
     for (int v0 : vars) {
-        const int v = v0 % 1000; a.split = v0 / 1000;   // 1000 * split + variant
+        const int v = v0 % 1000; a.wpr = v0 / 1000;   // 1000 * wpr + variant
         CK(hipMemset(bcol, 0, (size_t)B * T * R * 8));
         for (int i = 0; i < 3; ++i) CK(dfm::launch_collapse_dma(R, a, 0, v));
         CK(hipDeviceSynchronize());
@@ -66,7 +66,7 @@ int main(int argc, char** argv) {
             std::vector<double> sc((size_t)B * T);
             CK(hipMemcpy(sc.data(), scol, sc.size() * 8, hipMemcpyDeviceToHost));
             double m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const int ns = 4 * (a.split > 0 ? a.split : 1);
+            const int ns = a.wpr > 0 ? a.wpr : 4;
             for (int b = 0; b < B; ++b) for (int w = 0; w < ns; ++w) for (int k = 0; k < 8; ++k) m[k] += sc[(size_t)b * T + w * 8 + k] / (B * (double)ns);
             {   // wave records: concurrency = sum of wave lifetimes / kernel span; tick rate = ticks / real time
                 double tmin = 1e300, tmax = 0, life = 0, ticks = 0; int n = 0;
@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
             }
             printf("   per wave (s_memtime ticks): wait %.0f  read %.0f  issue %.0f  compute+store %.0f  total %.0f  blocks %.0f  prologue %.0f  epilogue %.0f\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
         }
-        printf("split %d variant %3d  %8.4f ms  %7.1f GB/s   maxdiff_vs_first %.3g\n", a.split, v, ms / K, (double)B * (T * N + N * R + N) * 8 / (ms / K * 1e-3) / 1e9, d);
+        printf("wpr %d variant %3d  %8.4f ms  %7.1f GB/s   maxdiff_vs_first %.3g\n", a.wpr, v, ms / K, (double)B * (T * N + N * R + N) * 8 / (ms / K * 1e-3) / 1e9, d);
     }
     return 0;
 }
