@@ -25,6 +25,10 @@ _PASS_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 10 + [c_uint]
 _EMSTEP_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 8 + [c_uint]
 _EM_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, ctypes.c_double] + [c_vp] * 4 + [c_uint]
 _PCA_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 8
+c_ll = ctypes.c_longlong
+_ALS_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, ctypes.c_double,
+             c_vp, c_int, c_vp, c_vp, c_vp]
+_OLS_ARGS = [c_vp, c_int, c_int, c_int, c_vp, c_ll, c_vp, c_ll, c_ll, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]
 
 # name -> (restype, argtypes); every prototype of include/dfm_hip.h
 SYMBOLS = {
@@ -44,6 +48,10 @@ SYMBOLS = {
     "dfm_em_batch": (c_int, _EM_ARGS),
     "dfm_pca_init_batch_dev": (c_int, _PCA_ARGS),
     "dfm_pca_init_batch": (c_int, _PCA_ARGS),
+    "dfm_als_batch_dev": (c_int, _ALS_ARGS),
+    "dfm_als_batch": (c_int, _ALS_ARGS),
+    "dfm_ols_batch_dev": (c_int, _OLS_ARGS),
+    "dfm_ols_batch": (c_int, _OLS_ARGS),
     "dfm_synth_panels_dev": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_int64, c_int, c_int, c_int, c_int,
                                      ctypes.c_double] + [c_vp] * 7),
 }

@@ -171,12 +171,11 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
       m.factor_var_model.M / G / seps     <- A (companion block), chol(Q) lower, Q      (cf. :477-492)
       m.fes.tss / nobs / ssr / R2         <- as estimate_factor! defines them (:342-343, :366, :372-380),
                                              with the common component Lam f_t|T in place of the ALS fit
-    `NonParametric()` is the reference's own pure-Julia path and is not re-implemented here."""
+    `NonParametric()` runs the reference's own estimator (ALS, loadings, VAR) on the HIP kernels of als.hip:
+    see estimate_nonparametric below."""
     method = Parametric() if method is None else method
     if isinstance(method, NonParametric):
-        raise NotImplementedError(
-            "estimate(m, NonParametric()) is the reference's own ALS path (dfm_functions.ipynb:530-543); this "
-            "package accelerates the Parametric() slot only")
+        return estimate_nonparametric(m, ctx=ctx, lam_constr_f=lam_constr_f, lam_constr_fl=lam_constr_fl)
     if not isinstance(method, Parametric):
         raise TypeError("method must be Parametric() or NonParametric()")
     if lam_constr_f is not None or lam_constr_fl is not None:
@@ -247,3 +246,183 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
     var.betahat[:] = 0.0
     var.betahat[(1 if var.withconst else 0):(1 if var.withconst else 0) + r, :] = A.T
     return m.loglik_path
+
+
+# ============================================================================= the NON-parametric path
+# `estimate!(m, ::NonParametric)` (dfm_functions.ipynb:530-543) = estimate_factor! -> estimate_factor_loading!
+# -> estimate_var!, with every regression run by the batched HIP kernels of als.hip (dfm_als_batch /
+# dfm_ols_batch) and the PCA start by pca.hip.  The host code below is what the reference's Julia host code is:
+# slicing, standardising, building lag matrices, copying results into the model object.
+def _lagmat(X: np.ndarray, lags) -> np.ndarray:
+    """dfm_functions.ipynb:295-303."""
+    X = X.reshape(X.shape[0], -1)
+    T, nc = X.shape
+    lags = list(lags)
+    out = np.full((T, nc * len(lags)), np.nan)
+    for k, lag in enumerate(lags):
+        out[lag:, nc * k: nc * (k + 1)] = X[: T - lag]
+    return out
+
+
+def _own(ctx):
+    if ctx is not None:
+        return ctx, False
+    from .kalman import DfmContext
+    return DfmContext(), True                                           # raises without a HIP device
+
+
+def pca_start(ctx, z: np.ndarray, r: int) -> np.ndarray:
+    """`pca_score` (dfm_functions.ipynb:179-183) of the columns of z without a missing cell (:345-348)."""
+    xbal, _ = drop_missing_col(z)
+    if xbal.shape[1] < r:
+        raise ValueError("fewer fully observed series than factors: cannot initialise by PCA")
+    _, F0 = ctx.pca_init_batch_host(xbal[None, :, :], r)
+    return F0[0]
+
+
+def estimate_factor(m: DFMModel, max_iter: int = 100000000, computeR2: bool = True, *, lam_constr=None, ctx=None):
+    """`estimate_factor!(m, max_iter, computeR2)` -- dfm_functions.ipynb:328-382 (nfac_o = 0, no constraint)."""
+    if lam_constr is not None:
+        raise NotImplementedError("loading constraints are not supported on the HIP path")
+    if m.nfac_o != 0:
+        raise NotImplementedError("observed factors (nfac_o > 0) are not supported (non-functional in the reference too)")
+    r = m.nfac_u
+    xdata = m.data[m.initperiod - 1:m.lastperiod, :][:, m.inclcode == 1]   # :335-336
+    z, _ = standardize_data(xdata)                                         # :339
+    m.fes.tss = float(np.nansum(z * z))                                    # :342
+    m.fes.nobs = int((~np.isnan(z)).sum())                                 # :343
+    ctx, own = _own(ctx)
+    try:
+        F0 = pca_start(ctx, z, r)                                          # :345-348
+        o = ctx.als_batch_host(z, F0[None], nt_min=m.nt_min_factor_estimation, max_iter=max_iter, tol=m.tol,
+                               want_R2=computeR2)                          # :352-370 (+ :372-380)
+    finally:
+        if own:
+            ctx.close()
+    m.factor[m.initperiod - 1:m.lastperiod, :] = o["F"][0]                 # :371
+    m.fes.ssr = float(o["ssr"][0])                                         # :366
+    if computeR2:
+        m.fes.R2 = o["R2"][0].copy()
+    m.als_iters = int(o["iters"][0])
+    return None
+
+
+def estimate_factor_loading(m: DFMModel, *, lam_constr=None, ctx=None):
+    """`estimate_factor_loading!(m)` -- dfm_functions.ipynb:391-415: every series (raw units) on [F 1] over the
+    complete cases of the window, r2, then an AR(n_uarlag) of the residuals."""
+    if lam_constr is not None:
+        raise NotImplementedError("loading constraints are not supported on the HIP path")
+    F = m.factor[m.initperiod - 1:m.lastperiod, :]
+    Y = m.data[m.initperiod - 1:m.lastperiod, :]
+    T, r = F.shape
+    X = np.column_stack([F, np.ones(T)])
+    ctx, own = _own(ctx)
+    try:
+        o = ctx.ols_batch_host(X, Y, nt_min=m.nt_min_factorloading_estimation)
+        ok = ~np.isnan(o["beta"][:, 0])
+        r2 = 1.0 - o["ssr"] / o["tss"]
+        m.lambda_[ok, :] = o["beta"][ok, :r]
+        m.r2[ok] = r2[ok]
+        # AR(n) of the residuals with the gaps closed up (the reference hands `uar` the residual VECTOR of the
+        # complete cases, :404-407); one regression problem per series, own lag matrix each
+        nlag = m.n_uarlag
+        idx = np.nonzero(ok & (r2 < 0.9999))[0]
+        if idx.size:
+            U = np.full((T, idx.size), np.nan)
+            XL = np.full((idx.size, T, nlag), np.nan)
+            nu = np.zeros(idx.size, dtype=int)
+            for q, i in enumerate(idx):
+                u = o["resid"][:, i]
+                u = u[~np.isnan(u)]
+                nu[q] = u.size
+                U[:u.size, q] = u
+                XL[q, :u.size] = _lagmat(u, range(1, nlag + 1))
+            a = ctx.ols_batch_host(XL, U, nt_min=0, want_resid=False)
+            m.uar_coef[idx, :] = a["beta"]
+            m.uar_ser[idx] = np.sqrt(a["ssr"] / (nu - nlag))                # :310
+        hi = np.nonzero(ok & ~(r2 < 0.9999))[0]
+        m.uar_coef[hi, :] = 0.0
+        m.uar_ser[hi] = 0.0
+    finally:
+        if own:
+            ctx.close()
+    return None
+
+
+def estimate_var(varm: VARModel, compute_matrices: bool = True, *, ctx=None):
+    """`estimate_var!(varm, compute_matrices)` + `fill_matrices!` -- dfm_functions.ipynb:444-492."""
+    yr = varm.y[varm.initperiod - 1:varm.lastperiod, :]
+    T, ns = yr.shape
+    x = _lagmat(yr, range(1, varm.nlag + 1))
+    if varm.withconst:
+        x = np.column_stack([np.ones(T), x])
+    rows_ok = ~np.isnan(x).any(axis=1) & ~np.isnan(yr).any(axis=1)         # the reference drops rows jointly (:455)
+    Y = np.where(rows_ok[:, None], yr, np.nan)
+    ctx, own = _own(ctx)
+    try:
+        o = ctx.ols_batch_host(x, Y, nt_min=0)
+    finally:
+        if own:
+            ctx.close()
+    K = x.shape[1]
+    varm.betahat = o["beta"].T.copy()
+    e = o["resid"][rows_ok]
+    T_used = int(rows_ok.sum())
+    varm.seps = e.T @ e / (T_used - K)
+    varm.resid[:] = np.nan
+    varm.resid[varm.initperiod - 1 + np.nonzero(rows_ok)[0]] = e
+    if compute_matrices:                                                   # fill_matrices! (:477-492)
+        b = varm.betahat[1:].T if varm.withconst else varm.betahat.T
+        k = ns * varm.nlag
+        varm.M = np.zeros((k, k)); varm.Q = np.zeros((ns, k)); varm.G = np.zeros((k, ns))
+        varm.M[:ns] = b
+        varm.M[ns:, :-ns] = np.eye(k - ns)
+        varm.Q[:, :ns] = np.eye(ns)
+        varm.G[:ns] = np.linalg.cholesky(varm.seps)
+    return None
+
+
+def estimate_nonparametric(m: DFMModel, *, ctx=None, lam_constr_f=None, lam_constr_fl=None):
+    """`estimate!(m, NonParametric())` -- dfm_functions.ipynb:530-543."""
+    if lam_constr_f is not None or lam_constr_fl is not None:
+        raise NotImplementedError("loading constraints are not supported on the HIP path")
+    ctx, own = _own(ctx)
+    try:
+        estimate_factor(m, lam_constr=lam_constr_f, ctx=ctx)
+        estimate_factor_loading(m, lam_constr=lam_constr_fl, ctx=ctx)
+        m.factor_var_model.y = m.factor
+        estimate_var(m.factor_var_model, ctx=ctx)
+    finally:
+        if own:
+            ctx.close()
+    return None
+
+
+def bai_ng_criterion(ssr: float, nobs: int, T: int, r: int) -> float:
+    """dfm_functions.ipynb:648-654 (ICp2 with nbar = nobs / T)."""
+    nbar = nobs / T
+    g = np.log(min(nbar, T)) * (nbar + T) / nobs
+    return float(np.log(ssr / nobs) + r * g)
+
+
+def estimate_factor_numbers(m: DFMModel, nfacs, *, ctx=None, with_aw: bool = False):
+    """`estimate_factor_numbers(m, nfacs)` -- dfm_functions.ipynb:698-725: the static-factor runs for every r in
+    `nfacs` go through ONE dfm_als_batch call (shared panel, r_each); Bai-Ng ICp2 per r.  Returns
+    dict(bn_icp, ssr_static, tss, nobs, T, iters)."""
+    nfacs = [int(k) for k in nfacs]
+    rmax = max(nfacs)
+    xdata = m.data[m.initperiod - 1:m.lastperiod, :][:, m.inclcode == 1]
+    z, _ = standardize_data(xdata)
+    T = z.shape[0]
+    tss = float(np.nansum(z * z)); nobs = int((~np.isnan(z)).sum())
+    ctx, own = _own(ctx)
+    try:
+        F0 = pca_start(ctx, z, rmax)                       # scores are nested: run r starts from the first r columns
+        o = ctx.als_batch_host(z, np.repeat(F0[None], len(nfacs), axis=0), r_each=nfacs,
+                               nt_min=m.nt_min_factor_estimation, tol=m.tol)
+    finally:
+        if own:
+            ctx.close()
+    bn = np.array([bai_ng_criterion(s, nobs, T, k) for s, k in zip(o["ssr"], nfacs)])
+    return dict(bn_icp=bn, ssr_static=o["ssr"].copy(), tss=tss, nobs=nobs, T=T, iters=o["iters"].copy(),
+                factors=o["F"])

@@ -41,11 +41,11 @@ struct dfm_handle {
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
-                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_COUNT };
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
                                                   "mstep_solve_kernel", "pca_kernels", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
-                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel"};
+                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel"};
 
 namespace {
 
@@ -793,3 +793,115 @@ int dfm_synth_panels_dev(dfm_handle* h, uint64_t seed, int64_t first_replicate, 
 }
 
 }  // extern "C"
+
+
+// ---- non-parametric estimator: batched ALS and batched complete-case OLS (als.hip) ---------------------
+int dfm_als_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* z, long long z_stride,
+                      const int* r_each, double* F, double* Lam, int nt_min, int max_iter, double tol,
+                      double* ssr_path, int path_cap, int* iters, double* ssr, double* R2) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || T < 1 || N < 1 || r < 1 || max_iter < 1 || z_stride < 0 || (ssr_path && path_cap < 1))
+        return fail(h, DFM_E_DIMS, "B, T, N, r, max_iter must be >= 1, z_stride >= 0%s");
+    if (r > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r > DFM_MAX_R (32)%s");
+    if (!z || !F || !Lam || !iters || !ssr) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    const int Rp = pad_r(r);
+    if (!als_fits(Rp, T, N)) return fail(h, DFM_E_DIMS, "(T + N) * pad(r) doubles exceed the 160 KB of LDS%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    AlsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.N = N; a.rmax = r; a.z = z; a.z_stride = z_stride; a.r_each = r_each; a.F = F; a.Lam = Lam;
+    a.nt_min = nt_min; a.max_iter = max_iter; a.tol = tol; a.ssr_path = ssr_path; a.path_cap = ssr_path ? path_cap : 0;
+    a.iters = iters; a.ssr = ssr; a.R2 = R2;
+    { ProfScope ps(h, K_ALS); HIP_TRY(h, launch_als(Rp, a, h->stream)); }
+    return 0;
+}
+
+int dfm_als_batch(dfm_handle* h, int B, int T, int N, int r, const double* z, long long z_stride, const int* r_each,
+                  double* F, double* Lam, int nt_min, int max_iter, double tol, double* ssr_path, int path_cap,
+                  int* iters, double* ssr, double* R2) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || T < 1 || N < 1 || r < 1 || z_stride < 0) return fail(h, DFM_E_DIMS, "B, T, N, r must be >= 1%s");
+    if (!z || !F || !Lam || !iters || !ssr) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double);
+    const size_t n_z = z_stride == 0 ? (size_t)T * N : (size_t)(B - 1) * z_stride + (size_t)T * N;
+    const size_t n_F = (size_t)B * T * r, n_L = (size_t)B * N * r, n_p = ssr_path ? (size_t)B * path_cap : 0,
+                 n_R2 = R2 ? (size_t)B * N : 0;
+    char* buf = nullptr;
+    const size_t bytes = (n_z + n_F + n_L + n_p + n_R2 + B) * d + (size_t)2 * B * sizeof(int) + 64;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), bytes));
+    double* z_d = reinterpret_cast<double*>(buf);
+    double* F_d = z_d + n_z; double* L_d = F_d + n_F; double* p_d = L_d + n_L; double* R2_d = p_d + n_p;
+    double* ssr_d = R2_d + n_R2;
+    int* it_d = reinterpret_cast<int*>(ssr_d + B);
+    int* re_d = it_d + B;
+    hipMemcpyAsync(z_d, z, n_z * d, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(F_d, F, n_F * d, hipMemcpyHostToDevice, h->stream);
+    if (r_each) hipMemcpyAsync(re_d, r_each, (size_t)B * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    int rc = dfm_als_batch_dev(h, B, T, N, r, z_d, z_stride, r_each ? re_d : nullptr, F_d, L_d, nt_min, max_iter, tol,
+                               ssr_path ? p_d : nullptr, path_cap, it_d, ssr_d, R2 ? R2_d : nullptr);
+    if (rc == 0) {
+        hipMemcpyAsync(F, F_d, n_F * d, hipMemcpyDeviceToHost, h->stream);
+        hipMemcpyAsync(Lam, L_d, n_L * d, hipMemcpyDeviceToHost, h->stream);
+        if (ssr_path) hipMemcpyAsync(ssr_path, p_d, n_p * d, hipMemcpyDeviceToHost, h->stream);
+        if (R2) hipMemcpyAsync(R2, R2_d, n_R2 * d, hipMemcpyDeviceToHost, h->stream);
+        hipMemcpyAsync(ssr, ssr_d, (size_t)B * d, hipMemcpyDeviceToHost, h->stream);
+        hipMemcpyAsync(iters, it_d, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    hipFree(buf);
+    return rc;
+}
+
+int dfm_ols_batch_dev(dfm_handle* h, int P, int T, int K, const double* X, long long x_stride, const double* y,
+                      long long y_stride, long long y_inc, int nt_min, double* beta, double* resid, double* ssr,
+                      double* tss, int* nobs) {
+    if (!h) return DFM_E_NULL;
+    if (P < 1 || T < 1 || K < 1 || x_stride < 0 || y_inc < 1 || y_stride < 0)
+        return fail(h, DFM_E_DIMS, "P, T, K, y_inc must be >= 1, strides >= 0%s");
+    if (K > 64) return fail(h, DFM_E_R_UNSUPPORTED, "K > 64 regressors%s");
+    if (!X || !y || !beta || !ssr || !nobs) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    OlsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P = P; a.T = T; a.K = K; a.X = X; a.x_stride = x_stride; a.y = y; a.y_stride = y_stride; a.y_inc = y_inc;
+    a.nt_min = nt_min; a.beta = beta; a.resid = resid; a.ssr = ssr; a.tss = tss; a.nobs = nobs;
+    { ProfScope ps(h, K_OLS); HIP_TRY(h, launch_ols(K > 32 ? 64 : pad_r(K), a, h->stream)); }
+    return 0;
+}
+
+int dfm_ols_batch(dfm_handle* h, int P, int T, int K, const double* X, long long x_stride, const double* y,
+                  long long y_stride, long long y_inc, int nt_min, double* beta, double* resid, double* ssr,
+                  double* tss, int* nobs) {
+    if (!h) return DFM_E_NULL;
+    if (P < 1 || T < 1 || K < 1 || x_stride < 0 || y_inc < 1 || y_stride < 0)
+        return fail(h, DFM_E_DIMS, "P, T, K, y_inc must be >= 1, strides >= 0%s");
+    if (!X || !y || !beta || !ssr || !nobs) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double);
+    const size_t n_X = (x_stride == 0 ? 0 : (size_t)(P - 1) * x_stride) + (size_t)T * K;
+    const size_t n_y = (size_t)(P - 1) * y_stride + (size_t)(T - 1) * y_inc + 1;
+    const size_t n_b = (size_t)P * K, n_e = resid ? (size_t)P * T : 0;
+    char* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), (n_X + n_y + n_b + n_e + 2 * (size_t)P) * d + (size_t)P * sizeof(int) + 64));
+    double* X_d = reinterpret_cast<double*>(buf);
+    double* y_d = X_d + n_X; double* b_d = y_d + n_y; double* e_d = b_d + n_b; double* ssr_d = e_d + n_e;
+    double* tss_d = ssr_d + P;
+    int* n_d = reinterpret_cast<int*>(tss_d + P);
+    hipMemcpyAsync(X_d, X, n_X * d, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(y_d, y, n_y * d, hipMemcpyHostToDevice, h->stream);
+    int rc = dfm_ols_batch_dev(h, P, T, K, X_d, x_stride, y_d, y_stride, y_inc, nt_min, b_d, resid ? e_d : nullptr, ssr_d,
+                               tss_d, n_d);
+    if (rc == 0) {
+        hipMemcpyAsync(beta, b_d, n_b * d, hipMemcpyDeviceToHost, h->stream);
+        if (resid) hipMemcpyAsync(resid, e_d, n_e * d, hipMemcpyDeviceToHost, h->stream);
+        hipMemcpyAsync(ssr, ssr_d, (size_t)P * d, hipMemcpyDeviceToHost, h->stream);
+        if (tss) hipMemcpyAsync(tss, tss_d, (size_t)P * d, hipMemcpyDeviceToHost, h->stream);
+        hipMemcpyAsync(nobs, n_d, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    hipFree(buf);
+    return rc;
+}

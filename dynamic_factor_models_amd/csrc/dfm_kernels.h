@@ -134,6 +134,35 @@ struct PcaArgs {
 hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s);
 hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s);
 
+// Non-parametric estimator (als.hip): batched alternating least squares and batched complete-case OLS.
+struct AlsArgs {
+    int B, T, N, rmax;
+    const double* z;            // standardised panels, [T][N] each, NaN = missing; problem b at z + b * z_stride
+    long long z_stride;         // 0: every problem reads the same panel
+    const int* r_each;          // [B] factors of each problem (<= rmax), or null (all rmax)
+    double* F;                  // [B][T][rmax]  in: start (PCA scores); out: factors after the last sweep
+    double* Lam;                // [B][N][rmax]  out: loadings of the last sweep (NaN: series without loadings)
+    int nt_min, max_iter;
+    double tol;
+    double* ssr_path; int path_cap;   // [B][path_cap] SSR after every sweep (NaN past the last), or null
+    int* iters; double* ssr;    // [B]
+    double* R2;                 // [B][N] or null
+};
+hipError_t launch_als(int Rpad, const AlsArgs& a, hipStream_t s);
+bool als_fits(int Rpad, int T, int N);      // factors + loadings fit the 160 KB of LDS
+
+struct OlsArgs {
+    int P, T, K;                // problems, rows, regressors (K <= 32)
+    const double* X; long long x_stride;          // [T][K] per problem; x_stride 0: shared regressors
+    const double* y; long long y_stride, y_inc;   // y_p[t] = y[p * y_stride + t * y_inc]
+    int nt_min;                 // fewer complete rows: coefficients NaN
+    double* beta;               // [P][K]
+    double* resid;              // [P][T] (NaN on dropped rows) or null
+    double* ssr; double* tss;   // [P]; tss = sum (y - ybar)^2 over the used rows, or null
+    int* nobs;                  // [P] complete rows
+};
+hipError_t launch_ols(int Rpad, const OlsArgs& a, hipStream_t s);
+
 // Device-side synthetic replicates (synth.hip); all arrays in the caller's layout (r).
 struct SynthArgs {
     int B, T, N, r;

@@ -242,3 +242,54 @@ class DfmContext:
             self._dev(A, "A"), self._dev(Q, "Q"), self._dev(mu0, "mu0"), self._dev(P0, "P0"))
         _check(self._h, rc)
         return panel, (Lam, R, A, Q, mu0, P0)
+
+    # ------------------------------------------------------------------ non-parametric estimator (als.hip)
+    def als_batch_host(self, z, F0, r_each=None, nt_min: int = 20, max_iter: int = 10 ** 8, tol: float = 1e-8,
+                       path_cap: int = 0, want_R2: bool = False, shared_panel: Optional[bool] = None):
+        """Batched `estimate_factor!` sweeps (dfm_functions.ipynb:352-370) through the host-pointer entry.
+
+        z: [T,N] (one panel shared by every run) or [B,T,N]; F0: [B,T,r] starting factors; r_each: [B] ints
+        or None.  Returns dict(F [B,T,r], Lam [B,N,r], iters [B], ssr [B], ssr_path [B,path_cap] or None,
+        R2 [B,N] or None)."""
+        z = np.ascontiguousarray(z, dtype=np.float64)
+        F = np.array(F0, dtype=np.float64, order="C", copy=True)
+        B, T, r = F.shape
+        if shared_panel is None:
+            shared_panel = z.ndim == 2
+        N = z.shape[-1]
+        if z.shape[-2] != T or (not shared_panel and z.shape[0] != B):
+            raise ValueError("z and F0 disagree on B or T")
+        stride = 0 if shared_panel else T * N
+        Lam = np.empty((B, N, r)); iters = np.empty(B, dtype=np.int32); ssr = np.empty(B)
+        path = np.empty((B, path_cap)) if path_cap > 0 else None
+        R2 = np.empty((B, N)) if want_R2 else None
+        re = None if r_each is None else np.ascontiguousarray(r_each, dtype=np.int32)
+        if re is not None and (re.shape != (B,) or re.min() < 1 or re.max() > r):
+            raise ValueError("r_each must hold B values in 1..r")
+        p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_als_batch(self._h, B, T, N, r, p(z), stride, p(re), p(F), p(Lam), int(nt_min),
+                                     int(min(max_iter, 2 ** 31 - 1)), float(tol), p(path), int(path_cap), p(iters),
+                                     p(ssr), p(R2))
+        _check(self._h, rc)
+        return dict(F=F, Lam=Lam, iters=iters, ssr=ssr, ssr_path=path, R2=R2)
+
+    def ols_batch_host(self, X, Y, nt_min: int = 0, shared_X: Optional[bool] = None, want_resid: bool = True):
+        """Batched complete-case OLS (`ols_skipmissing`, dfm_functions.ipynb:242-252) through the host entry.
+
+        X: [T,K] (shared regressors) or [P,T,K]; Y: [T,P] -- one problem per COLUMN (the reference's data
+        layout) -- with NaN for missing.  Returns dict(beta [P,K], resid [T,P] or None, ssr, tss, nobs [P])."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        T, P = Y.shape
+        if shared_X is None:
+            shared_X = X.ndim == 2
+        K = X.shape[-1]
+        if X.shape[-2] != T or (not shared_X and X.shape[0] != P):
+            raise ValueError("X and Y disagree on T or P")
+        beta = np.empty((P, K)); resid = np.empty((P, T)) if want_resid else None
+        ssr = np.empty(P); tss = np.empty(P); nobs = np.empty(P, dtype=np.int32)
+        p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_ols_batch(self._h, P, T, K, p(X), 0 if shared_X else T * K, p(Y), 1, P, int(nt_min),
+                                     p(beta), p(resid), p(ssr), p(tss), p(nobs))
+        _check(self._h, rc)
+        return dict(beta=beta, resid=None if resid is None else resid.T.copy(), ssr=ssr, tss=tss, nobs=nobs)

@@ -119,6 +119,39 @@ int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doub
 int dfm_pca_init_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam,
                        double* R, double* A, double* Q, double* mu0, double* P0, double* factors);
 
+/* --- the reference's NON-parametric estimator, batched ---------------------------------------------
+ * dfm_als_batch: `estimate_factor!` (dfm_functions.ipynb:328-382) for B independent runs -- the runs of
+ * `estimate_factor_numbers` / `amengual_watson_test` (:698-768), bootstrap draws, Monte-Carlo replicates.
+ * z: the standardised estimation window ([T][N] per run, NaN = missing, `standardize_data` :501-509 applied by
+ * the caller); run b reads z + b * z_stride (0: all runs share one panel).  F [B][T][r]: in = starting factors
+ * (`pca_score`, :179-183, columns >= r_each[b] ignored), out = factors after the last sweep.  Lam [B][N][r]:
+ * loadings of the last sweep, NaN for the series the reference leaves undefined (fewer than nt_min observed
+ * periods, :357).  A run stops after the sweep at which |SSR_old - SSR| < tol T N (SSR_old = 0 before the
+ * first sweep: at least one sweep always runs, :349-353, :367-368) or after max_iter sweeps.
+ * ssr_path [B][path_cap] (may be NULL): SSR after every sweep (`m.fes.ssr`, :366), NaN past iters[b].
+ * R2 [B][N] (may be NULL): :372-380.  r_each may be NULL (every run has r factors).  r <= DFM_MAX_R and
+ * (T + N) * pad(r) * 8 bytes must fit the 160 KB of LDS (DFM_E_DIMS otherwise). */
+int dfm_als_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* z, long long z_stride,
+                      const int* r_each, double* F, double* Lam, int nt_min, int max_iter, double tol,
+                      double* ssr_path, int path_cap, int* iters, double* ssr, double* R2);
+int dfm_als_batch(dfm_handle* h, int B, int T, int N, int r, const double* z, long long z_stride,
+                  const int* r_each, double* F, double* Lam, int nt_min, int max_iter, double tol,
+                  double* ssr_path, int path_cap, int* iters, double* ssr, double* R2);
+
+/* dfm_ols_batch: P complete-case least-squares problems (`ols_skipmissing(..., Balanced())`,
+ * dfm_functions.ipynb:242-252; the engine of `estimate_factor_loading!` :391-415, `uar` :305-311 and
+ * `estimate_var!` :444-468).  Problem p regresses y_p[t] = y[p * y_stride + t * y_inc] on the rows of X_p =
+ * X + p * x_stride ([T][K], x_stride 0 = shared regressors), dropping every row in which y or a regressor is
+ * NaN.  Outputs: beta [P][K]; resid [P][T] (NaN on dropped rows; may be NULL); ssr [P]; tss [P] = sum (y -
+ * ybar)^2 over the used rows (may be NULL; r2 = 1 - ssr / tss, `compute_r2` :565-569); nobs [P] = rows used.
+ * Problems with fewer than max(nt_min, K) complete rows get NaN.  K <= 64. */
+int dfm_ols_batch_dev(dfm_handle* h, int P, int T, int K, const double* X, long long x_stride, const double* y,
+                      long long y_stride, long long y_inc, int nt_min, double* beta, double* resid, double* ssr,
+                      double* tss, int* nobs);
+int dfm_ols_batch(dfm_handle* h, int P, int T, int K, const double* X, long long x_stride, const double* y,
+                  long long y_stride, long long y_inc, int nt_min, double* beta, double* resid, double* ssr,
+                  double* tss, int* nobs);
+
 /* --- synthetic replicates generated on the device (SURVEY.md §8(d) DGP; no reference
  * counterpart -- the reference has no RNG).  Writes the standardised panel and the DGP parameters
  * rescaled to it.  Counter-based generator keyed by (seed, first_replicate + b). */

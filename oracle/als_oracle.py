@@ -113,7 +113,7 @@ def _factor_step(z, obs, lam, solver):
 
 
 def estimate_factor(data, inclcode, init, last, r, tol=1e-8, nt_min=20, max_iter=10 ** 8,
-                    compute_r2_flag=True, solver="qr"):
+                    compute_r2_flag=True, solver="qr", f0=None):
     """`estimate_factor!` (dfm_functions.ipynb:328-382) with nfac_o = 0 and no loading constraint.
 
     Returns dict: factor (T_all x r, NaN outside the window), f (T x r), lam (ns x r, standardised units),
@@ -126,7 +126,7 @@ def estimate_factor(data, inclcode, init, last, r, tol=1e-8, nt_min=20, max_iter
     tss = float(np.nansum(z * z))                                 # :342
     nobs = int(obs.sum())                                         # :343
     xbal = z[:, obs.all(axis=0)]                                  # :345
-    f = pca_score(xbal, r)                                        # :348
+    f = pca_score(xbal, r) if f0 is None else np.array(f0, float)  # :348 (f0: start handed in by a test)
     T, ns = z.shape
     ssr, path = 0.0, []
     lam = np.full((ns, r), np.nan)

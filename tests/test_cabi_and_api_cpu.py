@@ -108,7 +108,9 @@ def test_standardize_data_is_population_sd_over_observed_cells():
 def test_estimate_rejects_what_the_path_does_not_cover():
     m = api.DFMModel(_data(), np.ones(7), 5, 5, 1, 40, 0, 2, 1e-8, 4, 4)
     with pytest.raises(NotImplementedError):
-        api.estimate(m, api.NonParametric())
+        api.estimate(m, api.NonParametric(), lam_constr_f=np.eye(2))     # loading constraints: not on the HIP path
+    with pytest.raises(RuntimeError, match="HIP device"):
+        api.estimate(m, api.NonParametric())                             # no CPU fallback
     with pytest.raises(TypeError):
         api.estimate(m, object())
     m2 = api.DFMModel(_data(), np.ones(7), 5, 5, 1, 40, 1, 2, 1e-8, 4, 4)
