@@ -52,6 +52,12 @@ SYMBOLS = {
     "dfm_als_batch": (c_int, _ALS_ARGS),
     "dfm_ols_batch_dev": (c_int, _OLS_ARGS),
     "dfm_ols_batch": (c_int, _OLS_ARGS),
+    "dfm_var_bootstrap_irf_dev": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                                          ctypes.c_uint64, c_vp, c_vp]),
+    "dfm_var_bootstrap_irf": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
+                                      ctypes.c_uint64, c_vp, c_vp]),
+    "dfm_quantile_bands_dev": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "dfm_quantile_bands": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "dfm_synth_panels_dev": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_int64, c_int, c_int, c_int, c_int,
                                      ctypes.c_double] + [c_vp] * 7),
 }

@@ -426,3 +426,42 @@ def estimate_factor_numbers(m: DFMModel, nfacs, *, ctx=None, with_aw: bool = Fal
     bn = np.array([bai_ng_criterion(s, nobs, T, k) for s, k in zip(o["ssr"], nfacs)])
     return dict(bn_icp=bn, ssr_static=o["ssr"].copy(), tss=tss, nobs=nobs, T=T, iters=o["iters"].copy(),
                 factors=o["F"])
+
+
+def impulse_response(varm: VARModel, shock_ids, T: int) -> np.ndarray:
+    """`impulse_response(varm, shock_ids, T)` -- dfm_functions.ipynb:793-816: irf[:, t, k] = Q M^t G[:, shock_k]
+    (point estimate; host arithmetic on the 16 x 16 companion, as in the reference)."""
+    shock_ids = [int(s) for s in np.atleast_1d(shock_ids)]
+    out = np.empty((varm.Q.shape[0], T, len(shock_ids)))
+    for k, s in enumerate(shock_ids):
+        x = varm.G[:, s].copy()
+        for t in range(T):
+            out[:, t, k] = varm.Q @ x
+            x = varm.M @ x
+    return out
+
+
+def bootstrap_irf_bands(varm: VARModel, H: int, ndraws: int = 10000, quantiles=(0.05, 0.16, 0.5, 0.84, 0.95),
+                        seed: int = 20160415, signs=None, ctx=None):
+    """Wild-bootstrap bands of the impulse responses of an estimated VARModel (BASELINE config 5; no reference
+    counterpart -- the reference stops at the point estimate).  Draws, re-estimation, Cholesky, IRF recursion and
+    the quantiles all run in boot.hip.  Returns dict(point [ns,H,ns], bands [len(q),ns,H,ns], draws [B,ns,H,ns])."""
+    rows = np.nonzero(~np.isnan(varm.resid).any(axis=1))[0]
+    if rows.size == 0:
+        raise ValueError("estimate_var(varm) first")
+    first = rows[0] - varm.nlag
+    if first < 0 or not np.array_equal(rows, np.arange(rows[0], rows[-1] + 1)):
+        raise ValueError("the VAR's estimation rows must be one contiguous block (no missing factors inside the window)")
+    y = varm.y[first:rows[-1] + 1]
+    resid = np.zeros_like(y)
+    resid[varm.nlag:] = varm.resid[rows]
+    if not varm.withconst:
+        raise NotImplementedError("bootstrap_irf_bands needs a VAR with constant (the reference's default)")
+    ctx, own = _own(ctx)
+    try:
+        draws = ctx.var_bootstrap_irf_host(y, varm.betahat, resid, varm.nlag, H, ndraws, signs=signs, seed=seed)
+        bands = ctx.quantile_bands_host(draws, np.asarray(quantiles, float))
+    finally:
+        if own:
+            ctx.close()
+    return dict(point=impulse_response(varm, range(varm.ns), H), bands=bands, draws=draws)

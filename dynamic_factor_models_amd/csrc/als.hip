@@ -281,7 +281,8 @@ __global__ __launch_bounds__(kAlsThreads) void ols_kernel(OlsArgs a) {
         for (int j = 0; j < R; ++j) Grow[j] = (j == k) ? 1.0 : 0.0;
         hk = 0.0;
     }
-    const double bk = group_solve<R>(Grow, hk, Xg, hb, k);
+    const double dk = equilibrate_rows<R>(Grow, Xg, k);      // raw-unit regressors (a constant next to levels)
+    const double bk = dk * group_solve<R>(Grow, hk * dk, Xg, hb, k);
     __syncthreads();
     hb[k] = bk;                                              // the coefficient vector, for the residual pass
     __syncthreads();

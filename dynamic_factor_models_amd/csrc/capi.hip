@@ -41,11 +41,11 @@ struct dfm_handle {
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
-                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_COUNT };
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
                                                   "mstep_solve_kernel", "pca_kernels", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
-                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel"};
+                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel"};
 
 namespace {
 
@@ -899,6 +899,87 @@ int dfm_ols_batch(dfm_handle* h, int P, int T, int K, const double* X, long long
         hipMemcpyAsync(ssr, ssr_d, (size_t)P * d, hipMemcpyDeviceToHost, h->stream);
         if (tss) hipMemcpyAsync(tss, tss_d, (size_t)P * d, hipMemcpyDeviceToHost, h->stream);
         hipMemcpyAsync(nobs, n_d, (size_t)P * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    hipFree(buf);
+    return rc;
+}
+
+
+// ---- wild-bootstrap IRF bands (boot.hip) -----------------------------------------------------------------
+int dfm_var_bootstrap_irf_dev(dfm_handle* h, int B, int T, int ns, int p, int H, const double* y, const double* betahat,
+                              const double* resid, const double* signs, uint64_t seed, double* beta_out, double* irf) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || ns < 1 || p < 1 || H < 1 || T <= p + 1 + ns * p)
+        return fail(h, DFM_E_DIMS, "B, ns, p, H must be >= 1 and T > p + 1 + ns p%s");
+    if (ns > 8 || 1 + ns * p > 64) return fail(h, DFM_E_R_UNSUPPORTED, "ns > 8 or 1 + ns p > 64%s");
+    if (!y || !betahat || !resid || !irf) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    BootArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.T = T; a.ns = ns; a.p = p; a.H = H; a.y = y; a.betahat = betahat; a.resid = resid; a.signs = signs;
+    a.seed = seed; a.beta_out = beta_out; a.irf = irf;
+    hipError_t e;
+    { ProfScope ps(h, K_BOOT); e = launch_var_boot(a, h->stream); }
+    if (e == hipErrorInvalidValue) return fail(h, DFM_E_DIMS, "T x ns too large for the bootstrap kernel's LDS%s");
+    HIP_TRY(h, e);
+    return 0;
+}
+
+int dfm_var_bootstrap_irf(dfm_handle* h, int B, int T, int ns, int p, int H, const double* y, const double* betahat,
+                          const double* resid, const double* signs, uint64_t seed, double* beta_out, double* irf) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || ns < 1 || p < 1 || H < 1 || T < 1) return fail(h, DFM_E_DIMS, "B, T, ns, p, H must be >= 1%s");
+    if (!y || !betahat || !resid || !irf) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double), K = 1 + (size_t)ns * p;
+    const size_t n_y = (size_t)T * ns, n_b = K * ns, n_s = signs ? (size_t)B * T : 0, n_bo = beta_out ? (size_t)B * K * ns : 0,
+                 n_irf = (size_t)B * ns * H * ns;
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), (2 * n_y + n_b + n_s + n_bo + n_irf) * d));
+    double *y_d = buf, *b_d = y_d + n_y, *e_d = b_d + n_b, *s_d = e_d + n_y, *bo_d = s_d + n_s, *irf_d = bo_d + n_bo;
+    hipMemcpyAsync(y_d, y, n_y * d, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(b_d, betahat, n_b * d, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(e_d, resid, n_y * d, hipMemcpyHostToDevice, h->stream);
+    if (signs) hipMemcpyAsync(s_d, signs, n_s * d, hipMemcpyHostToDevice, h->stream);
+    int rc = dfm_var_bootstrap_irf_dev(h, B, T, ns, p, H, y_d, b_d, e_d, signs ? s_d : nullptr, seed,
+                                       beta_out ? bo_d : nullptr, irf_d);
+    if (rc == 0) {
+        hipMemcpyAsync(irf, irf_d, n_irf * d, hipMemcpyDeviceToHost, h->stream);
+        if (beta_out) hipMemcpyAsync(beta_out, bo_d, n_bo * d, hipMemcpyDeviceToHost, h->stream);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    hipFree(buf);
+    return rc;
+}
+
+int dfm_quantile_bands_dev(dfm_handle* h, int B, int S, int nq, const double* x, const double* q, double* out) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || S < 1 || nq < 1 || B > 16384) return fail(h, DFM_E_DIMS, "B in 1..16384, S, nq >= 1%s");
+    if (!x || !q || !out) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    QuantArgs a;
+    a.B = B; a.S = S; a.nq = nq; a.x = x; a.q = q; a.out = out;
+    { ProfScope ps(h, K_QUANT); HIP_TRY(h, launch_quantiles(a, h->stream)); }
+    return 0;
+}
+
+int dfm_quantile_bands(dfm_handle* h, int B, int S, int nq, const double* x, const double* q, double* out) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || S < 1 || nq < 1) return fail(h, DFM_E_DIMS, "B, S, nq must be >= 1%s");
+    if (!x || !q || !out) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double), n_x = (size_t)B * S, n_o = (size_t)nq * S;
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), (n_x + nq + n_o) * d));
+    double *x_d = buf, *q_d = x_d + n_x, *o_d = q_d + nq;
+    hipMemcpyAsync(x_d, x, n_x * d, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(q_d, q, (size_t)nq * d, hipMemcpyHostToDevice, h->stream);
+    int rc = dfm_quantile_bands_dev(h, B, S, nq, x_d, q_d, o_d);
+    if (rc == 0) {
+        hipMemcpyAsync(out, o_d, n_o * d, hipMemcpyDeviceToHost, h->stream);
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }

@@ -163,6 +163,26 @@ struct OlsArgs {
 };
 hipError_t launch_ols(int Rpad, const OlsArgs& a, hipStream_t s);
 
+// Wild-bootstrap impulse responses of the factor VAR and quantile bands (boot.hip).
+struct BootArgs {
+    int B, T, ns, p, H;         // draws, periods of the window, variables, lags, horizons
+    const double* y;            // [T][ns] the VAR's data over the window (no NaN)
+    const double* betahat;      // [1 + ns p][ns] point estimate (constant first)
+    const double* resid;        // [T][ns] residuals (rows < p unused)
+    const double* signs;        // [B][T] +-1, or null: Rademacher signs from Philox(seed; draw, period)
+    uint64_t seed;
+    double* beta_out;           // [B][1 + ns p][ns] re-estimated coefficients, or null
+    double* irf;                // [B][ns][H][ns]  irf[d][i][h][k] = (Q M^h G[:, k])_i of draw d
+};
+hipError_t launch_var_boot(const BootArgs& a, hipStream_t s);
+struct QuantArgs {
+    int B, S, nq;               // draws, series per draw, quantiles
+    const double* x;            // [B][S]
+    const double* q;            // [nq] in (0, 1]
+    double* out;                // [nq][S]
+};
+hipError_t launch_quantiles(const QuantArgs& a, hipStream_t s);
+
 // Device-side synthetic replicates (synth.hip); all arrays in the caller's layout (r).
 struct SynthArgs {
     int B, T, N, r;

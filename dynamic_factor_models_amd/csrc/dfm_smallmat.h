@@ -96,6 +96,24 @@ __device__ __forceinline__ double gj_inverse(double (&m)[R], double* X, int i) {
     return det;
 }
 
+// Symmetric diagonal scaling of a normal matrix held one row per lane: row <- d_k row d, d_k = G_kk^-1/2
+// (G_kk > 0), exchanged through the group's R-double LDS row `dx`.  Returns d_k; the caller scales its
+// right-hand side entry by d_k before, and its solution entry by d_k after, the solve.  Regressors on very
+// different scales (a constant next to levels) otherwise cost the unpivoted elimination its accuracy.
+template <int R, bool WAVE = false>
+__device__ __forceinline__ double equilibrate_rows(double (&m)[R], double* dx, int i) {
+    double dk = 1.0;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        if (j == i) dk = m[j] > 0.0 ? 1.0 / sqrt(m[j]) : 1.0;
+    group_sync<WAVE>();
+    dx[i] = dk;
+    group_sync<WAVE>();
+#pragma unroll
+    for (int j = 0; j < R; ++j) m[j] *= dk * dx[j];
+    return dk;
+}
+
 __device__ __forceinline__ bool close_enough(double a, double b) {
     return fabs(a - b) <= kSteadyTol * fabs(b);
 }

@@ -293,3 +293,36 @@ class DfmContext:
                                      p(beta), p(resid), p(ssr), p(tss), p(nobs))
         _check(self._h, rc)
         return dict(beta=beta, resid=None if resid is None else resid.T.copy(), ssr=ssr, tss=tss, nobs=nobs)
+
+    # ------------------------------------------------------------------ wild-bootstrap IRF bands (boot.hip)
+    def var_bootstrap_irf_host(self, y, betahat, resid, p: int, H: int, ndraws: int, signs=None, seed: int = 0,
+                               want_beta: bool = False):
+        """B recursive-design wild-bootstrap draws of VAR(p) -> Cholesky -> impulse responses.
+        y, resid: [T,ns] over the estimation window; betahat: [1 + ns p, ns].  Returns irf [B,ns,H,ns]
+        (variable, horizon, shock) and, if asked, the re-estimated coefficients [B,1+ns p,ns]."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        y, betahat = c(y), c(betahat)
+        resid = c(np.nan_to_num(resid))
+        T, ns = y.shape
+        B = int(ndraws)
+        sg = None if signs is None else c(signs)
+        if sg is not None and sg.shape != (B, T):
+            raise ValueError("signs must be [ndraws, T]")
+        irf = np.empty((B, ns, H, ns)); bo = np.empty((B, 1 + ns * p, ns)) if want_beta else None
+        ptr = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_var_bootstrap_irf(self._h, B, T, ns, int(p), int(H), ptr(y), ptr(betahat), ptr(resid),
+                                             ptr(sg), ctypes.c_uint64(seed), ptr(bo), ptr(irf))
+        _check(self._h, rc)
+        return (irf, bo) if want_beta else irf
+
+    def quantile_bands_host(self, x, q):
+        """Nearest-rank quantiles over the first axis: x [B, ...] -> [len(q), ...]."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B = x.shape[0]
+        S = int(np.prod(x.shape[1:]))
+        out = np.empty((q.size, S))
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_quantile_bands(self._h, B, S, int(q.size), ptr(x), ptr(q), ptr(out))
+        _check(self._h, rc)
+        return out.reshape((q.size,) + x.shape[1:])

@@ -152,6 +152,28 @@ int dfm_ols_batch(dfm_handle* h, int P, int T, int K, const double* X, long long
                   long long y_stride, long long y_inc, int nt_min, double* beta, double* resid, double* ssr,
                   double* tss, int* nobs);
 
+/* --- wild-bootstrap impulse-response bands of the factor VAR (BASELINE config 5) --------------------
+ * The reference stops at the point estimate: `estimate_var!` (dfm_functions.ipynb:444-468), `fill_matrices!`
+ * (:477-492: companion M, selector Q, G = lower Cholesky of the residual covariance) and `impulse_response`
+ * (:793-816: irf[:, t, k] = Q M^t G[:, k]).  dfm_var_bootstrap_irf runs B recursive-design wild-bootstrap
+ * draws of that chain: e*_t = s_t e_t with one Rademacher sign per period, y*_t = c + sum_l A_l y*_{t-l} +
+ * e*_t (y*_t = y_t for the first p periods), VAR(p) with constant re-estimated on y*, irf* from its M*, G*.
+ * y [T][ns]: the VAR's data over the estimation window (no NaN); betahat [1 + ns p][ns] (constant first) and
+ * resid [T][ns] (rows < p ignored): the point estimate, e.g. from dfm_ols_batch.  signs [B][T] (+1 / -1) or
+ * NULL: signs drawn on the device (Philox4x32-10 keyed by seed, counter (period, draw); bit 0 of word 0).
+ * Outputs: irf [B][ns][H][ns] (variable, horizon, shock); beta_out [B][1 + ns p][ns] or NULL.
+ * ns <= 8, 1 + ns p <= 64.  A draw with all signs +1 reproduces the point estimate. */
+int dfm_var_bootstrap_irf_dev(dfm_handle* h, int B, int T, int ns, int p, int H, const double* y,
+                              const double* betahat, const double* resid, const double* signs, uint64_t seed,
+                              double* beta_out, double* irf);
+int dfm_var_bootstrap_irf(dfm_handle* h, int B, int T, int ns, int p, int H, const double* y,
+                          const double* betahat, const double* resid, const double* signs, uint64_t seed,
+                          double* beta_out, double* irf);
+/* Nearest-rank quantiles over draws: x [B][S] -> out [nq][S], out[j][s] = the ceil(q[j] B)-th smallest of
+ * x[0..B)[s] (NaN draws sort last).  B <= 16384 (the draws of one series are sorted in LDS). */
+int dfm_quantile_bands_dev(dfm_handle* h, int B, int S, int nq, const double* x, const double* q, double* out);
+int dfm_quantile_bands(dfm_handle* h, int B, int S, int nq, const double* x, const double* q, double* out);
+
 /* --- synthetic replicates generated on the device (SURVEY.md §8(d) DGP; no reference
  * counterpart -- the reference has no RNG).  Writes the standardised panel and the DGP parameters
  * rescaled to it.  Counter-based generator keyed by (seed, first_replicate + b). */

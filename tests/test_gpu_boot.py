@@ -1,0 +1,91 @@
+"""GPU parity tests of the wild-bootstrap IRF draws and quantile bands (boot.hip) against oracle/boot_oracle.py,
+and BASELINE config 5's shape (10 000 draws x FAVAR(4) of the 4 Stock-Watson factors) through properties."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import als_oracle as ao
+from oracle import boot_oracle as bo
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from dynamic_factor_models_amd import DfmContext
+    c = DfmContext()
+    yield c
+    c.close()
+
+
+def _var_data(seed, T, ns, p):
+    g = np.random.default_rng(seed)
+    y = np.zeros((T, ns))
+    A = [0.35 / (l + 1) * np.eye(ns) + 0.03 * g.standard_normal((ns, ns)) for l in range(p)]   # stationary
+    for t in range(p, T):
+        y[t] = 0.2 + sum(A[l] @ y[t - 1 - l] for l in range(p)) + g.standard_normal(ns) @ np.linalg.cholesky(
+            np.eye(ns) + 0.3)
+    return y
+
+
+@pytest.mark.parametrize("T,ns,p,H", [(120, 3, 2, 8), (222, 4, 4, 12), (90, 2, 1, 5), (150, 6, 3, 6), (200, 8, 4, 4)])
+def test_draws_match_oracle(ctx, T, ns, p, H):
+    y = _var_data(T + ns, T, ns, p)
+    B = 9
+    g = np.random.default_rng(5)
+    signs = np.where(g.random((B, T)) < 0.5, -1.0, 1.0)
+    signs[0] = 1.0                                               # the identity draw
+    irf_o, beta_o, v = bo.var_bootstrap_irf(y, p, H, signs)
+    resid = np.zeros_like(y); resid[p:] = v["resid"][p:]
+    irf, beta = ctx.var_bootstrap_irf_host(y, v["betahat"], resid, p, H, B, signs=signs, want_beta=True)
+    np.testing.assert_allclose(beta, beta_o, rtol=0, atol=1e-9 * np.abs(beta_o).max())
+    np.testing.assert_allclose(irf, irf_o, rtol=0, atol=1e-9 * np.abs(irf_o).max())
+    point = ao.impulse_response(v["M"], v["Q"], v["G"], range(ns), H)
+    np.testing.assert_allclose(irf[0], point, rtol=0, atol=1e-9 * np.abs(point).max())   # all signs +1 = point estimate
+
+
+def test_quantile_bands_are_order_statistics(ctx):
+    g = np.random.default_rng(0)
+    x = g.standard_normal((1000, 3, 5))
+    x[7, 1, 2] = np.nan
+    q = np.array([0.05, 0.16, 0.5, 0.84, 0.95, 1.0])
+    got = ctx.quantile_bands_host(x, q)
+    xs = np.sort(np.where(np.isnan(x), np.inf, x), axis=0)
+    for j, qq in enumerate(q):
+        np.testing.assert_array_equal(got[j], xs[int(np.ceil(qq * 1000)) - 1])
+    want = np.quantile(np.delete(x[:, 0, 0], []), q[:5], method="inverted_cdf")
+    np.testing.assert_array_equal(got[:5, 0, 0], want)
+
+
+def test_config5_shape_bands(ctx):
+    """BASELINE config 5: 10 000 draws of the 4-factor VAR(4) on the Stock-Watson panel; device-drawn signs."""
+    from dynamic_factor_models_amd import api
+    d = np.load(os.path.join(HERE, "golden", "sw_panel.npz"))
+    m = api.DFMModel(d["bpdata"], d["inclcode"], 20, 40, 3, 224, 0, 4, 1e-8, 4, 4)
+    api.estimate(m, api.NonParametric(), ctx=ctx)
+    out = api.bootstrap_irf_bands(m.factor_var_model, H=12, ndraws=10000, ctx=ctx)
+    assert out["draws"].shape == (10000, 4, 12, 4) and out["bands"].shape == (5, 4, 12, 4)
+    assert np.isfinite(out["draws"]).all()
+    b = out["bands"]
+    assert (np.diff(b, axis=0) >= 0).all()                       # quantiles are ordered
+    # impact responses: the lower Cholesky factor has a zero upper triangle in every draw
+    for i in range(4):
+        for k in range(i + 1, 4):
+            assert (out["draws"][:, i, 0, k] == 0).all()
+    # the median band tracks the point estimate (stationary VAR: wide tolerance, relative to the response scale)
+    scale = np.abs(out["point"]).max()
+    assert np.abs(b[2] - out["point"]).max() < 0.25 * scale
+    inside = (out["point"] >= b[0] - 1e-12) & (out["point"] <= b[4] + 1e-12)
+    assert inside.mean() > 0.9
+    # determinism of the device-drawn signs and dependence on the seed
+    again = api.bootstrap_irf_bands(m.factor_var_model, H=12, ndraws=64, ctx=ctx)
+    other = api.bootstrap_irf_bands(m.factor_var_model, H=12, ndraws=64, seed=1, ctx=ctx)
+    np.testing.assert_array_equal(again["draws"], out["draws"][:64])
+    assert not np.array_equal(other["draws"], again["draws"])
+    # the device-drawn signs differ across draws: every response has a non-degenerate bootstrap distribution
+    sd = out["draws"][:, :, 1:, :].std(axis=0)
+    assert (sd > 1e-6 * scale).all()
