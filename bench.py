@@ -168,13 +168,14 @@ def main():
         # algorithmic bytes per launch (DESIGN.md "Kernels"): compulsory inputs read once + outputs written once
         npack = r * (r + 1) // 2
         kern_bytes = {"collapse_mfma_kernel": B * panel_b, "collapse_dma_kernel": B * panel_b,
+                      "collapse_wide_kernel": B * panel_b,
                       "collapse_kernel": B * panel_b,
                       "recursion_kernel": B * (b_in - panel_b + b_out),
                       "meanscan_kernel": B * (b_in - panel_b + 8 * (T * r + 1)),
                       "pfill_kernel": B * 8 * T * npack,
                       "gram_kernel": B * 8 * (N * r + N), "cov_kernel": B * 8 * (3 * r * r + r)}
         avg = {k: v[0] / v[1] for k, v in prof.items()}
-        dom = max((k for k in avg if k in ("collapse_mfma_kernel", "collapse_dma_kernel", "collapse_kernel",
+        dom = max((k for k in avg if k in ("collapse_mfma_kernel", "collapse_dma_kernel", "collapse_wide_kernel", "collapse_kernel",
                                             "recursion_kernel", "meanscan_kernel")), key=avg.get)
         achieved = kern_bytes.get(dom, 0) / (avg[dom] * 1e-3) / 1e9
         traffic = None
@@ -202,10 +203,12 @@ def main():
             ph = panel[:S].cpu().numpy()
             pr = [p[:S].cpu().numpy() for p in params]
             cpu = cpu_baseline(ph, pr, args.cpu_seconds)
-        out = dict(metric="Kalman-smoother passes/sec, N=200 T=500 r=8 panel", value=passes_per_s,
+        out = dict(metric=f"Kalman-smoother passes/sec, N={N} T={T} r={r} panel", value=passes_per_s,
                    unit="passes/s", n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                   config=dict(workload=f"BASELINE configs[1]: synthetic panel N={N} T={T} r={r}, "
+                   config=dict(workload=("BASELINE configs[1]" if (N, T, r) == (200, 500, 8) else
+                                         "BASELINE configs[3]" if (N, T, r) == (1000, 2000, 20) else "custom")
+                                        + f": synthetic panel N={N} T={T} r={r}, "
                                         f"batch={B} replicates per GPU, one full Kalman-smoother pass per step"
                                         + (f", {args.missing:.0%} cells missing" if may_missing else ", balanced"),
                                N=N, T=T, r=r, batch_per_gpu=B, global_batch=world * B, missing=args.missing,

@@ -41,11 +41,11 @@ struct dfm_handle {
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
-                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COUNT };
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
                                                   "mstep_solve_kernel", "pca_kernels", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
-                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel"};
+                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel"};
 
 namespace {
 
@@ -173,8 +173,13 @@ int check_dims(dfm_handle* h, int B, int T, int N, int r) {
     if (!h) return DFM_E_NULL;
     if (B < 1 || T < 1 || N < 1 || r < 1) return fail(h, DFM_E_DIMS, "B, T, N, r must be >= 1%s");
     if (r > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r > DFM_MAX_R (32)%s");
+    return 0;
+}
+// panels with missing cells (and EM) go through collapse_kernel's register tiling
+int check_general_n(dfm_handle* h, int N, int r) {
     if (N > collapse_max_n(pad_r(r)))
-        return fail(h, DFM_E_DIMS, "N too large for this r (collapse kernel register tiling)%s");
+        return fail(h, DFM_E_DIMS, "N too large for this r on the path with missing cells / EM (collapse kernel register "
+                                   "tiling: N <= 1024 for r <= 8, 512 for r <= 16, 256 for r <= 32)%s");
     return 0;
 }
 
@@ -235,7 +240,8 @@ struct EmOpts {          // all-null for a plain pass
 
 // Balanced panel, even N, plain pass: may this call take the fast path (fastpath.hip)?
 bool fast_eligible(const dfm_handle* h, int N, int r, unsigned flags) {
-    return !h->force_general && !(flags & DFM_F_MAY_HAVE_MISSING) && collapse_dma_supported(pad_r(r), N);
+    if (h->force_general || (flags & DFM_F_MAY_HAVE_MISSING)) return false;
+    return collapse_dma_supported(pad_r(r), N) || collapse_wide_supported(pad_r(r), N);
 }
 
 // gram + cov on the side stream, beside the streaming collapse on the main stream; the batch is cut
@@ -261,7 +267,10 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     fa.bcol = ca.bcol; fa.ssum = ca.ssum; fa.wtab = at<double>(h, p.wtab);
     // collapse kernel of the balanced path: contraction on the matrix pipe where the shape allows it
     // (collapse_mfma.hip), else the VALU kernel (collapse_dma.hip); DFM_COLLAPSE_VARIANT < 200 forces the latter
-    const bool use_mfma = collapse_mfma_supported(p.Rp, N) && (h->collapse_variant == 0 || h->collapse_variant >= 200);
+    // shapes outside the register tilings (or DFM_COLLAPSE_VARIANT=198): the wide kernel
+    const bool use_wide = !collapse_dma_supported(p.Rp, N) || h->collapse_variant == 198;
+    if (use_wide) { fa.scol = ca.scol; fa.ntile = collapse_wide_tiles(T); }
+    const bool use_mfma = !use_wide && collapse_mfma_supported(p.Rp, N) && (h->collapse_variant == 0 || h->collapse_variant >= 200);
     const int cvariant = use_mfma ? (h->collapse_variant >= 200 ? h->collapse_variant : 200)
                                   : (h->collapse_variant == 199 ? 0 : h->collapse_variant);   // 199: the VALU kernel's default
     // MFMA collapse: as many period segments per replicate as the chip has resident wave slots for this batch
@@ -280,9 +289,9 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     fa.f_smooth = f_smooth; fa.P_smooth = P_smooth; fa.loglik = loglik;
     fa.abl = h->scan_abl;
     if (h->no_side) {   // diagnostics: everything in order on the main stream
-        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }
+        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }
         { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
-        { ProfScope ps(h, use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
+        { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA); HIP_TRY(h, use_wide ? launch_collapse_wide(p.Rp, ca, h->stream) : launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
         return 0;
     }
@@ -294,11 +303,11 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         // The covariance kernel (128 waves, 224 VGPRs each) must be resident BEFORE the streaming collapse fills
         // every CU, or it waits for the collapse to drain (measured: 285 us instead of 90).  It therefore goes
         // first on the caller's stream, and the collapse is the forked work: its queue starts ~6 us later.
-        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_gram(p.Rp, ca, h->stream)); }   // 12 us, alone
+        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }   // 12 us, alone
         HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
         { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
-        { ProfScope ps(h, use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA, h->side); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->side, cvariant)); }
+        { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA, h->side); HIP_TRY(h, use_wide ? launch_collapse_wide(p.Rp, ca, h->side) : launch_collapse_dma(p.Rp, ca, h->side, cvariant)); }
         HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
         if (!h->no_pfill && P_smooth) {   // the data-independent rows of P_smooth, beside the collapse
             ProfScope ps(h, K_PFILL);
@@ -318,7 +327,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_fork, 0));
-    if (!fuse_gram) { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, launch_gram(p.Rp, ca, h->side)); }
+    if (!fuse_gram) { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->side) : launch_gram_wide(p.Rp, ca, h->side)); }
     { ProfScope ps(h, K_COV, h->side); HIP_TRY(h, launch_cov(p.Rp, fa, h->side)); }
     HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
     HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));
@@ -417,6 +426,7 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
            double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path, int* iters,
            double* loglik_single, double* f_smooth, double* P_smooth, unsigned flags) {
     if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (int rc = check_general_n(h, N, r)) return rc;
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -597,6 +607,8 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     if (int rc = check_dims(h, B, T, N, r)) return rc;
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0 || !f_smooth || !loglik)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (!fast_eligible(h, N, r, flags))
+        if (int rc = check_general_n(h, N, r)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const Plan p = make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags));
     if (int rc = ensure_ws(h, p.total)) return rc;
@@ -676,6 +688,7 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
                  double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path, int* iters,
                  double* f_smooth, double* P_smooth, unsigned flags) {
     if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (int rc = check_general_n(h, N, r)) return rc;
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");

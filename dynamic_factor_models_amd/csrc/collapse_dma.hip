@@ -365,6 +365,10 @@ static hipError_t launch_gram_r(const CollapseArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+bool gram_supported(int Rpad, int N) {
+    return N <= 256 || (Rpad <= 16 && N <= 512) || (Rpad <= 8 && N <= 1024);
+}
+
 hipError_t launch_gram(int Rpad, const CollapseArgs& a, hipStream_t s) {
     switch (Rpad) {
         case 2: return launch_gram_r<2>(a, s);

@@ -83,6 +83,13 @@ hipError_t launch_gram(int Rpad, const CollapseArgs& a, hipStream_t s);
 // same contract as launch_collapse_dma, contraction on the fp64 matrix pipe (collapse_mfma.hip)
 bool collapse_mfma_supported(int Rpad, int N);
 hipError_t launch_collapse_mfma(int Rpad, const CollapseArgs& a, hipStream_t s, int variant);
+// cross-sections beyond the register tilings above (collapse_wide.hip): one wave per 16-period tile, weights
+// re-read from L2 per tile; per-tile partial sums of s_t go to scol[b][tile]
+bool collapse_wide_supported(int Rpad, int N);
+int collapse_wide_tiles(int T);
+hipError_t launch_collapse_wide(int Rpad, const CollapseArgs& a, hipStream_t s);
+hipError_t launch_gram_wide(int Rpad, const CollapseArgs& a, hipStream_t s);
+bool gram_supported(int Rpad, int N);       // launch_gram's register tilings
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
 hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
 bool mstep_needs_dmiss(int Rpad, int N);
@@ -107,6 +114,7 @@ struct FastArgs {
     // collapse -> meanscan
     const double* bcol; const double* ssum;                                  // ssum [B][kSsumSlots]
     int nseg;                   // slots of ssum that were written
+    const double* scol; int ntile;   // ntile > 0: sum_t s_t = sum of scol[b][0 .. ntile) instead (collapse_wide)
     double* wtab;               // [B][T][Rp] scratch
     // outputs
     double* f_smooth; double* P_smooth; double* loglik;

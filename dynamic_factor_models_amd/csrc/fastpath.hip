@@ -723,7 +723,11 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
         double d = 0.0, sq = 0.0;
 #pragma unroll
         for (int w = 0; w < kScanThreads / 64; ++w) d += s_red[w];
-        for (int w = 0; w < a.nseg; ++w) sq += a.ssum[(size_t)b * kSsumSlots + w];
+        if (a.ntile > 0) {
+            for (int w = 0; w < a.ntile; ++w) sq += a.scol[(size_t)b * T + w];
+        } else {
+            for (int w = 0; w < a.nseg; ++w) sq += a.ssum[(size_t)b * kSsumSlots + w];
+        }
         a.loglik[b] = -0.5 * (a.llc[b] + sq - d);
     }
 }

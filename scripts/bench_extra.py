@@ -1,0 +1,119 @@
+#!/usr/bin/env python
+"""Measurement lines for the rows of SURVEY.md section 8 beyond the headline pass (run on the GPU box):
+  als   -- BASELINE config 1: Stock-Watson real panel, r = 4, PCA + 10 ALS sweeps (`estimate_factor!(m, 10)`), B runs
+           of the same problem in one dfm_als_batch call (stand-in for B bootstrap / Monte-Carlo runs), next to the
+           CPU oracle (NumPy, one thread) on the same problem;
+  boot  -- BASELINE config 5: 10 000 wild-bootstrap draws of the 4-factor VAR(4) -> IRF bands, next to the CPU oracle
+           on a bounded sample of draws.
+Prints one JSON line per workload."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OMP_NUM_THREADS", "1")
+
+import torch  # noqa: E402
+
+from dynamic_factor_models_amd import DfmContext, api  # noqa: E402
+from oracle import als_oracle as ao  # noqa: E402
+from oracle import boot_oracle as bo  # noqa: E402
+
+d = np.load(os.path.join(ROOT, "tests", "golden", "sw_panel.npz"))
+bp, inc, cat = d["bpdata"], d["inclcode"], d["bpcatcode"]
+real = np.isin(np.floor(cat), [1, 2, 3, 5])
+ctx = DfmContext()
+dev = torch.device("cuda", ctx.device)
+
+# ---------------------------------------------------------------- ALS (config 1)
+z, _ = api.standardize_data(bp[2:224][:, real][:, inc[real] == 1])
+z = np.ascontiguousarray(z)
+T, N = z.shape
+F0 = api.pca_start(ctx, z, 4)
+B = 4096
+zt = torch.from_numpy(z).to(dev)
+F = torch.from_numpy(np.repeat(F0[None], B, axis=0)).to(dev)
+Lam = torch.empty((B, N, 4), dtype=torch.float64, device=dev)
+iters = torch.empty(B, dtype=torch.int32, device=dev)
+ssr = torch.empty(B, dtype=torch.float64, device=dev)
+import ctypes  # noqa: E402
+p = lambda t: ctypes.c_void_p(t.data_ptr())
+F_in = F.clone()
+
+
+def als_call():
+    F.copy_(F_in)
+    ctx._sync_stream()
+    rc = ctx._lib.dfm_als_batch_dev(ctx._h, B, T, N, 4, p(zt), 0, None, p(F), p(Lam), 20, 10, 1e-8, None, 0, p(iters),
+                                    p(ssr), None)
+    assert rc == 0
+
+
+als_call(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 5
+for _ in range(K):
+    als_call()
+torch.cuda.synchronize()
+gpu_s = (time.perf_counter() - t0) / K
+t0 = time.perf_counter(); n = 0
+while time.perf_counter() - t0 < 5.0:
+    o = ao.estimate_factor(bp[:, real], inc[real], 3, 224, 4, max_iter=10, solver="normal", compute_r2_flag=False, f0=F0)
+    n += 1
+cpu_s = (time.perf_counter() - t0) / n
+assert abs(float(ssr[0]) - o["ssr"]) < 1e-8 * o["ssr"] and abs(float(ssr[-1]) - o["ssr"]) < 1e-8 * o["ssr"]
+nobs = int((~np.isnan(z)).sum())
+print(json.dumps(dict(workload="BASELINE configs[0]: Stock-Watson real panel (222 x 58, 12 700 cells), r=4, PCA start + 10 ALS sweeps",
+                      metric="ALS runs/sec", value=B / gpu_s, unit="runs/s", batch=B, ms_per_batch=1e3 * gpu_s,
+                      sweeps_per_s=10 * B / gpu_s, dtype="f64",
+                      note="latency-bound (222 + 58 small dependent solves per sweep per run); panel 103 KB is L2-resident",
+                      cpu_baseline=dict(value=1.0 / cpu_s, unit="runs/s", cores=1, kind="port",
+                                        sample=f"{n} runs of oracle/als_oracle.py (NumPy normal equations) in 5 s"))))
+
+# ---------------------------------------------------------------- bootstrap IRF bands (config 5)
+m = api.DFMModel(bp, inc, 20, 40, 3, 224, 0, 4, 1e-8, 4, 4)
+api.estimate(m, api.NonParametric(), ctx=ctx)
+v = m.factor_var_model
+rows = np.nonzero(~np.isnan(v.resid).any(axis=1))[0]
+y = v.y[rows[0] - 4: rows[-1] + 1]
+resid = np.zeros_like(y); resid[4:] = v.resid[rows]
+Bd, H = 10000, 12
+yt, bt, et = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (y, v.betahat, resid))
+irf = torch.empty((Bd, 4, H, 4), dtype=torch.float64, device=dev)
+q = torch.tensor([0.05, 0.16, 0.5, 0.84, 0.95], dtype=torch.float64, device=dev)
+bands = torch.empty((5, 4 * H * 4), dtype=torch.float64, device=dev)
+
+
+def boot_call():
+    ctx._sync_stream()
+    rc = ctx._lib.dfm_var_bootstrap_irf_dev(ctx._h, Bd, y.shape[0], 4, 4, H, p(yt), p(bt), p(et), None,
+                                            ctypes.c_uint64(20160415), None, p(irf))
+    assert rc == 0
+    rc = ctx._lib.dfm_quantile_bands_dev(ctx._h, Bd, 4 * H * 4, 5, p(irf), p(q), p(bands))
+    assert rc == 0
+
+
+boot_call(); torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(K):
+    boot_call()
+torch.cuda.synchronize()
+gpu_s = (time.perf_counter() - t0) / K
+g = np.random.default_rng(0)
+nd = 4000
+signs = np.where(g.random((nd, y.shape[0])) < 0.5, -1.0, 1.0)
+t0 = time.perf_counter()
+bo.var_bootstrap_irf(y, 4, H, signs)
+cpu_s = (time.perf_counter() - t0) / nd
+print(json.dumps(dict(workload="BASELINE configs[4]: 10000 wild-bootstrap draws x VAR(4) of the 4 Stock-Watson factors (T=222), "
+                               "IRFs to 12 horizons, 5/16/50/84/95 % bands",
+                      metric="bootstrap draws/sec (draw + re-estimation + Cholesky + IRF + bands)", value=Bd / gpu_s,
+                      unit="draws/s", draws=Bd, ms_per_batch=1e3 * gpu_s, dtype="f64",
+                      note="latency-bound (218 dependent periods per draw, 17 x 17 normal equations)",
+                      cpu_baseline=dict(value=1.0 / cpu_s, unit="draws/s", cores=1, kind="port",
+                                        sample=f"{nd} draws of oracle/boot_oracle.py (NumPy) in {cpu_s * nd:.1f} s"))))
+ctx.close()

@@ -159,6 +159,10 @@ BALANCED_SHAPES = [
     (2, 400, 50, 16),          # too many MFMA steps for the register file: VALU kernel
     (2, 1000, 64, 8),          # 8N > 4 KiB rows: VALU kernel, 8-chunk tiling
     (2, 100, 40, 20),          # r padded to 32: VALU kernel
+    (2, 600, 70, 12),          # beyond every register tiling (N > 512 at r > 8): wide kernel, r padded to 16
+    (2, 300, 37, 20),          # wide kernel, r padded to 32, T not a multiple of the 16-period tile
+    (3, 31, 41, 3),            # odd N: wide kernel (8-byte loads)
+    (1, 1000, 2000, 20),       # BASELINE config 4's shape (N = 1000, T = 2000, r = 20), one replicate
 ]
 
 
@@ -184,10 +188,10 @@ def test_balanced_fast_path_matches_oracle(ctx, B, N, T, r):
     _compare(_run_dev(ctx, panel, st, may_have_missing=False), ref, f"fast B={B} N={N} T={T} r={r}")
 
 
-@pytest.mark.parametrize("env", [dict(DFM_COLLAPSE_VARIANT=199), dict(DFM_COLLAPSE_WPR=1), dict(DFM_COLLAPSE_WPR=3), dict(DFM_COLLAPSE_WPR=7),
+@pytest.mark.parametrize("env", [dict(DFM_COLLAPSE_VARIANT=199), dict(DFM_COLLAPSE_VARIANT=198), dict(DFM_COLLAPSE_WPR=1), dict(DFM_COLLAPSE_WPR=3), dict(DFM_COLLAPSE_WPR=7),
                                  dict(DFM_FORCE_GENERAL=1)])
 def test_balanced_kernel_choices_agree(env):
-    """The VALU collapse, the MFMA collapse with 1/3/7 period segments per replicate and the general
+    """The VALU collapse, the wide collapse, the MFMA collapse with 1/3/7 period segments per replicate and the general
     (sequential) path are the same function of the inputs."""
     c = _ctx_with_env(**env)
     try:
@@ -196,3 +200,28 @@ def test_balanced_kernel_choices_agree(env):
             _compare(_run_dev(c, panel, st, may_have_missing=False), _oracle(panel, st), f"{env} N={N} T={T} r={r}")
     finally:
         c.close()
+
+
+def test_config4_full_size_properties(ctx):
+    """BASELINE config 4 at full size (N = 1000, T = 2000, r = 20, 256 replicates; 4.1 GB of panels): the
+    size-independent properties of the pass -- linearity of the smoothed mean in the data (mu0 = 0), data-independent
+    smoothed covariance -- plus exact agreement of one replicate with the same replicate run alone."""
+    import torch
+    B, N, T, r = 256, 1000, 2000, 20
+    dev = torch.device("cuda", ctx.device)
+    g = torch.Generator(device="cuda").manual_seed(4)
+    panel = torch.randn((B, T, N), dtype=torch.float64, device=dev, generator=g)
+    _, st = _batch(1, N, T, r)
+    rep = lambda a: torch.from_numpy(a).to(dev).expand(B, *a.shape[1:]).contiguous()
+    args = [rep(st[k]) for k in ("Lam", "R", "A", "Q", "mu0", "P0")]
+    f1, P1, ll1 = ctx.ks_pass_batch(panel, *args, may_have_missing=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ll1).all())
+    one = [a[:1].contiguous() for a in args]
+    f0, P0, ll0 = ctx.ks_pass_batch(panel[17:18].contiguous(), *one, may_have_missing=False)
+    assert torch.equal(f0[0], f1[17]) and torch.equal(P0[0], P1[17]) and torch.equal(ll0[0], ll1[17])
+    panel.mul_(-2.0)
+    f2, P2, _ = ctx.ks_pass_batch(panel, *args, may_have_missing=False)
+    torch.cuda.synchronize()
+    assert torch.allclose(f2, -2.0 * f1, rtol=1e-10, atol=1e-12)
+    assert torch.equal(P1, P2) and torch.equal(P1[0], P1[-1])
