@@ -53,9 +53,9 @@ SYMBOLS = {
     "dfm_ols_batch_dev": (c_int, _OLS_ARGS),
     "dfm_ols_batch": (c_int, _OLS_ARGS),
     "dfm_var_bootstrap_irf_dev": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
-                                          ctypes.c_uint64, c_vp, c_vp]),
+                                          ctypes.c_uint64, ctypes.c_int64, c_vp, c_vp]),
     "dfm_var_bootstrap_irf": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp,
-                                      ctypes.c_uint64, c_vp, c_vp]),
+                                      ctypes.c_uint64, ctypes.c_int64, c_vp, c_vp]),
     "dfm_quantile_bands_dev": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "dfm_quantile_bands": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "dfm_synth_panels_dev": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_int64, c_int, c_int, c_int, c_int,

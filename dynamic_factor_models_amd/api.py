@@ -442,10 +442,15 @@ def impulse_response(varm: VARModel, shock_ids, T: int) -> np.ndarray:
 
 
 def bootstrap_irf_bands(varm: VARModel, H: int, ndraws: int = 10000, quantiles=(0.05, 0.16, 0.5, 0.84, 0.95),
-                        seed: int = 20160415, signs=None, ctx=None):
+                        seed: int = 20160415, signs=None, ctx=None, rank: int = 0, world: int = 1, gather=None):
     """Wild-bootstrap bands of the impulse responses of an estimated VARModel (BASELINE config 5; no reference
     counterpart -- the reference stops at the point estimate).  Draws, re-estimation, Cholesky, IRF recursion and
-    the quantiles all run in boot.hip.  Returns dict(point [ns,H,ns], bands [len(q),ns,H,ns], draws [B,ns,H,ns])."""
+    the quantiles all run in boot.hip.  Returns dict(point [ns,H,ns], bands [len(q),ns,H,ns], draws [B,ns,H,ns]).
+
+    Multi-GPU (one process per GPU): rank k of `world` computes the draws shard.replicate_range(ndraws, world, k)
+    -- the device-drawn signs depend on the global draw index only -- and `gather` (e.g. a function wrapping
+    shard.allgather_replicates) assembles the [ndraws, ...] array before the bands are taken; that all-gather is
+    the path's one collective."""
     rows = np.nonzero(~np.isnan(varm.resid).any(axis=1))[0]
     if rows.size == 0:
         raise ValueError("estimate_var(varm) first")
@@ -459,7 +464,14 @@ def bootstrap_irf_bands(varm: VARModel, H: int, ndraws: int = 10000, quantiles=(
         raise NotImplementedError("bootstrap_irf_bands needs a VAR with constant (the reference's default)")
     ctx, own = _own(ctx)
     try:
-        draws = ctx.var_bootstrap_irf_host(y, varm.betahat, resid, varm.nlag, H, ndraws, signs=signs, seed=seed)
+        from .shard import replicate_range
+        lo, hi = replicate_range(int(ndraws), world, rank)
+        draws = ctx.var_bootstrap_irf_host(y, varm.betahat, resid, varm.nlag, H, hi - lo, seed=seed, first_draw=lo,
+                                           signs=None if signs is None else np.asarray(signs)[lo:hi])
+        if world > 1:
+            if gather is None:
+                raise ValueError("world > 1 needs a gather function")
+            draws = np.asarray(gather(draws))
         bands = ctx.quantile_bands_host(draws, np.asarray(quantiles, float))
     finally:
         if own:

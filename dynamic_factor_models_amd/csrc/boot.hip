@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBootThreads) void var_boot_kernel(BootArgs a) {
             sgn = a.signs[(size_t)dd * T + t];
         } else {
             uint32_t o[4];
-            Philox::block(a.seed, (uint64_t)t, (uint64_t)dd, o);
+            Philox::block(a.seed, (uint64_t)t, (uint64_t)(a.first_draw + dd), o);
             sgn = (o[0] & 1u) ? 1.0 : -1.0;
         }
         double yn[NS];

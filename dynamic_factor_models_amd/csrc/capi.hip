@@ -922,7 +922,8 @@ int dfm_ols_batch(dfm_handle* h, int P, int T, int K, const double* X, long long
 
 // ---- wild-bootstrap IRF bands (boot.hip) -----------------------------------------------------------------
 int dfm_var_bootstrap_irf_dev(dfm_handle* h, int B, int T, int ns, int p, int H, const double* y, const double* betahat,
-                              const double* resid, const double* signs, uint64_t seed, double* beta_out, double* irf) {
+                              const double* resid, const double* signs, uint64_t seed, int64_t first_draw, double* beta_out,
+                              double* irf) {
     if (!h) return DFM_E_NULL;
     if (B < 1 || ns < 1 || p < 1 || H < 1 || T <= p + 1 + ns * p)
         return fail(h, DFM_E_DIMS, "B, ns, p, H must be >= 1 and T > p + 1 + ns p%s");
@@ -932,7 +933,7 @@ int dfm_var_bootstrap_irf_dev(dfm_handle* h, int B, int T, int ns, int p, int H,
     BootArgs a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.T = T; a.ns = ns; a.p = p; a.H = H; a.y = y; a.betahat = betahat; a.resid = resid; a.signs = signs;
-    a.seed = seed; a.beta_out = beta_out; a.irf = irf;
+    a.seed = seed; a.first_draw = first_draw; a.beta_out = beta_out; a.irf = irf;
     hipError_t e;
     { ProfScope ps(h, K_BOOT); e = launch_var_boot(a, h->stream); }
     if (e == hipErrorInvalidValue) return fail(h, DFM_E_DIMS, "T x ns too large for the bootstrap kernel's LDS%s");
@@ -941,7 +942,8 @@ int dfm_var_bootstrap_irf_dev(dfm_handle* h, int B, int T, int ns, int p, int H,
 }
 
 int dfm_var_bootstrap_irf(dfm_handle* h, int B, int T, int ns, int p, int H, const double* y, const double* betahat,
-                          const double* resid, const double* signs, uint64_t seed, double* beta_out, double* irf) {
+                          const double* resid, const double* signs, uint64_t seed, int64_t first_draw, double* beta_out,
+                          double* irf) {
     if (!h) return DFM_E_NULL;
     if (B < 1 || ns < 1 || p < 1 || H < 1 || T < 1) return fail(h, DFM_E_DIMS, "B, T, ns, p, H must be >= 1%s");
     if (!y || !betahat || !resid || !irf) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
@@ -956,7 +958,7 @@ int dfm_var_bootstrap_irf(dfm_handle* h, int B, int T, int ns, int p, int H, con
     hipMemcpyAsync(b_d, betahat, n_b * d, hipMemcpyHostToDevice, h->stream);
     hipMemcpyAsync(e_d, resid, n_y * d, hipMemcpyHostToDevice, h->stream);
     if (signs) hipMemcpyAsync(s_d, signs, n_s * d, hipMemcpyHostToDevice, h->stream);
-    int rc = dfm_var_bootstrap_irf_dev(h, B, T, ns, p, H, y_d, b_d, e_d, signs ? s_d : nullptr, seed,
+    int rc = dfm_var_bootstrap_irf_dev(h, B, T, ns, p, H, y_d, b_d, e_d, signs ? s_d : nullptr, seed, first_draw,
                                        beta_out ? bo_d : nullptr, irf_d);
     if (rc == 0) {
         hipMemcpyAsync(irf, irf_d, n_irf * d, hipMemcpyDeviceToHost, h->stream);

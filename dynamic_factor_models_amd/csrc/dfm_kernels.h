@@ -178,7 +178,7 @@ struct BootArgs {
     const double* betahat;      // [1 + ns p][ns] point estimate (constant first)
     const double* resid;        // [T][ns] residuals (rows < p unused)
     const double* signs;        // [B][T] +-1, or null: Rademacher signs from Philox(seed; draw, period)
-    uint64_t seed;
+    uint64_t seed; int64_t first_draw;   // device-drawn signs are a function of (seed, first_draw + d, period)
     double* beta_out;           // [B][1 + ns p][ns] re-estimated coefficients, or null
     double* irf;                // [B][ns][H][ns]  irf[d][i][h][k] = (Q M^h G[:, k])_i of draw d
 };

@@ -296,7 +296,7 @@ class DfmContext:
 
     # ------------------------------------------------------------------ wild-bootstrap IRF bands (boot.hip)
     def var_bootstrap_irf_host(self, y, betahat, resid, p: int, H: int, ndraws: int, signs=None, seed: int = 0,
-                               want_beta: bool = False):
+                               want_beta: bool = False, first_draw: int = 0):
         """B recursive-design wild-bootstrap draws of VAR(p) -> Cholesky -> impulse responses.
         y, resid: [T,ns] over the estimation window; betahat: [1 + ns p, ns].  Returns irf [B,ns,H,ns]
         (variable, horizon, shock) and, if asked, the re-estimated coefficients [B,1+ns p,ns]."""
@@ -311,7 +311,7 @@ class DfmContext:
         irf = np.empty((B, ns, H, ns)); bo = np.empty((B, 1 + ns * p, ns)) if want_beta else None
         ptr = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
         rc = self._lib.dfm_var_bootstrap_irf(self._h, B, T, ns, int(p), int(H), ptr(y), ptr(betahat), ptr(resid),
-                                             ptr(sg), ctypes.c_uint64(seed), ptr(bo), ptr(irf))
+                                             ptr(sg), ctypes.c_uint64(seed), ctypes.c_int64(first_draw), ptr(bo), ptr(irf))
         _check(self._h, rc)
         return (irf, bo) if want_beta else irf
 

@@ -160,15 +160,16 @@ int dfm_ols_batch(dfm_handle* h, int P, int T, int K, const double* X, long long
  * e*_t (y*_t = y_t for the first p periods), VAR(p) with constant re-estimated on y*, irf* from its M*, G*.
  * y [T][ns]: the VAR's data over the estimation window (no NaN); betahat [1 + ns p][ns] (constant first) and
  * resid [T][ns] (rows < p ignored): the point estimate, e.g. from dfm_ols_batch.  signs [B][T] (+1 / -1) or
- * NULL: signs drawn on the device (Philox4x32-10 keyed by seed, counter (period, draw); bit 0 of word 0).
+ * NULL: signs drawn on the device (Philox4x32-10 keyed by seed, counter (period, first_draw + d); bit 0 of
+ * word 0), a pure function of the GLOBAL draw index: a rank that owns draws [lo, hi) passes first_draw = lo.
  * Outputs: irf [B][ns][H][ns] (variable, horizon, shock); beta_out [B][1 + ns p][ns] or NULL.
  * ns <= 8, 1 + ns p <= 64.  A draw with all signs +1 reproduces the point estimate. */
 int dfm_var_bootstrap_irf_dev(dfm_handle* h, int B, int T, int ns, int p, int H, const double* y,
                               const double* betahat, const double* resid, const double* signs, uint64_t seed,
-                              double* beta_out, double* irf);
+                              int64_t first_draw, double* beta_out, double* irf);
 int dfm_var_bootstrap_irf(dfm_handle* h, int B, int T, int ns, int p, int H, const double* y,
                           const double* betahat, const double* resid, const double* signs, uint64_t seed,
-                          double* beta_out, double* irf);
+                          int64_t first_draw, double* beta_out, double* irf);
 /* Nearest-rank quantiles over draws: x [B][S] -> out [nq][S], out[j][s] = the ceil(q[j] B)-th smallest of
  * x[0..B)[s] (NaN draws sort last).  B <= 16384 (the draws of one series are sorted in LDS). */
 int dfm_quantile_bands_dev(dfm_handle* h, int B, int S, int nq, const double* x, const double* q, double* out);

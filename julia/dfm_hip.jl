@@ -87,6 +87,69 @@ function em(h::Handle, z::Matrix{Float64}, p; max_iter::Integer = 50, tol::Real 
             factor = permutedims(f[:, :, 1]))
 end
 
+# ---- the reference's NON-parametric estimator on the GPU (als.hip) ------------------------------------------------
+"`estimate_factor!` sweeps (dfm_functions.ipynb:352-370) for ONE run: z is the standardised T x N window (NaN =
+missing), F0 the T x r start (pca_score).  dfm_als_batch; returns factors, loadings (NaN rows: no loadings), ssr,
+iterations, R2."
+function als(h::Handle, z::Matrix{Float64}, F0::Matrix{Float64}; nt_min::Integer = 20,
+             max_iter::Integer = 100000000, tol::Real = 1e-8, want_R2::Bool = true)
+    T, N = size(z); r = size(F0, 2)
+    zc = permutedims(z, (2, 1))                                   # (N, T) column-major == C [t][i]
+    F = reshape(permutedims(F0, (2, 1)), r, T, 1)                 # C [b][t][k]
+    Lam = Array{Float64}(undef, r, N, 1); iters = Array{Cint}(undef, 1); ssr = Array{Float64}(undef, 1)
+    R2 = Array{Float64}(undef, N, 1)
+    GC.@preserve zc F Lam iters ssr R2 begin
+        rc = ccall((:dfm_als_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Clonglong, Ptr{Cint}, Ptr{Float64}, Ptr{Float64},
+                    Cint, Cint, Cdouble, Ptr{Float64}, Cint, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
+                   h.ptr, 1, T, N, r, zc, 0, C_NULL, F, Lam, nt_min, min(max_iter, typemax(Cint)), tol, C_NULL, 0,
+                   iters, ssr, want_R2 ? pointer(R2) : Ptr{Float64}(C_NULL))
+        check(h.ptr, rc)
+    end
+    return (factor = permutedims(F[:, :, 1]), Lam = permutedims(Lam[:, :, 1]), ssr = ssr[1], iters = Int(iters[1]),
+            R2 = R2[:, 1])
+end
+
+"P complete-case regressions (`ols_skipmissing(..., Balanced())`, dfm_functions.ipynb:242-252): column p of Y (T x P,
+NaN = missing) on the shared regressors X (T x K).  dfm_ols_batch; returns beta (K x P), resid (T x P), ssr, tss, nobs."
+function ols(h::Handle, X::Matrix{Float64}, Y::Matrix{Float64}; nt_min::Integer = 0)
+    T, K = size(X); P = size(Y, 2)
+    Xc = permutedims(X, (2, 1)); Yc = permutedims(Y, (2, 1))      # C [t][k], C [t][p]
+    beta = Array{Float64}(undef, K, P); resid = Array{Float64}(undef, T, P)
+    ssr = Array{Float64}(undef, P); tss = similar(ssr); nobs = Array{Cint}(undef, P)
+    GC.@preserve Xc Yc beta resid ssr tss nobs begin
+        rc = ccall((:dfm_ols_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Clonglong, Ptr{Float64}, Clonglong, Clonglong, Cint,
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cint}),
+                   h.ptr, P, T, K, Xc, 0, Yc, 1, P, nt_min, beta, resid, ssr, tss, nobs)
+        check(h.ptr, rc)
+    end
+    return (beta = beta, resid = resid, ssr = ssr, tss = tss, nobs = Int.(nobs))   # beta[:, p]: C [p][k] == Julia (k, p)
+end
+
+"B wild-bootstrap draws of the VAR's impulse responses (dfm_var_bootstrap_irf) and their nearest-rank quantile bands
+(dfm_quantile_bands).  y, resid: T x ns over the estimation window; betahat: (1 + ns p) x ns as in `estimate_var!`."
+function bootstrap_irf(h::Handle, y::Matrix{Float64}, betahat::Matrix{Float64}, resid::Matrix{Float64}, p::Integer,
+                       H::Integer, ndraws::Integer; seed::Integer = 20160415, first_draw::Integer = 0,
+                       quantiles = [0.05, 0.16, 0.5, 0.84, 0.95])
+    T, ns = size(y)
+    yc = permutedims(y, (2, 1)); bc = permutedims(betahat, (2, 1)); ec = permutedims(resid, (2, 1))
+    irf = Array{Float64}(undef, ns, H, ns, ndraws)                # C [d][i][h][k] == Julia (k, h, i, d)
+    q = Float64.(quantiles); bands = Array{Float64}(undef, ns, H, ns, length(q))
+    GC.@preserve yc bc ec irf q bands begin
+        rc = ccall((:dfm_var_bootstrap_irf, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    UInt64, Int64, Ptr{Float64}, Ptr{Float64}),
+                   h.ptr, ndraws, T, ns, p, H, yc, bc, ec, C_NULL, seed, first_draw, C_NULL, irf)
+        check(h.ptr, rc)
+        rc = ccall((:dfm_quantile_bands, LIB), Cint, (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                   h.ptr, ndraws, ns * H * ns, length(q), irf, q, bands)
+        check(h.ptr, rc)
+    end
+    # to the reference's irf[variable, horizon, shock] (dfm_functions.ipynb:793-816), draws / quantiles last
+    return (draws = permutedims(irf, (3, 2, 1, 4)), bands = permutedims(bands, (3, 2, 1, 4)))
+end
+
 end # module
 
 # ---------------------------------------------------------------------------------------------------------
@@ -131,4 +194,40 @@ function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em:
     var.seps[:, :] = fit.Q
     var.G[1:r, 1:r] = cholesky(Symmetric(fit.Q)).L
     return fit.loglik
+end
+
+
+# ---------------------------------------------------------------------------------------------------------
+# The reference's own estimator on the GPU: same arguments and effects as `estimate_factor!(m, max_iter, computeR2)`
+# (dfm_functions.ipynb:328-382).  To run Stock_Watson.ipynb unchanged on the GPU, forward the reference's method:
+#     estimate_factor!(m::DFMModel, max_iter::Integer = 100000000, computeR2::Bool = true; lam_constr = nothing) =
+#         estimate_factor_hip!(m, max_iter, computeR2)
+function estimate_factor_hip!(m::DFMModel, max_iter::Integer = 100000000, computeR2::Bool = true; device::Integer = 0,
+                              handle = nothing)
+    m.nfac_o == 0 || error("observed factors are not supported on the HIP path")
+    xdata = m.data[m.initperiod:m.lastperiod, m.inclcode .== 1]           # :335-336
+    xstd, _ = standardize_data(xdata)                                     # :339
+    m.fes.tss = sum(skipmissing(xstd .^ 2))                               # :342
+    m.fes.nobs = count(.!ismissing.(xstd))                                # :343
+    xbal, _ = drop_missing_col(xstd)                                      # :345
+    h = handle === nothing ? DFMHip.create(device) : handle
+    F0 = DFMHip.pca_init(h, Float64.(xbal), m.nfac_u).F                  # pca_score (:348)
+    z = reshape(DFMHip.nan_for_missing(xstd), size(xstd))
+    fit = DFMHip.als(h, z, F0; nt_min = m.nt_min_factor_estimation, max_iter = max_iter, tol = m.tol,
+                     want_R2 = computeR2)                                 # :352-370, :372-380
+    m.factor[m.initperiod:m.lastperiod, :] = fit.factor                   # :371
+    m.fes.ssr = fit.ssr                                                   # :366
+    computeR2 && (m.fes.R2 = fit.R2)
+    return nothing
+end
+
+# Wild-bootstrap bands of `impulse_response(varm, shock_ids, T)` (dfm_functions.ipynb:793-816) for an estimated VARModel.
+function bootstrap_irf_bands(varm::VARModel, H::Integer; ndraws::Integer = 10000, seed::Integer = 20160415,
+                             device::Integer = 0, handle = nothing)
+    rows = findall(t -> !any(ismissing, varm.resid[t, :]), 1:size(varm.resid, 1))
+    first = rows[1] - varm.nlag
+    y = Float64.(varm.y[first:rows[end], :])
+    resid = zeros(size(y)); resid[varm.nlag+1:end, :] = Float64.(varm.resid[rows, :])
+    h = handle === nothing ? DFMHip.create(device) : handle
+    return DFMHip.bootstrap_irf(h, y, Float64.(varm.betahat), resid, varm.nlag, H, ndraws; seed = seed)
 end

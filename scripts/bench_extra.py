@@ -91,7 +91,7 @@ bands = torch.empty((5, 4 * H * 4), dtype=torch.float64, device=dev)
 def boot_call():
     ctx._sync_stream()
     rc = ctx._lib.dfm_var_bootstrap_irf_dev(ctx._h, Bd, y.shape[0], 4, 4, H, p(yt), p(bt), p(et), None,
-                                            ctypes.c_uint64(20160415), None, p(irf))
+                                            ctypes.c_uint64(20160415), ctypes.c_int64(0), None, p(irf))
     assert rc == 0
     rc = ctx._lib.dfm_quantile_bands_dev(ctx._h, Bd, 4 * H * 4, 5, p(irf), p(q), p(bands))
     assert rc == 0

@@ -61,6 +61,14 @@ def test_quantile_bands_are_order_statistics(ctx):
     np.testing.assert_array_equal(got[:5, 0, 0], want)
 
 
+def _boot_inputs(m):
+    v = m.factor_var_model
+    rows = np.nonzero(~np.isnan(v.resid).any(axis=1))[0]
+    y = v.y[rows[0] - v.nlag: rows[-1] + 1]
+    resid = np.zeros_like(y); resid[v.nlag:] = v.resid[rows]
+    return y, v.betahat, resid
+
+
 def test_config5_shape_bands(ctx):
     """BASELINE config 5: 10 000 draws of the 4-factor VAR(4) on the Stock-Watson panel; device-drawn signs."""
     from dynamic_factor_models_amd import api
@@ -86,6 +94,10 @@ def test_config5_shape_bands(ctx):
     other = api.bootstrap_irf_bands(m.factor_var_model, H=12, ndraws=64, seed=1, ctx=ctx)
     np.testing.assert_array_equal(again["draws"], out["draws"][:64])
     assert not np.array_equal(other["draws"], again["draws"])
+    # sharded draws (two "ranks" on this GPU) reproduce the single-process draws: signs depend on the global index
+    parts = [ctx.var_bootstrap_irf_host(*_boot_inputs(m), 4, 12, hi - lo, seed=20160415, first_draw=lo)
+             for lo, hi in ((0, 31), (31, 64))]
+    np.testing.assert_array_equal(np.concatenate(parts), out["draws"][:64])
     # the device-drawn signs differ across draws: every response has a non-degenerate bootstrap distribution
     sd = out["draws"][:, :, 1:, :].std(axis=0)
     assert (sd > 1e-6 * scale).all()

@@ -72,3 +72,43 @@ def test_single_process_passthrough():
     assert shard.allgather_replicates(x, 6) is x
     with pytest.raises(ValueError):
         shard.allgather_replicates(x, 7)
+
+
+def _draw_worker(rank, world, port, ndraws, q):
+    """Bootstrap draws are sharded like replicates; the one collective is the all-gather of the draws before the
+    bands are taken (api.bootstrap_irf_bands(..., rank, world, gather))."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard.replicate_range(ndraws, world, rank)
+        # stand-in for the device draws: a pure function of the GLOBAL draw index, as the Philox signs are
+        g = np.arange(lo, hi, dtype=float)
+        local = np.stack([np.sin(g), g * g], axis=1).reshape(hi - lo, 2, 1)
+        full = shard.allgather_replicates(torch.from_numpy(local), ndraws).numpy()
+        med = np.quantile(full, 0.5, axis=0, method="inverted_cdf")
+        q.put((rank, full.copy(), med.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bootstrap_draws_gather_over_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    world, ndraws = 2, 101
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_draw_worker, args=(k, world, port, ndraws, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = np.arange(ndraws, dtype=float)
+    want = np.stack([np.sin(g), g * g], axis=1).reshape(ndraws, 2, 1)
+    for rank, full, med in got:
+        np.testing.assert_array_equal(full, want)                       # every rank: all draws, global order
+        np.testing.assert_array_equal(med, np.quantile(want, 0.5, axis=0, method="inverted_cdf"))
