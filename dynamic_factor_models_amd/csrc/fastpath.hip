@@ -32,6 +32,11 @@ constexpr int kScanThreads = 256;   // meanscan workgroup: 256 / R lane groups =
 // cov workgroup: 4 independent waves.  Four-wave workgroups put the 224-VGPR covariance waves on a quarter of
 // the CUs a one-wave workgroup would touch, which is what the streaming collapse beside them loses.
 __host__ __device__ constexpr int cov_threads(int R) { (void)R; return 64; }
+// minimum waves per SIMD the register allocation of cov_kernel must allow (3 = at most 168 VGPRs, the slot of one
+// collapse wave, was measured: spills slow the chain by 20 us and the collapse beside it gains nothing)
+#ifndef DFM_COV_MIN_WAVES
+#define DFM_COV_MIN_WAVES 2
+#endif
 // levels of the carry scan over the 256 / R chunks, and matrices kept per replicate in `stead`:
 // Z, J, G, then G^(L 2^k) and J^(L 2^k), k = 0 .. levels-1
 __host__ __device__ constexpr int scan_levels(int R) { int n = 0; while ((1 << n) < kScanThreads / R) ++n; return n; }
@@ -57,7 +62,7 @@ struct CovLayout {
 // separate gram_kernel launch: beside the streaming collapse, which fills every CU, a second dependent launch
 // on the side stream waits ~150 us for free registers.
 template <int R, int CPL2>
-__global__ __launch_bounds__(cov_threads(R)) void cov_kernel(FastArgs a) {
+__global__ __launch_bounds__(cov_threads(R), DFM_COV_MIN_WAVES) void cov_kernel(FastArgs a) {
     constexpr int kCovThreads = cov_threads(R);
     using LY = CovLayout<R>;
     constexpr int GPW = LY::GPW;
