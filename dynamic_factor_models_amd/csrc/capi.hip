@@ -29,6 +29,7 @@ struct dfm_handle {
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
     bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
+    bool em_general = false;               // DFM_EM_GENERAL=1: EM of balanced panels on the general path too (diagnostics)
     bool fuse_gram = false;                // DFM_FUSE_GRAM=1: Gram matrices inside cov_kernel instead of gram_kernel (slower: its
                                            // per-series loads are dependent round trips, ~5 us each beside the collapse)
     void* ws = nullptr;
@@ -41,11 +42,11 @@ struct dfm_handle {
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
-                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_COUNT };
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_EM_UPDATE, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
                                                   "mstep_solve_kernel", "pca_kernels", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
-                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel"};
+                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel", "em_update_kernel"};
 
 namespace {
 
@@ -249,7 +250,7 @@ bool fast_eligible(const dfm_handle* h, int N, int r, unsigned flags) {
 // (bandwidth-bound) collapse of sub-batch s+1.
 int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, const double* panel,
                       const PaddedParams& pp, const double* Rv, double* f_smooth, double* P_smooth,
-                      double* loglik) {
+                      double* loglik, const EmOpts* em = nullptr) {
     CollapseArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.B = B; ca.T = T; ca.N = N;
@@ -288,12 +289,29 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     if (fuse_gram) { fa.Lam = pp.Lam; fa.Rv = Rv; }
     fa.f_smooth = f_smooth; fa.P_smooth = P_smooth; fa.loglik = loglik;
     fa.abl = h->scan_abl;
+    if (em) {   // EM: covariance sums from cov_kernel, E[f_0 | X] from meanscan (workspace slots of S10 / S00 reused)
+        fa.SP11 = at<double>(h, p.S10); fa.SU = at<double>(h, p.S00); fa.P0s = at<double>(h, p.P0s);
+        fa.f0s = at<double>(h, p.f0s);
+    }
+    // after the scan: transition M-step + bookkeeping from the sufficient statistics
+    auto em_update = [&]() -> int {
+        if (!em) return 0;
+        EmUpdArgs ua;
+        memset(&ua, 0, sizeof(ua));
+        ua.B = B; ua.T = T; ua.fsm = f_smooth; ua.f0s = fa.f0s; ua.SP11 = fa.SP11; ua.SU = fa.SU; ua.P0s = fa.P0s;
+        ua.PT = fa.PT; ua.loglik = loglik; ua.S11 = at<double>(h, p.S11); ua.S11inv = at<double>(h, p.Sxf);
+        ua.A_out = em->A_out; ua.Q_out = em->Q_out; ua.mu0_out = em->mu0_out; ua.P0_out = em->P0_out;
+        ua.active = em->active; ua.iters = em->iters; ua.ll_path = em->ll_path; ua.k = em->k; ua.max_iter = em->max_iter;
+        ua.tol = em->tol;
+        { ProfScope ps(h, K_EM_UPDATE); HIP_TRY(h, launch_em_update(p.Rp, ua, h->stream)); }
+        return 0;
+    };
     if (h->no_side) {   // diagnostics: everything in order on the main stream
         if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }
         { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
         { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA); HIP_TRY(h, use_wide ? launch_collapse_wide(p.Rp, ca, h->stream) : launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
-        return 0;
+        return em_update();
     }
     // Measured on MI355X (profiles/r01): every cross-stream event edge costs 7-25 us, more than the
     // overlap buys at B = 1024, so the default is one sub-batch; DFM_SUBBATCH keeps the knob for big batches.
@@ -316,7 +334,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         }
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
-        return 0;
+        return em_update();
     }
     while ((int)h->ev_sub.size() < S) {
         hipEvent_t e;
@@ -344,7 +362,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     }
     HIP_TRY(h, hipEventRecord(h->ev_post, h->post));
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_post, 0));   // join
-    return 0;
+    return em_update();
 }
 
 // Enqueue collapse + recursion for already-planned workspace.  out_r = factor dimension of the
@@ -352,10 +370,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
 int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, const double* panel,
                  const PaddedParams& pp, const double* Rv, double* f_smooth, double* P_smooth, double* loglik,
                  const EmOpts* em) {
-    if (p.fast) {
-        if (em) return fail(h, DFM_E_DIMS, "internal: fast plan used for an EM pass%s");
-        return enqueue_pass_fast(h, p, B, T, N, out_r, panel, pp, Rv, f_smooth, P_smooth, loglik);
-    }
+    if (p.fast) return enqueue_pass_fast(h, p, B, T, N, out_r, panel, pp, Rv, f_smooth, P_smooth, loglik, em);
     CollapseArgs ca;
     ca.B = B; ca.T = T; ca.N = N;
     ca.panel = panel; ca.Lam = pp.Lam; ca.Rv = Rv;
@@ -430,7 +445,9 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
     HIP_TRY(h, hipSetDevice(h->device));
-    const Plan p = make_plan(B, T, N, r, flags, true);
+    // balanced panels: E-step on the fast path (collapse on the matrix pipe, time-parallel scan), transition
+    // M-step by em_update_kernel; panels with missing cells: recursion_kernel does both
+    const Plan p = make_plan(B, T, N, r, flags, true, fast_eligible(h, N, r, flags) && !h->em_general);
     if (int rc = ensure_ws(h, p.total)) return rc;
     HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     const int Rp = p.Rp;
@@ -527,6 +544,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
+    if (const char* v = getenv("DFM_EM_GENERAL")) h->em_general = atoi(v) != 0;
     if (const char* v = getenv("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_SUBBATCH")) h->subbatch = atoi(v);
     if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
@@ -725,7 +743,7 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
     }
     if (rc == 0) {
         int st = 0;
-        (void)hipMemcpy(&st, at<int>(h, make_plan(B, T, N, r, flags, true).status), sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&st, at<int>(h, make_plan(B, T, N, r, flags, true, fast_eligible(h, N, r, flags) && !h->em_general).status), sizeof(int), hipMemcpyDeviceToHost);
         if (st & 1) rc = fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
         for (int b = 0; rc == 0 && b < B; ++b)
             if (!isfinite(loglik_path[(size_t)b * max_iter])) rc = fail(h, DFM_E_NUMERIC, "non-finite log-likelihood%s");

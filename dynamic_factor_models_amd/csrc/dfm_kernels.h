@@ -122,6 +122,17 @@ struct FastArgs {
     int b0;                     // meanscan: first replicate of this launch (sub-batch pipelining)
     int abl;                    // diagnostics (DFM_SCAN_ABL): bit0 skip the P_smooth fill, bit1 skip the scans
 };
+struct EmUpdArgs {               // transition M-step + EM bookkeeping after a fast-path E-step (all padded, Rp)
+    int B, T;
+    const double* fsm;           // [B][T][Rp] smoothed means
+    const double* f0s;           // [B][Rp]    E[f_0 | X]
+    const double* SP11; const double* SU; const double* P0s; const double* PT;   // cov_kernel: [B][Rp][Rp]
+    const double* loglik;        // [B] log-likelihood of this E-step
+    double* S11; double* S11inv; // [B][Rp][Rp] for the loadings step
+    double* A_out; double* Q_out; double* mu0_out; double* P0_out;
+    int* active; int* iters; double* ll_path; int k, max_iter; double tol;   // as RecursionArgs
+};
+hipError_t launch_em_update(int Rpad, const EmUpdArgs& a, hipStream_t s);
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
 bool cov_fuses_gram(int Rpad, int N);   // launch_cov with a.Lam != nullptr is supported for this shape
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);

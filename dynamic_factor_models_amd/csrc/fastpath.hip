@@ -737,6 +737,146 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
     }
 }
 
+
+// ================================================================================================
+// em_update_kernel: the transition half of the M-step on the balanced fast path
+// ================================================================================================
+// Sufficient statistics from the smoother output (means: f_smooth in the padded layout, f0s; covariance sums
+// SP11, SU, P0s, P_T from cov_kernel):
+//     S11 = sum_{t=1..T} E[f_t f_t' | X],   S10 = sum_{t=1..T} E[f_t f_{t-1}' | X],   S00 = sum_{t=0..T-1} E[f_t f_t' | X]
+// then  A = S10 S00^-1,  Q = sym(S11 - A S10') / T,  mu0 = f_0|T,  P0 = sym(P_0|T)  (Shumway-Stoffer 1982), the
+// S11, S11^-1 the loadings step needs, and the per-replicate EM bookkeeping -- exactly the epilogue of
+// recursion_kernel (recursion.hip), which does the same for panels with missing cells.
+// One lane group of R lanes per replicate (lane i = row i), 64 / R replicates per wave.
+template <int R>
+__global__ __launch_bounds__(64) void em_update_kernel(EmUpdArgs a) {
+    constexpr int GPW = 64 / R;
+    __shared__ double Xs[GPW * (R * R + 2 * R)];
+    const int lane = threadIdx.x;
+    const int g = lane / R, i = lane % R;
+    int b = blockIdx.x * GPW + g;
+    const bool live = b < a.B;
+    if (!live) b = a.B - 1;
+    double* X = Xs + g * (R * R + 2 * R);
+    const int T = a.T;
+    const size_t o = (size_t)b * R * R + (size_t)i * R;
+    const double* __restrict__ f = a.fsm + (size_t)b * T * R;
+
+    double M11[R], M10[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) { M11[j] = 0.0; M10[j] = 0.0; }
+    double prev[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) prev[j] = a.f0s[(size_t)b * R + j];
+    const double f0i = a.f0s[(size_t)b * R + i];
+    double fTi = 0.0, fT[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) fT[j] = 0.0;
+#pragma unroll 4
+    for (int t = 0; t < T; ++t) {
+        double cur[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) cur[j] = f[(size_t)t * R + j];
+        double ci = 0.0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) ci = (j == i) ? cur[j] : ci;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            M11[j] = fma(ci, cur[j], M11[j]);
+            M10[j] = fma(ci, prev[j], M10[j]);
+            prev[j] = cur[j];
+        }
+        if (t == T - 1) {
+            fTi = ci;
+#pragma unroll
+            for (int j = 0; j < R; ++j) fT[j] = cur[j];
+        }
+    }
+    double S11[R], S10[R], S00[R], P0s[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        S11[j] = a.SP11[o + j] + M11[j];
+        S10[j] = a.SU[o + j] + M10[j];
+        P0s[j] = a.P0s[o + j];
+        S00[j] = S11[j] - fma(fTi, fT[j], a.PT[o + j]) + fma(f0i, a.f0s[(size_t)b * R + j], P0s[j]);
+    }
+    // EM bookkeeping (oracle/kalman_oracle.py em()): record ll_k; stop WITHOUT applying this M-step when the
+    // relative improvement over ll_{k-1} is below tol
+    bool em_apply = true;
+    if (a.active) {
+        const double ll = a.loglik[b];
+        const bool was = a.k == 0 ? true : (a.active[b] != 0);
+        bool go = was;
+        if (was && a.k >= 1 && a.tol > 0.0) {
+            const double llp = a.ll_path[(size_t)b * a.max_iter + a.k - 1];
+            go = !((ll - llp) / (0.5 * (fabs(ll) + fabs(llp))) < a.tol);
+        }
+        em_apply = go;
+        __syncthreads();                                     // every lane has read active / ll_path
+        if (live && i == 0) {
+            if (was) { a.ll_path[(size_t)b * a.max_iter + a.k] = ll; a.iters[b] = a.k + 1; }
+            a.active[b] = go ? 1 : 0;
+        }
+    }
+    double inv[R], An[R], tmp[R], Qn[R], P0n[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) inv[j] = S00[j];
+    (void)gj_inverse<R>(inv, X, i);
+    __syncthreads();
+    store_row<R>(X, i, inv);
+    __syncthreads();
+    mm_rows<R>(An, S10, X);                                  // A row i
+    __syncthreads();
+    store_row<R>(X, i, S10);
+    __syncthreads();
+    mm_rowsT<R>(tmp, An, X);                                 // (A S10')[i][:]
+#pragma unroll
+    for (int j = 0; j < R; ++j) Qn[j] = (S11[j] - tmp[j]) / (double)T;
+    __syncthreads();
+    store_row<R>(X, i, Qn);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j) Qn[j] = 0.5 * (Qn[j] + X[j * R + i]);
+    __syncthreads();
+    store_row<R>(X, i, P0s);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < R; ++j) P0n[j] = 0.5 * (P0s[j] + X[j * R + i]);
+#pragma unroll
+    for (int j = 0; j < R; ++j) inv[j] = S11[j];
+    (void)gj_inverse<R>(inv, X, i);
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) { a.S11[o + j] = S11[j]; a.S11inv[o + j] = inv[j]; }
+        if (em_apply) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                a.A_out[o + j] = An[j];
+                a.Q_out[o + j] = Qn[j];
+                a.P0_out[o + j] = P0n[j];
+            }
+            a.mu0_out[(size_t)b * R + i] = f0i;
+        }
+    }
+}
+
+template <int R>
+static hipError_t launch_em_update_r(const EmUpdArgs& a, hipStream_t s) {
+    constexpr int GPW = 64 / R;
+    hipLaunchKernelGGL((em_update_kernel<R>), dim3((a.B + GPW - 1) / GPW), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_em_update(int Rpad, const EmUpdArgs& a, hipStream_t s) {
+    switch (Rpad) {
+        case 2: return launch_em_update_r<2>(a, s);
+        case 4: return launch_em_update_r<4>(a, s);
+        case 8: return launch_em_update_r<8>(a, s);
+        case 16: return launch_em_update_r<16>(a, s);
+        case 32: return launch_em_update_r<32>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
 // ================================================================================================
 template <int R, int CPL2>
 static hipError_t launch_cov_rc(const FastArgs& a, hipStream_t s) {

@@ -116,4 +116,37 @@ print(json.dumps(dict(workload="BASELINE configs[4]: 10000 wild-bootstrap draws 
                       note="latency-bound (218 dependent periods per draw, 17 x 17 normal equations)",
                       cpu_baseline=dict(value=1.0 / cpu_s, unit="draws/s", cores=1, kind="port",
                                         sample=f"{nd} draws of oracle/boot_oracle.py (NumPy) in {cpu_s * nd:.1f} s"))))
+
+# ---------------------------------------------------------------- EM iterations/s and the 10 %-missing pass (config 2 shape)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+B2, N2, T2, r2 = 1024, 200, 500, 8
+for miss in (0.0, 0.1):
+    panel, params = bench.synth_on_device(torch, dev, B2, N2, T2, r2, seed=1, missing=miss)
+    f = torch.empty((B2, T2, r2), dtype=torch.float64, device=dev)
+    P = torch.empty((B2, T2, r2 * (r2 + 1) // 2), dtype=torch.float64, device=dev)
+    ll = torch.empty((B2,), dtype=torch.float64, device=dev)
+    if miss > 0:
+        for _ in range(3):
+            ctx.ks_pass_batch(panel, *params, may_have_missing=True, out=(f, P, ll))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20):
+            ctx.ks_pass_batch(panel, *params, may_have_missing=True, out=(f, P, ll))
+        torch.cuda.synchronize(); s_pass = (time.perf_counter() - t0) / 20
+        print(json.dumps(dict(workload="config-2 shape with 10 % of the cells missing (general path: collapse_kernel + recursion_kernel)",
+                              metric="Kalman-smoother passes/sec", value=B2 / s_pass, unit="passes/s", ms_per_batch=1e3 * s_pass,
+                              dtype="f64")))
+    pp = [x.clone() for x in params]
+    for _ in range(2):
+        ctx.em_step_batch(panel, *pp, may_have_missing=miss > 0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        ctx.em_step_batch(panel, *pp, may_have_missing=miss > 0)
+    torch.cuda.synchronize(); s_em = (time.perf_counter() - t0) / 10
+    print(json.dumps(dict(workload=f"config-2 shape, {miss:.0%} missing: one EM iteration (E-step pass + sufficient statistics + M-step, "
+                                   "second panel read)", metric="EM iterations/sec", value=B2 / s_em, unit="EM-iterations/s",
+                          ms_per_batch=1e3 * s_em, dtype="f64",
+                          algorithmic_bytes_per_iteration=8 * (2 * N2 * T2 + 2 * (N2 * r2 + N2 + 2 * r2 * r2) + r2 + r2 * r2)
+                          + 8 * (T2 * r2 + T2 * r2 * (r2 + 1) // 2 + 1))))
 ctx.close()

@@ -43,7 +43,9 @@ KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
 
 @pytest.mark.parametrize("B,N,T,r,missing,iters", [
     (4, 200, 500, 8, 0.0, 3),     # BASELINE config-2 shape
-    (9, 40, 80, 3, 0.0, 6),       # r padded 3 -> 4
+    (9, 40, 80, 3, 0.0, 6),       # r padded 3 -> 4  (balanced: fast-path E-step + em_update_kernel)
+    (3, 64, 48, 12, 0.0, 4),      # balanced, r padded to 16
+    (2, 31, 41, 5, 0.0, 5),       # balanced, odd N: wide collapse
     (5, 40, 80, 4, 0.15, 6),      # missing cells: per-series normal equations
     (3, 139, 222, 4, 0.05, 10),   # config 1 shape: 10 EM iterations
     (2, 60, 50, 12, 0.1, 3),      # r padded to 16: global Dmiss accumulators
