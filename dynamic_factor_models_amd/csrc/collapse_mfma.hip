@@ -56,6 +56,12 @@ constexpr bool kMfmaBench = true;
 constexpr bool kMfmaBench = false;
 #endif
 
+#ifdef DFM_MFMA_NO_PROGRESS_PRIO
+constexpr bool kMfmaProgressPrio = false;
+#else
+constexpr bool kMfmaProgressPrio = true;
+#endif
+
 // Geometry of one MFMA step for padded factor dimension R.
 template <int R>
 struct MfmaGeo {
@@ -196,6 +202,34 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
     auto now = [&]() -> unsigned long long { return ABL == 2 ? __builtin_amdgcn_s_memtime() : 0ull; };
     if constexpr (ABL == 2) t_start = now();
 
+    // b_t stores are deferred by kDefer row blocks and issued right behind a re-arm, 16 bytes per lane.
+    // Measured (profiles/r01/collapse_ablation.txt): the 32 MB of b_t cost ~30 us of the kernel's 170 -- NOT through
+    // the wave's in-order vmcnt stream (deferring, bursting 4-8 blocks, non-temporal and 16-byte stores all change
+    // nothing; stores to a few hot lines instead are free) but as write traffic mixed into the 6 TB/s read stream
+    // (bulk writes at the end of each wave still cost 16 us).  Open item: stage b_t in LDS for the consumer.
+    constexpr int kDefer = 1;
+    double pendD[kDefer][G::NINST];
+    int pendT[kDefer];                                       // period of the lane's pending value, -1: none
+#pragma unroll
+    for (int dq = 0; dq < kDefer; ++dq) {
+        pendT[dq] = -1;
+#pragma unroll
+        for (int m = 0; m < G::NINST; ++m) pendD[dq][m] = 0.0;
+    }
+    auto store_pending = [&](int dq) {
+#pragma unroll
+        for (int m = 0; m < G::NINST; ++m) {
+            const int f = 4 * (h + G::FPI * m) + q;
+            if constexpr (R >= 2) {                          // 16-byte stores: the even-q lane writes factors (f, f + 1)
+                const double hi = xor_lane<1>(pendD[dq][m]);
+                if (g == 0 && pendT[dq] >= 0 && (q & 1) == 0 && f < R)
+                    *reinterpret_cast<double2*>(&a.bcol[((size_t)b * T + pendT[dq]) * R + f]) = make_double2(pendD[dq][m], hi);
+            } else {
+                if (g == 0 && pendT[dq] >= 0 && f < R) a.bcol[((size_t)b * T + pendT[dq]) * R + f] = pendD[dq][m];
+            }
+        }
+    };
+
     // One row block.  MODE 0: main loop (counted wait; every slot of the block is re-armed with a period
     // that exists).  MODE 1: the block after the main loop (counted wait still valid; the last < 4 periods
     // are issued).  MODE 2: drain (nothing left to issue; rows of the block may lie past the segment).
@@ -204,12 +238,14 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
         constexpr bool REARM = MODE == 0;
         const int r0 = bk * 4;
         const unsigned long long s0 = now();
-        // rows < r0 + 4 have landed once at most (NB - 1) row blocks of DMAs, plus the b_t stores issued
-        // after them (one per earlier block, at most two still younger), are outstanding: one wave's
-        // loads and stores retire in issue order on the single gfx9 vmcnt counter.
+        // rows < r0 + 4 have landed once at most the operations YOUNGER than their DMAs are outstanding: one
+        // wave's loads and stores retire in issue order on the single gfx9 vmcnt counter.
         if constexpr (MODE <= 1) {
             constexpr int KW = (NB - 1) * 4 * NDR;
-            if (bk >= 2) wait_vm<(KW + 2 * G::NINST <= 63 ? KW + 2 * G::NINST : 63)>();
+            // younger than the DMAs this block needs (re-arm of iteration bk - NB): the deferred stores issued
+            // behind the re-arms of iterations bk - NB .. bk - 1 (NB of them once the queue is primed) and the
+            // re-arms of iterations bk - NB + 1 .. bk - 1
+            if (bk >= kDefer + NB) wait_vm<(KW + NB * G::NINST <= 63 ? KW + NB * G::NINST : 63)>();
             else wait_vm<(KW <= 63 ? KW : 63)>();
         } else {
             wait_vm<0>();
@@ -241,6 +277,7 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
                 if (issued + rr < nrows) issue_row(issued + rr, bslot * 4 + rr);
             issued += 4;
         }
+        if constexpr (ABL != 1 && ABL != 3) store_pending(kDefer - 1);   // the row block of kDefer iterations ago
         const unsigned long long s3 = now();
         if constexpr (ABL == 1) {                            // ablation: DMA + LDS reads only
             double z = 0.0;
@@ -258,11 +295,14 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
 #pragma unroll
             for (int s = 0; s < STEPS; ++s)
 #pragma unroll
-                for (int m = 0; m < G::NINST; ++m)
-                    D[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[s], Bw[s][m], D[m], 0, 0, 0);
+                for (int m = 0; m < G::NINST; ++m) {
+                    if constexpr (ABL == 5) D[m] += xa[s];   // ablation: no MFMA
+                    else D[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[s], Bw[s][m], D[m], 0, 0, 0);
+                }
             // s_t partial sums: rows past the end of the segment hold stale slots and are left out
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
+                if constexpr (ABL == 4) { if (rr > 0) continue; }   // ablation: (almost) no s_t pass
                 if (REARM || r0 + rr < nrows) {              // wave-uniform
 #pragma unroll
                     for (int j = 0; j < NQ; ++j) {
@@ -279,12 +319,18 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
             }
             // lane (K = period, g = 0, h, q) stores factor 4 (h + FPI m) + q of period r0 + K
             const int t = ta + r0 + K;
-            if (g == 0 && (REARM || t < tb)) {
+            if constexpr (ABL == 3) {                        // ablation: no b_t store
+                if (D[0] == 1.2345e300) a.bcol[(size_t)b * T + ta + bk] = D[0];
+            } else {
 #pragma unroll
-                for (int m = 0; m < G::NINST; ++m) {
-                    const int f = 4 * (h + G::FPI * m) + q;
-                    if (f < R) a.bcol[((size_t)b * T + t) * R + f] = D[m];
+                for (int dq = kDefer - 1; dq > 0; --dq) {
+                    pendT[dq] = pendT[dq - 1];
+#pragma unroll
+                    for (int m = 0; m < G::NINST; ++m) pendD[dq][m] = pendD[dq - 1][m];
                 }
+                pendT[0] = (REARM || t < tb) ? t : -1;
+#pragma unroll
+                for (int m = 0; m < G::NINST; ++m) pendD[0][m] = D[m];
             }
         }
         if constexpr (ABL == 2) {
@@ -299,6 +345,16 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
     int bslot = 0;
     int bk = 0;
     for (; bk < nmain; ++bk) {
+        if constexpr (kMfmaProgressPrio) {
+            // every wave of the grid has the same work and starts together, but the SQ issues oldest-first, so
+            // the waves of a CU drift apart and the stragglers cannot keep HBM busy alone: a wave that is
+            // further along yields (priority 3 -> 0 over its segment) and the CU's waves finish together
+            const int quarter = (4 * bk) / (nmain > 0 ? nmain : 1);
+            if (quarter == 0) __builtin_amdgcn_s_setprio(3);
+            else if (quarter == 1) __builtin_amdgcn_s_setprio(2);
+            else if (quarter == 2) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         row_block(bk, bslot, std::integral_constant<int, 0>{});
         bslot = (bslot + 1 == NB) ? 0 : bslot + 1;
     }
@@ -318,6 +374,8 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
             o[4] = (double)(now() - t_start); o[5] = (double)nblk; o[6] = (double)(t_start - t_entry);
         }
     }
+#pragma unroll
+    for (int dq = kDefer - 1; dq >= 0; --dq) store_pending(dq);   // the last kDefer row blocks
     const unsigned long long t_loop_end = now();
     wait_vm<0>();
     // s = sum_t sum_i x_it^2 / R_i over this wave's periods
@@ -378,6 +436,9 @@ static hipError_t mfma_launch_abl(const CollapseArgs& a, hipStream_t s, int abl)
     if constexpr (kMfmaBench) {
         if (abl == 1) return launch_mfma_one<R, STEPS, NB, NDR, 1>(a, s);
         if (abl == 2) return launch_mfma_one<R, STEPS, NB, NDR, 2>(a, s);
+        if (abl == 3) return launch_mfma_one<R, STEPS, NB, NDR, 3>(a, s);
+        if (abl == 4) return launch_mfma_one<R, STEPS, NB, NDR, 4>(a, s);
+        if (abl == 5) return launch_mfma_one<R, STEPS, NB, NDR, 5>(a, s);
     }
     return launch_mfma_one<R, STEPS, NB, NDR, 0>(a, s);
 }

@@ -46,7 +46,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<int> vars;
     for (int i = 1; i < argc; ++i) vars.push_back(atoi(argv[i]));
-    if (vars.empty()) vars = {200, 3200, 3202, 6200, 3201};
+    if (vars.empty()) vars = {107, 3200, 3203, 3201, 4200, 3200, 6200};
     std::vector<double> ref((size_t)B * T * R), got((size_t)B * T * R);
     for (int v0 : vars) {
         const int v = v0 % 1000; a.wpr = v0 / 1000;   // 1000 * wpr + variant
