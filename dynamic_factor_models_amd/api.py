@@ -134,10 +134,11 @@ def standardize_data(x: np.ndarray):
     returns ((x - mean) / sd, sd [1 x ns])."""
     x = np.asarray(x, dtype=np.float64)
     n = np.count_nonzero(~np.isnan(x), axis=0)
-    mu = np.nansum(x, axis=0) / n
-    d = np.where(np.isnan(x), 0.0, x - mu)
-    sd = np.sqrt((d * d).sum(axis=0) / n)
-    return (x - mu) / sd, sd[None, :]
+    with np.errstate(invalid="ignore", divide="ignore"):      # a column without observations stays all-NaN
+        mu = np.nansum(x, axis=0) / n
+        d = np.where(np.isnan(x), 0.0, x - mu)
+        sd = np.sqrt((d * d).sum(axis=0) / n)
+        return (x - mu) / sd, sd[None, :]
 
 
 def drop_missing_col(A: np.ndarray):
@@ -477,3 +478,32 @@ def bootstrap_irf_bands(varm: VARModel, H: int, ndraws: int = 10000, quantiles=(
         if own:
             ctx.close()
     return dict(point=impulse_response(varm, range(varm.ns), H), bands=bands, draws=draws)
+
+
+def amengual_watson_test(m: DFMModel, nlag: int = 4, *, ctx=None):
+    """`amengual_watson_test(m, nper)` -- dfm_functions.ipynb:734-768: the number of DYNAMIC factors.  Every
+    included series is regressed on [1, lags 1..nlag of the r estimated static factors] over all rows of the data
+    (one dfm_ols_batch call, 1 + nlag r <= 64 regressors); the ALS estimator is then run on the residual panel
+    for k = 1..r dynamic factors over rows initperiod + nlag .. lastperiod (one dfm_als_batch call, r runs on a
+    shared panel).  `m.factor` must hold the static factors (estimate_factor first).  Returns (aw_icp [r], ssr [r])."""
+    r = m.nfac_t
+    est = m.data[:, m.inclcode == 1]
+    T_all, ns = est.shape
+    x = np.column_stack([np.ones(T_all), _lagmat(m.factor, range(1, nlag + 1))])
+    ctx, own = _own(ctx)
+    try:
+        # the reference keeps a series when it has at least nt_min rows MORE than regressors (:744)
+        o = ctx.ols_batch_host(x, est, nt_min=x.shape[1] + m.nt_min_factor_estimation)
+        res = o["resid"]                                                   # NaN where a row was not used
+        init, last = m.initperiod + nlag, m.lastperiod
+        z, _ = standardize_data(res[init - 1:last])
+        T = z.shape[0]
+        nobs = int((~np.isnan(z)).sum())
+        F0 = pca_start(ctx, z, r)
+        a = ctx.als_batch_host(z, np.repeat(F0[None], r, axis=0), r_each=np.arange(1, r + 1),
+                               nt_min=m.nt_min_factor_estimation, tol=m.tol)
+    finally:
+        if own:
+            ctx.close()
+    aw = np.array([bai_ng_criterion(s, nobs, T, k + 1) for k, s in enumerate(a["ssr"])])
+    return aw, a["ssr"].copy()

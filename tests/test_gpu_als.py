@@ -241,3 +241,19 @@ def test_table5_canonical_correlations_on_the_gpu(ctx, sw):
     for x, g in zip(lev, GOLD["table5"]["A"]["level"]):
         assert _sig6(x, g), (x, g)
     np.testing.assert_allclose(fv.G[:8] @ fv.G[:8].T, fv.seps, rtol=1e-10)
+
+
+def test_table2C_amengual_watson_on_the_gpu(ctx, sw):
+    """Stock_Watson.ipynb:673-682: Amengual-Watson ICp2 for the number of dynamic factors given r static factors
+    (columns r = 1..10, rows k <= r): static ALS, residual regressions (41 regressors at r = 10) and the ALS runs
+    on the residual panels all on the HIP kernels."""
+    from dynamic_factor_models_amd import api
+    rows = GOLD["table2C_aw"]["rows"]
+    for r in (1, 2, 4, 7, 10):
+        m = _model(api, sw["all"], sw["inc_all"], r)
+        api.estimate_factor(m, computeR2=False, ctx=ctx)
+        aw, _ = api.amengual_watson_test(m, 4, ctx=ctx)
+        for k in range(r):
+            g = rows[k][1 + (r - 1)]
+            assert g is not None
+            assert _shown(aw[k]) == g or abs(aw[k] - g) <= 5.0001e-4, (r, k, aw[k], g)
