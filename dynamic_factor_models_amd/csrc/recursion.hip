@@ -146,6 +146,17 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
     int e = -1;
     bool need_cov = true;
 
+    double ctn[R];                                         // row i of C_t, one period ahead of the recursion
+#pragma unroll
+    for (int j = 0; j < R; ++j) ctn[j] = 0.0;
+    if (a.Ct) {
+        const double* ct = a.Ct + (size_t)b * T * NPp;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            ctn[j] = ct[hi * (hi + 1) / 2 + lo];
+        }
+    }
     issue_fwd(0);
     __syncthreads();
     commit_fwd(0);
@@ -202,12 +213,17 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
             if (full) {
 #pragma unroll
                 for (int j = 0; j < R; ++j) Omf_new[j] = Omp[j] + Cf[j];
-            } else {  // row i of the packed C_t of this period
-                const double* ct = a.Ct + ((size_t)b * T + t) * NPp;
+            } else {  // row i of the packed C_t of this period (fetched one period ahead: ctn)
+#pragma unroll
+                for (int j = 0; j < R; ++j) Omf_new[j] = Omp[j] + ctn[j];
+            }
+            if (a.Ct) {   // C_{t+1} for the next period: in flight during the rest of this step and the next inversion
+                const int tn = t + 1 < T ? t + 1 : T - 1;
+                const double* ct = a.Ct + ((size_t)b * T + tn) * NPp;
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     const int hi = i > j ? i : j, lo = i > j ? j : i;
-                    Omf_new[j] = Omp[j] + ct[hi * (hi + 1) / 2 + lo];
+                    ctn[j] = ct[hi * (hi + 1) / 2 + lo];
                 }
             }
             if (computed) {
