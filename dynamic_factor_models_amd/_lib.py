@@ -58,6 +58,8 @@ SYMBOLS = {
                                       ctypes.c_uint64, ctypes.c_int64, c_vp, c_vp]),
     "dfm_quantile_bands_dev": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "dfm_quantile_bands": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "dfm_chow_batch_dev": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
+    "dfm_chow_batch": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "dfm_synth_panels_dev": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_int64, c_int, c_int, c_int, c_int,
                                      ctypes.c_double] + [c_vp] * 7),
 }

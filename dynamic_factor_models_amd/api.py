@@ -507,3 +507,43 @@ def amengual_watson_test(m: DFMModel, nlag: int = 4, *, ctx=None):
             ctx.close()
     aw = np.array([bai_ng_criterion(s, nobs, T, k + 1) for k, s in enumerate(a["ssr"])])
     return aw, a["ssr"].copy()
+
+
+# ============================================================================= structural breaks
+def break_tests(m: DFMModel, T_break: int, ccut: float = 0.15, q: int = 6, min_obs: int = 80, *, ctx=None):
+    """Chow statistic at `T_break` and HAC QLR statistic of every series of `m.data` regressed on the estimated
+    factors -- the loop of the driver's Table 4 (Stock_Watson.ipynb:1085-1098) over `compute_chow` / `compute_qlr`
+    (dfm_functions.ipynb:891-902, 1019-1047), all (series x break date x bandwidth) problems in ONE dfm_chow_batch
+    call.  As in the driver, a series takes part when it has at least `min_obs` observations before and after
+    row `T_break` (1-based, inclusive), regressions run on the complete cases of [y X], and the break dates index
+    the complete-case rows.  Returns (chow [ns], qlr [ns]) with NaN for the series left out."""
+    X = m.factor
+    ns = m.data.shape[1]
+    chow = np.full(ns, np.nan); qlr = np.full(ns, np.nan)
+    ys, Xs, who = [], [], []
+    for i in range(ns):
+        y = m.data[:, i]
+        if (~np.isnan(y[:T_break])).sum() >= min_obs and (~np.isnan(y[T_break:])).sum() >= min_obs:
+            ok = ~np.isnan(y) & ~np.isnan(X).any(axis=1)
+            ys.append(y[ok]); Xs.append(X[ok]); who.append(i)
+    if not who:
+        return chow, qlr
+    ps, pb, pq, tag = [], [], [], []
+    for s, yv in enumerate(ys):
+        T = len(yv)
+        ps.append(s); pb.append(T_break); pq.append(q); tag.append(0)                 # the Chow test of the driver
+        n1 = int(np.floor(ccut * T))
+        for tb in range(n1, T - n1 + 1):                                               # compute_qlr's HAC leg
+            ps.append(s); pb.append(tb); pq.append(q); tag.append(1)
+    ctx, own = _own(ctx)
+    try:
+        stat = ctx.chow_batch_host(ys, Xs, ps, pb, pq)
+    finally:
+        if own:
+            ctx.close()
+    ps = np.asarray(ps); tag = np.asarray(tag)
+    for s, i in enumerate(who):
+        sel = ps == s
+        chow[i] = stat[sel & (tag == 0)][0]
+        qlr[i] = stat[sel & (tag == 1)].max()
+    return chow, qlr

@@ -42,11 +42,11 @@ struct dfm_handle {
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
-                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_EM_UPDATE, K_COUNT };
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_EM_UPDATE, K_CHOW, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
                                                   "mstep_solve_kernel", "pca_kernels", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
-                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel", "em_update_kernel"};
+                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel", "em_update_kernel", "chow_kernel"};
 
 namespace {
 
@@ -1013,6 +1013,59 @@ int dfm_quantile_bands(dfm_handle* h, int B, int S, int nq, const double* x, con
     int rc = dfm_quantile_bands_dev(h, B, S, nq, x_d, q_d, o_d);
     if (rc == 0) {
         hipMemcpyAsync(out, o_d, n_o * d, hipMemcpyDeviceToHost, h->stream);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    hipFree(buf);
+    return rc;
+}
+
+
+// ---- Chow / QLR statistics with HAC covariance (breaks.hip) ---------------------------------------------
+int dfm_chow_batch_dev(dfm_handle* h, int S, int Tmax, int k, const double* y, const double* X, const int* Tlen, int P,
+                       const int* prob_series, const int* prob_break, const int* prob_q, double* chow) {
+    if (!h) return DFM_E_NULL;
+    if (S < 1 || Tmax < 1 || k < 1 || P < 1) return fail(h, DFM_E_DIMS, "S, Tmax, k, P must be >= 1%s");
+    if (k > 8) return fail(h, DFM_E_R_UNSUPPORTED, "k > 8 regressors%s");
+    if (!y || !X || !Tlen || !prob_series || !prob_break || !prob_q || !chow)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    ChowArgs a;
+    a.S = S; a.Tmax = Tmax; a.k = k; a.P = P; a.y = y; a.X = X; a.Tlen = Tlen; a.prob_series = prob_series;
+    a.prob_break = prob_break; a.prob_q = prob_q; a.chow = chow;
+    { ProfScope ps(h, K_CHOW); HIP_TRY(h, launch_chow(a, h->stream)); }
+    return 0;
+}
+
+int dfm_chow_batch(dfm_handle* h, int S, int Tmax, int k, const double* y, const double* X, const int* Tlen, int P,
+                   const int* prob_series, const int* prob_break, const int* prob_q, double* chow) {
+    if (!h) return DFM_E_NULL;
+    if (S < 1 || Tmax < 1 || k < 1 || P < 1) return fail(h, DFM_E_DIMS, "S, Tmax, k, P must be >= 1%s");
+    if (!y || !X || !Tlen || !prob_series || !prob_break || !prob_q || !chow)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    for (int p = 0; p < P; ++p) {
+        const int s = prob_series[p];
+        if (s < 0 || s >= S || prob_q[p] < 0 || prob_q[p] > 15 || Tlen[s] < 1 || Tlen[s] > Tmax || prob_break[p] < 0 ||
+            prob_break[p] > Tlen[s])
+            return fail(h, DFM_E_DIMS, "problem list: series, break date or bandwidth out of range%s");
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double), n_y = (size_t)S * Tmax, n_X = n_y * k;
+    char* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), (n_y + n_X + P) * d + ((size_t)S + 3 * (size_t)P) * sizeof(int) + 64));
+    double* y_d = reinterpret_cast<double*>(buf);
+    double* X_d = y_d + n_y; double* c_d = X_d + n_X;
+    int* T_d = reinterpret_cast<int*>(c_d + P);
+    int* ps_d = T_d + S; int* pb_d = ps_d + P; int* pq_d = pb_d + P;
+    hipMemcpyAsync(y_d, y, n_y * d, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(X_d, X, n_X * d, hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(T_d, Tlen, (size_t)S * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(ps_d, prob_series, (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(pb_d, prob_break, (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    hipMemcpyAsync(pq_d, prob_q, (size_t)P * sizeof(int), hipMemcpyHostToDevice, h->stream);
+    int rc = dfm_chow_batch_dev(h, S, Tmax, k, y_d, X_d, T_d, P, ps_d, pb_d, pq_d, c_d);
+    if (rc == 0) {
+        hipMemcpyAsync(chow, c_d, (size_t)P * d, hipMemcpyDeviceToHost, h->stream);
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }

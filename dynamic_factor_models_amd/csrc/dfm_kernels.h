@@ -202,6 +202,17 @@ struct QuantArgs {
 };
 hipError_t launch_quantiles(const QuantArgs& a, hipStream_t s);
 
+// Batched Chow / QLR statistics with HAC covariance (breaks.hip).
+struct ChowArgs {
+    int S, Tmax, k, P;          // series, row capacity per series, regressors (before interaction), problems
+    const double* y;            // [S][Tmax] complete cases of each series
+    const double* X;            // [S][Tmax][k]
+    const int* Tlen;            // [S] rows in use
+    const int* prob_series; const int* prob_break; const int* prob_q;   // [P]
+    double* chow;               // [P]
+};
+hipError_t launch_chow(const ChowArgs& a, hipStream_t s);
+
 // Device-side synthetic replicates (synth.hip); all arrays in the caller's layout (r).
 struct SynthArgs {
     int B, T, N, r;

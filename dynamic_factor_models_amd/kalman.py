@@ -326,3 +326,23 @@ class DfmContext:
         rc = self._lib.dfm_quantile_bands(self._h, B, S, int(q.size), ptr(x), ptr(q), ptr(out))
         _check(self._h, rc)
         return out.reshape((q.size,) + x.shape[1:])
+
+    # ------------------------------------------------------------------ Chow / QLR with HAC covariance (breaks.hip)
+    def chow_batch_host(self, ys, Xs, prob_series, prob_break, prob_q):
+        """P Chow statistics with HAC covariance (`compute_chow`, dfm_functions.ipynb:891-902).  ys: list of S
+        complete-case vectors, Xs: list of S matrices (T_s x k); problem p = (series, break date, bandwidth)."""
+        S = len(ys)
+        k = Xs[0].shape[1]
+        Tlen = np.array([len(v) for v in ys], dtype=np.int32)
+        Tmax = int(Tlen.max())
+        y = np.zeros((S, Tmax)); X = np.zeros((S, Tmax, k))
+        for s in range(S):
+            y[s, :Tlen[s]] = ys[s]; X[s, :Tlen[s]] = Xs[s]
+        ps = np.ascontiguousarray(prob_series, dtype=np.int32); pb = np.ascontiguousarray(prob_break, dtype=np.int32)
+        pq = np.ascontiguousarray(prob_q, dtype=np.int32)
+        P = ps.size
+        out = np.empty(P)
+        ptr = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_chow_batch(self._h, S, Tmax, k, ptr(y), ptr(X), ptr(Tlen), P, ptr(ps), ptr(pb), ptr(pq), ptr(out))
+        _check(self._h, rc)
+        return out

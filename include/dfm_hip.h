@@ -175,6 +175,18 @@ int dfm_var_bootstrap_irf(dfm_handle* h, int B, int T, int ns, int p, int H, con
 int dfm_quantile_bands_dev(dfm_handle* h, int B, int S, int nq, const double* x, const double* q, double* out);
 int dfm_quantile_bands(dfm_handle* h, int B, int S, int nq, const double* x, const double* q, double* out);
 
+/* --- structural-break statistics ------------------------------------------------------
+ * dfm_chow_batch: P Chow statistics with HAC covariance -- `compute_chow` / `regress_hac` / `hac` /
+ * `form_hscrc` / `form_kernel` (dfm_functions.ipynb:832-977); a `compute_qlr` (:1019-1047) is the maximum over
+ * the problems of one series and bandwidth.  Series s: its complete cases y [S][Tmax], X [S][Tmax][k] (rows
+ * 0 .. Tlen[s]-1 in use; k <= 8).  Problem p: series prob_series[p], break date prob_break[p] (the first
+ * prob_break[p] rows are "before": D_t = 1 for t >= break, 0-based), Bartlett bandwidth prob_q[p] <= 15 (0 =
+ * heteroskedasticity-robust only).  chow[p] = gamma' V22^-1 gamma of y = X beta + (X D) gamma. */
+int dfm_chow_batch_dev(dfm_handle* h, int S, int Tmax, int k, const double* y, const double* X, const int* Tlen,
+                       int P, const int* prob_series, const int* prob_break, const int* prob_q, double* chow);
+int dfm_chow_batch(dfm_handle* h, int S, int Tmax, int k, const double* y, const double* X, const int* Tlen,
+                   int P, const int* prob_series, const int* prob_break, const int* prob_q, double* chow);
+
 /* --- synthetic replicates generated on the device (SURVEY.md §8(d) DGP; no reference
  * counterpart -- the reference has no RNG).  Writes the standardised panel and the DGP parameters
  * rescaled to it.  Counter-based generator keyed by (seed, first_replicate + b). */

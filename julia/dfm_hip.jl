@@ -127,6 +127,27 @@ function ols(h::Handle, X::Matrix{Float64}, Y::Matrix{Float64}; nt_min::Integer 
     return (beta = beta, resid = resid, ssr = ssr, tss = tss, nobs = Int.(nobs))   # beta[:, p]: C [p][k] == Julia (k, p)
 end
 
+"Chow statistics with HAC covariance (dfm_chow_batch): series s = complete cases ys[s] (vector), Xs[s] (T_s x k);
+problem p = (prob_series[p] (1-based), prob_break[p] rows before the break, bandwidth prob_q[p]).  `compute_qlr` is the
+maximum over the problems of one series (dfm_functions.ipynb:1019-1047)."
+function chow_batch(h::Handle, ys::Vector{Vector{Float64}}, Xs::Vector{Matrix{Float64}}, prob_series::Vector{<:Integer},
+                    prob_break::Vector{<:Integer}, prob_q::Vector{<:Integer})
+    S = length(ys); k = size(Xs[1], 2); Tlen = Cint[length(v) for v in ys]; Tmax = maximum(Tlen)
+    y = zeros(Tmax, S); X = zeros(k, Tmax, S)                     # C [s][t], C [s][t][k]
+    for s in 1:S
+        y[1:Tlen[s], s] = ys[s]; X[:, 1:Tlen[s], s] = permutedims(Xs[s], (2, 1))
+    end
+    ps = Cint.(prob_series .- 1); pb = Cint.(prob_break); pq = Cint.(prob_q); P = length(ps)
+    out = Array{Float64}(undef, P)
+    GC.@preserve y X Tlen ps pb pq out begin
+        rc = ccall((:dfm_chow_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Cint}, Cint, Ptr{Cint}, Ptr{Cint}, Ptr{Cint},
+                    Ptr{Float64}), h.ptr, S, Tmax, k, y, X, Tlen, P, ps, pb, pq, out)
+        check(h.ptr, rc)
+    end
+    return out
+end
+
 "B wild-bootstrap draws of the VAR's impulse responses (dfm_var_bootstrap_irf) and their nearest-rank quantile bands
 (dfm_quantile_bands).  y, resid: T x ns over the estimation window; betahat: (1 + ns p) x ns as in `estimate_var!`."
 function bootstrap_irf(h::Handle, y::Matrix{Float64}, betahat::Matrix{Float64}, resid::Matrix{Float64}, p::Integer,
