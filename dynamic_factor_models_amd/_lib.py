@@ -48,6 +48,7 @@ SYMBOLS = {
     "dfm_em_batch": (c_int, _EM_ARGS),
     "dfm_pca_init_batch_dev": (c_int, _PCA_ARGS),
     "dfm_pca_init_batch": (c_int, _PCA_ARGS),
+    "dfm_standardize_batch_dev": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "dfm_als_batch_dev": (c_int, _ALS_ARGS),
     "dfm_als_batch": (c_int, _ALS_ARGS),
     "dfm_ols_batch_dev": (c_int, _OLS_ARGS),

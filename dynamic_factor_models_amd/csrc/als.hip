@@ -317,6 +317,30 @@ __global__ __launch_bounds__(kAlsThreads) void ols_kernel(OlsArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// `standardize_data` (dfm_functions.ipynb:501-509) for B panels: per series, mean and POPULATION standard
+// deviation over the observed cells (two passes, as the reference), z = (x - mean) / sd in place; NaN stays NaN.
+// One workgroup per panel, thread = series (coalesced along i), HBM-bound: 3 reads + 1 write of the panel.
+__global__ __launch_bounds__(256) void standardize_kernel(int T, int N, double* panel, double* mean_out, double* sd_out) {
+    const int b = blockIdx.x;
+    double* x = panel + (size_t)b * T * N;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        double s = 0.0; int n = 0;
+        for (int t = 0; t < T; ++t) { const double v = x[(size_t)t * N + i]; if (v == v) { s += v; ++n; } }
+        const double mu = s / n;
+        double ss = 0.0;
+        for (int t = 0; t < T; ++t) { const double v = x[(size_t)t * N + i]; if (v == v) { const double d = v - mu; ss = fma(d, d, ss); } }
+        const double sd = sqrt(ss / n);
+        for (int t = 0; t < T; ++t) { const double v = x[(size_t)t * N + i]; x[(size_t)t * N + i] = (v - mu) / sd; }
+        if (mean_out) mean_out[(size_t)b * N + i] = mu;
+        if (sd_out) sd_out[(size_t)b * N + i] = sd;
+    }
+}
+hipError_t launch_standardize(int B, int T, int N, double* panel, double* mean_out, double* sd_out, hipStream_t s) {
+    hipLaunchKernelGGL(standardize_kernel, dim3(B), dim3(256), 0, s, T, N, panel, mean_out, sd_out);
+    return hipGetLastError();
+}
+
 template <int R>
 static hipError_t launch_als_r(const AlsArgs& a, hipStream_t s) {
     const size_t lds = AlsLds<R>::doubles(a.T, a.N) * sizeof(double);

@@ -1072,3 +1072,13 @@ int dfm_chow_batch(dfm_handle* h, int S, int Tmax, int k, const double* y, const
     hipFree(buf);
     return rc;
 }
+
+
+int dfm_standardize_batch_dev(dfm_handle* h, int B, int T, int N, double* panel, double* mean, double* sd) {
+    if (!h) return DFM_E_NULL;
+    if (B < 1 || T < 1 || N < 1) return fail(h, DFM_E_DIMS, "B, T, N must be >= 1%s");
+    if (!panel) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, launch_standardize(B, T, N, panel, mean, sd, h->stream));
+    return 0;
+}

@@ -181,6 +181,7 @@ struct OlsArgs {
     int* nobs;                  // [P] complete rows
 };
 hipError_t launch_ols(int Rpad, const OlsArgs& a, hipStream_t s);
+hipError_t launch_standardize(int B, int T, int N, double* panel, double* mean_out, double* sd_out, hipStream_t s);
 
 // Wild-bootstrap impulse responses of the factor VAR and quantile bands (boot.hip).
 struct BootArgs {

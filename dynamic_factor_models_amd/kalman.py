@@ -346,3 +346,17 @@ class DfmContext:
         rc = self._lib.dfm_chow_batch(self._h, S, Tmax, k, ptr(y), ptr(X), ptr(Tlen), P, ptr(ps), ptr(pb), ptr(pq), ptr(out))
         _check(self._h, rc)
         return out
+
+    def standardize_batch(self, panel, want_stats: bool = True):
+        """`standardize_data` (dfm_functions.ipynb:501-509) of a device tensor [B,T,N] IN PLACE; returns (mean, sd)
+        [B,N] device tensors (or None)."""
+        torch = self._torch
+        B, T, N = panel.shape
+        mu = torch.empty((B, N), dtype=torch.float64, device=panel.device) if want_stats else None
+        sd = torch.empty((B, N), dtype=torch.float64, device=panel.device) if want_stats else None
+        self._sync_stream()
+        rc = self._lib.dfm_standardize_batch_dev(self._h, B, T, N, self._dev(panel, "panel"),
+                                                 self._dev(mu, "mean") if want_stats else None,
+                                                 self._dev(sd, "sd") if want_stats else None)
+        _check(self._h, rc)
+        return mu, sd

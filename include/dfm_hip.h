@@ -138,6 +138,11 @@ int dfm_als_batch(dfm_handle* h, int B, int T, int N, int r, const double* z, lo
                   const int* r_each, double* F, double* Lam, int nt_min, int max_iter, double tol,
                   double* ssr_path, int path_cap, int* iters, double* ssr, double* R2);
 
+/* dfm_standardize_batch_dev: `standardize_data` (dfm_functions.ipynb:501-509) of B panels IN PLACE (device
+ * pointers): per series the mean and the POPULATION standard deviation over the observed cells; NaN stays NaN.
+ * mean [B][N], sd [B][N] may be NULL. */
+int dfm_standardize_batch_dev(dfm_handle* h, int B, int T, int N, double* panel, double* mean, double* sd);
+
 /* dfm_ols_batch: P complete-case least-squares problems (`ols_skipmissing(..., Balanced())`,
  * dfm_functions.ipynb:242-252; the engine of `estimate_factor_loading!` :391-415, `uar` :305-311 and
  * `estimate_var!` :444-468).  Problem p regresses y_p[t] = y[p * y_stride + t * y_inc] on the rows of X_p =
