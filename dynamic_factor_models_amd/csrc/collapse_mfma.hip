@@ -23,8 +23,11 @@
 // duplicate-free read of the row block (lane owns 16-byte column pairs), as in the VALU kernel.
 // Reference counterpart: forming Lambda' x_t in the per-period regression of x_t on Lambda
 // (dfm_functions.ipynb:271-286 called from :364).
+#include <string.h>
+
 #include <type_traits>
 
+#include "dfm_cov.h"
 #include "dfm_gram.h"
 #include "dfm_kernels.h"
 
@@ -81,8 +84,51 @@ __host__ __device__ inline unsigned mfma_slot_bytes(int N) {
 }
 
 // STEPS = ceil(N / CS) exactly (the B operands and the staged A operands are register arrays).
-template <int R, int STEPS, int NB, int NDR, int ABL>
-__global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) void collapse_mfma_kernel(CollapseArgs a, unsigned SB) {
+// FUSE: the first `ncov` workgroups of the grid are the covariance workgroups of the pass (cov_body of dfm_cov.h on
+// wave 0, then the data-independent rows of P_smooth for its replicates); the streaming workgroups follow.  One
+// launch instead of cov_kernel + pfill_kernel on a forked stream: the covariance waves are resident first by
+// construction (lowest block indices) and the pass loses two cross-stream event edges (~16 us).
+template <int R>
+struct FusedCov {   // LDS table depth that fits the collapse launch's dynamic LDS (4 waves x 8 slots x SB)
+    static constexpr int ECL = R <= 4 ? 8 : R <= 8 ? 3 : 0;
+    using LY = CovLayout<R, ECL>;
+    static constexpr size_t lds_bytes() { return (size_t)LY::GPW * LY::S * sizeof(double); }
+};
+
+template <int R, int STEPS, int NB, int NDR, int ABL, bool FUSE = false>
+__global__ __launch_bounds__(256, ((STEPS * MfmaGeo<R>::NINST <= 25 && !FUSE) ? 3 : 2)) void collapse_mfma_kernel(CollapseArgs a, unsigned SB,
+                                                                                                          FastArgs fa, int ncov) {
+    if constexpr (FUSE) {
+        if ((int)blockIdx.x < ncov) {
+            extern __shared__ __attribute__((aligned(16))) double csm[];
+            using FC = FusedCov<R>;
+            const int first = (int)blockIdx.x * FC::LY::GPW;
+            if (threadIdx.x < 64) {
+                __builtin_amdgcn_s_setprio(3);
+                cov_body<R, 0, FC::ECL>(fa, first, csm, (int)threadIdx.x);
+            }
+            __syncthreads();   // waves 1-3 wait here; wave 0's fill[] / PsInf stores are workgroup-visible after it
+            if (fa.P_smooth) {   // the fixed-point rows of P_smooth (pfill_kernel's work): the 4 waves take replicates in turn
+                const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+                const int npr = fa.r * (fa.r + 1) / 2;
+                double* ps = csm + wv * ((R * (R + 1) / 2 + 3) & ~3);
+                for (int rep = wv; rep < FC::LY::GPW; rep += 4) {
+                    const int bb = first + rep;
+                    if (bb >= fa.B) break;
+                    wave_lds_sync();
+                    for (int v = ln; v < npr; v += 64) {
+                        int ri = 0;
+                        while ((ri + 1) * (ri + 2) / 2 <= v) ++ri;
+                        ps[v] = fa.PsInf[(size_t)bb * R * R + ri * R + (v - ri * (ri + 1) / 2)];
+                    }
+                    wave_lds_sync();
+                    fill_psmooth_rows(fa, bb, ln, 64, ps);
+                }
+            }
+            return;
+        }
+    }
+    const int blk_first = FUSE ? ncov : 0;
     using G = MfmaGeo<R>;
     constexpr int NS = 4 * NB;                               // row slots per wave
     constexpr int CS = G::CS;
@@ -95,7 +141,7 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
     const int wpr = a.wpr > 0 ? a.wpr : 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gw = (int)blockIdx.x * 4 + wave;
+    const int gw = ((int)blockIdx.x - blk_first) * 4 + wave;
     if (gw >= a.B * wpr) return;
     const int b = gw / wpr + a.b0;
     const int segi = gw % wpr;
@@ -413,11 +459,37 @@ __global__ __launch_bounds__(256, (STEPS * MfmaGeo<R>::NINST <= 25 ? 3 : 2)) voi
 }
 
 // ---------------------------------------------------------------------------------------------
+constexpr bool mfma_can_fuse(int R) { return R == 4 || R == 8; }
+
 template <int R, int STEPS, int NB, int NDR, int ABL = 0>
 static hipError_t launch_mfma_one(const CollapseArgs& a, hipStream_t s) {
     const unsigned SB = mfma_slot_bytes(a.N);
-    const size_t lds = (size_t)4 * 4 * NB * SB;
+    size_t lds = (size_t)4 * 4 * NB * SB;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const int wpr = a.wpr > 0 ? a.wpr : 4;
+    if (wpr > kSsumSlots) return hipErrorInvalidValue;
+    const unsigned nstream = (unsigned)((a.B * wpr + 3) / 4);
+    if constexpr (ABL == 0 && mfma_can_fuse(R)) {
+        if (a.fuse_cov) {   // covariance workgroups at the front of the grid
+            const FastArgs& fa = *static_cast<const FastArgs*>(a.fuse_cov);
+            using FC = FusedCov<R>;
+            if (FC::lds_bytes() > lds) lds = FC::lds_bytes();
+            const int ncov = (a.B + FC::LY::GPW - 1) / FC::LY::GPW;
+            static bool attr_f = false;
+            if (!attr_f && lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_mfma_kernel<R, STEPS, NB, NDR, 0, true>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_f = true;
+            }
+            CollapseArgs ak = a;
+            ak.fuse_cov = nullptr;
+            hipLaunchKernelGGL((collapse_mfma_kernel<R, STEPS, NB, NDR, 0, true>), dim3(nstream + ncov), dim3(256), lds, s, ak, SB,
+                               fa, ncov);
+            return hipGetLastError();
+        }
+    }
+    if (a.fuse_cov) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>),
@@ -425,9 +497,9 @@ static hipError_t launch_mfma_one(const CollapseArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    const int wpr = a.wpr > 0 ? a.wpr : 4;
-    if (wpr > kSsumSlots) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>), dim3((a.B * wpr + 3) / 4), dim3(256), lds, s, a, SB);
+    FastArgs none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>), dim3(nstream), dim3(256), lds, s, a, SB, none, 0);
     return hipGetLastError();
 }
 
@@ -462,6 +534,8 @@ static hipError_t launch_mfma_steps(const CollapseArgs& a, hipStream_t s, int va
 }
 
 constexpr int kMfmaMaxSteps = 32;   // register budget: B operands + staged A operands, 2 doubles per step
+
+bool collapse_mfma_fuses_cov(int Rpad, int N) { return collapse_mfma_supported(Rpad, N) && mfma_can_fuse(Rpad); }
 
 // supported: Rp <= 16, even N, ceil(N / CS) <= 32, 8N <= 4096
 bool collapse_mfma_supported(int Rpad, int N) {

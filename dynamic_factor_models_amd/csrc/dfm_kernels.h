@@ -29,6 +29,8 @@ struct CollapseArgs {
     double* ldfull;       // [B]
     int* status;          // bit0: NaN met while Ct == nullptr
     double* ssum;         // [B][kSsumSlots]  balanced path only: sum_t s_t of each wave's periods (slots 0 .. nseg-1)
+    const void* fuse_cov; // collapse_mfma only, HOST pointer read by the launcher (not by the kernel): FastArgs of the pass whose
+                          // covariance workgroups + P_smooth fill ride at the front of this launch, or null
     int wpr;              // collapse_mfma only: waves (period segments) per replicate (0 = 4); nseg = wpr <= kSsumSlots
 };
 
@@ -82,6 +84,7 @@ hipError_t launch_collapse_dma(int Rpad, const CollapseArgs& a, hipStream_t s, i
 hipError_t launch_gram(int Rpad, const CollapseArgs& a, hipStream_t s);
 // same contract as launch_collapse_dma, contraction on the fp64 matrix pipe (collapse_mfma.hip)
 bool collapse_mfma_supported(int Rpad, int N);
+bool collapse_mfma_fuses_cov(int Rpad, int N);   // launch_collapse_mfma honours CollapseArgs::fuse_cov for this shape
 hipError_t launch_collapse_mfma(int Rpad, const CollapseArgs& a, hipStream_t s, int variant);
 // cross-sections beyond the register tilings above (collapse_wide.hip): one wave per 16-period tile, weights
 // re-read from L2 per tile; per-tile partial sums of s_t go to scol[b][tile]

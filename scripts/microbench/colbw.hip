@@ -37,10 +37,10 @@ int main(int argc, char** argv) {
     {
         int nb = 0;
         for (size_t lds : {(size_t)32768, (size_t)40960, (size_t)51200, (size_t)53248, (size_t)65536}) {
-            CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dfm::collapse_mfma_kernel<8, 25, 2, 2, 0>, 256, lds));
+            CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, dfm::collapse_mfma_kernel<8, 25, 2, 2, 0, false>, 256, lds));
             printf("occupancy API: collapse_mfma_kernel<8,25,2,2,0> with %zu B LDS -> %d blocks/CU\n", lds, nb);
         }
-        hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)dfm::collapse_mfma_kernel<8, 25, 2, 2, 0>));
+        hipFuncAttributes fa; CK(hipFuncGetAttributes(&fa, (const void*)dfm::collapse_mfma_kernel<8, 25, 2, 2, 0, false>));
         printf("numRegs %d sharedSizeBytes %zu maxDynamicShared %d\n", fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -188,10 +188,11 @@ def test_balanced_fast_path_matches_oracle(ctx, B, N, T, r):
     _compare(_run_dev(ctx, panel, st, may_have_missing=False), ref, f"fast B={B} N={N} T={T} r={r}")
 
 
-@pytest.mark.parametrize("env", [dict(DFM_COLLAPSE_VARIANT=199), dict(DFM_COLLAPSE_VARIANT=198), dict(DFM_COLLAPSE_WPR=1), dict(DFM_COLLAPSE_WPR=3), dict(DFM_COLLAPSE_WPR=7),
+@pytest.mark.parametrize("env", [dict(DFM_COLLAPSE_VARIANT=199), dict(DFM_COLLAPSE_VARIANT=198), dict(DFM_NO_FUSE_COV=1), dict(DFM_COLLAPSE_WPR=1), dict(DFM_COLLAPSE_WPR=3), dict(DFM_COLLAPSE_WPR=7),
                                  dict(DFM_FORCE_GENERAL=1)])
 def test_balanced_kernel_choices_agree(env):
-    """The VALU collapse, the wide collapse, the MFMA collapse with 1/3/7 period segments per replicate and the general
+    """The VALU collapse, the wide collapse, the MFMA collapse with its covariance workgroups as separate launches,
+    with 1/3/7 period segments per replicate, and the general
     (sequential) path are the same function of the inputs."""
     c = _ctx_with_env(**env)
     try:
