@@ -29,6 +29,7 @@ struct dfm_handle {
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
     bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
+    bool fused_gram = true;                // DFM_FUSED_GRAM=0: gram_kernel as its own launch in front of the fused collapse launch
     bool no_fuse_cov = false;              // DFM_NO_FUSE_COV=1: cov_kernel / pfill_kernel as their own launches on a forked stream
     bool em_general = false;               // DFM_EM_GENERAL=1: EM of balanced panels on the general path too (diagnostics)
     bool fuse_gram = false;                // DFM_FUSE_GRAM=1: Gram matrices inside cov_kernel instead of gram_kernel (slower: its
@@ -319,9 +320,10 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     int S = h->subbatch > 0 ? h->subbatch : 1;
     if (S > B) S = B;
     if (S == 1 && use_mfma && !fuse_gram && !h->no_fuse_cov && collapse_mfma_fuses_cov(p.Rp, N)) {
-        // ONE stream, three launches: gram -> [covariance workgroups + P_smooth fill | streaming collapse] -> scan.
+        // ONE stream, two launches: [Gram + covariance workgroups + P_smooth fill | streaming collapse] -> scan.
         // The covariance waves sit at the front of the collapse grid (resident first, no cross-stream events).
-        { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }
+        if (h->fused_gram) { fa.Lam = pp.Lam; fa.Rv = Rv; }   // the covariance workgroups compute their Gram matrices themselves
+        else { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }
         ca.fuse_cov = &fa;
         { ProfScope ps(h, K_COLLAPSE_MFMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
         ca.fuse_cov = nullptr;
@@ -556,6 +558,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
+    if (const char* v = getenv("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;
     if (const char* v = getenv("DFM_EM_GENERAL")) h->em_general = atoi(v) != 0;
     if (const char* v = getenv("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;

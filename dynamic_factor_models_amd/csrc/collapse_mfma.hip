@@ -103,6 +103,35 @@ __global__ __launch_bounds__(256, ((STEPS * MfmaGeo<R>::NINST <= 25 && !FUSE) ? 
             extern __shared__ __attribute__((aligned(16))) double csm[];
             using FC = FusedCov<R>;
             const int first = (int)blockIdx.x * FC::LY::GPW;
+            if (fa.Lam != nullptr) {   // Gram matrices of this workgroup's replicates (gram_kernel's work), one per wave at a time
+                const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+                const int N = fa.N;
+                for (int rep = wv; rep < FC::LY::GPW; rep += 4) {
+                    const int bb = (first + rep < fa.B) ? first + rep : fa.B - 1;
+                    const double* __restrict__ Lg = fa.Lam + (size_t)bb * N * R;
+                    const double* __restrict__ Rg = fa.Rv + (size_t)bb * N;
+                    double W[NDR][2][R];
+                    bool own[NDR][2];
+                    double ld = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NDR; ++j)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int c = 2 * ln + 128 * j + e;
+                            own[j][e] = c < N;
+                            const int cc = own[j][e] ? c : N - 1;
+                            const double rv = own[j][e] ? Rg[cc] : 1.0;
+                            const double ri = own[j][e] ? 1.0 / rv : 0.0;
+                            ld += log(rv);
+#pragma unroll
+                            for (int k2 = 0; k2 < R; ++k2) W[j][e][k2] = Lg[(size_t)cc * R + k2] * ri;
+                        }
+                    c_all<R, NDR, 0, true>(W, Lg, own, ln, const_cast<double*>(fa.Cfull) + (size_t)bb * R * R);
+                    ld = wave_allsum(ld);
+                    if (ln == 0) const_cast<double*>(fa.ldfull)[bb] = ld;
+                }
+                __syncthreads();   // Cfull / ldfull of the workgroup's replicates are written (workgroup-visible)
+            }
             if (threadIdx.x < 64) {
                 __builtin_amdgcn_s_setprio(3);
                 cov_body<R, 0, FC::ECL>(fa, first, csm, (int)threadIdx.x);
