@@ -389,48 +389,51 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
 // One lane group of R lanes per replicate (lane i = row i), 64 / R replicates per wave.
 template <int R>
 __global__ __launch_bounds__(64) void em_update_kernel(EmUpdArgs a) {
+    // one WAVE per replicate: lane (i = l % R, slice = l / R) sums row i of f_t f_t' and f_t f_{t-1}' over the
+    // periods t = slice (mod 64 / R) -- independent loads, 64 / R times fewer dependent steps than one lane group
+    // per replicate -- then the slices are folded with xor-shuffles and every slice runs the (tiny) epilogue
+    // redundantly on its own LDS region; slice 0 writes.
     constexpr int GPW = 64 / R;
     __shared__ double Xs[GPW * (R * R + 2 * R)];
     const int lane = threadIdx.x;
     const int g = lane / R, i = lane % R;
-    int b = blockIdx.x * GPW + g;
-    const bool live = b < a.B;
-    if (!live) b = a.B - 1;
+    const int b = blockIdx.x;
+    const bool live = (g == 0);
     double* X = Xs + g * (R * R + 2 * R);
     const int T = a.T;
     const size_t o = (size_t)b * R * R + (size_t)i * R;
     const double* __restrict__ f = a.fsm + (size_t)b * T * R;
+    const double* __restrict__ f0 = a.f0s + (size_t)b * R;
 
     double M11[R], M10[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) { M11[j] = 0.0; M10[j] = 0.0; }
-    double prev[R];
+#pragma unroll 2
+    for (int t = g; t < T; t += GPW) {
+        double cur[R], prev[R];
+        const double* pp = (t == 0) ? f0 : f + (size_t)(t - 1) * R;
 #pragma unroll
-    for (int j = 0; j < R; ++j) prev[j] = a.f0s[(size_t)b * R + j];
-    const double f0i = a.f0s[(size_t)b * R + i];
-    double fTi = 0.0, fT[R];
-#pragma unroll
-    for (int j = 0; j < R; ++j) fT[j] = 0.0;
-#pragma unroll 4
-    for (int t = 0; t < T; ++t) {
-        double cur[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) cur[j] = f[(size_t)t * R + j];
-        double ci = 0.0;
-#pragma unroll
-        for (int j = 0; j < R; ++j) ci = (j == i) ? cur[j] : ci;
+        for (int j = 0; j < R; ++j) { cur[j] = f[(size_t)t * R + j]; prev[j] = pp[j]; }
+        const double ci = f[(size_t)t * R + i];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             M11[j] = fma(ci, cur[j], M11[j]);
             M10[j] = fma(ci, prev[j], M10[j]);
-            prev[j] = cur[j];
-        }
-        if (t == T - 1) {
-            fTi = ci;
-#pragma unroll
-            for (int j = 0; j < R; ++j) fT[j] = cur[j];
         }
     }
+#pragma unroll
+    for (int off = R; off < 64; off <<= 1) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            M11[j] += __shfl_xor(M11[j], off, kWave);
+            M10[j] += __shfl_xor(M10[j], off, kWave);
+        }
+    }
+    const double f0i = f0[i];
+    const double fTi = f[(size_t)(T - 1) * R + i];
+    double fT[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) fT[j] = f[(size_t)(T - 1) * R + j];
     double S11[R], S10[R], S00[R], P0s[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -501,8 +504,7 @@ __global__ __launch_bounds__(64) void em_update_kernel(EmUpdArgs a) {
 
 template <int R>
 static hipError_t launch_em_update_r(const EmUpdArgs& a, hipStream_t s) {
-    constexpr int GPW = 64 / R;
-    hipLaunchKernelGGL((em_update_kernel<R>), dim3((a.B + GPW - 1) / GPW), dim3(64), 0, s, a);
+    hipLaunchKernelGGL((em_update_kernel<R>), dim3(a.B), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_em_update(int Rpad, const EmUpdArgs& a, hipStream_t s) {
