@@ -31,6 +31,7 @@ struct dfm_handle {
     bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
     bool fused_gram = true;                // DFM_FUSED_GRAM=0: gram_kernel as its own launch in front of the fused collapse launch
     bool no_fuse_cov = false;              // DFM_NO_FUSE_COV=1: cov_kernel / pfill_kernel as their own launches on a forked stream
+    bool no_mstep_mfma = false;            // DFM_NO_MSTEP_MFMA=1: VALU M-step for balanced panels too (diagnostics)
     bool em_general = false;               // DFM_EM_GENERAL=1: EM of balanced panels on the general path too (diagnostics)
     bool fuse_gram = false;                // DFM_FUSE_GRAM=1: Gram matrices inside cov_kernel instead of gram_kernel (slower: its
                                            // per-series loads are dependent round trips, ~5 us each beside the collapse)
@@ -44,11 +45,11 @@ struct dfm_handle {
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
-                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_EM_UPDATE, K_CHOW, K_COUNT };
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_EM_UPDATE, K_CHOW, K_MSTEP_MFMA, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
                                                   "mstep_solve_kernel", "pca_kernels", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
-                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel", "em_update_kernel", "chow_kernel"};
+                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel", "em_update_kernel", "chow_kernel", "mstep_mfma_kernel"};
 
 namespace {
 
@@ -89,6 +90,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t S11, S10, S00, P0s, f0s, fsm, Psm, Sxf, Sxx, Dmiss, llbuf, active;
     // balanced fast path (fastpath.hip); (size_t)-1 when the plan is for the general path
     size_t f_tab, f_E, f_stead, f_xi0, f_PT, f_llc, f_fill, f_PsInf, f_ssum;
+    size_t ms_ws = (size_t)-1; int ms_wpr = 0;   // mstep_mfma partial sums (EM on the fast path)
     bool fast;
     size_t total;
 };
@@ -149,6 +151,13 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.llbuf = take(off, (size_t)B * d);
         p.active = take(off, (size_t)B * sizeof(int));
         if (mstep_needs_dmiss(Rp, N)) p.Dmiss = take(off, (size_t)B * N * np * d);
+        if (fast && mstep_mfma_supported(Rp, N)) {
+            int w = (256 * 12) / B;
+            w = w < 1 ? 1 : (w > 8 ? 8 : w);
+            while (w > 1 && T / w < 8) --w;
+            p.ms_wpr = w;
+            p.ms_ws = take(off, mstep_mfma_workspace(B, N, Rp, w));
+        }
     }
     p.total = off;
     return p;
@@ -444,6 +453,11 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
     ma.S11 = at<double>(h, p.S11); ma.S11inv = at<double>(h, p.Sxf);
     ma.Dmiss = at<double>(h, p.Dmiss);
     ma.active = eo.active; ma.Lam_out = LamP; ma.R_out = Rv; ma.lam_stride = Rp;
+    if (p.fast && p.ms_ws != (size_t)-1 && !h->no_mstep_mfma) {   // balanced panel: second panel read on the matrix pipe
+        ProfScope ps(h, K_MSTEP_MFMA);
+        HIP_TRY(h, launch_mstep_mfma(Rp, ma, p.ms_wpr, at<double>(h, p.ms_ws), h->stream));
+        return 0;
+    }
     if (ma.Dmiss)
         HIP_TRY(h, hipMemsetAsync(ma.Dmiss, 0, (size_t)B * N * (Rp * (Rp + 1) / 2) * sizeof(double), h->stream));
     { ProfScope ps(h, K_MSTEP_STATS); HIP_TRY(h, launch_mstep_lam(Rp, ma, h->stream)); }
@@ -560,6 +574,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
     if (const char* v = getenv("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;
+    if (const char* v = getenv("DFM_NO_MSTEP_MFMA")) h->no_mstep_mfma = atoi(v) != 0;
     if (const char* v = getenv("DFM_EM_GENERAL")) h->em_general = atoi(v) != 0;
     if (const char* v = getenv("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_SUBBATCH")) h->subbatch = atoi(v);

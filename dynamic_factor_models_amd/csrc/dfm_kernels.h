@@ -96,6 +96,11 @@ bool gram_supported(int Rpad, int N);       // launch_gram's register tilings
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
 hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
 bool mstep_needs_dmiss(int Rpad, int N);
+// balanced panels: the same M-step with the contraction on the matrix pipe (mstep_mfma.hip); workspace for the
+// per-segment partial sums
+bool mstep_mfma_supported(int Rpad, int N);
+size_t mstep_mfma_workspace(int B, int N, int Rpad, int wpr);
+hipError_t launch_mstep_mfma(int Rpad, const MstepArgs& a, int wpr, double* workspace, hipStream_t s);
 
 // Balanced-panel fast path (fastpath.hip): data-independent covariance steps (cov_kernel) and the
 // time-parallel mean recursion (meanscan_kernel).  All matrices in the padded dimension Rp.
