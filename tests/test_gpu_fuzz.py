@@ -1,0 +1,93 @@
+"""Randomised shape sweep of the balanced fast path and of EM (seeded): every kernel choice the dispatcher can make
+-- MFMA / VALU / wide collapse, fused and separate covariance launches, 1..8 period segments per replicate, padded r,
+ragged T -- against the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import kalman_oracle as ko
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from dynamic_factor_models_amd import DfmContext
+    c = DfmContext()
+    yield c
+    c.close()
+
+
+def _shapes(seed, n):
+    g = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        r = int(g.integers(1, 13))
+        N = int(g.integers(max(4, r + 2), 260))
+        if g.random() < 0.7:
+            N += N & 1                                   # mostly even (MFMA / DMA kernels), some odd (wide kernel)
+        T = int(g.integers(3, 140))
+        B = int(g.integers(1, 12))
+        out.append((B, N, T, r))
+    return out
+
+
+@pytest.mark.parametrize("B,N,T,r", _shapes(20160415, 28))
+def test_random_balanced_pass(ctx, B, N, T, r):
+    import torch
+    reps = [ko.synth_replicate(b, N, T, r, seed=ko.SEED0 + 31 * N + T) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    st = {k: np.stack([p[k] for _, p in reps]) for k in reps[0][1]}
+    if not np.isfinite(panel).all():
+        pytest.skip("degenerate standardisation")
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_batch(t(panel), t(st["Lam"]), t(st["R"]), t(st["A"]), t(st["Q"]), t(st["mu0"]), t(st["P0"]),
+                                 may_have_missing=False)
+    torch.cuda.synchronize()
+    fo, Po, llo = co.ks_pass_batch(panel, st["Lam"], st["R"], st["A"], st["Q"], st["mu0"], st["P0"])
+    np.testing.assert_allclose(ll.cpu().numpy(), llo, rtol=RTOL)
+    assert np.abs(f.cpu().numpy() - fo).max() <= RTOL * np.abs(fo).max()
+    assert np.abs(P.cpu().numpy() - Po).max() <= RTOL * np.abs(Po).max()
+
+
+@pytest.mark.parametrize("B,N,T,r", _shapes(7, 10))
+def test_random_balanced_em(ctx, B, N, T, r):
+    import torch
+    if T < 3 * r + 4 or N < 2 * r + 2:
+        # the PCA start fits a VAR(1) on T-1 pairs: with T-1 < 2r its residual covariance Q is singular, and the
+        # information-form recursion needs Q^-1 (DESIGN.md "known limits"; test_singular_Q_is_reported below)
+        pytest.skip("too few periods for a positive definite PCA start")
+    reps = [ko.synth_replicate(b, N, T, r, seed=ko.SEED0 + 17 * N + T) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    if not np.isfinite(panel).all():
+        pytest.skip("degenerate standardisation")
+    starts = [ko.pca_init(panel[b], r)[0] for b in range(B)]
+    keys = ("Lam", "R", "A", "Q", "mu0", "P0")
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = {k: t(np.stack([s[k] for s in starts])) for k in keys}
+    path, its, f, P = ctx.em_batch(t(panel), *[d[k] for k in keys], max_iter=3, tol=0.0)
+    torch.cuda.synchronize()
+    for b in range(B):
+        p, opath, out = ko.em(panel[b], starts[b], max_iter=3, tol=0.0)
+        np.testing.assert_allclose(path[b].cpu().numpy(), opath, rtol=1e-8)
+        for k in keys:
+            got = d[k][b].cpu().numpy()
+            assert np.abs(got - p[k]).max() <= 1e-8 * max(1.0, np.abs(p[k]).max()), (k, b)
+
+
+def test_singular_Q_is_reported(ctx):
+    """T-1 < 2r: the PCA start's Q is rank deficient.  The covariance-form oracle still runs; the information-form
+    HIP path cannot, and the synchronising host entry point must say so (DFM_E_NUMERIC), not hand back numbers."""
+    from dynamic_factor_models_amd._lib import DfmError
+    B, N, T, r = 1, 52, 18, 11
+    x, _ = ko.synth_replicate(0, N, T, r, seed=ko.SEED0 + 17 * N + T)
+    start = ko.pca_init(x, r)[0]
+    assert np.linalg.matrix_rank(start["Q"], tol=1e-10) < r
+    with pytest.raises(DfmError) as e:
+        ctx.ks_pass_batch_host(x[None], *[start[k][None] for k in ("Lam", "R", "A", "Q", "mu0", "P0")])
+    assert e.value.code == -5
