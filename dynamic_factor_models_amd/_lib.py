@@ -17,6 +17,7 @@ c_int = ctypes.c_int
 c_uint = ctypes.c_uint
 
 DFM_F_MAY_HAVE_MISSING = 1
+DFM_F_SINGULAR_Q = 2
 DFM_MAX_R = 32
 ERRORS = {-1: "DFM_E_DIMS", -2: "DFM_E_R_UNSUPPORTED", -3: "DFM_E_NULL", -4: "DFM_E_MISSING",
           -5: "DFM_E_NUMERIC", -6: "DFM_E_NO_DEVICE"}
@@ -24,6 +25,8 @@ ERRORS = {-1: "DFM_E_DIMS", -2: "DFM_E_R_UNSUPPORTED", -3: "DFM_E_NULL", -4: "DF
 _PASS_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 10 + [c_uint]
 _EMSTEP_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 8 + [c_uint]
 _EM_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, ctypes.c_double] + [c_vp] * 4 + [c_uint]
+_VPASS_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_int] + [c_vp] * 10 + [c_uint]
+_VEM_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, ctypes.c_double] + [c_vp] * 4 + [c_uint]
 _PCA_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 8
 c_ll = ctypes.c_longlong
 _ALS_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, ctypes.c_double,
@@ -46,6 +49,10 @@ SYMBOLS = {
     "dfm_em_step_batch_dev": (c_int, _EMSTEP_ARGS),
     "dfm_em_batch_dev": (c_int, _EM_ARGS),
     "dfm_em_batch": (c_int, _EM_ARGS),
+    "dfm_ks_pass_varp_batch_dev": (c_int, _VPASS_ARGS),
+    "dfm_ks_pass_varp_batch": (c_int, _VPASS_ARGS),
+    "dfm_em_varp_batch_dev": (c_int, _VEM_ARGS),
+    "dfm_em_varp_batch": (c_int, _VEM_ARGS),
     "dfm_pca_init_batch_dev": (c_int, _PCA_ARGS),
     "dfm_pca_init_batch": (c_int, _PCA_ARGS),
     "dfm_standardize_batch_dev": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -92,6 +92,8 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t f_tab, f_E, f_stead, f_xi0, f_PT, f_llc, f_fill, f_PsInf, f_ssum;
     size_t ms_ws = (size_t)-1; int ms_wpr = 0;   // mstep_mfma partial sums (EM on the fast path)
     bool fast;
+    // covariance-form recursion (DFM_F_SINGULAR_Q) and companion states (dfm_*_varp_*): see RecursionArgs
+    bool cov = false; int Rc = 0, rl = 0, kdim = 0;
     size_t total;
 };
 
@@ -106,6 +108,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
     const int Rp = pad_r(r);
     p.Rp = Rp;
     p.fast = fast;
+    p.cov = (flags & DFM_F_SINGULAR_Q) != 0;
     const size_t d = sizeof(double), rr = (size_t)Rp * Rp, np = (size_t)Rp * (Rp + 1) / 2;
     size_t off = 0;
     p.LamP = take(off, (size_t)B * N * Rp * d);
@@ -252,7 +255,7 @@ struct EmOpts {          // all-null for a plain pass
 
 // Balanced panel, even N, plain pass: may this call take the fast path (fastpath.hip)?
 bool fast_eligible(const dfm_handle* h, int N, int r, unsigned flags) {
-    if (h->force_general || (flags & DFM_F_MAY_HAVE_MISSING)) return false;
+    if (h->force_general || (flags & (DFM_F_MAY_HAVE_MISSING | DFM_F_SINGULAR_Q))) return false;
     return collapse_dma_supported(pad_r(r), N) || collapse_wide_supported(pad_r(r), N);
 }
 
@@ -400,10 +403,11 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ca.bcol = at<double>(h, p.bcol); ca.scol = at<double>(h, p.scol); ca.nobs = at<int>(h, p.nobs);
     ca.ldrow = at<double>(h, p.ldrow); ca.Ct = at<double>(h, p.Ct); ca.Cfull = at<double>(h, p.Cfull);
     ca.ldfull = at<double>(h, p.ldfull); ca.status = at<int>(h, p.status);
-    { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(p.Rp, ca, h->stream)); }
+    { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(p.Rc ? p.Rc : p.Rp, ca, h->stream)); }
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
+    ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim;
     ra.A = pp.A; ra.Q = pp.Q; ra.mu0 = pp.mu0; ra.P0 = pp.P0;
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
@@ -443,7 +447,7 @@ int copy_block(dfm_handle* h, size_t nb, int rs, int cs, int rd, int cd, const d
 int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double* panel, double* LamP,
                  double* Rv, double* AP, double* QP, double* mu0P, double* P0P, double* fsm, double* Psm,
                  double* loglik, EmOpts eo) {
-    const int Rp = p.Rp;
+    const int Rp = p.Rc ? p.Rc : p.Rp;          // width of the loadings (narrower than the state for a companion model)
     PaddedParams pp{LamP, AP, QP, mu0P, P0P};
     eo.A_out = AP; eo.Q_out = QP; eo.mu0_out = mu0P; eo.P0_out = P0P;
     if (int rc = enqueue_pass(h, p, B, T, N, Rp, panel, pp, Rv, fsm, Psm, loglik, &eo)) return rc;
@@ -451,7 +455,7 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
     ma.B = B; ma.T = T; ma.N = N; ma.r = Rp;
     ma.panel = panel; ma.fsm = fsm; ma.Psm = Psm;
     ma.S11 = at<double>(h, p.S11); ma.S11inv = at<double>(h, p.Sxf);
-    ma.Dmiss = at<double>(h, p.Dmiss);
+    ma.Dmiss = mstep_needs_dmiss(Rp, N) ? at<double>(h, p.Dmiss) : nullptr;
     ma.active = eo.active; ma.Lam_out = LamP; ma.R_out = Rv; ma.lam_stride = Rp;
     if (p.fast && p.ms_ws != (size_t)-1 && !h->no_mstep_mfma) {   // balanced panel: second panel read on the matrix pipe
         ProfScope ps(h, K_MSTEP_MFMA);
@@ -526,6 +530,100 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
         if (P_smooth && Psm != P_smooth)
             HIP_TRY(h, hipMemcpyAsync(P_smooth, Psm, (size_t)B * T * np * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     }
+    return 0;
+}
+
+// ---- VAR(p) factor dynamics in companion form ---------------------------------------------
+// z_t = (f_t, .., f_{t-p+1}), k = r p <= 32;  M = [A_1 .. A_p; I 0],  Q_z = [Q 0; 0 0]  (dfm_functions.ipynb:477-492);
+// padded to Rk x Rk with the usual identity / zero padding.  Loadings padded to Rc = pad_r(r).
+__global__ void companion_pad_kernel(int B, int N, int r, int k, int Rc, int Rk, const double* Lam, const double* Avar,
+                                     const double* Q, const double* mu0, const double* P0, double* LamP, double* AP,
+                                     double* QP, double* mu0P, double* P0P) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nl = (size_t)B * N * Rc, nm = (size_t)B * Rk * Rk, nv = (size_t)B * Rk;
+    if (tid < nl) {
+        const int c = tid % Rc;
+        const size_t bn = tid / Rc;
+        LamP[tid] = c < r ? Lam[bn * r + c] : 0.0;
+    }
+    if (tid < nm) {
+        const int j = tid % Rk, i = (tid / Rk) % Rk;
+        const size_t b = tid / ((size_t)Rk * Rk);
+        double a = 0.0, q = 0.0, p0 = 0.0;
+        if (i < r && j < k) a = Avar[(b * r + i) * k + j];
+        else if (i >= r && i < k && j == i - r) a = 1.0;
+        if (i < r && j < r) q = Q[(b * r + i) * r + j];
+        else if (i >= k && i == j) q = 1.0;
+        if (i < k && j < k) p0 = P0[(b * k + i) * k + j];
+        else if (i >= k && i == j) p0 = 1.0;
+        AP[tid] = a; QP[tid] = q; P0P[tid] = p0;
+    }
+    if (tid < nv) {
+        const int i = tid % Rk;
+        const size_t b = tid / Rk;
+        mu0P[tid] = i < k ? mu0[b * k + i] : 0.0;
+    }
+}
+
+int varp_run(dfm_handle* h, int B, int T, int N, int r, int nlag, const double* panel, double* Lam, double* R,
+             double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path, int* iters,
+             double* loglik_single, double* f_smooth, double* P_smooth, unsigned flags, bool em) {
+    if (!h) return DFM_E_NULL;
+    if (nlag < 1) return fail(h, DFM_E_DIMS, "number of factor lags must be >= 1%s");
+    if (int rc = check_dims(h, B, T, N, r)) return rc;
+    const int k = r * nlag;
+    if (k > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r * p > DFM_MAX_R (32)%s");
+    if (int rc = check_general_n(h, N, r)) return rc;
+    if (!panel || !Lam || !R || !Avar || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    Plan p = make_plan(B, T, N, k, flags | DFM_F_SINGULAR_Q, em, false);
+    p.Rc = pad_r(r); p.rl = r; p.kdim = k;
+    if (int rc = ensure_ws(h, p.total)) return rc;
+    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
+    const int Rk = p.Rp, Rc = p.Rc;
+    double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
+           *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P);
+    {
+        const size_t n = (size_t)B * N * Rc > (size_t)B * Rk * Rk ? (size_t)B * N * Rc : (size_t)B * Rk * Rk;
+        hipLaunchKernelGGL(companion_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B, N, r, k,
+                           Rc, Rk, Lam, Avar, Q, mu0, P0, LamP, AP, QP, mu0P, P0P);
+        HIP_TRY(h, hipGetLastError());
+    }
+    PaddedParams pp{LamP, AP, QP, mu0P, P0P};
+    if (!em)   // plain pass: smoothed moments of f_t = z_t[:r] straight into the caller's layout
+        return enqueue_pass(h, p, B, T, N, r, panel, pp, R, f_smooth, P_smooth, loglik_single, nullptr);
+    const size_t np = (size_t)r * (r + 1) / 2, npc = (size_t)Rc * (Rc + 1) / 2;
+    double* fsm = at<double>(h, p.fsm);
+    double* Psm = at<double>(h, p.Psm);
+    double* llbuf = loglik_single ? loglik_single : at<double>(h, p.llbuf);
+    const bool book = loglik_path != nullptr;
+    int* active = book ? at<int>(h, p.active) : nullptr;
+    if (book) {
+        HIP_TRY(h, hipMemsetAsync(loglik_path, 0xFF, (size_t)B * max_iter * sizeof(double), h->stream));  // NaN
+        HIP_TRY(h, hipMemsetAsync(iters, 0, (size_t)B * sizeof(int), h->stream));
+    }
+    std::vector<int> act_host;
+    for (int it = 0; it < max_iter; ++it) {
+        EmOpts eo;
+        eo.active = active; eo.iters = iters; eo.ll_path = loglik_path; eo.k = it; eo.max_iter = max_iter; eo.tol = tol;
+        if (int rc = em_iteration(h, p, B, T, N, panel, LamP, R, AP, QP, mu0P, P0P, fsm, Psm, llbuf, eo)) return rc;
+        if (book && tol > 0.0 && it + 1 < max_iter) {
+            act_host.resize(B);
+            HIP_TRY(h, hipMemcpyAsync(act_host.data(), active, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            bool any = false;
+            for (int b = 0; b < B; ++b) any = any || act_host[b] != 0;
+            if (!any) break;
+        }
+    }
+    if (int rc = copy_block(h, (size_t)B * N, 1, Rc, 1, r, LamP, Lam)) return rc;
+    if (int rc = copy_block(h, B, Rk, Rk, r, k, AP, Avar)) return rc;
+    if (int rc = copy_block(h, B, Rk, Rk, r, r, QP, Q)) return rc;
+    if (int rc = copy_block(h, B, Rk, Rk, k, k, P0P, P0)) return rc;
+    if (int rc = copy_block(h, B, 1, Rk, 1, k, mu0P, mu0)) return rc;
+    if (f_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, Rc, 1, r, fsm, f_smooth)) return rc;
+    if (P_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, (int)npc, 1, (int)np, Psm, P_smooth)) return rc;
     return 0;
 }
 
@@ -782,6 +880,101 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
     (void)hipFree(buf);
     return rc;
 }
+// ---- VAR(p) factor dynamics -------------------------------------------------------------------------
+int dfm_ks_pass_varp_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel, const double* Lam,
+                               const double* R, const double* Avar, const double* Q, const double* mu0, const double* P0,
+                               double* f_smooth, double* P_smooth, double* loglik, unsigned flags) {
+    if (!h) return DFM_E_NULL;
+    if (!f_smooth || !loglik) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    return varp_run(h, B, T, N, r, p, panel, const_cast<double*>(Lam), const_cast<double*>(R), const_cast<double*>(Avar),
+                    const_cast<double*>(Q), const_cast<double*>(mu0), const_cast<double*>(P0), 1, 0.0, nullptr, nullptr,
+                    loglik, f_smooth, P_smooth, flags, false);
+}
+
+int dfm_em_varp_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel, double* Lam, double* R,
+                          double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                          int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
+    if (!h) return DFM_E_NULL;
+    if (!loglik_path || !iters) return fail(h, DFM_E_NULL, "loglik_path / iters is NULL%s");
+    return varp_run(h, B, T, N, r, p, panel, Lam, R, Avar, Q, mu0, P0, max_iter, tol, loglik_path, iters, nullptr,
+                    f_smooth, P_smooth, flags, true);
+}
+
+// host-pointer variants: one device block for inputs and outputs, parameters copied in and (EM) out
+static int varp_host(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel, double* Lam, double* R,
+                     double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                     int* iters, double* f_smooth, double* P_smooth, double* loglik, unsigned flags, bool em) {
+    if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (p < 1 || r * p > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "need 1 <= p and r * p <= DFM_MAX_R (32)%s");
+    if (!panel || !Lam || !R || !Avar || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (em ? (!loglik_path || !iters) : (!f_smooth || !loglik)) return fail(h, DFM_E_NULL, "required output pointer is NULL%s");
+    if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double), k = (size_t)r * p, np = (size_t)r * (r + 1) / 2;
+    const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_a = (size_t)B * r * k,
+                 n_q = (size_t)B * r * r, n_v = (size_t)B * k, n_p0 = (size_t)B * k * k, n_f = (size_t)B * T * r,
+                 n_P = (size_t)B * T * np, n_ll = em ? (size_t)B * max_iter : (size_t)B;
+    const size_t total = (n_panel + n_lam + n_R + n_a + n_q + n_v + n_p0 + n_f + n_P + n_ll) * d + (size_t)B * sizeof(int);
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), total));
+    double* dp = buf;
+    auto up = [&](const double* src, size_t n) -> double* {
+        double* dst = dp; dp += n;
+        (void)hipMemcpyAsync(dst, src, n * d, hipMemcpyHostToDevice, h->stream);
+        return dst;
+    };
+    double *x_d = up(panel, n_panel), *lam_d = up(Lam, n_lam), *R_d = up(R, n_R), *A_d = up(Avar, n_a), *Q_d = up(Q, n_q),
+           *mu_d = up(mu0, n_v), *P0_d = up(P0, n_p0);
+    double* f_d = dp; dp += n_f;
+    double* P_d = dp; dp += n_P;
+    double* ll_d = dp; dp += n_ll;
+    int* it_d = reinterpret_cast<int*>(dp);
+    int rc = em ? dfm_em_varp_batch_dev(h, B, T, N, r, p, x_d, lam_d, R_d, A_d, Q_d, mu_d, P0_d, max_iter, tol, ll_d, it_d,
+                                        f_smooth ? f_d : nullptr, P_smooth ? P_d : nullptr, flags)
+                : dfm_ks_pass_varp_batch_dev(h, B, T, N, r, p, x_d, lam_d, R_d, A_d, Q_d, mu_d, P0_d, f_d,
+                                             P_smooth ? P_d : nullptr, ll_d, flags);
+    if (rc == 0) {
+        auto down = [&](void* dst, const void* src, size_t bytes) { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream); };
+        if (em) {
+            down(Lam, lam_d, n_lam * d); down(R, R_d, n_R * d); down(Avar, A_d, n_a * d); down(Q, Q_d, n_q * d);
+            down(mu0, mu_d, n_v * d); down(P0, P0_d, n_p0 * d); down(loglik_path, ll_d, n_ll * d);
+            down(iters, it_d, (size_t)B * sizeof(int));
+        } else {
+            down(loglik, ll_d, n_ll * d);
+        }
+        if (f_smooth) down(f_smooth, f_d, n_f * d);
+        if (P_smooth) down(P_smooth, P_d, n_P * d);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    if (rc == 0) {
+        int st = 0;
+        (void)hipMemcpy(&st, at<int>(h, make_plan(B, T, N, (int)k, flags | DFM_F_SINGULAR_Q, em, false).status), sizeof(int),
+                        hipMemcpyDeviceToHost);
+        if (st & 1) rc = fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
+        const double* llh = em ? loglik_path : loglik;
+        for (int b = 0; rc == 0 && b < B; ++b)
+            if (!isfinite(llh[em ? (size_t)b * max_iter : (size_t)b])) rc = fail(h, DFM_E_NUMERIC, "non-finite log-likelihood%s");
+    }
+    (void)hipFree(buf);
+    return rc;
+}
+
+int dfm_ks_pass_varp_batch(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel, const double* Lam,
+                           const double* R, const double* Avar, const double* Q, const double* mu0, const double* P0,
+                           double* f_smooth, double* P_smooth, double* loglik, unsigned flags) {
+    return varp_host(h, B, T, N, r, p, panel, const_cast<double*>(Lam), const_cast<double*>(R), const_cast<double*>(Avar),
+                     const_cast<double*>(Q), const_cast<double*>(mu0), const_cast<double*>(P0), 1, 0.0, nullptr, nullptr,
+                     f_smooth, P_smooth, loglik, flags, false);
+}
+
+int dfm_em_varp_batch(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel, double* Lam, double* R,
+                      double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                      int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
+    return varp_host(h, B, T, N, r, p, panel, Lam, R, Avar, Q, mu0, P0, max_iter, tol, loglik_path, iters, f_smooth,
+                     P_smooth, nullptr, flags, true);
+}
+
 int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,
                            double* A, double* Q, double* mu0, double* P0, double* factors) {
     if (!h) return DFM_E_NULL;

@@ -60,6 +60,11 @@ struct RecursionArgs {
     double* ll_path;      // [B][max_iter] or null
     int k, max_iter;      // current EM iteration
     double tol;
+    // covariance-form recursion (Q may be singular) and companion states (recursion.hip, COV = true); all 0 otherwise
+    int cov;              // 1: covariance-form forward sweep
+    int Rc;               // padded width of bcol / Ct / Cfull when narrower than the state (0: same as the state)
+    int rl;               // > 0: observation loads on the first rl state components only; outputs / S11 in the Rc layout
+    int kdim;             // > 0: companion state of width kdim = rl * p: the M-step keeps the shift rows and Q's zero blocks
 };
 
 struct MstepArgs {

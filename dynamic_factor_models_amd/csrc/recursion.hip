@@ -40,7 +40,14 @@ struct RecLayout {
     }
 };
 
-template <int R>
+// COV = true: the same sweeps with the forward covariance step in COVARIANCE form,
+//       P_p = A P_f A' + Q,  Om_p = P_p^-1,  J = P_f A' Om_p,  Z = P_f - J A P_f,  w = (I - J A) m_f,
+//       P_f <- (Om_p + C_t)^-1,  m_f <- P_f (Om_p A m_f + b_t),   log det(I + C_t P_p) = log det(Om_p + C_t) + log det P_p
+// which never inverts Q: the state innovation covariance may be singular (companion form of VAR(p) factor dynamics,
+// SURVEY.md §8 f3; dfm_functions.ipynb:477-492 builds that companion for the reference's factor VAR).  Costs two
+// inversions and four products per distinct covariance step instead of one and two.  The collapsed observations may
+// then be narrower than the state (a.Rc: loadings only on the first a.rl state components).
+template <int R, bool COV>
 __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
     using LY = RecLayout<R>;
     constexpr int GPW = LY::GPW;
@@ -66,7 +73,9 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
     const double* Ab = a.A + (size_t)b * R * R;
     const double* Qb = a.Q + (size_t)b * R * R;
     const double* P0b = a.P0 + (size_t)b * R * R;
-    const double* bcol = a.bcol + (size_t)b * T * R;
+    const int Rc = a.Rc > 0 ? a.Rc : R;                     // width of the collapsed observations (<= R)
+    const int NPc = Rc * (Rc + 1) / 2;
+    const double* bcol = a.bcol + (size_t)b * T * Rc;
     const double* scol = a.scol + (size_t)b * T;
     const int* nobs = a.nobs + (size_t)b * T;
     const double* ldrow = a.ldrow + (size_t)b * T;
@@ -75,34 +84,43 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
     double* wtab = a.wtab + (size_t)b * T * R;
 
     // ---------------- prologue: constants --------------------------------------------------------
+    // COV: Qi holds Q (never inverted), Omf holds P_f (P0 to start), xi holds m_f (mu0 to start), PSI holds A
     double Arow[R], Qi[R], PsiT[R], Phi[R], Cf[R], Omf[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         Arow[j] = Ab[i * R + j];
         Qi[j] = Qb[i * R + j];
-        Cf[j] = a.Cfull[(size_t)b * R * R + i * R + j];
+        Cf[j] = (i < Rc && j < Rc) ? a.Cfull[(size_t)b * Rc * Rc + i * Rc + j] : 0.0;
         Omf[j] = P0b[i * R + j];
+        PsiT[j] = 0.0; Phi[j] = 0.0;
     }
     const double mu0i = a.mu0[(size_t)b * R + i];
-    const double detQ = gj_inverse<R>(Qi, X, i);
-    const double detP0 = gj_inverse<R>(Omf, X, i);       // Omf = P0^-1 = Om_f,0
-    __syncthreads();
-    store_row<R>(X, i, Arow);                              // X = A rows
-    __syncthreads();
-    mm_rows<R>(PsiT, Qi, X);                               // Psi' = Qi A   (row i)
+    double detQ = 1.0, detP0 = 1.0, xi = mu0i, q0_part = 0.0;
+    if constexpr (!COV) {
+        detQ = gj_inverse<R>(Qi, X, i);
+        detP0 = gj_inverse<R>(Omf, X, i);                  // Omf = P0^-1 = Om_f,0
+        __syncthreads();
+        store_row<R>(X, i, Arow);                          // X = A rows
+        __syncthreads();
+        mm_rows<R>(PsiT, Qi, X);                           // Psi' = Qi A   (row i)
 #pragma unroll
-    for (int j = 0; j < R; ++j) PSI[j * R + i] = PsiT[j];  // PSI = Psi rows (transpose of Psi')
-    __syncthreads();
-    {
-        double prow[R];
+        for (int j = 0; j < R; ++j) PSI[j * R + i] = PsiT[j];  // PSI = Psi rows (transpose of Psi')
+        __syncthreads();
+        {
+            double prow[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) prow[k] = PSI[i * R + k];
-        mm_rows<R>(Phi, prow, X);                          // Phi = Psi A
+            for (int k = 0; k < R; ++k) prow[k] = PSI[i * R + k];
+            mm_rows<R>(Phi, prow, X);                      // Phi = Psi A
+        }
+        V0[i] = mu0i;
+        __syncthreads();
+        xi = dot_vec<R>(Omf, V0);                          // xi_0 = P0^-1 mu0
+        q0_part = mu0i * xi;
+    } else {
+        __syncthreads();
+        store_row<R>(PSI, i, Arow);                        // PSI = A rows for the whole sweep
+        __syncthreads();
     }
-    V0[i] = mu0i;
-    __syncthreads();
-    double xi = dot_vec<R>(Omf, V0);                       // xi_0 = P0^-1 mu0
-    const double q0_part = mu0i * xi;
 
     // ---------------- forward sweep --------------------------------------------------------------
     const int nchunks = (T + CH - 1) / CH;
@@ -114,7 +132,7 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
         for (int s = 0; s < CH; ++s) {
             int t = c * CH + s;
             t = t < T ? t : T - 1;
-            pb[s] = bcol[(size_t)t * R + i];
+            pb[s] = i < Rc ? bcol[(size_t)t * Rc + i] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < SPL; ++q) {
@@ -150,11 +168,11 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
 #pragma unroll
     for (int j = 0; j < R; ++j) ctn[j] = 0.0;
     if (a.Ct) {
-        const double* ct = a.Ct + (size_t)b * T * NPp;
+        const double* ct = a.Ct + (size_t)b * T * NPc;
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int hi = i > j ? i : j, lo = i > j ? j : i;
-            ctn[j] = ct[hi * (hi + 1) / 2 + lo];
+            ctn[j] = hi < Rc ? ct[hi * (hi + 1) / 2 + lo] : 0.0;
         }
     }
     issue_fwd(0);
@@ -168,6 +186,84 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
         const int smax = (T - c * CH) < CH ? (T - c * CH) : CH;
         for (int s = 0; s < smax; ++s) {
             const int t = c * CH + s;
+            if constexpr (COV) {
+                const double* rs = ring + s * (R + 3);
+                const double nt = rs[R + 1];
+                const bool full = (nt == (double)N);
+                double Crow[R];                            // row i of this period's C_t
+#pragma unroll
+                for (int j = 0; j < R; ++j) Crow[j] = full ? Cf[j] : ctn[j];
+                if (a.Ct) {   // C_{t+1}: in flight during this step
+                    const int tn = t + 1 < T ? t + 1 : T - 1;
+                    const double* ct = a.Ct + ((size_t)b * T + tn) * NPc;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        const int hi = i > j ? i : j, lo = i > j ? j : i;
+                        ctn[j] = hi < Rc ? ct[hi * (hi + 1) / 2 + lo] : 0.0;
+                    }
+                }
+                // need_cov == false: the last computed step had a full row and reproduced its own P_f (fixed point)
+                const bool compute = !__all(!need_cov && full);
+                if (compute) {  // wave-uniform
+                    double AP[R], tmp[R];
+                    __syncthreads();
+                    store_row<R>(X, i, Omf);               // X = P_f
+                    __syncthreads();
+                    mm_rows<R>(AP, Arow, X);               // A P_f      (row i)
+                    mm_rowsT<R>(tmp, AP, PSI);             // A P_f A'
+#pragma unroll
+                    for (int j = 0; j < R; ++j) Omp[j] = tmp[j] + Qi[j];   // P_p
+                    const double detPp = gj_inverse<R>(Omp, X, i);          // Om_p = P_p^-1
+                    __syncthreads();
+                    store_row<R>(JS, i, AP);
+                    __syncthreads();
+                    mm_rows<R>(tmp, Omp, JS);              // G = Om_p A P_f
+                    store_row<R>(X, i, tmp);
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < R; ++j) Jr[j] = X[j * R + i];       // J = G'
+                    mm_rows<R>(tmp, Jr, JS);               // J A P_f
+                    bool same = full;
+                    double Pn[R];
+#pragma unroll
+                    for (int j = 0; j < R; ++j) { Z[j] = Omf[j] - tmp[j]; Pn[j] = Omp[j] + Crow[j]; }
+                    const double detOf = gj_inverse<R>(Pn, X, i);           // P_f' = (Om_p + C_t)^-1
+                    ldz_cur = log(detOf) + log(detPp);     // log det(I + C_t P_p)
+#pragma unroll
+                    for (int j = 0; j < R; ++j) { same = same && close_enough(Pn[j], Omf[j]); Omf[j] = Pn[j]; }
+                    need_cov = !__all(same);
+                    ++e;
+                    {
+                        double* zt = ZJ + ((size_t)e * 2 + 0) * R * R + i * R;
+                        double* jt = ZJ + ((size_t)e * 2 + 1) * R * R + i * R;
+#pragma unroll
+                        for (int j = 0; j < R; ++j) { zt[j] = Z[j]; jt[j] = Jr[j]; }
+                    }
+                    if (lane == 0) cmask[t >> 5] |= 1u << (t & 31);
+                }
+                // mean recursion: m_p = A m_f, w = m_f - J m_p, m_f' = P_f' (Om_p m_p + b_t)
+                __syncthreads();
+                V0[i] = xi;
+                __syncthreads();
+                const double mp = dot_vec<R>(Arow, V0);
+                V1[i] = mp;
+                __syncthreads();
+                const double w = xi - dot_vec<R>(Jr, V1);
+                const double bi = rs[i];
+                const double y = dot_vec<R>(Omp, V1) + bi;
+                const double cm = dot_vec<R>(Crow, V1);
+                wtab[(size_t)t * R + i] = w;
+                V0[i] = y;
+                __syncthreads();
+                const double mfn = dot_vec<R>(Omf, V0);
+                sum_xw = fma(bi, mp, fma(bi - cm, mfn, sum_xw));   // quad_t = s_t - sum_i (b_i m_p,i + u_i m_f,i)
+                sum_ldz += ldz_cur;
+                ssum += rs[R];
+                nsum += nt;
+                ldsum += rs[R + 2];
+                xi = mfn;
+                continue;
+            }
             const bool computed = need_cov;
             double Omf_used[R];
             if (need_cov) {  // wave-uniform
@@ -219,11 +315,11 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
             }
             if (a.Ct) {   // C_{t+1} for the next period: in flight during the rest of this step and the next inversion
                 const int tn = t + 1 < T ? t + 1 : T - 1;
-                const double* ct = a.Ct + ((size_t)b * T + tn) * NPp;
+                const double* ct = a.Ct + ((size_t)b * T + tn) * NPc;
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
                     const int hi = i > j ? i : j, lo = i > j ? j : i;
-                    ctn[j] = ct[hi * (hi + 1) / 2 + lo];
+                    ctn[j] = hi < Rc ? ct[hi * (hi + 1) / 2 + lo] : 0.0;
                 }
             }
             if (computed) {
@@ -248,19 +344,24 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
     double Ps[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) Ps[j] = Omf[j];
-    const double detOmT = gj_inverse<R>(Ps, X, i);
-    __syncthreads();
-    V0[i] = xi;
-    __syncthreads();
-    double fs = dot_vec<R>(Ps, V0);
+    double detOmT = 1.0, fs = xi;                          // COV: P_T = P_f, f_T = m_f as they stand
+    if constexpr (!COV) {
+        detOmT = gj_inverse<R>(Ps, X, i);
+        __syncthreads();
+        V0[i] = xi;
+        __syncthreads();
+        fs = dot_vec<R>(Ps, V0);
+    }
     {
-        const double part = q0_part - xi * fs - sum_xw;    // lane part of mu0'P0^-1mu0 - xi_T'f_T - sum xi'w
+        // lane part of mu0'P0^-1mu0 - xi_T'f_T - sum xi'w   (COV: of -sum (b'm_p + u'm_f))
+        const double part = COV ? -sum_xw : q0_part - xi * fs - sum_xw;
+        __syncthreads();
         V1[i] = part;
         __syncthreads();
         double qd = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) qd += V1[k];
-        const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) - sum_ldz;
+        const double LD = COV ? sum_ldz : log(detOmT) + log(detP0) + (double)T * log(detQ) - sum_ldz;
         const double ll = -0.5 * (nsum * kLog2Pi + ldsum + LD + ssum + qd);
         if (live && i == 0) {
             a.loglik[b] = ll;
@@ -285,14 +386,17 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
 
     // ---------------- backward sweep -------------------------------------------------------------
     const int npr = r * (r + 1) / 2;
+    // a.rl > 0: only the first rl state components are factors of the observation equation; components rl..r-1 of
+    // the output layout are padding for the loadings step (mean 0, identity covariance, like padded factors)
+    const int rl = a.rl > 0 ? a.rl : R;
     auto emit = [&](int trow, const double (&P)[R], double f) {   // smoothed moments of period trow+1
         if (!live || i >= r) return;
-        a.f_smooth[((size_t)b * T + trow) * r + i] = f;
+        a.f_smooth[((size_t)b * T + trow) * r + i] = i < rl ? f : 0.0;
         if (a.P_smooth) {
             double* po = a.P_smooth + ((size_t)b * T + trow) * npr + i * (i + 1) / 2;
 #pragma unroll
             for (int j = 0; j < R; ++j)
-                if (j <= i) po[j] = P[j];
+                if (j <= i) po[j] = i < rl ? P[j] : (j == i ? 1.0 : 0.0);
         }
     };
     emit(T - 1, Ps, fs);
@@ -420,7 +524,7 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
         if (live) {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                a.S11[o + j] = S11[j];
+                if (a.rl == 0) a.S11[o + j] = S11[j];      // (rl > 0: written below in the loadings layout)
                 a.S10[o + j] = S10[j];
                 a.S00[o + j] = S00[j];
                 a.P0s[o + j] = Ps[j];
@@ -430,6 +534,7 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
         if (a.A_out) {
             // A = S10 S00^-1 ;  Q = sym(S11 - A S10') / T ;  mu0 = f_0|T ;  P0 = sym(P_0|T) ;  S11^-1
             double inv[R], An[R], tmp[R], Qn[R], P0n[R];
+            const int kd = a.kdim;                         // > 0: companion state (f_t, .., f_{t-p+1}) of width kd
 #pragma unroll
             for (int j = 0; j < R; ++j) inv[j] = S00[j];
             (void)gj_inverse<R>(inv, X, i);
@@ -448,6 +553,13 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < R; ++j) Qn[j] = 0.5 * (Qn[j] + X[j * R + i]);
+            if (kd > 0) {   // only [A_1 .. A_p] and the innovation covariance of f_t are free (dfm_functions.ipynb:477-492)
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (i >= rl && i < kd) An[j] = (j == i - rl) ? 1.0 : 0.0;
+                    if ((i >= rl && i < kd) || (j >= rl && j < kd)) Qn[j] = 0.0;
+                }
+            }
             __syncthreads();
             store_row<R>(X, i, Ps);
             __syncthreads();
@@ -455,10 +567,28 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
             for (int j = 0; j < R; ++j) P0n[j] = 0.5 * (Ps[j] + X[j * R + i]);
 #pragma unroll
             for (int j = 0; j < R; ++j) inv[j] = S11[j];
+            if (a.rl > 0) {   // loadings step sees the factor block only: S11 <- [S11[:rl,:rl] 0; 0 T I] in the Rc layout
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    if (i >= rl || j >= rl) inv[j] = (i == j) ? (double)T : 0.0;
+                if (live && i < Rc) {
+#pragma unroll
+                    for (int j = 0; j < R; ++j)
+                        if (j < Rc) a.S11[(size_t)b * Rc * Rc + (size_t)i * Rc + j] = inv[j];
+                }
+            }
             (void)gj_inverse<R>(inv, X, i);
             if (live) {
+                if (a.rl > 0) {
+                    if (i < Rc) {
 #pragma unroll
-                for (int j = 0; j < R; ++j) a.S11inv[o + j] = inv[j];
+                        for (int j = 0; j < R; ++j)
+                            if (j < Rc) a.S11inv[(size_t)b * Rc * Rc + (size_t)i * Rc + j] = inv[j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < R; ++j) a.S11inv[o + j] = inv[j];
+                }
                 if (em_apply) {
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
@@ -473,7 +603,7 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
     }
 }
 
-template <int R>
+template <int R, bool COV>
 static hipError_t launch_rec(const RecursionArgs& a, hipStream_t s) {
     using LY = RecLayout<R>;
     const int grid = (a.B + LY::GPW - 1) / LY::GPW;
@@ -481,22 +611,32 @@ static hipError_t launch_rec(const RecursionArgs& a, hipStream_t s) {
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&recursion_kernel<R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&recursion_kernel<R, COV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((recursion_kernel<R>), dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL((recursion_kernel<R, COV>), dim3(grid), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s) {
+    if (a.cov) {
+        switch (Rpad) {
+            case 2: return launch_rec<2, true>(a, s);
+            case 4: return launch_rec<4, true>(a, s);
+            case 8: return launch_rec<8, true>(a, s);
+            case 16: return launch_rec<16, true>(a, s);
+            case 32: return launch_rec<32, true>(a, s);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (Rpad) {
-        case 2: return launch_rec<2>(a, s);
-        case 4: return launch_rec<4>(a, s);
-        case 8: return launch_rec<8>(a, s);
-        case 16: return launch_rec<16>(a, s);
-        case 32: return launch_rec<32>(a, s);
+        case 2: return launch_rec<2, false>(a, s);
+        case 4: return launch_rec<4, false>(a, s);
+        case 8: return launch_rec<8, false>(a, s);
+        case 16: return launch_rec<16, false>(a, s);
+        case 32: return launch_rec<32, false>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

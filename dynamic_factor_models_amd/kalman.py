@@ -83,22 +83,22 @@ class DfmContext:
         return out
 
     @staticmethod
-    def _flags(panel, may_have_missing):
+    def _flags(panel, may_have_missing, singular_q=False):
         import torch
         if may_have_missing is None:
             may_have_missing = bool(torch.isnan(panel).any().item())
-        return _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        return (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
 
     # ------------------------------------------------------------------ smoother pass
     def ks_pass_batch(self, panel, Lam, R, A, Q, mu0, P0, want_P: bool = True,
-                      may_have_missing: Optional[bool] = None, out=None):
+                      may_have_missing: Optional[bool] = None, out=None, singular_q: bool = False):
         """One Kalman-smoother pass per replicate (device tensors in, device tensors out).
         Returns (f_smooth [B,T,r], P_smooth [B,T,r(r+1)/2] or None, loglik [B]).  Asynchronous on
         torch's current stream."""
         torch = self._torch
         B, T, N = panel.shape
         r = Lam.shape[2]
-        flags = self._flags(panel, may_have_missing)
+        flags = self._flags(panel, may_have_missing, singular_q)   # singular_q: DFM_F_SINGULAR_Q (covariance form)
         if out is None:
             f = torch.empty((B, T, r), dtype=torch.float64, device=panel.device)
             P = torch.empty((B, T, r * (r + 1) // 2), dtype=torch.float64, device=panel.device) if want_P else None
@@ -115,7 +115,7 @@ class DfmContext:
         return f, P, ll
 
     def ks_pass_batch_host(self, panel, Lam, R, A, Q, mu0, P0, want_P: bool = True,
-                           may_have_missing: Optional[bool] = None):
+                           may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """Same through the HOST-pointer entry point (what Julia's ccall binds): NumPy in/out."""
         c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         panel, Lam, R, A, Q, mu0, P0 = map(c, (panel, Lam, R, A, Q, mu0, P0))
@@ -123,7 +123,7 @@ class DfmContext:
         r = Lam.shape[2]
         if may_have_missing is None:
             may_have_missing = bool(np.isnan(panel).any())
-        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
         f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2)) if want_P else None
         ll = np.empty(B)
         p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
@@ -150,13 +150,14 @@ class DfmContext:
         return ll
 
     def em_batch(self, panel, Lam, R, A, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
-                 want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None):
+                 want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None,
+                 singular_q: bool = False):
         """max_iter EM iterations (parameters updated in place).  Returns
         (loglik_path [B,max_iter] (NaN past iters[b]), iters [B] int32, f_smooth, P_smooth)."""
         torch = self._torch
         B, T, N = panel.shape
         r = Lam.shape[2]
-        flags = self._flags(panel, may_have_missing)
+        flags = self._flags(panel, may_have_missing, singular_q)
         dev = panel.device
         path = torch.empty((B, max_iter), dtype=torch.float64, device=dev)
         iters = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -192,6 +193,92 @@ class DfmContext:
                                     int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags)
         _check(self._h, rc)
         return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
+
+    # ------------------------------------------------------------------ VAR(p) factor dynamics (companion form)
+    def ks_pass_varp_batch(self, panel, Lam, R, Avar, Q, mu0, P0, want_P: bool = True,
+                           may_have_missing: Optional[bool] = None):
+        """Smoother pass of x_t = Lam f_t + e_t, f_t = A_1 f_{t-1} + .. + A_p f_{t-p} + eta_t (device tensors).
+        Avar [B,r,r p] = [A_1 .. A_p], Q [B,r,r], mu0 [B,r p], P0 [B,r p,r p].  Returns (f_smooth, P_smooth, loglik)."""
+        torch = self._torch
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        k = Avar.shape[2]
+        p = k // r
+        flags = self._flags(panel, may_have_missing)
+        f = torch.empty((B, T, r), dtype=torch.float64, device=panel.device)
+        P = torch.empty((B, T, r * (r + 1) // 2), dtype=torch.float64, device=panel.device) if want_P else None
+        ll = torch.empty((B,), dtype=torch.float64, device=panel.device)
+        self._sync_stream()
+        rc = self._lib.dfm_ks_pass_varp_batch_dev(
+            self._h, B, T, N, r, p, self._dev(panel, "panel"), self._dev(Lam, "Lam", (B, N, r)),
+            self._dev(R, "R", (B, N)), self._dev(Avar, "Avar", (B, r, r * p)), self._dev(Q, "Q", (B, r, r)),
+            self._dev(mu0, "mu0", (B, k)), self._dev(P0, "P0", (B, k, k)), self._dev(f, "f_smooth"),
+            self._dev(P, "P_smooth") if P is not None else None, self._dev(ll, "loglik"), flags)
+        _check(self._h, rc)
+        return f, P, ll
+
+    def em_varp_batch(self, panel, Lam, R, Avar, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
+                      want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None):
+        """EM for the VAR(p) model, parameters (device tensors) updated in place.
+        Returns (loglik_path [B,max_iter], iters [B] int32, f_smooth, P_smooth)."""
+        torch = self._torch
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        k = Avar.shape[2]
+        p = k // r
+        flags = self._flags(panel, may_have_missing)
+        dev = panel.device
+        path = torch.empty((B, max_iter), dtype=torch.float64, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        f = torch.empty((B, T, r), dtype=torch.float64, device=dev) if want_smooth else None
+        P = torch.empty((B, T, r * (r + 1) // 2), dtype=torch.float64, device=dev) if (want_smooth and want_P) else None
+        self._sync_stream()
+        rc = self._lib.dfm_em_varp_batch_dev(
+            self._h, B, T, N, r, p, self._dev(panel, "panel"), self._dev(Lam, "Lam", (B, N, r)),
+            self._dev(R, "R", (B, N)), self._dev(Avar, "Avar", (B, r, r * p)), self._dev(Q, "Q", (B, r, r)),
+            self._dev(mu0, "mu0", (B, k)), self._dev(P0, "P0", (B, k, k)), int(max_iter), float(tol),
+            self._dev(path, "loglik_path"), ctypes.c_void_p(iters.data_ptr()),
+            self._dev(f, "f_smooth") if f is not None else None,
+            self._dev(P, "P_smooth") if P is not None else None, flags)
+        _check(self._h, rc)
+        return path, iters, f, P
+
+    def em_varp_batch_host(self, panel, Lam, R, Avar, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
+                           may_have_missing: Optional[bool] = None):
+        """Host-pointer entry (what Julia's ccall binds).  Returns (params dict, loglik_path, iters, f_smooth,
+        P_smooth); inputs are not modified."""
+        c = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
+        panel = np.ascontiguousarray(panel, dtype=np.float64)
+        Lam, R, Avar, Q, mu0, P0 = map(c, (Lam, R, Avar, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        p_lag = Avar.shape[2] // r
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
+        f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2))
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_em_varp_batch(self._h, B, T, N, r, p_lag, p(panel), p(Lam), p(R), p(Avar), p(Q), p(mu0),
+                                         p(P0), int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags)
+        _check(self._h, rc)
+        return dict(Lam=Lam, R=R, Avar=Avar, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
+
+    def ks_pass_varp_batch_host(self, panel, Lam, R, Avar, Q, mu0, P0, may_have_missing: Optional[bool] = None):
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        panel, Lam, R, Avar, Q, mu0, P0 = map(c, (panel, Lam, R, Avar, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        p_lag = Avar.shape[2] // r
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2)); ll = np.empty(B)
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_ks_pass_varp_batch(self._h, B, T, N, r, p_lag, p(panel), p(Lam), p(R), p(Avar), p(Q), p(mu0),
+                                              p(P0), p(f), p(P), p(ll), flags)
+        _check(self._h, rc)
+        return f, P, ll
 
     # ------------------------------------------------------------------ PCA initialisation / synthetic panels
     def pca_init_batch(self, panel, r: int, want_factors: bool = True):

@@ -50,6 +50,10 @@ enum {
 
 /* flags */
 #define DFM_F_MAY_HAVE_MISSING 1u /* panel may contain NaN: allocate the per-period C_t workspace */
+#define DFM_F_SINGULAR_Q 2u       /* Q (state innovation covariance) may be singular or ill-conditioned: run the
+                                   * recursion in covariance form (never inverts Q; P0 must still be positive
+                                   * definite).  Slower than the default information form; balanced panels lose the
+                                   * time-parallel fast path. */
 
 typedef struct dfm_handle dfm_handle;
 
@@ -109,6 +113,30 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
                  double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol,
                  double* loglik_path, int* iters, double* f_smooth, double* P_smooth,
                  unsigned flags);
+
+/* --- VAR(p) factor dynamics ------------------------------------------------------
+ *   x_t = Lam f_t + e_t,   f_t = A_1 f_{t-1} + ... + A_p f_{t-p} + eta_t,  eta_t ~ N(0, Q)
+ * the parametric model with the reference's `n_factorlag` lags (DFMModel, dfm_functions.ipynb:120-146), run in the
+ * companion form its `fill_matrices!` builds for the factor VAR (dfm_functions.ipynb:477-492): state
+ * z_t = (f_t, .., f_{t-p+1}), k = r p <= DFM_MAX_R, transition [A_1 .. A_p; I 0], innovation covariance [Q 0; 0 0]
+ * (singular: covariance-form recursion, as with DFM_F_SINGULAR_Q).
+ *   Avar [B][r][r p] = [A_1 .. A_p],  Q [B][r][r],  mu0 [B][r p], P0 [B][r p][r p] = moments of z_0 (P0 positive definite)
+ * Outputs as dfm_ks_pass_batch / dfm_em_batch, for f_t = z_t[:r].  The M-step re-estimates Lam, R, [A_1..A_p], Q,
+ * mu0, P0 and keeps the companion structure (oracle/varp_oracle.py).  p = 1 is dfm_em_batch's model. */
+int dfm_ks_pass_varp_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel,
+                               const double* Lam, const double* R, const double* Avar, const double* Q,
+                               const double* mu0, const double* P0, double* f_smooth, double* P_smooth,
+                               double* loglik, unsigned flags);
+int dfm_ks_pass_varp_batch(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel,
+                           const double* Lam, const double* R, const double* Avar, const double* Q,
+                           const double* mu0, const double* P0, double* f_smooth, double* P_smooth,
+                           double* loglik, unsigned flags);
+int dfm_em_varp_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel, double* Lam,
+                          double* R, double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol,
+                          double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags);
+int dfm_em_varp_batch(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel, double* Lam,
+                      double* R, double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol,
+                      double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags);
 
 /* --- PCA initialisation (reference: pca_score, dfm_functions.ipynb:179-183, on the standardised
  * balanced panel, :339-348) followed by the OLS start of EM: Lam = OLS(x on F), R = residual

@@ -1,0 +1,125 @@
+"""VAR(p) factor dynamics in companion form and the covariance-form recursion (DFM_F_SINGULAR_Q):
+HIP path through the C-ABI against oracle/varp_oracle.py / kalman_oracle.py.  Tolerances: 1e-9 on the pass, 1e-8 on EM
+(north_star asks 1e-6)."""
+import numpy as np
+import pytest
+
+from oracle import kalman_oracle as ko
+from oracle import varp_oracle as vo
+
+pytestmark = pytest.mark.gpu
+KEYS = ("Lam", "R", "Avar", "Q", "mu0", "P0")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from dynamic_factor_models_amd import DfmContext
+    c = DfmContext()
+    yield c
+    c.close()
+
+
+def _batch(B, N, T, r, p, miss):
+    xs, qs = [], []
+    for b in range(B):
+        x = vo.synth_varp(b, N, T, r, p, missing=miss)
+        q, _ = vo.varp_init(np.nan_to_num(x), r, p)
+        xs.append(x); qs.append(q)
+    return np.stack(xs), {k: np.stack([q[k] for q in qs]) for k in KEYS}
+
+
+def _close(got, want, tol, what):
+    assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), what
+
+
+@pytest.mark.parametrize("B,N,T,r,p,miss", [(3, 30, 60, 2, 2, 0.0), (2, 40, 80, 4, 4, 0.0), (3, 25, 50, 3, 2, 0.15),
+                                             (2, 60, 70, 4, 4, 0.1), (5, 20, 40, 1, 5, 0.0), (2, 30, 45, 8, 4, 0.05),
+                                             (2, 24, 40, 3, 1, 0.1), (1, 139, 222, 4, 4, 0.1)])
+def test_varp_pass(ctx, B, N, T, r, p, miss):
+    import torch
+    x, q = _batch(B, N, T, r, p, miss)
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_varp_batch(t(x), *[t(q[k]) for k in KEYS])
+    torch.cuda.synchronize()
+    tri = np.tril_indices(r)
+    for b in range(B):
+        o = vo.kfs_pass_varp(x[b], p=p, **{k: q[k][b] for k in KEYS})
+        assert abs(ll[b].item() - o["loglik"]) <= 1e-9 * abs(o["loglik"])
+        _close(f[b].cpu().numpy(), o["f_smooth"][:, :r], 1e-9, "f_smooth")
+        _close(P[b].cpu().numpy(), o["P_smooth"][:, :r, :r][:, tri[0], tri[1]], 1e-9, "P_smooth")
+
+
+@pytest.mark.parametrize("B,N,T,r,p,miss", [(3, 30, 60, 2, 2, 0.0), (2, 40, 80, 4, 4, 0.0), (2, 25, 50, 3, 2, 0.15),
+                                             (2, 50, 70, 4, 4, 0.1), (2, 24, 40, 3, 1, 0.1)])
+def test_varp_em(ctx, B, N, T, r, p, miss):
+    import torch
+    x, q = _batch(B, N, T, r, p, miss)
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = {k: t(q[k]) for k in KEYS}
+    path, its, f, P = ctx.em_varp_batch(t(x), *[d[k] for k in KEYS], max_iter=4, tol=0.0)
+    torch.cuda.synchronize()
+    for b in range(B):
+        qo, opath, out = vo.em_varp(x[b], {k: q[k][b] for k in KEYS}, p, 4)
+        np.testing.assert_allclose(path[b].cpu().numpy(), opath, rtol=1e-8)
+        for k in KEYS:
+            _close(d[k][b].cpu().numpy(), qo[k], 1e-8, k)
+        _close(f[b].cpu().numpy(), out["f_smooth"][:, :r], 1e-8, "f_smooth")
+
+
+def test_varp_em_host_entry_and_tolerance_stop(ctx):
+    x, q = _batch(2, 30, 60, 2, 3, 0.0)
+    new, path, its, f, P = ctx.em_varp_batch_host(x, *[q[k] for k in KEYS], max_iter=30, tol=1e-4)
+    for b in range(2):
+        qo, opath, _ = vo.em_varp(x[b], {k: q[k][b] for k in KEYS}, 3, 30, 1e-4)
+        assert its[b] == len(opath)
+        np.testing.assert_allclose(path[b, :its[b]], opath, rtol=1e-8)
+        _close(new["Avar"][b], qo["Avar"], 1e-7, "Avar")
+    f2, P2, ll = ctx.ks_pass_varp_batch_host(x, *[new[k] for k in KEYS])
+    assert np.isfinite(ll).all()
+
+
+def test_singular_Q_flag_runs_the_start_the_information_form_cannot(ctx):
+    """T - 1 < 2r: rank-deficient Q from the PCA start (tests/test_gpu_fuzz.py::test_singular_Q_is_reported);
+    with DFM_F_SINGULAR_Q the covariance-form recursion reproduces the oracle."""
+    import torch
+    B, N, T, r = 2, 52, 18, 11
+    xs = [ko.synth_replicate(b, N, T, r, seed=ko.SEED0 + 17 * N + T)[0] for b in range(B)]
+    starts = [ko.pca_init(x, r)[0] for x in xs]
+    keys = ("Lam", "R", "A", "Q", "mu0", "P0")
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = np.stack(xs)
+    st = {k: np.stack([s[k] for s in starts]) for k in keys}
+    f, P, ll = ctx.ks_pass_batch(t(x), *[t(st[k]) for k in keys], may_have_missing=False, singular_q=True)
+    torch.cuda.synchronize()
+    for b in range(B):
+        o = ko.kfs_pass(x[b], **starts[b])
+        assert abs(ll[b].item() - o["loglik"]) <= 1e-8 * abs(o["loglik"])
+        _close(f[b].cpu().numpy(), o["f_smooth"], 1e-7, "f_smooth")
+    d = {k: t(st[k]) for k in keys}
+    path, its, f, P = ctx.em_batch(t(x), *[d[k] for k in keys], max_iter=3, tol=0.0, singular_q=True)
+    torch.cuda.synchronize()
+    for b in range(B):
+        _, opath, _ = ko.em(x[b], starts[b], 3)
+        np.testing.assert_allclose(path[b].cpu().numpy(), opath, rtol=1e-7)
+
+
+@pytest.mark.parametrize("miss", [0.0, 0.1])
+def test_covariance_form_equals_information_form(ctx, miss):
+    import torch
+    B, N, T, r = 4, 40, 70, 5
+    reps = [ko.synth_replicate(b, N, T, r, missing=miss) for b in range(B)]
+    x = np.stack([a for a, _ in reps])
+    st = {k: np.stack([p[k] for _, p in reps]) for k in reps[0][1]}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(st[k]) for k in ("Lam", "R", "A", "Q", "mu0", "P0")]
+    a = ctx.ks_pass_batch(t(x), *args)
+    b = ctx.ks_pass_batch(t(x), *args, singular_q=True)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        _close(v.cpu().numpy(), u.cpu().numpy(), 1e-10, "cov vs info")
