@@ -159,7 +159,7 @@ def _ols_rows(y: np.ndarray, X: np.ndarray):
 
 # ----------------------------------------------------------------------------- estimate!(m, ::Parametric)
 def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int = 50, tol_em: float = 1e-6,
-             ctx=None, lam_constr_f=None, lam_constr_fl=None):
+             factor_lags: Optional[int] = None, ctx=None, lam_constr_f=None, lam_constr_fl=None):
     """`estimate!(m::DFMModel, ::Parametric; max_em_iter, tol_em)`: PCA-initialised EM for the exact
     Gaussian state-space DFM  x_t = Lam f_t + e_t,  f_t = A f_{t-1} + eta_t  on the standardised
     estimation window (rows initperiod..lastperiod, series with inclcode == 1), fitted with the HIP
@@ -172,6 +172,9 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
       m.factor_var_model.M / G / seps     <- A (companion block), chol(Q) lower, Q      (cf. :477-492)
       m.fes.tss / nobs / ssr / R2         <- as estimate_factor! defines them (:342-343, :366, :372-380),
                                              with the common component Lam f_t|T in place of the ALS fit
+    `factor_lags` = p of the factor VAR, f_t = A_1 f_{t-1} + .. + A_p f_{t-p} + eta_t; default: the model's own
+    `n_factorlag` (dfm_functions.ipynb:120-146), run in the companion form `fill_matrices!` builds (:477-492)
+    through dfm_em_varp_batch (r p <= 32); then M, G, seps, betahat hold [A_1 .. A_p], chol(Q), Q.
     `NonParametric()` runs the reference's own estimator (ALS, loadings, VAR) on the HIP kernels of als.hip:
     see estimate_nonparametric below."""
     method = Parametric() if method is None else method
@@ -184,6 +187,9 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
     if m.nfac_o != 0:
         raise NotImplementedError("observed factors (nfac_o > 0) are not supported (non-functional in the reference too)")
     r = m.nfac_u
+    nlag = m.n_factorlag if factor_lags is None else int(factor_lags)
+    if nlag < 1 or r * nlag > 32:
+        raise ValueError("need 1 <= factor_lags and nfac_u * factor_lags <= 32 (DFM_MAX_R)")
     incl = m.inclcode == 1
     xdata = m.data[m.initperiod - 1:m.lastperiod, :][:, incl]           # :335-336
     z, sd = standardize_data(xdata)                                     # :339
@@ -209,10 +215,27 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
         Lam[balmask] = p0["Lam"][0]; R[balmask] = p0["R"][0]
         for i in np.nonzero(~balmask)[0]:                               # series with gaps: complete-case OLS on F0
             Lam[i], R[i], _ = _ols_rows(z[:, i], F0)
-        start = dict(Lam=Lam[None], R=R[None], A=p0["A"], Q=p0["Q"], mu0=p0["mu0"], P0=p0["P0"])
-        params, path, iters, f, P = ctx.em_batch_host(z[None], start["Lam"], start["R"], start["A"], start["Q"],
-                                                      start["mu0"], start["P0"], max_iter=max_em_iter, tol=tol_em,
-                                                      may_have_missing=bool((~obs).any()))
+        if nlag == 1:
+            start = dict(Lam=Lam[None], R=R[None], A=p0["A"], Q=p0["Q"], mu0=p0["mu0"], P0=p0["P0"])
+            params, path, iters, f, P = ctx.em_batch_host(z[None], start["Lam"], start["R"], start["A"], start["Q"],
+                                                          start["mu0"], start["P0"], max_iter=max_em_iter, tol=tol_em,
+                                                          may_have_missing=bool((~obs).any()))
+        else:
+            # VAR(p) start (oracle/varp_oracle.py varp_init): OLS of the PCA factors on their p lags without constant
+            # (dfm_ols_batch), Q = residual covariance / (T - p), z_0 ~ N(0, second moment of the stacked lags)
+            if T - nlag <= r * nlag:
+                raise ValueError("too few periods for a VAR(factor_lags) start")
+            Z = np.hstack([F0[nlag - 1 - l:T - l] for l in range(nlag)])
+            o = ctx.ols_batch_host(Z[:-1], F0[nlag:], want_resid=True)  # one regression per factor
+            Avar = o["beta"].copy()                                     # [A_1 .. A_p]  (r, r p)
+            e = o["resid"]
+            Qv = e.T @ e / (T - nlag); Qv = 0.5 * (Qv + Qv.T)
+            P0v = Z.T @ Z / Z.shape[0]; P0v = 0.5 * (P0v + P0v.T)
+            params, path, iters, f, P = ctx.em_varp_batch_host(z[None], Lam[None], R[None], Avar[None], Qv[None],
+                                                               np.zeros((1, r * nlag)), P0v[None], max_iter=max_em_iter,
+                                                               tol=tol_em, may_have_missing=bool((~obs).any()))
+            params = dict(params)
+            params["A"] = params["Avar"]
     finally:
         if own_ctx:
             ctx.close()
@@ -238,14 +261,16 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
     m.r2[cols] = R2
     var = m.factor_var_model                                            # fill_matrices! (:477-492) for VAR(1)
     var.M[:] = 0.0; var.Q[:] = 0.0; var.G[:] = 0.0
-    var.M[:r, :r] = A
+    ka = min(A.shape[1], var.M.shape[1])                                # [A_1 .. A_p] into the model's companion (:484-486)
+    var.M[:r, :ka] = A[:, :ka]
     if var.nlag > 1:
         var.M[r:, :-r] = np.eye(r * (var.nlag - 1))
     var.Q[:, :r] = np.eye(r)
     var.seps[:] = Q
     var.G[:r, :r] = np.linalg.cholesky(Q)
     var.betahat[:] = 0.0
-    var.betahat[(1 if var.withconst else 0):(1 if var.withconst else 0) + r, :] = A.T
+    c0 = 1 if var.withconst else 0
+    var.betahat[c0:c0 + ka, :] = A[:, :ka].T
     return m.loglik_path
 
 

@@ -87,6 +87,31 @@ function em(h::Handle, z::Matrix{Float64}, p; max_iter::Integer = 50, tol::Real 
             factor = permutedims(f[:, :, 1]))
 end
 
+"EM for VAR(p) factor dynamics in companion form (dfm_em_varp_batch; include/dfm_hip.h): p.Avar is r x (r p) =
+[A_1 .. A_p], p.mu0 / p.P0 the moments of z_0 = (f_0, .., f_{1-p})."
+function em_varp(h::Handle, z::Matrix{Float64}, p, nlag::Integer; max_iter::Integer = 50, tol::Real = 1e-6)
+    T, N = size(z); r = size(p.Lam, 2); k = r * nlag
+    panel = to_c_panel(z)
+    Lam = reshape(permutedims(p.Lam), r, N, 1); R = reshape(copy(p.R), N, 1)
+    Avar = reshape(permutedims(p.Avar), k, r, 1); Q = reshape(permutedims(p.Q), r, r, 1)
+    mu0 = reshape(copy(p.mu0), k, 1); P0 = reshape(permutedims(p.P0), k, k, 1)
+    path = Array{Float64}(undef, max_iter, 1); iters = Array{Cint}(undef, 1)
+    f = Array{Float64}(undef, r, T, 1); np = div(r * (r + 1), 2); P = Array{Float64}(undef, np, T, 1)
+    flags = any(isnan, z) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    GC.@preserve panel Lam R Avar Q mu0 P0 path iters f P begin
+        rc = ccall((:dfm_em_varp_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cdouble, Ptr{Float64}, Ptr{Cint},
+                    Ptr{Float64}, Ptr{Float64}, Cuint),
+                   h.ptr, 1, T, N, r, nlag, panel, Lam, R, Avar, Q, mu0, P0, max_iter, tol, path, iters, f, P, flags)
+        check(h.ptr, rc)
+    end
+    kk = Int(iters[1])
+    return (Lam = permutedims(Lam[:, :, 1]), R = R[:, 1], A = permutedims(Avar[:, :, 1]), Q = permutedims(Q[:, :, 1]),
+            mu0 = mu0[:, 1], P0 = permutedims(P0[:, :, 1]), loglik = path[1:kk, 1], iters = kk,
+            factor = permutedims(f[:, :, 1]))
+end
+
 # ---- the reference's NON-parametric estimator on the GPU (als.hip) ------------------------------------------------
 "`estimate_factor!` sweeps (dfm_functions.ipynb:352-370) for ONE run: z is the standardised T x N window (NaN =
 missing), F0 the T x r start (pca_score).  dfm_als_batch; returns factors, loadings (NaN rows: no loadings), ssr,
@@ -177,9 +202,11 @@ end # module
 # The new method.  Same mutate-in-place convention as the reference's estimate! (dfm_functions.ipynb:530-543);
 # additionally returns the per-iteration log-likelihood vector.
 function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em::Real = 1e-6,
-                   device::Integer = 0, handle = nothing)
+                   factor_lags::Integer = m.n_factorlag, device::Integer = 0, handle = nothing)
     m.nfac_o == 0 || error("observed factors are not supported on the parametric path")
     r = m.nfac_u
+    nlag = Int(factor_lags)
+    (nlag >= 1 && r * nlag <= 32) || error("need 1 <= factor_lags and nfac_u * factor_lags <= 32")
     incl = m.inclcode .== 1
     xdata = m.data[m.initperiod:m.lastperiod, incl]                       # dfm_functions.ipynb:335-336
     xstd, xsd = standardize_data(xdata)                                   # :339
@@ -197,8 +224,18 @@ function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em:
         b, e, rows = ols_skipmissing(xstd[:, i], p0.F, Balanced())
         Lam[i, :] = b; R[i] = sum(abs2, e) / count(rows)
     end
-    fit = DFMHip.em(h, z, (Lam = Lam, R = R, A = p0.A, Q = p0.Q, mu0 = p0.mu0, P0 = p0.P0);
-                    max_iter = max_em_iter, tol = tol_em)
+    fit = if nlag == 1
+        DFMHip.em(h, z, (Lam = Lam, R = R, A = p0.A, Q = p0.Q, mu0 = p0.mu0, P0 = p0.P0);
+                  max_iter = max_em_iter, tol = tol_em)
+    else   # VAR(p) start: OLS of the PCA factors on their lags, no constant (dfm_ols_batch); companion-form EM
+        T = size(z, 1)
+        Z = hcat([p0.F[nlag-l:T-l, :] for l in 0:nlag-1]...)                  # row j: (f_{p-1+j}, .., f_j)
+        o = DFMHip.ols(h, Z[1:end-1, :], p0.F[nlag+1:end, :])
+        Qv = o.resid' * o.resid / (T - nlag)
+        P0v = Z' * Z / size(Z, 1)
+        DFMHip.em_varp(h, z, (Lam = Lam, R = R, Avar = permutedims(o.beta), Q = (Qv + Qv') / 2, mu0 = zeros(r * nlag),
+                              P0 = (P0v + P0v') / 2), nlag; max_iter = max_em_iter, tol = tol_em)
+    end
     m.factor[m.initperiod:m.lastperiod, :] = fit.factor                   # in place: aliases factor_var_model.y (:80, :371)
     cols = findall(incl)
     m.lambda[cols, :] = fit.Lam .* vec(xsd)
@@ -209,7 +246,8 @@ function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em:
     m.fes.ssr = sum(abs2, e)                                              # :366
     var = m.factor_var_model                                              # fill_matrices! (:477-492), VAR(1) block
     fill!(var.M, 0.0); fill!(var.Q, 0.0); fill!(var.G, 0.0)
-    var.M[1:r, 1:r] = fit.A
+    ka = min(size(fit.A, 2), size(var.M, 2))
+    var.M[1:r, 1:ka] = fit.A[:, 1:ka]                                     # [A_1 .. A_p] (:484-486)
     var.nlag > 1 && (var.M[r+1:end, 1:end-r] = Matrix(1.0I, r * (var.nlag - 1), r * (var.nlag - 1)))
     var.Q[1:r, 1:r] = Matrix(1.0I, r, r)
     var.seps[:, :] = fit.Q

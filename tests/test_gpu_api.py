@@ -19,7 +19,7 @@ def test_estimate_parametric_matches_oracle_pipeline():
     inclcode = np.ones(ns, dtype=int); inclcode[[4, 9]] = 0
     init, last = 3, 118
     m = api.DFMModel(raw, inclcode, 20, 40, init, last, 0, r, 1e-8, 4, 4)
-    path = api.estimate(m, api.Parametric(), max_em_iter=8, tol_em=0.0)
+    path = api.estimate(m, api.Parametric(), max_em_iter=8, tol_em=0.0, factor_lags=1)
 
     # oracle pipeline
     z, sd = api.standardize_data(raw[init - 1:last][:, inclcode == 1])
@@ -49,3 +49,40 @@ def test_estimate_parametric_matches_oracle_pipeline():
     np.testing.assert_allclose(m.factor_var_model.G[:r, :r] @ m.factor_var_model.G[:r, :r].T, m.em_params["Q"], rtol=1e-10)
     assert 0 < m.fes.ssr < m.fes.tss and m.fes.nobs == int((~np.isnan(z)).sum())
     assert np.all(np.diff(path) > -1e-8 * np.abs(path[:-1]))   # EM monotone
+
+
+def test_estimate_parametric_with_the_models_factor_lags():
+    """Default factor_lags = m.n_factorlag (4): the companion-form EM (dfm_em_varp_batch) against the oracle pipeline."""
+    from dynamic_factor_models_amd import api
+    from oracle import varp_oracle as vo
+    rng = np.random.default_rng(8)
+    T_all, ns, r, p = 130, 28, 2, 4
+    x = vo.synth_varp(3, ns, T_all, r, p)
+    raw = 1.0 + x * rng.uniform(0.5, 2.0, ns)
+    raw[rng.random(raw.shape) < 0.05] = np.nan
+    raw[:, :16][np.isnan(raw[:, :16])] = 0.5
+    inclcode = np.ones(ns, dtype=int); inclcode[3] = 0
+    init, last = 2, 128
+    m = api.DFMModel(raw, inclcode, 20, 40, init, last, 0, r, 1e-8, 4, p)
+    path = api.estimate(m, api.Parametric(), max_em_iter=6, tol_em=0.0)
+
+    z, sd = api.standardize_data(raw[init - 1:last][:, inclcode == 1])
+    xbal, bal = api.drop_missing_col(z)
+    q0, F0 = vo.varp_init(xbal, r, p)
+    N = z.shape[1]
+    Lam = np.empty((N, r)); R = np.empty(N)
+    Lam[bal] = q0["Lam"]; R[bal] = q0["R"]
+    for i in np.nonzero(~bal)[0]:
+        ok = ~np.isnan(z[:, i])
+        b = np.linalg.lstsq(F0[ok], z[ok, i], rcond=None)[0]
+        e = z[ok, i] - F0[ok] @ b
+        Lam[i] = b; R[i] = e @ e / ok.sum()
+    start = dict(q0); start["Lam"] = Lam; start["R"] = R
+    qe, pathe, out = vo.em_varp(z, start, p, 6)
+    np.testing.assert_allclose(path, pathe, rtol=1e-7)
+    f = m.factor[init - 1:last]
+    np.testing.assert_allclose(f, out["f_smooth"][:, :r], atol=1e-6 * np.abs(out["f_smooth"]).max())
+    var = m.factor_var_model
+    np.testing.assert_allclose(var.M[:r], m.em_params["Avar"], rtol=1e-12)
+    np.testing.assert_allclose(var.M[r:, :-r], np.eye(r * (p - 1)))
+    np.testing.assert_allclose(var.seps, m.em_params["Q"], rtol=1e-12)
