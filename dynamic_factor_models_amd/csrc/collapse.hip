@@ -45,16 +45,39 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
             for (int k = 0; k < R; ++k) W[j][e][k] = own[j][e] ? L[(size_t)c * R + k] * ri : 0.0;
         }
 
+    // LDS tables for the rows with missing cells: loadings, 1/R, log R per series, the packed full-row C, its log det term
+    extern __shared__ __attribute__((aligned(16))) double csm[];
+    double* LamS = csm;                       // [N][R]
+    double* rinvS = LamS + (size_t)N * R;     // [N]
+    double* logRS = rinvS + N;                // [N]
+    double* CfS = logRS + N;                  // [NP] packed lower triangle of C over all series, then ldfull
+    for (int q = threadIdx.x; q < N * R; q += 256) LamS[q] = L[q];
+    for (int q = threadIdx.x; q < N; q += 256) { const double rv = Rv[q]; rinvS[q] = 1.0 / rv; logRS[q] = log(rv); }
+    __syncthreads();
     if (wave == 0) {  // per-replicate constants for the balanced rows
         c_all<R, CPL2, 0, true>(W, L, own, lane, a.Cfull + (size_t)b * R * R);
+        c_all<R, CPL2, 0, false>(W, L, own, lane, CfS);
         double ld = 0.0;
 #pragma unroll
         for (int j = 0; j < CPL2; ++j)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
-                if (own[j][e]) ld += log(Rv[2 * lane + 128 * j + e]);
+                if (own[j][e]) ld += logRS[2 * lane + 128 * j + e];
         ld = wave_allsum(ld);
-        if (lane == 0) a.ldfull[b] = ld;
+        if (lane == 0) { a.ldfull[b] = ld; CfS[NP] = ld; }
+    }
+    __syncthreads();
+    // packed entries of C_t this lane produces on the slow path: v = lane + 64 q -> LDS offsets of lam_k, lam_k'
+    constexpr int EPL = (NP + 63) / 64;
+    int ek[EPL], ekp[EPL];
+#pragma unroll
+    for (int q = 0; q < EPL; ++q) {
+        int v = lane + 64 * q;
+        v = v < NP ? v : NP - 1;
+        int k = 0;
+        while ((k + 1) * (k + 2) / 2 <= v) ++k;
+        ek[q] = k;
+        ekp[q] = v - k * (k + 1) / 2;
     }
 
     constexpr int NV = RB * (R + 1);
@@ -70,11 +93,13 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = 0.0;
         bool nanrow[RB];
+        unsigned nanbits[RB];                    // bit 2 j + e: this lane's cell (j, e) of the row is missing
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
             const int t = (t0 + rr < T) ? t0 + rr : T - 1;
             const double* xr = X + (size_t)t * N;
             bool anynan = false;
+            unsigned nb = 0;
 #pragma unroll
             for (int j = 0; j < CPL2; ++j) {
                 const int c0 = 2 * lane + 128 * j;
@@ -91,6 +116,7 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
                 }
                 const bool n0 = x0 != x0, n1 = x1 != x1;
                 anynan = anynan || n0 || n1;
+                nb |= (n0 ? 1u : 0u) << (2 * j) | (n1 ? 2u : 0u) << (2 * j);
                 x0 = n0 ? 0.0 : x0;
                 x1 = n1 ? 0.0 : x1;
 #pragma unroll
@@ -102,6 +128,7 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
                 acc[rr * (R + 1) + R] = fma(x1 * Ri[j][1], x1, acc[rr * (R + 1) + R]);
             }
             nanrow[rr] = anynan;
+            nanbits[rr] = nb;
         }
         wave_transpose_reduce<NV>(acc, lane);
         unsigned nanmask = 0;  // bit rr set: period t0+rr has a missing cell somewhere in the row
@@ -129,26 +156,54 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
                     }
                     continue;
                 }
-                const double* xr = X + (size_t)t * N;
-                bool m[CPL2][2];
-                double cnt = 0.0, ld = 0.0;
+                // C_t = C_full - sum over the MISSING series (or the plain sum over the observed ones when those
+                // are fewer): a wave-uniform loop over the set bits of the per-slot ballots, every lane accumulating
+                // its own packed entries from the LDS tables -- no per-lane Gram partials, no 64-lane reduction
+                unsigned long long mm[CPL2][2];
+                int nmiss = 0;
 #pragma unroll
                 for (int j = 0; j < CPL2; ++j)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const int c = 2 * lane + 128 * j + e;
-                        bool ok = false;
-                        if (c < N) { const double x = xr[c]; ok = (x == x); }
-                        m[j][e] = ok;
-                        if (ok) { cnt += 1.0; ld += log(Rv[c]); }
+                        mm[j][e] = __ballot((nanbits[rr] >> (2 * j + e)) & 1u);
+                        nmiss += __popcll(mm[j][e]);
                     }
-                cnt = wave_allsum(cnt);
-                ld = wave_allsum(ld);
-                if (lane == 0) {
-                    a.nobs[(size_t)b * T + t] = (int)(cnt + 0.5);
-                    a.ldrow[(size_t)b * T + t] = ld;
+                const bool comp = 2 * nmiss <= N;          // complement form
+                if (!comp) {
+#pragma unroll
+                    for (int j = 0; j < CPL2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) mm[j][e] = __ballot(own[j][e] && !((nanbits[rr] >> (2 * j + e)) & 1u));
                 }
-                c_all<R, CPL2, 0, false>(W, L, m, lane, a.Ct + ((size_t)b * T + t) * NP);
+                double cacc[EPL], ldacc = 0.0;
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) cacc[q] = 0.0;
+#pragma unroll
+                for (int j = 0; j < CPL2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        unsigned long long bits = mm[j][e];
+                        while (bits) {
+                            const int l = __ffsll((long long)bits) - 1;
+                            bits &= bits - 1;
+                            const int c = 2 * l + 128 * j + e;
+                            const double* lc = LamS + (size_t)c * R;
+                            const double ri = rinvS[c];
+                            ldacc += logRS[c];
+#pragma unroll
+                            for (int q = 0; q < EPL; ++q) cacc[q] = fma(lc[ek[q]] * ri, lc[ekp[q]], cacc[q]);
+                        }
+                    }
+                if (lane == 0) {
+                    a.nobs[(size_t)b * T + t] = N - nmiss;
+                    a.ldrow[(size_t)b * T + t] = comp ? CfS[NP] - ldacc : ldacc;
+                }
+                double* ct = a.Ct + ((size_t)b * T + t) * NP;
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) {
+                    const int v = lane + 64 * q;
+                    if (v < NP) ct[v] = comp ? CfS[v] - cacc[q] : cacc[q];
+                }
             }
         }
     }
@@ -157,7 +212,16 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
 // ---------------------------------------------------------------------------------------------
 template <int R, int CPL2, int RB>
 static hipError_t launch_one(const CollapseArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((collapse_kernel<R, CPL2, RB>), dim3(a.B), dim3(256), 0, s, a);
+    const size_t lds = ((size_t)a.N * R + 2 * (size_t)a.N + R * (R + 1) / 2 + 1) * sizeof(double);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_kernel<R, CPL2, RB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((collapse_kernel<R, CPL2, RB>), dim3(a.B), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

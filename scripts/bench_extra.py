@@ -149,4 +149,46 @@ for miss in (0.0, 0.1):
                           ms_per_batch=1e3 * s_em, dtype="f64",
                           algorithmic_bytes_per_iteration=8 * (2 * N2 * T2 + 2 * (N2 * r2 + N2 + 2 * r2 * r2) + r2 + r2 * r2)
                           + 8 * (T2 * r2 + T2 * r2 * (r2 + 1) // 2 + 1))))
+
+# ---------------------------------------------------------------- VAR(p) factor dynamics: companion-form EM
+from oracle import varp_oracle as vo  # noqa: E402
+
+Bv, Nv, Tv, rv, pv = 1024, 139, 222, 4, 4           # the Stock-Watson :All window shape, the model's r = 4, n_factorlag = 4
+KEYS = ("Lam", "R", "Avar", "Q", "mu0", "P0")
+for miss in (0.0, 0.1):
+    xs, qs = [], []
+    for b in range(16):
+        x = vo.synth_varp(b, Nv, Tv, rv, pv, missing=miss)
+        xs.append(x); qs.append(vo.varp_init(np.nan_to_num(x), rv, pv)[0])
+    reps = Bv // 16
+    tile = lambda a: torch.from_numpy(np.ascontiguousarray(np.tile(a, (reps,) + (1,) * (a.ndim - 1)))).to(dev)
+    xv = tile(np.stack(xs))
+    d0 = {k: tile(np.stack([q[k] for q in qs])) for k in KEYS}
+    dd = {k: v.clone() for k, v in d0.items()}
+    ctx.em_varp_batch(xv, *[dd[k] for k in KEYS], max_iter=2, tol=0.0, may_have_missing=miss > 0)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    nit = 10
+    path, its, fv, Pv = ctx.em_varp_batch(xv, *[dd[k] for k in KEYS], max_iter=nit, tol=0.0, may_have_missing=miss > 0)
+    torch.cuda.synchronize(); s_it = (time.perf_counter() - t0) / nit
+    t0 = time.perf_counter(); n = 0
+    q = dict(qs[0])
+    while time.perf_counter() - t0 < 4.0:
+        vo.em_step_varp(xs[0], p=pv, **q); n += 1
+    cpu_s = (time.perf_counter() - t0) / n
+    print(json.dumps(dict(workload=f"VAR(4) factor dynamics, r=4 (companion state 16), N={Nv} T={Tv} (Stock-Watson :All window shape), "
+                                   f"{miss:.0%} missing, batch {Bv}: one EM iteration (dfm_em_varp_batch, covariance-form recursion)",
+                          metric="EM iterations/sec", value=Bv / s_it, unit="EM-iterations/s", ms_per_batch=1e3 * s_it, dtype="f64",
+                          cpu_baseline=dict(value=1.0 / cpu_s, unit="EM-iterations/s", cores=1, kind="port",
+                                            sample=f"{n} iterations of oracle/varp_oracle.py em_step_varp (NumPy) in 4 s"))))
+# covariance form against information form on the config-2 shape with missing cells
+panel, params = bench.synth_on_device(torch, dev, B2, N2, T2, r2, seed=1, missing=0.1)
+for sq in (False, True):
+    for _ in range(2):
+        ctx.ks_pass_batch(panel, *params, may_have_missing=True, singular_q=sq)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10):
+        ctx.ks_pass_batch(panel, *params, may_have_missing=True, singular_q=sq)
+    torch.cuda.synchronize(); s_pass = (time.perf_counter() - t0) / 10
+    print(json.dumps(dict(workload="config-2 shape, 10 % missing, " + ("covariance-form recursion (DFM_F_SINGULAR_Q)" if sq else "information-form recursion (default)"),
+                          metric="Kalman-smoother passes/sec", value=B2 / s_pass, unit="passes/s", ms_per_batch=1e3 * s_pass, dtype="f64")))
 ctx.close()
