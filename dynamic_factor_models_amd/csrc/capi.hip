@@ -536,12 +536,12 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
 // ---- VAR(p) factor dynamics in companion form ---------------------------------------------
 // z_t = (f_t, .., f_{t-p+1}), k = r p <= 32;  M = [A_1 .. A_p; I 0],  Q_z = [Q 0; 0 0]  (dfm_functions.ipynb:477-492);
 // padded to Rk x Rk with the usual identity / zero padding.  Loadings padded to Rc = pad_r(r).
-__global__ void companion_pad_kernel(int B, int N, int r, int k, int Rc, int Rk, const double* Lam, const double* Avar,
+__global__ void companion_pad_kernel(int B, int N, int r, int k, int ka, int Rc, int Rk, const double* Lam, const double* Avar,
                                      const double* Q, const double* mu0, const double* P0, double* LamP, double* AP,
                                      double* QP, double* mu0P, double* P0P) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nl = (size_t)B * N * Rc, nm = (size_t)B * Rk * Rk, nv = (size_t)B * Rk;
-    if (tid < nl) {
+    if (Lam && tid < nl) {
         const int c = tid % Rc;
         const size_t bn = tid / Rc;
         LamP[tid] = c < r ? Lam[bn * r + c] : 0.0;
@@ -550,7 +550,7 @@ __global__ void companion_pad_kernel(int B, int N, int r, int k, int Rc, int Rk,
         const int j = tid % Rk, i = (tid / Rk) % Rk;
         const size_t b = tid / ((size_t)Rk * Rk);
         double a = 0.0, q = 0.0, p0 = 0.0;
-        if (i < r && j < k) a = Avar[(b * r + i) * k + j];
+        if (i < r && j < ka) a = Avar[(b * r + i) * ka + j];        // [A_1 .. A_p], ka = r p <= k
         else if (i >= r && i < k && j == i - r) a = 1.0;
         if (i < r && j < r) q = Q[(b * r + i) * r + j];
         else if (i >= k && i == j) q = 1.0;
@@ -586,7 +586,7 @@ int varp_run(dfm_handle* h, int B, int T, int N, int r, int nlag, const double* 
            *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P);
     {
         const size_t n = (size_t)B * N * Rc > (size_t)B * Rk * Rk ? (size_t)B * N * Rc : (size_t)B * Rk * Rk;
-        hipLaunchKernelGGL(companion_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B, N, r, k,
+        hipLaunchKernelGGL(companion_pad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B, N, r, k, k,
                            Rc, Rk, Lam, Avar, Q, mu0, P0, LamP, AP, QP, mu0P, P0P);
         HIP_TRY(h, hipGetLastError());
     }
@@ -625,6 +625,74 @@ int varp_run(dfm_handle* h, int B, int T, int N, int r, int nlag, const double* 
     if (f_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, Rc, 1, r, fsm, f_smooth)) return rc;
     if (P_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, (int)npc, 1, (int)np, Psm, P_smooth)) return rc;
     return 0;
+}
+
+// ---- AR idiosyncratic terms by quasi-differencing ----------------------------------------------
+// x~_it = x_it - sum_l rho_il x_i,t-l (NaN when x_it or a lag is NaN);  loadings [lam_i, -rho_i1 lam_i, .., -rho_iq lam_i, 0..]
+__global__ void quasi_diff_kernel(int B, int T, int N, int q, const double* x, const double* rho, double* out) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)B * (T - q) * N;
+    if (tid >= n) return;
+    const int i = tid % N;
+    const int t = (tid / N) % (T - q);
+    const size_t b = tid / ((size_t)N * (T - q));
+    const double* xb = x + b * (size_t)T * N;
+    double v = xb[(size_t)(t + q) * N + i];
+    for (int l = 1; l <= q; ++l) v -= rho[(b * N + i) * q + (l - 1)] * xb[(size_t)(t + q - l) * N + i];
+    out[tid] = v;
+}
+__global__ void ar_loadings_kernel(int B, int N, int r, int q, int Rk, const double* Lam, const double* rho, double* LamK) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (size_t)B * N * Rk) return;
+    const int c = tid % Rk;
+    const size_t bn = tid / Rk;
+    const int l = c / r, cc = c % r;
+    double v = 0.0;
+    if (l <= q) v = (l == 0 ? 1.0 : -rho[bn * q + (l - 1)]) * Lam[bn * r + cc];
+    LamK[tid] = v;
+}
+
+int ar_pass_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, const double* panel, const double* Lam,
+                const double* sig2, const double* rho, const double* Avar, const double* Q, const double* mu0,
+                const double* P0, double* f_smooth, double* P_smooth, double* loglik, unsigned flags) {
+    if (!h) return DFM_E_NULL;
+    if (nlag < 1 || q < 0) return fail(h, DFM_E_DIMS, "need p >= 1 factor lags and q >= 0 idiosyncratic lags%s");
+    if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (T <= q) return fail(h, DFM_E_DIMS, "T must exceed the number of idiosyncratic lags%s");
+    const int m = nlag > q + 1 ? nlag : q + 1, k = r * m;
+    if (k > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r * max(p, q + 1) > DFM_MAX_R (32)%s");
+    if (int rc = check_general_n(h, N, k)) return rc;
+    if (!panel || !Lam || !sig2 || (q > 0 && !rho) || !Avar || !Q || !mu0 || !P0 || !f_smooth || !loglik)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int Tq = T - q;
+    Plan p = make_plan(B, Tq, N, k, flags | DFM_F_SINGULAR_Q, false, false);
+    const size_t xoff = (p.total + 255) & ~(size_t)255;
+    if (int rc = ensure_ws(h, xoff + (size_t)B * Tq * N * sizeof(double))) return rc;
+    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
+    const int Rk = p.Rp;
+    double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
+           *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P), *xq = at<double>(h, xoff);
+    const double* xin = panel;
+    if (q > 0) {
+        const size_t n = (size_t)B * Tq * N;
+        hipLaunchKernelGGL(quasi_diff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B, T, N, q, panel,
+                           rho, xq);
+        HIP_TRY(h, hipGetLastError());
+        xin = xq;
+    }
+    {
+        const size_t n = (size_t)B * N * Rk;
+        hipLaunchKernelGGL(ar_loadings_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B, N, r, q, Rk, Lam,
+                           rho, LamP);
+        HIP_TRY(h, hipGetLastError());
+        const size_t nm = (size_t)B * Rk * Rk;
+        hipLaunchKernelGGL(companion_pad_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, h->stream, B, N, r, k,
+                           r * nlag, Rk, Rk, (const double*)nullptr, Avar, Q, mu0, P0, LamP, AP, QP, mu0P, P0P);
+        HIP_TRY(h, hipGetLastError());
+    }
+    PaddedParams pp{LamP, AP, QP, mu0P, P0P};
+    return enqueue_pass(h, p, B, Tq, N, r, xin, pp, sig2, f_smooth, P_smooth, loglik, nullptr);
 }
 
 }  // namespace
@@ -973,6 +1041,54 @@ int dfm_em_varp_batch(dfm_handle* h, int B, int T, int N, int r, int p, const do
                       int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
     return varp_host(h, B, T, N, r, p, panel, Lam, R, Avar, Q, mu0, P0, max_iter, tol, loglik_path, iters, f_smooth,
                      P_smooth, nullptr, flags, true);
+}
+
+// ---- AR idiosyncratic terms -----------------------------------------------------------------------
+int dfm_ks_pass_ar_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, int q, const double* panel, const double* Lam,
+                             const double* sig2, const double* rho, const double* Avar, const double* Q, const double* mu0,
+                             const double* P0, double* f_smooth, double* P_smooth, double* loglik, unsigned flags) {
+    return ar_pass_run(h, B, T, N, r, p, q, panel, Lam, sig2, rho, Avar, Q, mu0, P0, f_smooth, P_smooth, loglik, flags);
+}
+
+int dfm_ks_pass_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, const double* panel, const double* Lam,
+                         const double* sig2, const double* rho, const double* Avar, const double* Q, const double* mu0,
+                         const double* P0, double* f_smooth, double* P_smooth, double* loglik, unsigned flags) {
+    if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (p < 1 || q < 0 || T <= q) return fail(h, DFM_E_DIMS, "need p >= 1, 0 <= q < T%s");
+    const int m = p > q + 1 ? p : q + 1;
+    if (r * m > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r * max(p, q + 1) > DFM_MAX_R (32)%s");
+    if (!panel || !Lam || !sig2 || (q > 0 && !rho) || !Avar || !Q || !mu0 || !P0 || !f_smooth || !loglik)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double), k = (size_t)r * m, np = (size_t)r * (r + 1) / 2, Tq = (size_t)(T - q);
+    const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_rho = (size_t)B * N * q,
+                 n_a = (size_t)B * r * r * p, n_q = (size_t)B * r * r, n_v = (size_t)B * k, n_p0 = (size_t)B * k * k,
+                 n_f = (size_t)B * Tq * r, n_P = (size_t)B * Tq * np;
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), (n_panel + n_lam + n_R + n_rho + n_a + n_q + n_v + n_p0 + n_f + n_P + B) * d));
+    double* dp = buf;
+    auto up = [&](const double* src, size_t n) -> double* {
+        double* dst = dp; dp += n;
+        if (n) (void)hipMemcpyAsync(dst, src, n * d, hipMemcpyHostToDevice, h->stream);
+        return dst;
+    };
+    double *x_d = up(panel, n_panel), *lam_d = up(Lam, n_lam), *R_d = up(sig2, n_R), *rho_d = up(rho, n_rho),
+           *A_d = up(Avar, n_a), *Q_d = up(Q, n_q), *mu_d = up(mu0, n_v), *P0_d = up(P0, n_p0);
+    double* f_d = dp; dp += n_f;
+    double* P_d = dp; dp += n_P;
+    double* ll_d = dp;
+    int rc = ar_pass_run(h, B, T, N, r, p, q, x_d, lam_d, R_d, rho_d, A_d, Q_d, mu_d, P0_d, f_d, P_smooth ? P_d : nullptr, ll_d,
+                         flags);
+    if (rc == 0) {
+        (void)hipMemcpyAsync(f_smooth, f_d, n_f * d, hipMemcpyDeviceToHost, h->stream);
+        if (P_smooth) (void)hipMemcpyAsync(P_smooth, P_d, n_P * d, hipMemcpyDeviceToHost, h->stream);
+        (void)hipMemcpyAsync(loglik, ll_d, (size_t)B * d, hipMemcpyDeviceToHost, h->stream);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    if (rc == 0) rc = post_check(h, make_plan(B, (int)Tq, N, (int)k, flags | DFM_F_SINGULAR_Q, false, false), loglik, B);
+    (void)hipFree(buf);
+    return rc;
 }
 
 int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,

@@ -280,6 +280,50 @@ class DfmContext:
         _check(self._h, rc)
         return f, P, ll
 
+    # ------------------------------------------------------------------ AR idiosyncratic terms (quasi-differencing)
+    def ks_pass_ar_batch(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, want_P: bool = True,
+                         may_have_missing: Optional[bool] = None):
+        """Smoother pass with AR(q) idiosyncratic terms (rho [B,N,q], sig2 [B,N]: the reference's uar_coef, uar_ser^2)
+        and VAR(p) factors (Avar [B,r,r p]); mu0 [B,r m], P0 [B,r m,r m], m = max(p, q+1).  Device tensors.
+        Returns (f_smooth [B,T-q,r], P_smooth or None, loglik [B]) for rows q+1..T."""
+        torch = self._torch
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        p = Avar.shape[2] // r
+        q = rho.shape[2]
+        k = r * max(p, q + 1)
+        flags = self._flags(panel, may_have_missing)
+        f = torch.empty((B, T - q, r), dtype=torch.float64, device=panel.device)
+        P = torch.empty((B, T - q, r * (r + 1) // 2), dtype=torch.float64, device=panel.device) if want_P else None
+        ll = torch.empty((B,), dtype=torch.float64, device=panel.device)
+        self._sync_stream()
+        rc = self._lib.dfm_ks_pass_ar_batch_dev(
+            self._h, B, T, N, r, p, q, self._dev(panel, "panel"), self._dev(Lam, "Lam", (B, N, r)),
+            self._dev(sig2, "sig2", (B, N)), self._dev(rho, "rho", (B, N, q)) if q else None,
+            self._dev(Avar, "Avar", (B, r, r * p)), self._dev(Q, "Q", (B, r, r)), self._dev(mu0, "mu0", (B, k)),
+            self._dev(P0, "P0", (B, k, k)), self._dev(f, "f_smooth"), self._dev(P, "P_smooth") if P is not None else None,
+            self._dev(ll, "loglik"), flags)
+        _check(self._h, rc)
+        return f, P, ll
+
+    def ks_pass_ar_batch_host(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, may_have_missing: Optional[bool] = None):
+        """Host-pointer entry (what Julia's ccall binds)."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        panel, Lam, sig2, rho, Avar, Q, mu0, P0 = map(c, (panel, Lam, sig2, rho, Avar, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        p_lag = Avar.shape[2] // r
+        q = rho.shape[2]
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        f = np.empty((B, T - q, r)); P = np.empty((B, T - q, r * (r + 1) // 2)); ll = np.empty(B)
+        p = lambda a: ctypes.c_void_p(a.ctypes.data) if a.size else None
+        rc = self._lib.dfm_ks_pass_ar_batch(self._h, B, T, N, r, p_lag, q, p(panel), p(Lam), p(sig2), p(rho), p(Avar), p(Q),
+                                            p(mu0), p(P0), p(f), p(P), p(ll), flags)
+        _check(self._h, rc)
+        return f, P, ll
+
     # ------------------------------------------------------------------ PCA initialisation / synthetic panels
     def pca_init_batch(self, panel, r: int, want_factors: bool = True):
         """PCA + OLS start of EM on balanced standardised panels (device tensor [B,T,N], no NaN).

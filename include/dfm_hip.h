@@ -138,6 +138,24 @@ int dfm_em_varp_batch(dfm_handle* h, int B, int T, int N, int r, int p, const do
                       double* R, double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol,
                       double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags);
 
+/* --- AR idiosyncratic terms --------------------------------------------------------
+ *   x_it = lam_i' f_t + e_it,   e_it = rho_i1 e_i,t-1 + .. + rho_iq e_i,t-q + eps_it,  eps_it ~ N(0, sig2_i)
+ * with rho [B][N][q] / sig2 [B][N] in the role of the reference's uar_coef / uar_ser^2 (AR(n_uarlag) of the loading
+ * regression residuals, dfm_functions.ipynb:305-311, 405-412) and VAR(p) factor dynamics as above.  The panel is
+ * quasi-differenced on the device (x~_it = x_it - sum_l rho_il x_i,t-l, missing when x_it or one of its q lags is), the
+ * state is z_t = (f_t, .., f_{t-m+1}), m = max(p, q + 1), r m <= DFM_MAX_R, loadings [lam_i, -rho_i1 lam_i, ..]; the
+ * likelihood is conditional on the first q rows.  mu0 [B][r m], P0 [B][r m][r m]: moments of z_q (P0 positive definite).
+ * Outputs for the T - q rows q+1..T: f_smooth [B][T-q][r], P_smooth [B][T-q][r(r+1)/2] or NULL, loglik [B].
+ * q = 0 is dfm_ks_pass_varp_batch.  (Smoother pass only: rho / sig2 come from the reference's own estimator.) */
+int dfm_ks_pass_ar_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, int q, const double* panel,
+                             const double* Lam, const double* sig2, const double* rho, const double* Avar,
+                             const double* Q, const double* mu0, const double* P0, double* f_smooth,
+                             double* P_smooth, double* loglik, unsigned flags);
+int dfm_ks_pass_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, const double* panel,
+                         const double* Lam, const double* sig2, const double* rho, const double* Avar,
+                         const double* Q, const double* mu0, const double* P0, double* f_smooth,
+                         double* P_smooth, double* loglik, unsigned flags);
+
 /* --- PCA initialisation (reference: pca_score, dfm_functions.ipynb:179-183, on the standardised
  * balanced panel, :339-348) followed by the OLS start of EM: Lam = OLS(x on F), R = residual
  * variance, A/Q = VAR(1) OLS of F, mu0 = 0, P0 = F'F/T.  Balanced panels only (no NaN). */
