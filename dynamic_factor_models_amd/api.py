@@ -505,6 +505,68 @@ def bootstrap_irf_bands(varm: VARModel, H: int, ndraws: int = 10000, quantiles=(
     return dict(point=impulse_response(varm, range(varm.ns), H), bands=bands, draws=draws)
 
 
+def smooth_factors_ar_idio(m: DFMModel, *, ctx=None):
+    """Kalman-smoothed factors and Gaussian log-likelihood of the parametric model with AR(n_uarlag)
+    idiosyncratic terms, assembled from what the reference's own estimator leaves in the model (`estimate!(m)`):
+
+        x_it = c_i + lam_i' f_t + e_it,   e_it = sum_l uar_coef[i,l] e_i,t-l + eps_it,  sd(eps_it) = uar_ser[i]   (:391-415)
+        f_t  = c_f + A_1 f_{t-1} + .. + A_p f_{t-p} + eta_t,  Var(eta_t) = seps      (factor_var_model, :444-492)
+
+    in deviations from the VAR's mean (the reference does not keep c_i: it is re-derived as the mean residual of the
+    loading regression).  Series used: included (inclcode == 1) with loadings, AR coefficients and uar_ser > 0.  Runs
+    dfm_ks_pass_ar_batch (quasi-differenced observation equation, state (f_t .. f_{t-m+1}), m = max(p, n_uarlag + 1),
+    nfac_u * m <= 32; likelihood conditional on the first n_uarlag window rows).  z_q ~ N(0, stationary covariance of
+    the companion VAR) -- or the sample second moment of the stacked factor estimates when the VAR is not stable.
+    Returns dict(loglik, factor [T_all, r] (NaN outside rows initperiod + n_uarlag .. lastperiod), P [T - q, r(r+1)/2],
+    series (column indices used), inputs (the arrays handed to the library, for the parity test))."""
+    if m.nfac_o != 0:
+        raise NotImplementedError("observed factors (nfac_o > 0) are not supported (non-functional in the reference too)")
+    var = m.factor_var_model
+    r, p, q = m.nfac_u, var.nlag, m.n_uarlag
+    mm = max(p, q + 1)
+    k = r * mm
+    if k > 32:
+        raise ValueError("nfac_u * max(n_factorlag, n_uarlag + 1) must not exceed 32 (DFM_MAX_R)")
+    if np.isnan(var.betahat).any() or np.isnan(var.seps).any():
+        raise ValueError("factor_var_model is not estimated: run estimate(m, NonParametric()) first")
+    rows = slice(m.initperiod - 1, m.lastperiod)
+    F = m.factor[rows]
+    use = (m.inclcode == 1) & ~np.isnan(m.lambda_).any(axis=1) & ~np.isnan(m.uar_coef).any(axis=1) & (m.uar_ser > 0)
+    cols = np.nonzero(use)[0]
+    if cols.size == 0:
+        raise ValueError("no series with loadings and AR coefficients: run estimate(m, NonParametric()) first")
+    Y = m.data[rows][:, cols]
+    lam, rho, sig2 = m.lambda_[cols], m.uar_coef[cols], m.uar_ser[cols] ** 2
+    c0 = 1 if var.withconst else 0
+    Avar = np.ascontiguousarray(var.betahat[c0:c0 + r * p].T)            # [A_1 .. A_p]
+    c_f = var.betahat[0] if var.withconst else np.zeros(r)
+    Asum = sum(Avar[:, l * r:(l + 1) * r] for l in range(p))
+    mu_f = np.linalg.solve(np.eye(r) - Asum, c_f)
+    c_i = np.nanmean(Y - F @ lam.T, axis=0)                              # intercept of the loading regression (:396-400)
+    x = Y - c_i - lam @ mu_f
+    M = np.zeros((k, k)); M[:r, :r * p] = Avar
+    M[r:, :k - r] = np.eye(k - r)
+    Qk = np.zeros((k, k)); Qk[:r, :r] = var.seps
+    if np.abs(np.linalg.eigvals(M)).max() < 0.999:
+        P0 = np.linalg.solve(np.eye(k * k) - np.kron(M, M), Qk.ravel()).reshape(k, k)
+    else:
+        Fd = F - mu_f
+        Z = np.hstack([Fd[mm - 1 - l:Fd.shape[0] - l] for l in range(mm)])
+        P0 = Z.T @ Z / Z.shape[0]
+    P0 = 0.5 * (P0 + P0.T) + 1e-10 * np.eye(k)
+    inputs = dict(x=x, Lam=lam, sig2=sig2, rho=rho, Avar=Avar, Q=np.array(var.seps), mu0=np.zeros(k), P0=P0)
+    ctx, own = _own(ctx)
+    try:
+        f, P, ll = ctx.ks_pass_ar_batch_host(x[None], lam[None], sig2[None], rho[None], Avar[None], inputs["Q"][None],
+                                             inputs["mu0"][None], P0[None])
+    finally:
+        if own:
+            ctx.close()
+    factor = np.full((m.T_all if hasattr(m, "T_all") else m.data.shape[0], r), np.nan)
+    factor[m.initperiod - 1 + q:m.lastperiod] = f[0] + mu_f
+    return dict(loglik=float(ll[0]), factor=factor, P=P[0], series=cols, inputs=inputs, mu_f=mu_f)
+
+
 def amengual_watson_test(m: DFMModel, nlag: int = 4, *, ctx=None):
     """`amengual_watson_test(m, nper)` -- dfm_functions.ipynb:734-768: the number of DYNAMIC factors.  Every
     included series is regressed on [1, lags 1..nlag of the r estimated static factors] over all rows of the data

@@ -112,6 +112,27 @@ function em_varp(h::Handle, z::Matrix{Float64}, p, nlag::Integer; max_iter::Inte
             factor = permutedims(f[:, :, 1]))
 end
 
+"Smoother pass with AR(q) idiosyncratic terms (dfm_ks_pass_ar_batch; include/dfm_hip.h): x is T x N (NaN = missing, in
+deviations from its intercept), Lam N x r, sig2 = uar_ser.^2, rho = uar_coef (N x q), Avar r x (r p), Q r x r, mu0 / P0
+the moments of z_q, r max(p, q+1) wide.  Returns the smoothed factors of rows q+1..T and the conditional log-likelihood."
+function ks_pass_ar(h::Handle, x::Matrix{Float64}, Lam::Matrix{Float64}, sig2::Vector{Float64}, rho::Matrix{Float64},
+                    Avar::Matrix{Float64}, Q::Matrix{Float64}, mu0::Vector{Float64}, P0::Matrix{Float64})
+    T, N = size(x); r = size(Lam, 2); q = size(rho, 2); p = div(size(Avar, 2), r)
+    panel = to_c_panel(x)
+    LamC = permutedims(Lam); rhoC = permutedims(rho); AC = permutedims(Avar); QC = permutedims(Q); P0C = permutedims(P0)
+    f = Array{Float64}(undef, r, T - q); np = div(r * (r + 1), 2); P = Array{Float64}(undef, np, T - q)
+    ll = Array{Float64}(undef, 1)
+    flags = any(isnan, x) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    GC.@preserve panel LamC sig2 rhoC AC QC mu0 P0C f P ll begin
+        rc = ccall((:dfm_ks_pass_ar_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cuint),
+                   h.ptr, 1, T, N, r, p, q, panel, LamC, sig2, rhoC, AC, QC, mu0, P0C, f, P, ll, flags)
+        check(h.ptr, rc)
+    end
+    return (factor = permutedims(f), P = permutedims(P), loglik = ll[1])
+end
+
 # ---- the reference's NON-parametric estimator on the GPU (als.hip) ------------------------------------------------
 "`estimate_factor!` sweeps (dfm_functions.ipynb:352-370) for ONE run: z is the standardised T x N window (NaN =
 missing), F0 the T x r start (pca_score).  dfm_als_batch; returns factors, loadings (NaN rows: no loadings), ssr,

@@ -64,3 +64,24 @@ def test_ar_pass_host_entry_and_dimension_limit(ctx):
     with pytest.raises(DfmError) as e:
         ctx.ks_pass_ar_batch_host(x[None], *[a[k][None] for k in KEYS])
     assert e.value.code == -2
+
+
+def test_smooth_factors_ar_idio_on_the_stock_watson_panel():
+    """estimate(m, NonParametric()) (the reference's estimator on the GPU) -> AR-idiosyncratic smoother with its
+    uar_coef / uar_ser / factor VAR; library result == oracle on the same inputs; smoothed factors track the ALS ones."""
+    import os
+    from dynamic_factor_models_amd import api
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sw_panel.npz"))
+    m = api.DFMModel(d["bpdata"], d["inclcode"], 20, 40, 3, 224, 0, 4, 1e-8, 4, 4)
+    api.estimate(m, api.NonParametric())
+    out = api.smooth_factors_ar_idio(m)
+    a = out["inputs"]
+    o = aro.kfs_pass_ar(a["x"], a["Lam"], a["sig2"], a["rho"], a["Avar"], a["Q"], a["mu0"], a["P0"])
+    assert abs(out["loglik"] - o["loglik"]) <= 1e-8 * abs(o["loglik"])
+    q = m.n_uarlag
+    fs = out["factor"][m.initperiod - 1 + q:m.lastperiod]
+    np.testing.assert_allclose(fs - out["mu_f"], o["f_smooth"][:, :4], atol=1e-7 * np.abs(o["f_smooth"]).max())
+    assert np.isnan(out["factor"][:m.initperiod - 1 + q]).all()
+    fa = m.factor[m.initperiod - 1 + q:m.lastperiod]
+    for j in range(4):
+        assert abs(np.corrcoef(fs[:, j], fa[:, j])[0, 1]) > 0.9
