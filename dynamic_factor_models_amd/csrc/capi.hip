@@ -28,6 +28,7 @@ struct dfm_handle {
     int num_cu = 256;
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
+    bool no_rec_wave = false;              // DFM_NO_RECURSION_WAVE=1: lane-group recursion_kernel also at Rp = 8 (A/B)
     bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
     bool fused_gram = true;                // DFM_FUSED_GRAM=0: gram_kernel as its own launch in front of the fused collapse launch
     bool no_fuse_cov = false;              // DFM_NO_FUSE_COV=1: cov_kernel / pfill_kernel as their own launches on a forked stream
@@ -407,7 +408,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
-    ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim;
+    ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim; ra.wave = h->no_rec_wave ? 0 : 1;
     ra.A = pp.A; ra.Q = pp.Q; ra.mu0 = pp.mu0; ra.P0 = pp.P0;
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
@@ -737,6 +738,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_COLLAPSE_WPR")) { h->collapse_wpr = atoi(v); if (h->collapse_wpr < 0 || h->collapse_wpr > kSsumSlots) h->collapse_wpr = 0; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
+    if (const char* v = getenv("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
     if (const char* v = getenv("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;

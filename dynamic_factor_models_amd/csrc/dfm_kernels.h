@@ -65,6 +65,7 @@ struct RecursionArgs {
     int Rc;               // padded width of bcol / Ct / Cfull when narrower than the state (0: same as the state)
     int rl;               // > 0: observation loads on the first rl state components only; outputs / S11 in the Rc layout
     int kdim;             // > 0: companion state of width kdim = rl * p: the M-step keeps the shift rows and Q's zero blocks
+    int wave;             // 1: one wave per replicate where recursion_wave.hip supports the shape (Rp = 8, information form)
 };
 
 struct MstepArgs {
@@ -82,6 +83,8 @@ struct MstepArgs {
 };
 
 hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
+bool recursion_wave_supported(int Rpad, const RecursionArgs& a);
+hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s);
 int collapse_max_n(int Rpad);
 // balanced panels (no NaN), even N: LDS-DMA streaming collapse (writes bcol, scol only) + Gram kernel
 bool collapse_dma_supported(int Rpad, int N);

@@ -1,0 +1,362 @@
+// recursion_wave.hip -- recursion_kernel's algebra (recursion.hip: information-form filter + "Z-smoother", EM statistics
+// and transition M-step) with ONE WAVE PER REPLICATE for Rp = 8 (5 <= r <= 8).
+//
+// recursion_kernel gives a replicate r lanes (lane i = row i): at B = 1024 that is 128 waves on 1024 SIMDs, each walking
+// 500 dependent periods at ~6 us a period (an r x r Gauss-Jordan through LDS, four r x r products of 64 FMAs per lane).
+// Here lane l = 8 i + j holds ELEMENT (i, j) of every 8 x 8 matrix:
+//   * inverse: symmetric sweep operator, pivot row / column by ds_bpermute (no LDS memory), pivot by v_readlane;
+//     one FMA per lane per sweep instead of eight;
+//   * products: both operands staged row-wise in a 512-byte LDS tile, 8 x ds_read_b128 + 8 FMAs per lane;
+//   * matrix-vector products: vectors live "column-distributed" (lane (i,j) holds x_j) or "row-distributed" (x_i);
+//     M x is one multiply and a 3-step DPP reduction over j (row-distributed result), M' x the same over i
+//     (column-distributed result), so the mean recursion alternates forms and never transposes;
+//   * 1024 waves instead of 128: every SIMD of the chip walks a replicate.
+// Same inputs, scratch tables (Z_e, J_e row-major, w_t) and outputs as recursion_kernel; same memoisation of repeated
+// covariance steps.  The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
+#include "dfm_kernels.h"
+#include "dfm_smallmat.h"
+
+namespace dfm {
+
+namespace {
+
+constexpr double kLog2PiW = 1.8378770664093454835606594728112;
+constexpr int CHW = 4;                // periods per prefetch chunk
+
+__device__ __forceinline__ double uniform_lane(double v, int src) {   // src wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double sum_over_j(double v) {   // over the 8 lanes of a row group; all of them get the total
+    v += xor_lane<1>(v);
+    v += xor_lane<2>(v);
+    v += xor_lane<4>(v);
+    return v;
+}
+__device__ __forceinline__ double sum_over_i(double v) {   // over the 8 row groups
+    v += xor_lane<8>(v);
+    v += xor_lane<16>(v);
+    v += xor_lane<32>(v);
+    return v;
+}
+// In-place inverse of a symmetric positive definite 8 x 8 matrix (element per lane) by the symmetric sweep operator
+// (Beaton): after sweeping every pivot the register holds -M^-1.  Returns det M = product of the pivots.
+__device__ __forceinline__ double sweep_inverse(double& m, int i, int j) {
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const double piv = uniform_lane(m, 9 * k);
+        const double qj = __shfl(m, 8 * k + j, 64);
+        const double qi = __shfl(m, 8 * k + i, 64);
+        const double d = 1.0 / piv;
+        det *= piv;
+        const double t = qi * d;
+        double nm = fma(-t, qj, m);
+        nm = (i == k) ? qj * d : nm;
+        nm = (j == k) ? t : nm;
+        nm = (i == k && j == k) ? -d : nm;
+        m = nm;
+    }
+    m = -m;
+    return det;
+}
+__device__ __forceinline__ double transposed(double v, int i, int j) { return __shfl(v, 8 * j + i, 64); }
+// sum_k X[i][k] Y[j][k], X and Y staged row-major in LDS
+__device__ __forceinline__ double dot_rows(const double* xs, const double* ys, int i, int j) {
+    const double2* a = reinterpret_cast<const double2*>(xs + 8 * i);
+    const double2* b = reinterpret_cast<const double2*>(ys + 8 * j);
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const double2 u = a[q], v = b[q];
+        s0 = fma(u.x, v.x, s0);
+        s1 = fma(u.y, v.y, s1);
+    }
+    return s0 + s1;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
+    constexpr int R = 8, NPp = R * (R + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) double wsm[];
+    double* LK = wsm;            // K = Q^-1 A, rows (constant)
+    double* L0 = LK + 64;
+    double* L1 = L0 + 64;
+    double* LJ = L1 + 64;        // J rows (backward sweep)
+    unsigned* cmask = reinterpret_cast<unsigned*>(LJ + 64);
+    const int lane = threadIdx.x;
+    const int i = lane >> 3, j = lane & 7;
+    const int T = a.T, N = a.N, r = a.r;
+    const int b = blockIdx.x;
+    const bool diag = (i == j);
+    const int nwords = (T + 31) / 32 + 1;
+    for (int w = lane; w < nwords; w += 64) cmask[w] = 0u;
+
+    const double* bcol = a.bcol + (size_t)b * T * R;
+    const double* scol = a.scol + (size_t)b * T;
+    const int* nobs = a.nobs + (size_t)b * T;
+    const double* ldrow = a.ldrow + (size_t)b * T;
+    const double ldfull = a.ldfull[b];
+    double* ZJ = a.ZJtab + (size_t)b * (T + 1) * 2 * R * R;
+    double* wtab = a.wtab + (size_t)b * T * R;
+    const int pk = (i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i;   // packed lower-triangle index of (i, j)
+
+    // ---------------- prologue: constants --------------------------------------------------------------------
+    const double Ael = a.A[(size_t)b * 64 + lane];
+    double Qi = a.Q[(size_t)b * 64 + lane];
+    const double Cf = a.Cfull[(size_t)b * 64 + lane];
+    double Omf = a.P0[(size_t)b * 64 + lane];
+    const double mu0c = a.mu0[(size_t)b * R + j];            // column-distributed
+    const double detQ = sweep_inverse(Qi, i, j);
+    const double detP0 = sweep_inverse(Omf, i, j);           // Om_f,0 = P0^-1
+    // K = Qi A:  K_ij = sum_k Qi[i][k] A[k][j] = row i of Qi . row j of A'
+    L0[lane] = Qi;
+    L1[8 * j + i] = Ael;                                     // A'
+    wave_lds_sync();
+    const double K = dot_rows(L0, L1, i, j);
+    wave_lds_sync();
+    LK[lane] = K;
+    L0[8 * j + i] = K;                                       // K' rows = K columns
+    wave_lds_sync();
+    const double KT = L0[lane];                              // K_ji
+    // Phi = K' A = A' Qi A:  Phi_ij = sum_k K[k][i] A[k][j] = row i of K' . row j of A'
+    const double Phi = dot_rows(L0, L1, i, j);
+    wave_lds_sync();
+    double xi = sum_over_j(Omf * mu0c);                      // xi_0 = P0^-1 mu0, row-distributed
+    const double q0_part = diag ? mu0c * xi : 0.0;
+    xi = transposed(xi, i, j);                               // column-distributed from here on
+
+    // ---------------- forward sweep ---------------------------------------------------------------------------
+    const int nchunks = (T + CHW - 1) / CHW;
+    double cb[CHW], cs[CHW], cl[CHW], cc[CHW], nb_[CHW], ns_[CHW], nl_[CHW], nc_[CHW];
+    int cn[CHW], nn_[CHW];
+    auto issue_fwd = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < CHW; ++s) {
+            int t = c * CHW + s;
+            t = t < T ? t : T - 1;
+            nb_[s] = bcol[(size_t)t * R + j];
+            ns_[s] = scol[t];
+            nn_[s] = nobs[t];
+            nl_[s] = ldrow[t];
+            nc_[s] = a.Ct ? a.Ct[((size_t)b * T + t) * NPp + pk] : 0.0;
+        }
+    };
+    auto take_fwd = [&]() {
+#pragma unroll
+        for (int s = 0; s < CHW; ++s) { cb[s] = nb_[s]; cs[s] = ns_[s]; cn[s] = nn_[s]; cl[s] = nl_[s]; cc[s] = nc_[s]; }
+    };
+
+    double Z = 0.0, Jr = 0.0, Omp = 0.0;
+    double ldz_cur = 0.0, sum_ldz = 0.0, sum_xw = 0.0, ssum = 0.0, nsum = 0.0, ldsum = 0.0;
+    int e = -1;
+    bool need_cov = true;
+    issue_fwd(0);
+    for (int c = 0; c < nchunks; ++c) {
+        take_fwd();
+        if (c + 1 < nchunks) issue_fwd(c + 1);
+        const int smax = (T - c * CHW) < CHW ? (T - c * CHW) : CHW;
+#pragma unroll
+        for (int s = 0; s < CHW; ++s) {
+            if (s < smax) {
+                const int t = c * CHW + s;
+                const bool computed = need_cov;
+                const double Omf_used = Omf;
+                if (need_cov) {  // wave-uniform
+                    Z = Omf + Phi;
+                    const double detM = sweep_inverse(Z, i, j);
+                    ldz_cur = -log(detM);
+                    wave_lds_sync();
+                    L0[lane] = Z;
+                    wave_lds_sync();
+                    Jr = dot_rows(L0, LK, i, j);               // J = Z K'
+                    L1[8 * j + i] = Jr;                        // J' rows = J columns
+                    wave_lds_sync();
+                    Omp = Qi - dot_rows(LK, L1, i, j);         // Om_p = Qi - K J
+                    ++e;
+                    ZJ[((size_t)e * 2 + 0) * 64 + lane] = Z;
+                    ZJ[((size_t)e * 2 + 1) * 64 + lane] = Jr;
+                    if (lane == 0) cmask[t >> 5] |= 1u << (t & 31);
+                }
+                // mean recursion: w = Z xi (row-distributed), xi <- K w + b_t (column-distributed)
+                const double w = sum_over_j(Z * xi);
+                sum_xw += diag ? xi * w : 0.0;
+                sum_ldz += ldz_cur;
+                if (j == 0) wtab[(size_t)t * R + i] = w;
+                xi = sum_over_i(KT * w) + cb[s];
+                ssum += cs[s];
+                const double nt = (double)cn[s];
+                nsum += nt;
+                const bool full = (cn[s] == N);
+                ldsum += full ? ldfull : cl[s];                // ldrow is only written for rows with NaN
+                const double Omf_new = Omp + (full ? Cf : cc[s]);
+                if (computed) {
+                    const bool same = full && close_enough(Omf_new, Omf_used);
+                    need_cov = !__all(same);
+                } else {
+                    need_cov = !full;
+                }
+                Omf = Omf_new;
+            }
+        }
+    }
+
+    // ---------------- terminal: P_T = Om_f^-1, f_T = P_T xi, log-likelihood ------------------------------------
+    bool em_apply = true;
+    double Ps = Omf;
+    const double detOmT = sweep_inverse(Ps, i, j);
+    double fs_r = sum_over_j(Ps * xi);                         // f_T, row-distributed
+    {
+        double part = (diag ? q0_part - xi * fs_r : 0.0) - sum_xw;
+        const double qd = sum_over_i(sum_over_j(part));
+        const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) - sum_ldz;
+        const double ll = -0.5 * (nsum * kLog2PiW + ldsum + LD + ssum + qd);
+        if (lane == 0) {
+            a.loglik[b] = ll;
+            if (a.ncov) a.ncov[b] = e + 1;
+        }
+        if (a.active) {   // EM bookkeeping, as recursion_kernel
+            const bool was = a.k == 0 ? true : (a.active[b] != 0);
+            bool go = was;
+            if (was && a.k >= 1 && a.tol > 0.0) {
+                const double llp = a.ll_path[(size_t)b * a.max_iter + a.k - 1];
+                go = !((ll - llp) / (0.5 * (fabs(ll) + fabs(llp))) < a.tol);
+            }
+            em_apply = go;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                if (was) { a.ll_path[(size_t)b * a.max_iter + a.k] = ll; a.iters[b] = a.k + 1; }
+                a.active[b] = go ? 1 : 0;
+            }
+        }
+    }
+
+    // ---------------- backward sweep ----------------------------------------------------------------------------
+    const int npr = r * (r + 1) / 2;
+    auto emit = [&](int trow, double P, double f_row) {        // smoothed moments of period trow + 1
+        if (i >= r) return;
+        if (j == 0) a.f_smooth[((size_t)b * T + trow) * r + i] = f_row;
+        if (a.P_smooth && j <= i) a.P_smooth[((size_t)b * T + trow) * npr + i * (i + 1) / 2 + j] = P;
+    };
+    emit(T - 1, Ps, fs_r);
+    double fs_c = transposed(fs_r, i, j);
+    const bool em = a.S11 != nullptr;
+    const double termT = fma(fs_r, fs_c, Ps);                  // E[f_T f_T'] element
+    double S11 = termT, S10 = 0.0, U = 0.0;
+
+    double wc[CHW], wn[CHW];
+    auto issue_bwd = [&](int c) {
+#pragma unroll
+        for (int s = 0; s < CHW; ++s) {
+            int t = c * CHW + s;
+            t = t < T ? t : T - 1;
+            wn[s] = wtab[(size_t)t * R + i];                   // row-distributed
+        }
+    };
+    double Zn, Jn;
+    auto load_entry = [&](int ee, double& zz, double& jj) {
+        const int ec = ee < 0 ? 0 : ee;
+        zz = ZJ[((size_t)ec * 2 + 0) * 64 + lane];
+        jj = ZJ[((size_t)ec * 2 + 1) * 64 + lane];
+    };
+    int e_cur = e;
+    load_entry(e_cur - 1, Zn, Jn);
+    wave_lds_sync();
+    LJ[lane] = Jr;
+    wave_lds_sync();
+    bool need_b = true;
+    issue_bwd(nchunks - 1);
+    for (int c = nchunks - 1; c >= 0; --c) {
+#pragma unroll
+        for (int s = 0; s < CHW; ++s) wc[s] = wn[s];
+        if (c - 1 >= 0) issue_bwd(c - 1);
+        const int smax = (T - c * CHW) < CHW ? (T - c * CHW) : CHW;
+#pragma unroll
+        for (int s = CHW - 1; s >= 0; --s) {
+            if (s < smax) {
+                const int t = c * CHW + s;       // step t: from period t+1 to period t (t = 0: initial state)
+                bool changed = false;
+                if (t + 1 < T && ((cmask[(t + 1) >> 5] >> ((t + 1) & 31)) & 1u)) {
+                    --e_cur;
+                    Z = Zn; Jr = Jn;
+                    load_entry(e_cur - 1, Zn, Jn);
+                    wave_lds_sync();
+                    LJ[lane] = Jr;
+                    wave_lds_sync();
+                    changed = true;
+                }
+                if (need_b || changed) {  // wave-uniform
+                    wave_lds_sync();
+                    L0[lane] = Ps;
+                    wave_lds_sync();
+                    U = dot_rows(L0, LJ, i, j);                // U = P_s J' = Cov(f_{t+1}, f_t | X)
+                    L1[8 * j + i] = U;                         // U' rows = U columns
+                    wave_lds_sync();
+                    const double pn_ = Z + dot_rows(LJ, L1, i, j);   // Z + J U
+                    const bool same = close_enough(pn_, Ps);
+                    Ps = pn_;
+                    need_b = !__all(same);
+                }
+                const double fnew = wc[s] + sum_over_j(Jr * fs_c);   // w_t + J f_{t+1}, row-distributed
+                const double fprev_r = fs_r;
+                fs_r = fnew;
+                fs_c = transposed(fs_r, i, j);
+                if (em) {
+                    S10 += fma(fprev_r, fs_c, U);              // E[f_{t+1} f_t']
+                    if (t > 0) S11 += fma(fs_r, fs_c, Ps);
+                }
+                if (t > 0) emit(t - 1, Ps, fs_r);
+            }
+        }
+    }
+    // now fs / Ps are the smoothed moments of the initial state f_0
+    if (em) {
+        const size_t o = (size_t)b * 64 + lane;
+        const double S00 = S11 - termT + fma(fs_r, fs_c, Ps);
+        a.S11[o] = S11;
+        a.S10[o] = S10;
+        a.S00[o] = S00;
+        a.P0s[o] = Ps;
+        if (j == 0) a.f0s[(size_t)b * R + i] = fs_r;
+        if (a.A_out) {
+            // A = S10 S00^-1 ;  Q = sym(S11 - A S10') / T ;  mu0 = f_0|T ;  P0 = sym(P_0|T) ;  S11^-1
+            double inv = S00;
+            (void)sweep_inverse(inv, i, j);
+            wave_lds_sync();
+            L0[lane] = S10;
+            L1[lane] = inv;                                    // symmetric: rows = columns
+            wave_lds_sync();
+            const double An = dot_rows(L0, L1, i, j);
+            wave_lds_sync();
+            L1[lane] = An;
+            wave_lds_sync();
+            double Qn = (S11 - dot_rows(L1, L0, i, j)) / (double)T;   // (A S10')_ij = row i of A . row j of S10
+            Qn = 0.5 * (Qn + transposed(Qn, i, j));
+            const double P0n = 0.5 * (Ps + transposed(Ps, i, j));
+            double inv2 = S11;
+            (void)sweep_inverse(inv2, i, j);
+            a.S11inv[o] = inv2;
+            if (em_apply) {
+                a.A_out[o] = An;
+                a.Q_out[o] = Qn;
+                a.P0_out[o] = P0n;
+                if (j == 0) a.mu0_out[(size_t)b * R + i] = fs_r;
+            }
+        }
+    }
+}
+
+bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
+    return Rpad == 8 && !a.cov && a.Rc == 0 && a.rl == 0 && a.kdim == 0;
+}
+
+hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s) {
+    const size_t lds = 4 * 64 * sizeof(double) + (size_t)((a.T + 31) / 32 + 1) * sizeof(unsigned);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(recursion_wave_kernel, dim3(a.B), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace dfm
