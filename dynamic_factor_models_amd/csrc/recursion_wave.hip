@@ -34,12 +34,33 @@ __device__ __forceinline__ double sum_over_j(double v) {   // over the 8 lanes o
     v += xor_lane<4>(v);
     return v;
 }
-__device__ __forceinline__ double sum_over_i(double v) {   // over the 8 row groups
+__device__ __forceinline__ double sum_over_i(double v) {   // over the 8 row groups: DPP, then the two permlane swaps (no LDS crossbar)
     v += xor_lane<8>(v);
-    v += xor_lane<16>(v);
-    v += xor_lane<32>(v);
-    return v;
+    double a = v, b = v;
+    swap_rows16(a, b);        // a = rows {0,0,2,2}, b = rows {1,1,3,3} of v
+    v = a + b;
+    a = v; b = v;
+    swap_halves32(a, b);      // a = low half twice, b = high half twice
+    return a + b;
 }
+// 1 / x for a positive, normal x: v_rcp_f64 refined by two Newton steps (no scaling / fix-up: pivots of an SPD matrix)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+// running log of a product of positive numbers without a log per factor: mantissa product + exponent sum
+struct LogProd {
+    double m = 1.0;
+    int e = 0;
+    __device__ __forceinline__ void mul(double x) {
+        m *= x;
+        e += __builtin_amdgcn_frexp_exp(m);
+        m = __builtin_amdgcn_frexp_mant(m);
+    }
+    __device__ __forceinline__ double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
+};
 // In-place inverse of a symmetric positive definite 8 x 8 matrix (element per lane) by the symmetric sweep operator
 // (Beaton): after sweeping every pivot the register holds -M^-1.  Returns det M = product of the pivots.
 __device__ __forceinline__ double sweep_inverse(double& m, int i, int j) {
@@ -49,7 +70,7 @@ __device__ __forceinline__ double sweep_inverse(double& m, int i, int j) {
         const double piv = uniform_lane(m, 9 * k);
         const double qj = __shfl(m, 8 * k + j, 64);
         const double qi = __shfl(m, 8 * k + i, 64);
-        const double d = 1.0 / piv;
+        const double d = fast_rcp(piv);
         det *= piv;
         const double t = qi * d;
         double nm = fma(-t, qj, m);
@@ -85,14 +106,12 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     double* L0 = LK + 64;
     double* L1 = L0 + 64;
     double* LJ = L1 + 64;        // J rows (backward sweep)
-    unsigned* cmask = reinterpret_cast<unsigned*>(LJ + 64);
+    int* eidxS = reinterpret_cast<int*>(LJ + 64);   // [T] covariance-table entry of forward step t
     const int lane = threadIdx.x;
     const int i = lane >> 3, j = lane & 7;
     const int T = a.T, N = a.N, r = a.r;
     const int b = blockIdx.x;
     const bool diag = (i == j);
-    const int nwords = (T + 31) / 32 + 1;
-    for (int w = lane; w < nwords; w += 64) cmask[w] = 0u;
 
     const double* bcol = a.bcol + (size_t)b * T * R;
     const double* scol = a.scol + (size_t)b * T;
@@ -150,12 +169,35 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     };
 
     double Z = 0.0, Jr = 0.0, Omp = 0.0;
-    double ldz_cur = 0.0, sum_ldz = 0.0, sum_xw = 0.0, ssum = 0.0, nsum = 0.0, ldsum = 0.0;
+    double detM_cur = 1.0, sum_xw = 0.0, ssum = 0.0, nsum = 0.0, ldsum = 0.0;
+    LogProd detprod;                                           // prod_t det(Om_f,t + Phi)
     int e = -1;
     bool need_cov = true;
+    // Loads and stores share the in-order vmcnt counter on gfx9: a store issued just before a wait for prefetched loads
+    // would expose its full latency.  So a chunk's outputs are buffered in registers and flushed at the top of the NEXT
+    // chunk, right before that chunk issues the prefetch of the one after: every wait then covers operations that are a
+    // whole chunk old.
+    double zb[CHW], jb[CHW], wb[CHW];
+    int eb[CHW];
+#pragma unroll
+    for (int s = 0; s < CHW; ++s) { zb[s] = 0.0; jb[s] = 0.0; wb[s] = 0.0; eb[s] = -1; }
+    auto flush_fwd = [&](int c) {                              // outputs of chunk c
+#pragma unroll
+        for (int s = 0; s < CHW; ++s) {
+            const int t = c * CHW + s;
+            if (t < T) {
+                if (eb[s] >= 0) {
+                    ZJ[((size_t)eb[s] * 2 + 0) * 64 + lane] = zb[s];
+                    ZJ[((size_t)eb[s] * 2 + 1) * 64 + lane] = jb[s];
+                }
+                if (j == 0) wtab[(size_t)t * R + i] = wb[s];
+            }
+        }
+    };
     issue_fwd(0);
     for (int c = 0; c < nchunks; ++c) {
         take_fwd();
+        if (c > 0) flush_fwd(c - 1);
         if (c + 1 < nchunks) issue_fwd(c + 1);
         const int smax = (T - c * CHW) < CHW ? (T - c * CHW) : CHW;
 #pragma unroll
@@ -164,10 +206,10 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                 const int t = c * CHW + s;
                 const bool computed = need_cov;
                 const double Omf_used = Omf;
+                eb[s] = -1;
                 if (need_cov) {  // wave-uniform
                     Z = Omf + Phi;
-                    const double detM = sweep_inverse(Z, i, j);
-                    ldz_cur = -log(detM);
+                    detM_cur = sweep_inverse(Z, i, j);
                     wave_lds_sync();
                     L0[lane] = Z;
                     wave_lds_sync();
@@ -176,15 +218,14 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     wave_lds_sync();
                     Omp = Qi - dot_rows(LK, L1, i, j);         // Om_p = Qi - K J
                     ++e;
-                    ZJ[((size_t)e * 2 + 0) * 64 + lane] = Z;
-                    ZJ[((size_t)e * 2 + 1) * 64 + lane] = Jr;
-                    if (lane == 0) cmask[t >> 5] |= 1u << (t & 31);
+                    zb[s] = Z; jb[s] = Jr; eb[s] = e;
                 }
+                if (lane == 0) eidxS[t] = e;
                 // mean recursion: w = Z xi (row-distributed), xi <- K w + b_t (column-distributed)
                 const double w = sum_over_j(Z * xi);
                 sum_xw += diag ? xi * w : 0.0;
-                sum_ldz += ldz_cur;
-                if (j == 0) wtab[(size_t)t * R + i] = w;
+                detprod.mul(detM_cur);
+                wb[s] = w;
                 xi = sum_over_i(KT * w) + cb[s];
                 ssum += cs[s];
                 const double nt = (double)cn[s];
@@ -202,6 +243,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
             }
         }
     }
+    flush_fwd(nchunks - 1);
 
     // ---------------- terminal: P_T = Om_f^-1, f_T = P_T xi, log-likelihood ------------------------------------
     bool em_apply = true;
@@ -211,7 +253,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     {
         double part = (diag ? q0_part - xi * fs_r : 0.0) - sum_xw;
         const double qd = sum_over_i(sum_over_j(part));
-        const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) - sum_ldz;
+        const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) + detprod.log_value();   // sum_ldz = -log prod
         const double ll = -0.5 * (nsum * kLog2PiW + ldsum + LD + ssum + qd);
         if (lane == 0) {
             a.loglik[b] = ll;
@@ -240,52 +282,63 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
         if (j == 0) a.f_smooth[((size_t)b * T + trow) * r + i] = f_row;
         if (a.P_smooth && j <= i) a.P_smooth[((size_t)b * T + trow) * npr + i * (i + 1) / 2 + j] = P;
     };
-    emit(T - 1, Ps, fs_r);
     double fs_c = transposed(fs_r, i, j);
+    double Jt = 0.0;                                           // J_ji
     const bool em = a.S11 != nullptr;
     const double termT = fma(fs_r, fs_c, Ps);                  // E[f_T f_T'] element
     double S11 = termT, S10 = 0.0, U = 0.0;
 
-    double wc[CHW], wn[CHW];
+    // per chunk: w_t in both distributions and the table entry (Z, J) of every step, addressed through the LDS index
+    // the forward sweep left; outputs buffered and flushed like the forward sweep's
+    double wc[CHW], wn[CHW], wcc[CHW], wnc[CHW], zc[CHW], zn[CHW], jc[CHW], jn[CHW];
+    int ec[CHW], en[CHW];
     auto issue_bwd = [&](int c) {
 #pragma unroll
         for (int s = 0; s < CHW; ++s) {
             int t = c * CHW + s;
             t = t < T ? t : T - 1;
             wn[s] = wtab[(size_t)t * R + i];                   // row-distributed
+            wnc[s] = wtab[(size_t)t * R + j];                  // column-distributed
+            const int ee = eidxS[t];
+            en[s] = ee;
+            zn[s] = ZJ[((size_t)ee * 2 + 0) * 64 + lane];
+            jn[s] = ZJ[((size_t)ee * 2 + 1) * 64 + lane];
         }
     };
-    double Zn, Jn;
-    auto load_entry = [&](int ee, double& zz, double& jj) {
-        const int ec = ee < 0 ? 0 : ee;
-        zz = ZJ[((size_t)ec * 2 + 0) * 64 + lane];
-        jj = ZJ[((size_t)ec * 2 + 1) * 64 + lane];
+    double pb[CHW + 1], fb[CHW + 1];                           // smoothed moments to emit: rows c CHW - 1 + s, and T - 1 first
+    int tb[CHW + 1];
+#pragma unroll
+    for (int s = 0; s <= CHW; ++s) { pb[s] = 0.0; fb[s] = 0.0; tb[s] = -1; }
+    pb[CHW] = Ps; fb[CHW] = fs_r; tb[CHW] = T - 1;
+    auto flush_bwd = [&]() {
+#pragma unroll
+        for (int s = 0; s <= CHW; ++s) {
+            if (tb[s] >= 0) emit(tb[s], pb[s], fb[s]);
+            tb[s] = -1;
+        }
     };
-    int e_cur = e;
-    load_entry(e_cur - 1, Zn, Jn);
-    wave_lds_sync();
-    LJ[lane] = Jr;
-    wave_lds_sync();
+    wave_lds_sync();                                           // eidxS complete
+    int e_prev = -1;                                           // entry staged in LJ
     bool need_b = true;
     issue_bwd(nchunks - 1);
     for (int c = nchunks - 1; c >= 0; --c) {
 #pragma unroll
-        for (int s = 0; s < CHW; ++s) wc[s] = wn[s];
+        for (int s = 0; s < CHW; ++s) { wc[s] = wn[s]; wcc[s] = wnc[s]; zc[s] = zn[s]; jc[s] = jn[s]; ec[s] = en[s]; }
+        flush_bwd();
         if (c - 1 >= 0) issue_bwd(c - 1);
         const int smax = (T - c * CHW) < CHW ? (T - c * CHW) : CHW;
 #pragma unroll
         for (int s = CHW - 1; s >= 0; --s) {
             if (s < smax) {
                 const int t = c * CHW + s;       // step t: from period t+1 to period t (t = 0: initial state)
-                bool changed = false;
-                if (t + 1 < T && ((cmask[(t + 1) >> 5] >> ((t + 1) & 31)) & 1u)) {
-                    --e_cur;
-                    Z = Zn; Jr = Jn;
-                    load_entry(e_cur - 1, Zn, Jn);
+                const bool changed = ec[s] != e_prev;          // wave-uniform
+                if (changed) {
+                    Z = zc[s]; Jr = jc[s];
+                    e_prev = ec[s];
                     wave_lds_sync();
                     LJ[lane] = Jr;
                     wave_lds_sync();
-                    changed = true;
+                    Jt = LJ[8 * j + i];
                 }
                 if (need_b || changed) {  // wave-uniform
                     wave_lds_sync();
@@ -299,18 +352,21 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     Ps = pn_;
                     need_b = !__all(same);
                 }
-                const double fnew = wc[s] + sum_over_j(Jr * fs_c);   // w_t + J f_{t+1}, row-distributed
+                // f_t = w_t + J f_{t+1} in both distributions, by two independent reductions (no transpose on the chain)
+                const double fnew = wc[s] + sum_over_j(Jr * fs_c);
+                const double fnew_c = wcc[s] + sum_over_i(Jt * fs_r);
                 const double fprev_r = fs_r;
                 fs_r = fnew;
-                fs_c = transposed(fs_r, i, j);
+                fs_c = fnew_c;
                 if (em) {
                     S10 += fma(fprev_r, fs_c, U);              // E[f_{t+1} f_t']
                     if (t > 0) S11 += fma(fs_r, fs_c, Ps);
                 }
-                if (t > 0) emit(t - 1, Ps, fs_r);
+                if (t > 0) { pb[s] = Ps; fb[s] = fs_r; tb[s] = t - 1; }
             }
         }
     }
+    flush_bwd();
     // now fs / Ps are the smoothed moments of the initial state f_0
     if (em) {
         const size_t o = (size_t)b * 64 + lane;
@@ -349,11 +405,11 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
 }
 
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
-    return Rpad == 8 && !a.cov && a.Rc == 0 && a.rl == 0 && a.kdim == 0;
+    return Rpad == 8 && !a.cov && a.Rc == 0 && a.rl == 0 && a.kdim == 0 && a.T <= 15000;   // LDS: 4 bytes per period
 }
 
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s) {
-    const size_t lds = 4 * 64 * sizeof(double) + (size_t)((a.T + 31) / 32 + 1) * sizeof(unsigned);
+    const size_t lds = 4 * 64 * sizeof(double) + (size_t)a.T * sizeof(int);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(recursion_wave_kernel, dim3(a.B), dim3(64), lds, s, a);
     return hipGetLastError();
