@@ -18,10 +18,21 @@
 
 namespace dfm {
 
+#ifdef DFM_WAVE_PROF
+#define TICK(var) do { var -= (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define TOCK(var) do { var += (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TICK(var) do {} while (0)
+#define TOCK(var) do {} while (0)
+#endif
+
 namespace {
 
 constexpr double kLog2PiW = 1.8378770664093454835606594728112;
-constexpr int CHW = 4;                // periods per prefetch chunk
+#ifndef DFM_WAVE_CHW
+#define DFM_WAVE_CHW 8
+#endif
+constexpr int CHW = DFM_WAVE_CHW;     // periods per prefetch chunk
 
 __device__ __forceinline__ double uniform_lane(double v, int src) {   // src wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -110,6 +121,12 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     const int lane = threadIdx.x;
     const int i = lane >> 3, j = lane & 7;
     const int T = a.T, N = a.N, r = a.r;
+    long long p_inv = 0, p_mm = 0, p_mean = 0, p_bcov = 0, p_bmean = 0, p_tot = 0, p_stage = 0;
+    (void)p_inv; (void)p_mm; (void)p_mean; (void)p_bcov; (void)p_bmean; (void)p_tot; (void)p_stage;
+#ifdef DFM_WAVE_PROF
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    unsigned long long t_fwd_end = 0, t_bwd_start = 0;
+#endif
     const int b = blockIdx.x;
     const bool diag = (i == j);
 
@@ -209,7 +226,10 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                 eb[s] = -1;
                 if (need_cov) {  // wave-uniform
                     Z = Omf + Phi;
+                    TICK(p_inv);
                     detM_cur = sweep_inverse(Z, i, j);
+                    TOCK(p_inv);
+                    TICK(p_mm);
                     wave_lds_sync();
                     L0[lane] = Z;
                     wave_lds_sync();
@@ -219,7 +239,9 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     Omp = Qi - dot_rows(LK, L1, i, j);         // Om_p = Qi - K J
                     ++e;
                     zb[s] = Z; jb[s] = Jr; eb[s] = e;
+                    TOCK(p_mm);
                 }
+                TICK(p_mean);
                 if (lane == 0) eidxS[t] = e;
                 // mean recursion: w = Z xi (row-distributed), xi <- K w + b_t (column-distributed)
                 const double w = sum_over_j(Z * xi);
@@ -240,10 +262,14 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     need_cov = !full;
                 }
                 Omf = Omf_new;
+                TOCK(p_mean);
             }
         }
     }
     flush_fwd(nchunks - 1);
+#ifdef DFM_WAVE_PROF
+    t_fwd_end = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---------------- terminal: P_T = Om_f^-1, f_T = P_T xi, log-likelihood ------------------------------------
     bool em_apply = true;
@@ -317,6 +343,9 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
             tb[s] = -1;
         }
     };
+#ifdef DFM_WAVE_PROF
+    t_bwd_start = __builtin_amdgcn_s_memtime();
+#endif
     wave_lds_sync();                                           // eidxS complete
     int e_prev = -1;                                           // entry staged in LJ
     bool need_b = true;
@@ -325,6 +354,12 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
 #pragma unroll
         for (int s = 0; s < CHW; ++s) { wc[s] = wn[s]; wcc[s] = wnc[s]; zc[s] = zn[s]; jc[s] = jn[s]; ec[s] = en[s]; }
         flush_bwd();
+#ifdef DFM_WAVE_PROF
+    p_tot = (long long)(__builtin_amdgcn_s_memtime() - t_start);
+    if (b == 5 && lane == 0)
+        printf("wave prof: fwd span %lld bwd span %lld | (memtime ticks): total %lld  fwd: inverse %lld products %lld mean %lld | bwd: stage %lld cov %lld mean %lld  (T=%d)\n",
+               (long long)(t_fwd_end - t_start), p_tot - (long long)(t_bwd_start - t_start), p_tot, p_inv, p_mm, p_mean, p_stage, p_bcov, p_bmean, T);
+#endif
         if (c - 1 >= 0) issue_bwd(c - 1);
         const int smax = (T - c * CHW) < CHW ? (T - c * CHW) : CHW;
 #pragma unroll
@@ -332,6 +367,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
             if (s < smax) {
                 const int t = c * CHW + s;       // step t: from period t+1 to period t (t = 0: initial state)
                 const bool changed = ec[s] != e_prev;          // wave-uniform
+                TICK(p_stage);
                 if (changed) {
                     Z = zc[s]; Jr = jc[s];
                     e_prev = ec[s];
@@ -340,6 +376,8 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     wave_lds_sync();
                     Jt = LJ[8 * j + i];
                 }
+                TOCK(p_stage);
+                TICK(p_bcov);
                 if (need_b || changed) {  // wave-uniform
                     wave_lds_sync();
                     L0[lane] = Ps;
@@ -352,6 +390,8 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     Ps = pn_;
                     need_b = !__all(same);
                 }
+                TOCK(p_bcov);
+                TICK(p_bmean);
                 // f_t = w_t + J f_{t+1} in both distributions, by two independent reductions (no transpose on the chain)
                 const double fnew = wc[s] + sum_over_j(Jr * fs_c);
                 const double fnew_c = wcc[s] + sum_over_i(Jt * fs_r);
@@ -363,6 +403,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     if (t > 0) S11 += fma(fs_r, fs_c, Ps);
                 }
                 if (t > 0) { pb[s] = Ps; fb[s] = fs_r; tb[s] = t - 1; }
+                TOCK(p_bmean);
             }
         }
     }
