@@ -108,25 +108,64 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
     }
     double* dmg = a.Dmiss ? a.Dmiss + (size_t)b * N * NP : nullptr;   // global accumulators (zeroed by the host)
 
-    constexpr int UN = 4;
-    for (int t0 = 0; t0 < T; t0 += UN) {
-        double xv[UN][CPL];
+    // Periods are taken in groups of UN.  The panel rows of group g+1 and its smoothed moments (E[f_t], Var[f_t]:
+    // wave-uniform, R + NP doubles a period) are in flight while group g is processed: rows into registers, moments
+    // through a double-buffered LDS tile that all four waves read back as broadcasts -- a period no longer waits for
+    // its own (scalar) loads.
+    constexpr int UN = (R <= 8) ? 8 : 4;
+    constexpr int PER = R + NP;                               // moments per period
+    constexpr int NLD = (UN * PER + 255) / 256;               // loads per thread and group
+    __shared__ double mom[2][UN * PER];
+    const int ngroups = (T + UN - 1) / UN;
+    double xn[UN][CPL], mn[NLD];
+    auto issue = [&](int g) {
+        const int t0 = g * UN;
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = (t0 + u < T) ? t0 + u : T - 1;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 const int col = tid + 256 * j;
-                xv[u][j] = (col < N) ? X[(size_t)t * N + col] : 0.0;
+                xn[u][j] = (col < N) ? X[(size_t)t * N + col] : 0.0;
             }
         }
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = tid + 256 * q;                      // [0, UN R): means, then covariances
+            double v = 0.0;
+            if (e < UN * R) {
+                const size_t at = (size_t)t0 * R + e;
+                if (at < (size_t)T * R) v = F[at];
+            } else if (e < UN * PER) {
+                const size_t at = (size_t)t0 * NP + (e - UN * R);
+                if (at < (size_t)T * NP) v = PS[at];
+            }
+            mn[q] = v;
+        }
+    };
+    issue(0);
+    for (int g = 0; g < ngroups; ++g) {
+        const int t0 = g * UN;
+        double* mb = mom[g & 1];
+        double xv[UN][CPL];
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) xv[u][j] = xn[u][j];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = tid + 256 * q;
+            if (e < UN * PER) mb[e] = mn[q];
+        }
+        __syncthreads();
+        if (g + 1 < ngroups) issue(g + 1);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = t0 + u;
             if (t >= T) break;
             double f[R];
 #pragma unroll
-            for (int k = 0; k < R; ++k) f[k] = F[(size_t)t * R + k];
+            for (int k = 0; k < R; ++k) f[k] = mb[u * R + k];
             bool miss_any = false;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
@@ -143,24 +182,21 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
                 for (int k = 0; k < R; ++k) sxf[j][k] = fma(xz, f[k], sxf[j][k]);
             }
             if (__any(miss_any)) {   // wave-uniform: somebody in this wave lacks period t
-                double ef[NP];
-#pragma unroll
-                for (int i = 0; i < R; ++i)
-#pragma unroll
-                    for (int jj = 0; jj <= i; ++jj)
-                        ef[i * (i + 1) / 2 + jj] = fma(f[i], f[jj], PS[(size_t)t * NP + i * (i + 1) / 2 + jj]);
+                const double* pv = mb + UN * R + u * NP;
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
                     const int col = tid + 256 * j;
                     const double x = xv[u][j];
                     if (col < N && x != x) {
-                        if constexpr (REGD) {
 #pragma unroll
-                            for (int v = 0; v < NP; ++v) dm[j][v] += ef[v];
-                        } else {
+                        for (int i = 0; i < R; ++i)
 #pragma unroll
-                            for (int v = 0; v < NP; ++v) dmg[(size_t)col * NP + v] += ef[v];
-                        }
+                            for (int jj = 0; jj <= i; ++jj) {
+                                const int v = i * (i + 1) / 2 + jj;
+                                const double ef = fma(f[i], f[jj], pv[v]);
+                                if constexpr (REGD) dm[j][v] += ef;
+                                else dmg[(size_t)col * NP + v] += ef;
+                            }
                     }
                 }
             }
