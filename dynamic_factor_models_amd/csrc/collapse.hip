@@ -87,19 +87,14 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
     const bool vec2 = (N & 1) == 0;
     const int nrb = (T + RB - 1) / RB;
 
-    for (int rb = wave; rb < nrb; rb += 4) {
-        const int t0 = rb * RB;
-        double acc[NV];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-        bool nanrow[RB];
-        unsigned nanbits[RB];                    // bit 2 j + e: this lane's cell (j, e) of the row is missing
+    // the wave's NEXT row block is in flight while the current one is processed
+    double xq[RB][CPL2][2];
+    auto fetch = [&](int rb) {
 #pragma unroll
         for (int rr = 0; rr < RB; ++rr) {
-            const int t = (t0 + rr < T) ? t0 + rr : T - 1;
+            int t = rb * RB + rr;
+            t = t < T ? t : T - 1;
             const double* xr = X + (size_t)t * N;
-            bool anynan = false;
-            unsigned nb = 0;
 #pragma unroll
             for (int j = 0; j < CPL2; ++j) {
                 const int c0 = 2 * lane + 128 * j;
@@ -114,6 +109,34 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
                     if (c0 < N) x0 = xr[c0];
                     if (c0 + 1 < N) x1 = xr[c0 + 1];
                 }
+                xq[rr][j][0] = x0;
+                xq[rr][j][1] = x1;
+            }
+        }
+    };
+    constexpr bool PREF = CPL2 <= 2;          // wider cross-sections have no registers to spare for a second block
+    if (PREF && wave < nrb) fetch(wave);
+    for (int rb = wave; rb < nrb; rb += 4) {
+        const int t0 = rb * RB;
+        if (!PREF) fetch(rb);
+        double xc[RB][CPL2][2];
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+            for (int j = 0; j < CPL2; ++j) { xc[rr][j][0] = xq[rr][j][0]; xc[rr][j][1] = xq[rr][j][1]; }
+        if (PREF && rb + 4 < nrb) fetch(rb + 4);
+        double acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+        bool nanrow[RB];
+        unsigned nanbits[RB];                    // bit 2 j + e: this lane's cell (j, e) of the row is missing
+#pragma unroll
+        for (int rr = 0; rr < RB; ++rr) {
+            bool anynan = false;
+            unsigned nb = 0;
+#pragma unroll
+            for (int j = 0; j < CPL2; ++j) {
+                double x0 = xc[rr][j][0], x1 = xc[rr][j][1];
                 const bool n0 = x0 != x0, n1 = x1 != x1;
                 anynan = anynan || n0 || n1;
                 nb |= (n0 ? 1u : 0u) << (2 * j) | (n1 ? 2u : 0u) << (2 * j);
