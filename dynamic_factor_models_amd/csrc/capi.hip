@@ -28,6 +28,7 @@ struct dfm_handle {
     int num_cu = 256;
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
+    size_t status_off = 0;                 // status word of the plan used by the last call
     bool no_rec_wave = false;              // DFM_NO_RECURSION_WAVE=1: lane-group recursion_kernel also at Rp = 8 (A/B)
     bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
     bool fused_gram = true;                // DFM_FUSED_GRAM=0: gram_kernel as its own launch in front of the fused collapse launch
@@ -104,12 +105,22 @@ size_t take(size_t& off, size_t bytes) {
     return at;
 }
 
+// Sequential path with r <= 4: the state is padded to 8 so that the one-wave-per-replicate recursion (recursion_wave.hip)
+// applies; collapse, loadings and the loadings M-step stay pad_r(r) wide (Plan::Rc).  DFM_NO_RECURSION_WAVE=1 turns it off.
+bool g_widen_small_r = true;
+
 Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = false) {
     Plan p;
-    const int Rp = pad_r(r);
-    p.Rp = Rp;
+    int Rp = pad_r(r);
     p.fast = fast;
     p.cov = (flags & DFM_F_SINGULAR_Q) != 0;
+    // (one wave per replicate pays while the batch leaves SIMDs idle under the lane-group kernel: measured crossover
+    // at r = 4 between B = 1024 (0.39 vs 0.60 ms) and B = 4096 (1.52 vs 0.65 ms))
+    if (!fast && !p.cov && Rp < 8 && g_widen_small_r && B <= 1536) {
+        p.Rc = Rp; p.rl = Rp;
+        Rp = 8;
+    }
+    p.Rp = Rp;
     const size_t d = sizeof(double), rr = (size_t)Rp * Rp, np = (size_t)Rp * (Rp + 1) / 2;
     size_t off = 0;
     p.LamP = take(off, (size_t)B * N * Rp * d);
@@ -200,14 +211,14 @@ int check_general_n(dfm_handle* h, int N, int r) {
 }
 
 // Embed caller parameters (factor dimension r) into the padded dimension Rp.
-__global__ void pad_params_kernel(int B, int N, int r, int Rp, const double* Lam, const double* A,
+__global__ void pad_params_kernel(int B, int N, int r, int Rp, int Rl, const double* Lam, const double* A,
                                   const double* Q, const double* mu0, const double* P0, double* LamP,
                                   double* AP, double* QP, double* mu0P, double* P0P) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nl = (size_t)B * N * Rp, nm = (size_t)B * Rp * Rp, nv = (size_t)B * Rp;
+    const size_t nl = (size_t)B * N * Rl, nm = (size_t)B * Rp * Rp, nv = (size_t)B * Rp;
     if (tid < nl) {
-        const int k = tid % Rp;
-        const size_t bn = tid / Rp;
+        const int k = tid % Rl;
+        const size_t bn = tid / Rl;
         LamP[tid] = k < r ? Lam[bn * r + k] : 0.0;
     }
     if (tid < nm) {
@@ -239,7 +250,7 @@ int pad_params(dfm_handle* h, const Plan& p, int B, int N, int r, const double* 
     const size_t n = (size_t)B * N * p.Rp > (size_t)B * p.Rp * p.Rp ? (size_t)B * N * p.Rp : (size_t)B * p.Rp * p.Rp;
     const int threads = 256;
     const unsigned blocks = (unsigned)((n + threads - 1) / threads);
-    hipLaunchKernelGGL(pad_params_kernel, dim3(blocks), dim3(threads), 0, h->stream, B, N, r, p.Rp, Lam, A, Q,
+    hipLaunchKernelGGL(pad_params_kernel, dim3(blocks), dim3(threads), 0, h->stream, B, N, r, p.Rp, p.Rc ? p.Rc : p.Rp, Lam, A, Q,
                        mu0, P0, at<double>(h, p.LamP), at<double>(h, p.AP), at<double>(h, p.QP),
                        at<double>(h, p.mu0P), at<double>(h, p.P0P));
     HIP_TRY(h, hipGetLastError());
@@ -482,9 +493,10 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
     // M-step by em_update_kernel; panels with missing cells: recursion_kernel does both
     const Plan p = make_plan(B, T, N, r, flags, true, fast_eligible(h, N, r, flags) && !h->em_general);
     if (int rc = ensure_ws(h, p.total)) return rc;
+    h->status_off = p.status;
     HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
-    const int Rp = p.Rp;
-    const size_t np = (size_t)r * (r + 1) / 2, npp = (size_t)Rp * (Rp + 1) / 2;
+    const int Rp = p.Rp, Rl = p.Rc ? p.Rc : p.Rp;            // state width, loadings width
+    const size_t np = (size_t)r * (r + 1) / 2, npp = (size_t)Rl * (Rl + 1) / 2;
     const bool padded = (r != Rp);
     double *LamP = Lam, *AP = A, *QP = Q, *mu0P = mu0, *P0P = P0;
     if (padded) {
@@ -518,12 +530,12 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
         }
     }
     if (padded) {
-        if (int rc = copy_block(h, (size_t)B * N, 1, Rp, 1, r, LamP, Lam)) return rc;
+        if (int rc = copy_block(h, (size_t)B * N, 1, Rl, 1, r, LamP, Lam)) return rc;
         if (int rc = copy_block(h, B, Rp, Rp, r, r, AP, A)) return rc;
         if (int rc = copy_block(h, B, Rp, Rp, r, r, QP, Q)) return rc;
         if (int rc = copy_block(h, B, Rp, Rp, r, r, P0P, P0)) return rc;
         if (int rc = copy_block(h, B, 1, Rp, 1, r, mu0P, mu0)) return rc;
-        if (f_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, Rp, 1, r, fsm, f_smooth)) return rc;
+        if (f_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, Rl, 1, r, fsm, f_smooth)) return rc;
         if (P_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, (int)npp, 1, (int)np, Psm, P_smooth)) return rc;
     } else {
         if (f_smooth && fsm != f_smooth)
@@ -581,6 +593,7 @@ int varp_run(dfm_handle* h, int B, int T, int N, int r, int nlag, const double* 
     Plan p = make_plan(B, T, N, k, flags | DFM_F_SINGULAR_Q, em, false);
     p.Rc = pad_r(r); p.rl = r; p.kdim = k;
     if (int rc = ensure_ws(h, p.total)) return rc;
+    h->status_off = p.status;
     HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     const int Rk = p.Rp, Rc = p.Rc;
     double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
@@ -670,6 +683,7 @@ int ar_pass_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, cons
     Plan p = make_plan(B, Tq, N, k, flags | DFM_F_SINGULAR_Q, false, false);
     const size_t xoff = (p.total + 255) & ~(size_t)255;
     if (int rc = ensure_ws(h, xoff + (size_t)B * Tq * N * sizeof(double))) return rc;
+    h->status_off = p.status;
     HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     const int Rk = p.Rp;
     double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
@@ -738,7 +752,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_COLLAPSE_WPR")) { h->collapse_wpr = atoi(v); if (h->collapse_wpr < 0 || h->collapse_wpr > kSsumSlots) h->collapse_wpr = 0; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
-    if (const char* v = getenv("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
+    if (const char* v = getenv("DFM_NO_RECURSION_WAVE")) { h->no_rec_wave = atoi(v) != 0; g_widen_small_r = !h->no_rec_wave; }
     if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
     if (const char* v = getenv("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;
@@ -829,6 +843,7 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     HIP_TRY(h, hipSetDevice(h->device));
     const Plan p = make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags));
     if (int rc = ensure_ws(h, p.total)) return rc;
+    h->status_off = p.status;
     HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     PaddedParams pp;
     if (int rc = pad_params(h, p, B, N, r, Lam, A, Q, mu0, P0, &pp)) return rc;
@@ -836,9 +851,9 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
 }
 
 // status word / log-likelihood sanity after a synchronising call
-static int post_check(dfm_handle* h, const Plan& p, const double* loglik_host, int B) {
+static int post_check(dfm_handle* h, const double* loglik_host, int B) {
     int st = 0;
-    HIP_TRY(h, hipMemcpy(&st, at<int>(h, p.status), sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost));
     if (st & 1) return fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
     for (int b = 0; b < B; ++b)
         if (!isfinite(loglik_host[b])) return fail(h, DFM_E_NUMERIC, "non-finite log-likelihood (Q or P0 not positive definite?)%s");
@@ -878,7 +893,7 @@ int dfm_ks_pass_batch(dfm_handle* h, int B, int T, int N, int r, const double* p
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }
-    if (rc == 0) rc = post_check(h, make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags)), loglik, B);
+    if (rc == 0) rc = post_check(h, loglik, B);
     hipFree(buf);
     return rc;
 }
@@ -942,7 +957,7 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
     }
     if (rc == 0) {
         int st = 0;
-        (void)hipMemcpy(&st, at<int>(h, make_plan(B, T, N, r, flags, true, fast_eligible(h, N, r, flags) && !h->em_general).status), sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost);
         if (st & 1) rc = fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
         for (int b = 0; rc == 0 && b < B; ++b)
             if (!isfinite(loglik_path[(size_t)b * max_iter])) rc = fail(h, DFM_E_NUMERIC, "non-finite log-likelihood%s");
@@ -1019,8 +1034,7 @@ static int varp_host(dfm_handle* h, int B, int T, int N, int r, int p, const dou
     }
     if (rc == 0) {
         int st = 0;
-        (void)hipMemcpy(&st, at<int>(h, make_plan(B, T, N, (int)k, flags | DFM_F_SINGULAR_Q, em, false).status), sizeof(int),
-                        hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost);
         if (st & 1) rc = fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
         const double* llh = em ? loglik_path : loglik;
         for (int b = 0; rc == 0 && b < B; ++b)
@@ -1088,7 +1102,7 @@ int dfm_ks_pass_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }
-    if (rc == 0) rc = post_check(h, make_plan(B, (int)Tq, N, (int)k, flags | DFM_F_SINGULAR_Q, false, false), loglik, B);
+    if (rc == 0) rc = post_check(h, loglik, B);
     (void)hipFree(buf);
     return rc;
 }

@@ -111,7 +111,7 @@ __device__ __forceinline__ double dot_rows(const double* xs, const double* ys, i
 }  // namespace
 
 __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
-    constexpr int R = 8, NPp = R * (R + 1) / 2;
+    constexpr int R = 8;
     extern __shared__ __attribute__((aligned(16))) double wsm[];
     double* LK = wsm;            // K = Q^-1 A, rows (constant)
     double* L0 = LK + 64;
@@ -130,7 +130,10 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     const int b = blockIdx.x;
     const bool diag = (i == j);
 
-    const double* bcol = a.bcol + (size_t)b * T * R;
+    const int Rc = a.Rc > 0 ? a.Rc : R;                      // width of the collapsed observations (state padded beyond it)
+    const int NPc = Rc * (Rc + 1) / 2;
+    const bool inC = i < Rc && j < Rc;
+    const double* bcol = a.bcol + (size_t)b * T * Rc;
     const double* scol = a.scol + (size_t)b * T;
     const int* nobs = a.nobs + (size_t)b * T;
     const double* ldrow = a.ldrow + (size_t)b * T;
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     // ---------------- prologue: constants --------------------------------------------------------------------
     const double Ael = a.A[(size_t)b * 64 + lane];
     double Qi = a.Q[(size_t)b * 64 + lane];
-    const double Cf = a.Cfull[(size_t)b * 64 + lane];
+    const double Cf = inC ? a.Cfull[(size_t)b * Rc * Rc + i * Rc + j] : 0.0;
     double Omf = a.P0[(size_t)b * 64 + lane];
     const double mu0c = a.mu0[(size_t)b * R + j];            // column-distributed
     const double detQ = sweep_inverse(Qi, i, j);
@@ -173,11 +176,11 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
         for (int s = 0; s < CHW; ++s) {
             int t = c * CHW + s;
             t = t < T ? t : T - 1;
-            nb_[s] = bcol[(size_t)t * R + j];
+            nb_[s] = j < Rc ? bcol[(size_t)t * Rc + j] : 0.0;
             ns_[s] = scol[t];
             nn_[s] = nobs[t];
             nl_[s] = ldrow[t];
-            nc_[s] = a.Ct ? a.Ct[((size_t)b * T + t) * NPp + pk] : 0.0;
+            nc_[s] = (a.Ct && inC) ? a.Ct[((size_t)b * T + t) * NPc + pk] : 0.0;
         }
     };
     auto take_fwd = [&]() {
@@ -412,7 +415,9 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     if (em) {
         const size_t o = (size_t)b * 64 + lane;
         const double S00 = S11 - termT + fma(fs_r, fs_c, Ps);
-        a.S11[o] = S11;
+        // a.rl > 0: the loadings step sees the first Rc components only -- S11 / S11^-1 go out in its [Rc][Rc] layout
+        const bool narrow = a.rl > 0;
+        if (!narrow) a.S11[o] = S11;
         a.S10[o] = S10;
         a.S00[o] = S00;
         a.P0s[o] = Ps;
@@ -433,8 +438,13 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
             Qn = 0.5 * (Qn + transposed(Qn, i, j));
             const double P0n = 0.5 * (Ps + transposed(Ps, i, j));
             double inv2 = S11;
+            if (narrow) {
+                if (!inC) inv2 = (i == j) ? (double)T : 0.0;
+                if (inC) a.S11[(size_t)b * Rc * Rc + i * Rc + j] = inv2;
+            }
             (void)sweep_inverse(inv2, i, j);
-            a.S11inv[o] = inv2;
+            if (narrow) { if (inC) a.S11inv[(size_t)b * Rc * Rc + i * Rc + j] = inv2; }
+            else a.S11inv[o] = inv2;
             if (em_apply) {
                 a.A_out[o] = An;
                 a.Q_out[o] = Qn;
@@ -446,7 +456,11 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
 }
 
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
-    return Rpad == 8 && !a.cov && a.Rc == 0 && a.rl == 0 && a.kdim == 0 && a.T <= 15000;   // LDS: 4 bytes per period
+    // information form only; a narrower collapse (a.Rc) is fine, a companion M-step (a.kdim) is recursion_kernel's
+    // Batch size: a wave per replicate costs ~0.85 ms per 1024 replicates (C2 shape) and scales with B; the lane-group
+    // kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~3000.
+    if (a.Rc == 0 && a.B > 3072) return false;
+    return Rpad == 8 && !a.cov && a.kdim == 0 && (a.rl == 0 || a.rl == a.Rc) && a.T <= 15000;   // LDS: 4 bytes per period
 }
 
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s) {
