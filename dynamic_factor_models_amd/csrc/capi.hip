@@ -752,7 +752,8 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_COLLAPSE_WPR")) { h->collapse_wpr = atoi(v); if (h->collapse_wpr < 0 || h->collapse_wpr > kSsumSlots) h->collapse_wpr = 0; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
-    if (const char* v = getenv("DFM_NO_RECURSION_WAVE")) { h->no_rec_wave = atoi(v) != 0; g_widen_small_r = !h->no_rec_wave; }
+    if (const char* v = getenv("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
+    g_widen_small_r = !h->no_rec_wave;      // process-wide: follows the most recently created handle
     if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
     if (const char* v = getenv("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;

@@ -91,3 +91,36 @@ def test_singular_Q_is_reported(ctx):
     with pytest.raises(DfmError) as e:
         ctx.ks_pass_batch_host(x[None], *[start[k][None] for k in ("Lam", "R", "A", "Q", "mu0", "P0")])
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("r", [3, 8])
+def test_lane_group_recursion_kernel_still_matches(r, monkeypatch):
+    """DFM_NO_RECURSION_WAVE=1: the r-lanes-per-replicate recursion_kernel (what large batches and r > 8 use) on the
+    shapes the default dispatch now gives to the wave-per-replicate kernel."""
+    import torch
+    from dynamic_factor_models_amd import DfmContext
+    monkeypatch.setenv("DFM_NO_RECURSION_WAVE", "1")
+    c = DfmContext()
+    try:
+        B, N, T = 3, 40, 60
+        reps = [ko.synth_replicate(b, N, T, r, missing=0.1) for b in range(B)]
+        x = np.stack([a for a, _ in reps])
+        st = {k: np.stack([p[k] for _, p in reps]) for k in reps[0][1]}
+        keys = ("Lam", "R", "A", "Q", "mu0", "P0")
+        dev = torch.device("cuda", c.device)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        f, P, ll = c.ks_pass_batch(t(x), *[t(st[k]) for k in keys])
+        d = {k: t(st[k]) for k in keys}
+        path, its, f2, P2 = c.em_batch(t(x), *[d[k] for k in keys], max_iter=3, tol=0.0)
+        torch.cuda.synchronize()
+        for b in range(B):
+            o = ko.kfs_pass(x[b], **reps[b][1])
+            assert abs(ll[b].item() - o["loglik"]) <= RTOL * abs(o["loglik"])
+            assert np.abs(f[b].cpu().numpy() - o["f_smooth"]).max() <= RTOL * np.abs(o["f_smooth"]).max()
+            p, opath, _ = ko.em(x[b], reps[b][1], 3)
+            np.testing.assert_allclose(path[b].cpu().numpy(), opath, rtol=1e-8)
+            assert np.abs(d["Lam"][b].cpu().numpy() - p["Lam"]).max() <= 1e-8 * np.abs(p["Lam"]).max()
+    finally:
+        c.close()
+        monkeypatch.delenv("DFM_NO_RECURSION_WAVE")
+        DfmContext().close()              # resets the process-wide dispatch default
