@@ -110,6 +110,8 @@ __device__ __forceinline__ double dot_rows(const double* xs, const double* ys, i
 
 }  // namespace
 
+// COV = true: covariance-form forward step (recursion.hip, COV): Q may be singular (companion states, DFM_F_SINGULAR_Q)
+template <bool COV>
 __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     constexpr int R = 8;
     extern __shared__ __attribute__((aligned(16))) double wsm[];
@@ -148,24 +150,32 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     const double Cf = inC ? a.Cfull[(size_t)b * Rc * Rc + i * Rc + j] : 0.0;
     double Omf = a.P0[(size_t)b * 64 + lane];
     const double mu0c = a.mu0[(size_t)b * R + j];            // column-distributed
-    const double detQ = sweep_inverse(Qi, i, j);
-    const double detP0 = sweep_inverse(Omf, i, j);           // Om_f,0 = P0^-1
-    // K = Qi A:  K_ij = sum_k Qi[i][k] A[k][j] = row i of Qi . row j of A'
-    L0[lane] = Qi;
-    L1[8 * j + i] = Ael;                                     // A'
-    wave_lds_sync();
-    const double K = dot_rows(L0, L1, i, j);
-    wave_lds_sync();
-    LK[lane] = K;
-    L0[8 * j + i] = K;                                       // K' rows = K columns
-    wave_lds_sync();
-    const double KT = L0[lane];                              // K_ji
-    // Phi = K' A = A' Qi A:  Phi_ij = sum_k K[k][i] A[k][j] = row i of K' . row j of A'
-    const double Phi = dot_rows(L0, L1, i, j);
-    wave_lds_sync();
-    double xi = sum_over_j(Omf * mu0c);                      // xi_0 = P0^-1 mu0, row-distributed
-    const double q0_part = diag ? mu0c * xi : 0.0;
-    xi = transposed(xi, i, j);                               // column-distributed from here on
+    // COV: Qi stays Q (never inverted), Omf holds P_f (P0 to start), xi holds m_f (mu0 to start), LK holds A rows
+    double detQ = 1.0, detP0 = 1.0, K = 0.0, KT = 0.0, Phi = 0.0, q0_part = 0.0, xi = mu0c;
+    if constexpr (!COV) {
+        detQ = sweep_inverse(Qi, i, j);
+        detP0 = sweep_inverse(Omf, i, j);                    // Om_f,0 = P0^-1
+        // K = Qi A:  K_ij = sum_k Qi[i][k] A[k][j] = row i of Qi . row j of A'
+        L0[lane] = Qi;
+        L1[8 * j + i] = Ael;                                 // A'
+        wave_lds_sync();
+        K = dot_rows(L0, L1, i, j);
+        wave_lds_sync();
+        LK[lane] = K;
+        L0[8 * j + i] = K;                                   // K' rows = K columns
+        wave_lds_sync();
+        KT = L0[lane];                                       // K_ji
+        // Phi = K' A = A' Qi A:  Phi_ij = sum_k K[k][i] A[k][j] = row i of K' . row j of A'
+        Phi = dot_rows(L0, L1, i, j);
+        wave_lds_sync();
+        xi = sum_over_j(Omf * mu0c);                         // xi_0 = P0^-1 mu0, row-distributed
+        q0_part = diag ? mu0c * xi : 0.0;
+        xi = transposed(xi, i, j);                           // column-distributed from here on
+    } else {
+        LK[lane] = Ael;
+        wave_lds_sync();
+    }
+    (void)K;
 
     // ---------------- forward sweep ---------------------------------------------------------------------------
     const int nchunks = (T + CHW - 1) / CHW;
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
         for (int s = 0; s < CHW; ++s) { cb[s] = nb_[s]; cs[s] = ns_[s]; cn[s] = nn_[s]; cl[s] = nl_[s]; cc[s] = nc_[s]; }
     };
 
-    double Z = 0.0, Jr = 0.0, Omp = 0.0;
+    double Z = 0.0, Jr = 0.0, Omp = 0.0, Gm = 0.0, mf_r = 0.0, detP_cur = 1.0;
     double detM_cur = 1.0, sum_xw = 0.0, ssum = 0.0, nsum = 0.0, ldsum = 0.0;
     LogProd detprod;                                           // prod_t det(Om_f,t + Phi)
     int e = -1;
@@ -210,7 +220,8 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     ZJ[((size_t)eb[s] * 2 + 0) * 64 + lane] = zb[s];
                     ZJ[((size_t)eb[s] * 2 + 1) * 64 + lane] = jb[s];
                 }
-                if (j == 0) wtab[(size_t)t * R + i] = wb[s];
+                if constexpr (COV) { if (i == 0) wtab[(size_t)t * R + j] = wb[s]; }   // w_t column-distributed there
+                else { if (j == 0) wtab[(size_t)t * R + i] = wb[s]; }
             }
         }
     };
@@ -224,9 +235,56 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
         for (int s = 0; s < CHW; ++s) {
             if (s < smax) {
                 const int t = c * CHW + s;
+                eb[s] = -1;
+                if constexpr (COV) {
+                    const bool full = (cn[s] == N);
+                    const double Crow = full ? Cf : cc[s];
+                    if (need_cov || !full) {  // wave-uniform; need_cov == false: the last computed step had a full row and reproduced its P_f
+                        wave_lds_sync();
+                        L0[lane] = Omf;                            // P_f rows (symmetric)
+                        wave_lds_sync();
+                        const double AP = dot_rows(LK, L0, i, j);  // A P_f
+                        wave_lds_sync();
+                        L1[lane] = AP;
+                        L0[8 * j + i] = AP;                        // (A P_f)' rows = its columns
+                        wave_lds_sync();
+                        Omp = dot_rows(L1, LK, i, j) + Qi;         // P_p = A P_f A' + Q
+                        detP_cur = sweep_inverse(Omp, i, j);       // Om_p = P_p^-1
+                        wave_lds_sync();
+                        LJ[lane] = Omp;
+                        wave_lds_sync();
+                        Gm = dot_rows(LJ, L0, i, j);               // G = Om_p A P_f
+                        Jr = dot_rows(LJ, L0, j, i);               // J = G' = P_f A' Om_p
+                        wave_lds_sync();
+                        L1[lane] = Jr;
+                        wave_lds_sync();
+                        Z = Omf - dot_rows(L1, L0, i, j);          // Z = P_f - J A P_f
+                        double Pn = Omp + Crow;
+                        detM_cur = sweep_inverse(Pn, i, j);        // P_f' = (Om_p + C_t)^-1
+                        const bool same = full && close_enough(Pn, Omf);
+                        Omf = Pn;
+                        need_cov = !__all(same);
+                        ++e;
+                        zb[s] = Z; jb[s] = Jr; eb[s] = e;
+                    }
+                    if (lane == 0) eidxS[t] = e;
+                    // m_p = A m_f, w = m_f - J m_p, m_f' = P_f' (Om_p m_p + b_t)
+                    const double mp = sum_over_j(Ael * xi);                    // row-distributed
+                    wb[s] = xi - sum_over_i(Gm * mp);                          // column-distributed
+                    const double y = sum_over_i(Omp * mp) + cb[s];             // column-distributed (Om_p symmetric)
+                    const double cm = sum_over_i(Crow * mp);
+                    mf_r = sum_over_j(Omf * y);                                // row-distributed
+                    sum_xw += diag ? fma(cb[s], mp, (cb[s] - cm) * mf_r) : 0.0;   // quad_t = s_t - sum_i (b_i m_p,i + u_i m_f,i)
+                    detprod.mul(detM_cur);                                     // log det(I + C_t P_p) = log det(Om_p + C_t) + log det P_p
+                    detprod.mul(detP_cur);
+                    xi = transposed(mf_r, i, j);
+                    ssum += cs[s];
+                    nsum += (double)cn[s];
+                    ldsum += full ? ldfull : cl[s];
+                    continue;
+                }
                 const bool computed = need_cov;
                 const double Omf_used = Omf;
-                eb[s] = -1;
                 if (need_cov) {  // wave-uniform
                     Z = Omf + Phi;
                     TICK(p_inv);
@@ -277,12 +335,16 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     // ---------------- terminal: P_T = Om_f^-1, f_T = P_T xi, log-likelihood ------------------------------------
     bool em_apply = true;
     double Ps = Omf;
-    const double detOmT = sweep_inverse(Ps, i, j);
-    double fs_r = sum_over_j(Ps * xi);                         // f_T, row-distributed
+    double detOmT = 1.0, fs_r = mf_r;                          // COV: P_T = P_f, f_T = m_f as they stand
+    if constexpr (!COV) {
+        detOmT = sweep_inverse(Ps, i, j);
+        fs_r = sum_over_j(Ps * xi);                            // f_T, row-distributed
+    }
     {
-        double part = (diag ? q0_part - xi * fs_r : 0.0) - sum_xw;
+        double part = COV ? -sum_xw : (diag ? q0_part - xi * fs_r : 0.0) - sum_xw;
         const double qd = sum_over_i(sum_over_j(part));
-        const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) + detprod.log_value();   // sum_ldz = -log prod
+        const double LD = COV ? detprod.log_value()
+                              : log(detOmT) + log(detP0) + (double)T * log(detQ) + detprod.log_value();   // sum_ldz = -log prod
         const double ll = -0.5 * (nsum * kLog2PiW + ldsum + LD + ssum + qd);
         if (lane == 0) {
             a.loglik[b] = ll;
@@ -306,10 +368,12 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
 
     // ---------------- backward sweep ----------------------------------------------------------------------------
     const int npr = r * (r + 1) / 2;
+    const int rl = a.rl > 0 ? a.rl : R;      // observation loads on the first rl state components; the rest of the output
+    const bool inL = i < rl && j < rl;       // layout is padding for the loadings step (mean 0, identity covariance)
     auto emit = [&](int trow, double P, double f_row) {        // smoothed moments of period trow + 1
         if (i >= r) return;
-        if (j == 0) a.f_smooth[((size_t)b * T + trow) * r + i] = f_row;
-        if (a.P_smooth && j <= i) a.P_smooth[((size_t)b * T + trow) * npr + i * (i + 1) / 2 + j] = P;
+        if (j == 0) a.f_smooth[((size_t)b * T + trow) * r + i] = i < rl ? f_row : 0.0;
+        if (a.P_smooth && j <= i) a.P_smooth[((size_t)b * T + trow) * npr + i * (i + 1) / 2 + j] = inL ? P : (i == j ? 1.0 : 0.0);
     };
     double fs_c = transposed(fs_r, i, j);
     double Jt = 0.0;                                           // J_ji
@@ -436,17 +500,23 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
             wave_lds_sync();
             double Qn = (S11 - dot_rows(L1, L0, i, j)) / (double)T;   // (A S10')_ij = row i of A . row j of S10
             Qn = 0.5 * (Qn + transposed(Qn, i, j));
+            double Aout = An;
+            if (a.kdim > 0) {   // companion state: only [A_1 .. A_p] and the innovation covariance of f_t are free
+                const int kd = a.kdim;
+                if (i >= rl && i < kd) Aout = (j == i - rl) ? 1.0 : 0.0;
+                if ((i >= rl && i < kd) || (j >= rl && j < kd)) Qn = 0.0;
+            }
             const double P0n = 0.5 * (Ps + transposed(Ps, i, j));
             double inv2 = S11;
             if (narrow) {
-                if (!inC) inv2 = (i == j) ? (double)T : 0.0;
+                if (!inL) inv2 = (i == j) ? (double)T : 0.0;
                 if (inC) a.S11[(size_t)b * Rc * Rc + i * Rc + j] = inv2;
             }
             (void)sweep_inverse(inv2, i, j);
             if (narrow) { if (inC) a.S11inv[(size_t)b * Rc * Rc + i * Rc + j] = inv2; }
             else a.S11inv[o] = inv2;
             if (em_apply) {
-                a.A_out[o] = An;
+                a.A_out[o] = Aout;
                 a.Q_out[o] = Qn;
                 a.P0_out[o] = P0n;
                 if (j == 0) a.mu0_out[(size_t)b * R + i] = fs_r;
@@ -456,17 +526,17 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
 }
 
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
-    // information form only; a narrower collapse (a.Rc) is fine, a companion M-step (a.kdim) is recursion_kernel's
     // Batch size: a wave per replicate costs ~0.85 ms per 1024 replicates (C2 shape) and scales with B; the lane-group
     // kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~3000.
     if (a.Rc == 0 && a.B > 3072) return false;
-    return Rpad == 8 && !a.cov && a.kdim == 0 && (a.rl == 0 || a.rl == a.Rc) && a.T <= 15000;   // LDS: 4 bytes per period
+    return Rpad == 8 && (a.rl == 0 || a.Rc > 0) && a.T <= 15000;   // LDS: 4 bytes per period
 }
 
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s) {
     const size_t lds = 4 * 64 * sizeof(double) + (size_t)a.T * sizeof(int);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(recursion_wave_kernel, dim3(a.B), dim3(64), lds, s, a);
+    if (a.cov) hipLaunchKernelGGL(recursion_wave_kernel<true>, dim3(a.B), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL(recursion_wave_kernel<false>, dim3(a.B), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
