@@ -84,7 +84,7 @@ struct MstepArgs {
 
 hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a);
-hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s);
+hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad);
 int collapse_max_n(int Rpad);
 // balanced panels (no NaN), even N: LDS-DMA streaming collapse (writes bcol, scol only) + Gram kernel
 bool collapse_dma_supported(int Rpad, int N);

@@ -1,5 +1,6 @@
 // recursion_wave.hip -- recursion_kernel's algebra (recursion.hip: information-form filter + "Z-smoother", EM statistics
-// and transition M-step) with ONE WAVE PER REPLICATE for Rp = 8 (5 <= r <= 8).
+// and transition M-step) with ONE WAVE PER REPLICATE for Rp = 8 (state 5..8 wide; narrower states are padded to it), and
+// the same element-per-thread layout on a 256-thread workgroup per replicate for Rp = 16 (Grid<16>).
 //
 // recursion_kernel gives a replicate r lanes (lane i = row i): at B = 1024 that is 128 waves on 1024 SIMDs, each walking
 // 500 dependent periods at ~6 us a period (an r x r Gauss-Jordan through LDS, four r x r products of 64 FMAs per lane).
@@ -32,27 +33,12 @@ constexpr double kLog2PiW = 1.8378770664093454835606594728112;
 #ifndef DFM_WAVE_CHW
 #define DFM_WAVE_CHW 8
 #endif
-constexpr int CHW = DFM_WAVE_CHW;     // periods per prefetch chunk
+constexpr int kChunk8 = DFM_WAVE_CHW; // periods per prefetch chunk (Rp = 8); Rp = 16 takes 4 (code size)
 
 __device__ __forceinline__ double uniform_lane(double v, int src) {   // src wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
     return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double sum_over_j(double v) {   // over the 8 lanes of a row group; all of them get the total
-    v += xor_lane<1>(v);
-    v += xor_lane<2>(v);
-    v += xor_lane<4>(v);
-    return v;
-}
-__device__ __forceinline__ double sum_over_i(double v) {   // over the 8 row groups: DPP, then the two permlane swaps (no LDS crossbar)
-    v += xor_lane<8>(v);
-    double a = v, b = v;
-    swap_rows16(a, b);        // a = rows {0,0,2,2}, b = rows {1,1,3,3} of v
-    v = a + b;
-    a = v; b = v;
-    swap_halves32(a, b);      // a = low half twice, b = high half twice
-    return a + b;
 }
 // 1 / x for a positive, normal x: v_rcp_f64 refined by two Newton steps (no scaling / fix-up: pivots of an SPD matrix)
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -72,35 +58,96 @@ struct LogProd {
     }
     __device__ __forceinline__ double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
-// In-place inverse of a symmetric positive definite 8 x 8 matrix (element per lane) by the symmetric sweep operator
-// (Beaton): after sweeping every pivot the register holds -M^-1.  Returns det M = product of the pivots.
-__device__ __forceinline__ double sweep_inverse(double& m, int i, int j) {
-    double det = 1.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const double piv = uniform_lane(m, 9 * k);
-        const double qj = __shfl(m, 8 * k + j, 64);
-        const double qi = __shfl(m, 8 * k + i, 64);
-        const double d = fast_rcp(piv);
-        det *= piv;
-        const double t = qi * d;
-        double nm = fma(-t, qj, m);
-        nm = (i == k) ? qj * d : nm;
-        nm = (j == k) ? t : nm;
-        nm = (i == k && j == k) ? -d : nm;
-        m = nm;
+
+// Cross-thread plumbing of one replicate's R x R element grid (thread l = R i + j).  R = 8: one wave, everything stays in
+// registers / the LDS crossbar.  R = 16: four waves of a workgroup; what crosses waves goes through small LDS buffers
+// with ONE s_barrier per exchange (buffers alternate, so the next exchange's writes cannot overtake this one's reads).
+template <int R>
+struct Grid {
+    double* prow;   // [2][R]      pivot row of a sweep            (R = 16)
+    double* red;    // [2][4][R]   per-wave column partial sums    (R = 16)
+    double* tt;     // [2][R][R]   transposes                      (R = 16)
+    int pr = 0, pt = 0;
+    int l, i, j;
+
+    __device__ __forceinline__ void sync() const {
+        if constexpr (R == 8) wave_lds_sync(); else __syncthreads();
     }
-    m = -m;
-    return det;
-}
-__device__ __forceinline__ double transposed(double v, int i, int j) { return __shfl(v, 8 * j + i, 64); }
+    __device__ __forceinline__ bool all_true(bool v) const {
+        if constexpr (R == 8) return __all(v); else return __syncthreads_and(v) != 0;
+    }
+    // over the R lanes of a row group (a DPP row or half-row): every one of them gets the total
+    __device__ __forceinline__ double sum_j(double v) const {
+        v += xor_lane<1>(v);
+        v += xor_lane<2>(v);
+        v += xor_lane<4>(v);
+        if constexpr (R == 16) v += xor_lane<8>(v);
+        return v;
+    }
+    // over the R row groups: threads with the same j
+    __device__ __forceinline__ double sum_i(double v) {
+        if constexpr (R == 8) v += xor_lane<8>(v);
+        double a = v, b = v;
+        swap_rows16(a, b);        // a = rows {0,0,2,2}, b = rows {1,1,3,3} of v
+        v = a + b;
+        a = v; b = v;
+        swap_halves32(a, b);      // a = low half twice, b = high half twice
+        v = a + b;
+        if constexpr (R == 16) {
+            double* rb = red + (pr ^= 1) * 4 * R;
+            if ((l & 63) < R) rb[(l >> 6) * R + j] = v;
+            __syncthreads();
+            v = (rb[j] + rb[R + j]) + (rb[2 * R + j] + rb[3 * R + j]);
+        }
+        return v;
+    }
+    __device__ __forceinline__ double transposed(double v) {
+        if constexpr (R == 8) return __shfl(v, 8 * j + i, 64);
+        else {
+            double* tb = tt + (pt ^= 1) * R * R;
+            tb[R * j + i] = v;
+            __syncthreads();
+            return tb[l];
+        }
+    }
+    // In-place inverse of a symmetric positive definite R x R matrix (element per thread) by the symmetric sweep
+    // operator (Beaton): after sweeping every pivot the register holds -M^-1.  Returns det M = product of the pivots.
+    __device__ __forceinline__ double sweep_inverse(double& m) {
+        double det = 1.0;
+#pragma unroll (R == 8 ? 8 : 1)       // R = 16: a real loop (16 unrolled copies in every unrolled period: 36 k instructions)
+        for (int k = 0; k < R; ++k) {
+            double piv, qj, qi;
+            if constexpr (R == 8) {
+                piv = uniform_lane(m, 9 * k);
+                qj = __shfl(m, 8 * k + j, 64);
+                qi = __shfl(m, 8 * k + i, 64);
+            } else {
+                double* pb = prow + (k & 1) * R;
+                if (i == k) pb[j] = m;
+                __syncthreads();
+                piv = pb[k]; qj = pb[j]; qi = pb[i];
+            }
+            const double d = fast_rcp(piv);
+            det *= piv;
+            const double t = qi * d;
+            double nm = fma(-t, qj, m);
+            nm = (i == k) ? qj * d : nm;
+            nm = (j == k) ? t : nm;
+            nm = (i == k && j == k) ? -d : nm;
+            m = nm;
+        }
+        m = -m;
+        return det;
+    }
+};
 // sum_k X[i][k] Y[j][k], X and Y staged row-major in LDS
+template <int R>
 __device__ __forceinline__ double dot_rows(const double* xs, const double* ys, int i, int j) {
-    const double2* a = reinterpret_cast<const double2*>(xs + 8 * i);
-    const double2* b = reinterpret_cast<const double2*>(ys + 8 * j);
+    const double2* a = reinterpret_cast<const double2*>(xs + R * i);
+    const double2* b = reinterpret_cast<const double2*>(ys + R * j);
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < R / 2; ++q) {
         const double2 u = a[q], v = b[q];
         s0 = fma(u.x, v.x, s0);
         s1 = fma(u.y, v.y, s1);
@@ -111,17 +158,28 @@ __device__ __forceinline__ double dot_rows(const double* xs, const double* ys, i
 }  // namespace
 
 // COV = true: covariance-form forward step (recursion.hip, COV): Q may be singular (companion states, DFM_F_SINGULAR_Q)
-template <bool COV>
-__global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
-    constexpr int R = 8;
+template <int R, bool COV>
+#ifndef DFM_WG16_WAVES
+#define DFM_WG16_WAVES 2
+#endif
+// R = 16: a workgroup is one wave on each SIMD of a CU and a chain of barrier-separated exchanges -- latency-bound; the
+// register budget is capped so that several workgroups share a CU and fill each other's waits.
+__global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursion_wave_kernel(RecursionArgs a) {
+    constexpr int RR = R * R;
+    constexpr int CHW = R == 16 ? 4 : kChunk8;
     extern __shared__ __attribute__((aligned(16))) double wsm[];
-    double* LK = wsm;            // K = Q^-1 A, rows (constant)
-    double* L0 = LK + 64;
-    double* L1 = L0 + 64;
-    double* LJ = L1 + 64;        // J rows (backward sweep)
-    int* eidxS = reinterpret_cast<int*>(LJ + 64);   // [T] covariance-table entry of forward step t
+    double* LK = wsm;            // K = Q^-1 A, rows (constant; COV: A rows)
+    double* L0 = LK + RR;
+    double* L1 = L0 + RR;
+    double* LJ = L1 + RR;        // J rows (backward sweep)
+    Grid<R> G;
+    G.prow = LJ + RR;            // (R = 8: unused, zero bytes reserved)
+    G.red = G.prow + (R == 16 ? 2 * R : 0);
+    G.tt = G.red + (R == 16 ? 2 * 4 * R : 0);
+    int* eidxS = reinterpret_cast<int*>(G.tt + (R == 16 ? 2 * RR : 0));   // [T] covariance-table entry of forward step t
     const int lane = threadIdx.x;
-    const int i = lane >> 3, j = lane & 7;
+    const int i = lane / R, j = lane % R;
+    G.l = lane; G.i = i; G.j = j;
     const int T = a.T, N = a.N, r = a.r;
     long long p_inv = 0, p_mm = 0, p_mean = 0, p_bcov = 0, p_bmean = 0, p_tot = 0, p_stage = 0;
     (void)p_inv; (void)p_mm; (void)p_mean; (void)p_bcov; (void)p_bmean; (void)p_tot; (void)p_stage;
@@ -145,35 +203,35 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     const int pk = (i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i;   // packed lower-triangle index of (i, j)
 
     // ---------------- prologue: constants --------------------------------------------------------------------
-    const double Ael = a.A[(size_t)b * 64 + lane];
-    double Qi = a.Q[(size_t)b * 64 + lane];
+    const double Ael = a.A[(size_t)b * RR + lane];
+    double Qi = a.Q[(size_t)b * RR + lane];
     const double Cf = inC ? a.Cfull[(size_t)b * Rc * Rc + i * Rc + j] : 0.0;
-    double Omf = a.P0[(size_t)b * 64 + lane];
+    double Omf = a.P0[(size_t)b * RR + lane];
     const double mu0c = a.mu0[(size_t)b * R + j];            // column-distributed
     // COV: Qi stays Q (never inverted), Omf holds P_f (P0 to start), xi holds m_f (mu0 to start), LK holds A rows
     double detQ = 1.0, detP0 = 1.0, K = 0.0, KT = 0.0, Phi = 0.0, q0_part = 0.0, xi = mu0c;
     if constexpr (!COV) {
-        detQ = sweep_inverse(Qi, i, j);
-        detP0 = sweep_inverse(Omf, i, j);                    // Om_f,0 = P0^-1
+        detQ = G.sweep_inverse(Qi);
+        detP0 = G.sweep_inverse(Omf);                    // Om_f,0 = P0^-1
         // K = Qi A:  K_ij = sum_k Qi[i][k] A[k][j] = row i of Qi . row j of A'
         L0[lane] = Qi;
-        L1[8 * j + i] = Ael;                                 // A'
-        wave_lds_sync();
-        K = dot_rows(L0, L1, i, j);
-        wave_lds_sync();
+        L1[R * j + i] = Ael;                                 // A'
+        G.sync();
+        K = dot_rows<R>(L0, L1, i, j);
+        G.sync();
         LK[lane] = K;
-        L0[8 * j + i] = K;                                   // K' rows = K columns
-        wave_lds_sync();
+        L0[R * j + i] = K;                                   // K' rows = K columns
+        G.sync();
         KT = L0[lane];                                       // K_ji
         // Phi = K' A = A' Qi A:  Phi_ij = sum_k K[k][i] A[k][j] = row i of K' . row j of A'
-        Phi = dot_rows(L0, L1, i, j);
-        wave_lds_sync();
-        xi = sum_over_j(Omf * mu0c);                         // xi_0 = P0^-1 mu0, row-distributed
+        Phi = dot_rows<R>(L0, L1, i, j);
+        G.sync();
+        xi = G.sum_j(Omf * mu0c);                         // xi_0 = P0^-1 mu0, row-distributed
         q0_part = diag ? mu0c * xi : 0.0;
-        xi = transposed(xi, i, j);                           // column-distributed from here on
+        xi = G.transposed(xi);                           // column-distributed from here on
     } else {
         LK[lane] = Ael;
-        wave_lds_sync();
+        G.sync();
     }
     (void)K;
 
@@ -217,8 +275,8 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
             const int t = c * CHW + s;
             if (t < T) {
                 if (eb[s] >= 0) {
-                    ZJ[((size_t)eb[s] * 2 + 0) * 64 + lane] = zb[s];
-                    ZJ[((size_t)eb[s] * 2 + 1) * 64 + lane] = jb[s];
+                    ZJ[((size_t)eb[s] * 2 + 0) * RR + lane] = zb[s];
+                    ZJ[((size_t)eb[s] * 2 + 1) * RR + lane] = jb[s];
                 }
                 if constexpr (COV) { if (i == 0) wtab[(size_t)t * R + j] = wb[s]; }   // w_t column-distributed there
                 else { if (j == 0) wtab[(size_t)t * R + i] = wb[s]; }
@@ -240,44 +298,44 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                     const bool full = (cn[s] == N);
                     const double Crow = full ? Cf : cc[s];
                     if (need_cov || !full) {  // wave-uniform; need_cov == false: the last computed step had a full row and reproduced its P_f
-                        wave_lds_sync();
+                        G.sync();
                         L0[lane] = Omf;                            // P_f rows (symmetric)
-                        wave_lds_sync();
-                        const double AP = dot_rows(LK, L0, i, j);  // A P_f
-                        wave_lds_sync();
+                        G.sync();
+                        const double AP = dot_rows<R>(LK, L0, i, j);  // A P_f
+                        G.sync();
                         L1[lane] = AP;
-                        L0[8 * j + i] = AP;                        // (A P_f)' rows = its columns
-                        wave_lds_sync();
-                        Omp = dot_rows(L1, LK, i, j) + Qi;         // P_p = A P_f A' + Q
-                        detP_cur = sweep_inverse(Omp, i, j);       // Om_p = P_p^-1
-                        wave_lds_sync();
+                        L0[R * j + i] = AP;                        // (A P_f)' rows = its columns
+                        G.sync();
+                        Omp = dot_rows<R>(L1, LK, i, j) + Qi;         // P_p = A P_f A' + Q
+                        detP_cur = G.sweep_inverse(Omp);       // Om_p = P_p^-1
+                        G.sync();
                         LJ[lane] = Omp;
-                        wave_lds_sync();
-                        Gm = dot_rows(LJ, L0, i, j);               // G = Om_p A P_f
-                        Jr = dot_rows(LJ, L0, j, i);               // J = G' = P_f A' Om_p
-                        wave_lds_sync();
+                        G.sync();
+                        Gm = dot_rows<R>(LJ, L0, i, j);               // G = Om_p A P_f
+                        Jr = dot_rows<R>(LJ, L0, j, i);               // J = G' = P_f A' Om_p
+                        G.sync();
                         L1[lane] = Jr;
-                        wave_lds_sync();
-                        Z = Omf - dot_rows(L1, L0, i, j);          // Z = P_f - J A P_f
+                        G.sync();
+                        Z = Omf - dot_rows<R>(L1, L0, i, j);          // Z = P_f - J A P_f
                         double Pn = Omp + Crow;
-                        detM_cur = sweep_inverse(Pn, i, j);        // P_f' = (Om_p + C_t)^-1
+                        detM_cur = G.sweep_inverse(Pn);        // P_f' = (Om_p + C_t)^-1
                         const bool same = full && close_enough(Pn, Omf);
                         Omf = Pn;
-                        need_cov = !__all(same);
+                        need_cov = !G.all_true(same);
                         ++e;
                         zb[s] = Z; jb[s] = Jr; eb[s] = e;
                     }
                     if (lane == 0) eidxS[t] = e;
                     // m_p = A m_f, w = m_f - J m_p, m_f' = P_f' (Om_p m_p + b_t)
-                    const double mp = sum_over_j(Ael * xi);                    // row-distributed
-                    wb[s] = xi - sum_over_i(Gm * mp);                          // column-distributed
-                    const double y = sum_over_i(Omp * mp) + cb[s];             // column-distributed (Om_p symmetric)
-                    const double cm = sum_over_i(Crow * mp);
-                    mf_r = sum_over_j(Omf * y);                                // row-distributed
+                    const double mp = G.sum_j(Ael * xi);                    // row-distributed
+                    wb[s] = xi - G.sum_i(Gm * mp);                          // column-distributed
+                    const double y = G.sum_i(Omp * mp) + cb[s];             // column-distributed (Om_p symmetric)
+                    const double cm = G.sum_i(Crow * mp);
+                    mf_r = G.sum_j(Omf * y);                                // row-distributed
                     sum_xw += diag ? fma(cb[s], mp, (cb[s] - cm) * mf_r) : 0.0;   // quad_t = s_t - sum_i (b_i m_p,i + u_i m_f,i)
                     detprod.mul(detM_cur);                                     // log det(I + C_t P_p) = log det(Om_p + C_t) + log det P_p
                     detprod.mul(detP_cur);
-                    xi = transposed(mf_r, i, j);
+                    xi = G.transposed(mf_r);
                     ssum += cs[s];
                     nsum += (double)cn[s];
                     ldsum += full ? ldfull : cl[s];
@@ -288,16 +346,16 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                 if (need_cov) {  // wave-uniform
                     Z = Omf + Phi;
                     TICK(p_inv);
-                    detM_cur = sweep_inverse(Z, i, j);
+                    detM_cur = G.sweep_inverse(Z);
                     TOCK(p_inv);
                     TICK(p_mm);
-                    wave_lds_sync();
+                    G.sync();
                     L0[lane] = Z;
-                    wave_lds_sync();
-                    Jr = dot_rows(L0, LK, i, j);               // J = Z K'
-                    L1[8 * j + i] = Jr;                        // J' rows = J columns
-                    wave_lds_sync();
-                    Omp = Qi - dot_rows(LK, L1, i, j);         // Om_p = Qi - K J
+                    G.sync();
+                    Jr = dot_rows<R>(L0, LK, i, j);               // J = Z K'
+                    L1[R * j + i] = Jr;                        // J' rows = J columns
+                    G.sync();
+                    Omp = Qi - dot_rows<R>(LK, L1, i, j);         // Om_p = Qi - K J
                     ++e;
                     zb[s] = Z; jb[s] = Jr; eb[s] = e;
                     TOCK(p_mm);
@@ -305,11 +363,11 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                 TICK(p_mean);
                 if (lane == 0) eidxS[t] = e;
                 // mean recursion: w = Z xi (row-distributed), xi <- K w + b_t (column-distributed)
-                const double w = sum_over_j(Z * xi);
+                const double w = G.sum_j(Z * xi);
                 sum_xw += diag ? xi * w : 0.0;
                 detprod.mul(detM_cur);
                 wb[s] = w;
-                xi = sum_over_i(KT * w) + cb[s];
+                xi = G.sum_i(KT * w) + cb[s];
                 ssum += cs[s];
                 const double nt = (double)cn[s];
                 nsum += nt;
@@ -318,7 +376,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                 const double Omf_new = Omp + (full ? Cf : cc[s]);
                 if (computed) {
                     const bool same = full && close_enough(Omf_new, Omf_used);
-                    need_cov = !__all(same);
+                    need_cov = !G.all_true(same);
                 } else {
                     need_cov = !full;
                 }
@@ -337,12 +395,12 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     double Ps = Omf;
     double detOmT = 1.0, fs_r = mf_r;                          // COV: P_T = P_f, f_T = m_f as they stand
     if constexpr (!COV) {
-        detOmT = sweep_inverse(Ps, i, j);
-        fs_r = sum_over_j(Ps * xi);                            // f_T, row-distributed
+        detOmT = G.sweep_inverse(Ps);
+        fs_r = G.sum_j(Ps * xi);                            // f_T, row-distributed
     }
     {
         double part = COV ? -sum_xw : (diag ? q0_part - xi * fs_r : 0.0) - sum_xw;
-        const double qd = sum_over_i(sum_over_j(part));
+        const double qd = G.sum_i(G.sum_j(part));
         const double LD = COV ? detprod.log_value()
                               : log(detOmT) + log(detP0) + (double)T * log(detQ) + detprod.log_value();   // sum_ldz = -log prod
         const double ll = -0.5 * (nsum * kLog2PiW + ldsum + LD + ssum + qd);
@@ -375,7 +433,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
         if (j == 0) a.f_smooth[((size_t)b * T + trow) * r + i] = i < rl ? f_row : 0.0;
         if (a.P_smooth && j <= i) a.P_smooth[((size_t)b * T + trow) * npr + i * (i + 1) / 2 + j] = inL ? P : (i == j ? 1.0 : 0.0);
     };
-    double fs_c = transposed(fs_r, i, j);
+    double fs_c = G.transposed(fs_r);
     double Jt = 0.0;                                           // J_ji
     const bool em = a.S11 != nullptr;
     const double termT = fma(fs_r, fs_c, Ps);                  // E[f_T f_T'] element
@@ -394,8 +452,8 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
             wnc[s] = wtab[(size_t)t * R + j];                  // column-distributed
             const int ee = eidxS[t];
             en[s] = ee;
-            zn[s] = ZJ[((size_t)ee * 2 + 0) * 64 + lane];
-            jn[s] = ZJ[((size_t)ee * 2 + 1) * 64 + lane];
+            zn[s] = ZJ[((size_t)ee * 2 + 0) * RR + lane];
+            jn[s] = ZJ[((size_t)ee * 2 + 1) * RR + lane];
         }
     };
     double pb[CHW + 1], fb[CHW + 1];                           // smoothed moments to emit: rows c CHW - 1 + s, and T - 1 first
@@ -413,7 +471,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
 #ifdef DFM_WAVE_PROF
     t_bwd_start = __builtin_amdgcn_s_memtime();
 #endif
-    wave_lds_sync();                                           // eidxS complete
+    G.sync();                                           // eidxS complete
     int e_prev = -1;                                           // entry staged in LJ
     bool need_b = true;
     issue_bwd(nchunks - 1);
@@ -438,30 +496,30 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
                 if (changed) {
                     Z = zc[s]; Jr = jc[s];
                     e_prev = ec[s];
-                    wave_lds_sync();
+                    G.sync();
                     LJ[lane] = Jr;
-                    wave_lds_sync();
-                    Jt = LJ[8 * j + i];
+                    G.sync();
+                    Jt = LJ[R * j + i];
                 }
                 TOCK(p_stage);
                 TICK(p_bcov);
                 if (need_b || changed) {  // wave-uniform
-                    wave_lds_sync();
+                    G.sync();
                     L0[lane] = Ps;
-                    wave_lds_sync();
-                    U = dot_rows(L0, LJ, i, j);                // U = P_s J' = Cov(f_{t+1}, f_t | X)
-                    L1[8 * j + i] = U;                         // U' rows = U columns
-                    wave_lds_sync();
-                    const double pn_ = Z + dot_rows(LJ, L1, i, j);   // Z + J U
+                    G.sync();
+                    U = dot_rows<R>(L0, LJ, i, j);                // U = P_s J' = Cov(f_{t+1}, f_t | X)
+                    L1[R * j + i] = U;                         // U' rows = U columns
+                    G.sync();
+                    const double pn_ = Z + dot_rows<R>(LJ, L1, i, j);   // Z + J U
                     const bool same = close_enough(pn_, Ps);
                     Ps = pn_;
-                    need_b = !__all(same);
+                    need_b = !G.all_true(same);
                 }
                 TOCK(p_bcov);
                 TICK(p_bmean);
                 // f_t = w_t + J f_{t+1} in both distributions, by two independent reductions (no transpose on the chain)
-                const double fnew = wc[s] + sum_over_j(Jr * fs_c);
-                const double fnew_c = wcc[s] + sum_over_i(Jt * fs_r);
+                const double fnew = wc[s] + G.sum_j(Jr * fs_c);
+                const double fnew_c = wcc[s] + G.sum_i(Jt * fs_r);
                 const double fprev_r = fs_r;
                 fs_r = fnew;
                 fs_c = fnew_c;
@@ -477,7 +535,7 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
     flush_bwd();
     // now fs / Ps are the smoothed moments of the initial state f_0
     if (em) {
-        const size_t o = (size_t)b * 64 + lane;
+        const size_t o = (size_t)b * RR + lane;
         const double S00 = S11 - termT + fma(fs_r, fs_c, Ps);
         // a.rl > 0: the loadings step sees the first Rc components only -- S11 / S11^-1 go out in its [Rc][Rc] layout
         const bool narrow = a.rl > 0;
@@ -489,30 +547,30 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
         if (a.A_out) {
             // A = S10 S00^-1 ;  Q = sym(S11 - A S10') / T ;  mu0 = f_0|T ;  P0 = sym(P_0|T) ;  S11^-1
             double inv = S00;
-            (void)sweep_inverse(inv, i, j);
-            wave_lds_sync();
+            (void)G.sweep_inverse(inv);
+            G.sync();
             L0[lane] = S10;
             L1[lane] = inv;                                    // symmetric: rows = columns
-            wave_lds_sync();
-            const double An = dot_rows(L0, L1, i, j);
-            wave_lds_sync();
+            G.sync();
+            const double An = dot_rows<R>(L0, L1, i, j);
+            G.sync();
             L1[lane] = An;
-            wave_lds_sync();
-            double Qn = (S11 - dot_rows(L1, L0, i, j)) / (double)T;   // (A S10')_ij = row i of A . row j of S10
-            Qn = 0.5 * (Qn + transposed(Qn, i, j));
+            G.sync();
+            double Qn = (S11 - dot_rows<R>(L1, L0, i, j)) / (double)T;   // (A S10')_ij = row i of A . row j of S10
+            Qn = 0.5 * (Qn + G.transposed(Qn));
             double Aout = An;
             if (a.kdim > 0) {   // companion state: only [A_1 .. A_p] and the innovation covariance of f_t are free
                 const int kd = a.kdim;
                 if (i >= rl && i < kd) Aout = (j == i - rl) ? 1.0 : 0.0;
                 if ((i >= rl && i < kd) || (j >= rl && j < kd)) Qn = 0.0;
             }
-            const double P0n = 0.5 * (Ps + transposed(Ps, i, j));
+            const double P0n = 0.5 * (Ps + G.transposed(Ps));
             double inv2 = S11;
             if (narrow) {
                 if (!inL) inv2 = (i == j) ? (double)T : 0.0;
                 if (inC) a.S11[(size_t)b * Rc * Rc + i * Rc + j] = inv2;
             }
-            (void)sweep_inverse(inv2, i, j);
+            (void)G.sweep_inverse(inv2);
             if (narrow) { if (inC) a.S11inv[(size_t)b * Rc * Rc + i * Rc + j] = inv2; }
             else a.S11inv[o] = inv2;
             if (em_apply) {
@@ -526,18 +584,28 @@ __global__ __launch_bounds__(64) void recursion_wave_kernel(RecursionArgs a) {
 }
 
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
-    // Batch size: a wave per replicate costs ~0.85 ms per 1024 replicates (C2 shape) and scales with B; the lane-group
-    // kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~3000.
+    if (a.T > 12000) return false;                               // LDS: 4 bytes per period
+    if (a.rl != 0 && a.Rc == 0) return false;
+    // Rp = 16 (state 9..16 wide: r = 4 factors with VAR(4) dynamics): a 256-thread workgroup per replicate
+    if (Rpad == 16) return true;
+    // Rp = 8, batch size: a wave per replicate costs ~0.85 ms per 1024 replicates (C2 shape) and scales with B; the
+    // lane-group kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~3000.
     if (a.Rc == 0 && a.B > 3072) return false;
-    return Rpad == 8 && (a.rl == 0 || a.Rc > 0) && a.T <= 15000;   // LDS: 4 bytes per period
+    return Rpad == 8;
 }
 
-hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s) {
-    const size_t lds = 4 * 64 * sizeof(double) + (size_t)a.T * sizeof(int);
+template <int R>
+static hipError_t launch_wave(const RecursionArgs& a, hipStream_t s) {
+    const size_t extra = R == 16 ? (2 * R + 2 * 4 * R + 2 * R * R) : 0;
+    const size_t lds = (4 * R * R + extra) * sizeof(double) + (size_t)a.T * sizeof(int);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
-    if (a.cov) hipLaunchKernelGGL(recursion_wave_kernel<true>, dim3(a.B), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL(recursion_wave_kernel<false>, dim3(a.B), dim3(64), lds, s, a);
+    if (a.cov) hipLaunchKernelGGL((recursion_wave_kernel<R, true>), dim3(a.B), dim3(R * R), lds, s, a);
+    else hipLaunchKernelGGL((recursion_wave_kernel<R, false>), dim3(a.B), dim3(R * R), lds, s, a);
     return hipGetLastError();
+}
+
+hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad) {
+    return Rpad == 16 ? launch_wave<16>(a, s) : launch_wave<8>(a, s);
 }
 
 }  // namespace dfm

@@ -5,7 +5,7 @@ from oracle import varp_oracle as vo
 from dynamic_factor_models_amd import DfmContext
 ctx = DfmContext(); dev = torch.device("cuda", ctx.device)
 KEYS = ("Lam", "R", "Avar", "Q", "mu0", "P0")
-for (Bv, Nv, Tv, rv, pv, miss) in [(1024, 139, 222, 4, 4, 0.0), (1024, 139, 222, 4, 4, 0.1), (1024, 139, 222, 4, 2, 0.1)]:
+for (Bv, Nv, Tv, rv, pv, miss) in [(256, 139, 222, 4, 4, 0.1), (512, 139, 222, 4, 4, 0.1), (1024, 139, 222, 4, 4, 0.1), (2048, 139, 222, 4, 4, 0.1), (1024, 139, 222, 4, 4, 0.0)]:
     xs, qs = [], []
     for b in range(8):
         x = vo.synth_varp(b, Nv, Tv, rv, pv, missing=miss)
