@@ -86,3 +86,45 @@ def test_estimate_parametric_with_the_models_factor_lags():
     np.testing.assert_allclose(var.M[:r], m.em_params["Avar"], rtol=1e-12)
     np.testing.assert_allclose(var.M[r:, :-r], np.eye(r * (p - 1)))
     np.testing.assert_allclose(var.seps, m.em_params["Q"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("lags", [1, 4])
+def test_config1_stock_watson_panel_pca_plus_10_em_iterations(lags):
+    """BASELINE configs[0]: the Stock-Watson panel, r = 4, PCA start + 10 EM iterations through estimate(m, Parametric())
+    -- unbalanced real data (the :All window: 222 periods, 139 included series) -- against the oracle pipeline, with
+    VAR(1) factor dynamics and with the model's own n_factorlag = 4 (companion state 16)."""
+    import os
+    from dynamic_factor_models_amd import api
+    from oracle import varp_oracle as vo
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sw_panel.npz"))
+    r, init, last = 4, 3, 224
+    m = api.DFMModel(d["bpdata"], d["inclcode"], 20, 40, init, last, 0, r, 1e-8, 4, 4)
+    path = api.estimate(m, api.Parametric(), max_em_iter=10, tol_em=0.0, factor_lags=lags)
+
+    incl = d["inclcode"] == 1
+    z, sd = api.standardize_data(d["bpdata"][init - 1:last][:, incl])
+    enough = (~np.isnan(z)).sum(axis=0) >= 20
+    z = z[:, enough]
+    xbal, bal = api.drop_missing_col(z)
+    q0, F0 = vo.varp_init(xbal, r, lags)
+    N = z.shape[1]
+    Lam = np.empty((N, r)); R = np.empty(N)
+    Lam[bal] = q0["Lam"]; R[bal] = q0["R"]
+    for i in np.nonzero(~bal)[0]:
+        ok = ~np.isnan(z[:, i])
+        b = np.linalg.lstsq(F0[ok], z[ok, i], rcond=None)[0]
+        e = z[ok, i] - F0[ok] @ b
+        Lam[i] = b; R[i] = e @ e / ok.sum()
+    if lags == 1:
+        p0, _ = ko.pca_init(xbal, r)
+        start = dict(Lam=Lam, R=R, A=p0["A"], Q=p0["Q"], mu0=p0["mu0"], P0=p0["P0"])
+        qe, pathe, out = ko.em(z, start, max_iter=10, tol=0.0)
+        fo = out["f_smooth"]
+    else:
+        start = dict(q0); start["Lam"] = Lam; start["R"] = R
+        qe, pathe, out = vo.em_varp(z, start, lags, 10)
+        fo = out["f_smooth"][:, :r]
+    assert m.em_iters == 10 and np.all(np.diff(pathe) > 0)
+    np.testing.assert_allclose(path, pathe, rtol=1e-6)                     # north_star: 1e-6 relative
+    f = m.factor[init - 1:last]
+    assert np.abs(f - fo).max() <= 1e-6 * np.abs(fo).max()
