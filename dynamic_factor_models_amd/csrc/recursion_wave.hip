@@ -65,7 +65,7 @@ struct LogProd {
 template <int R>
 struct Grid {
     double* prow;   // [2][R]      pivot row of a sweep            (R = 16)
-    double* red;    // [2][4][R]   per-wave column partial sums    (R = 16)
+    double* red;    // [2][R][NW]  per-wave column partial sums    (R >= 16; NW = R R / 64 waves)
     double* tt;     // [2][R][R]   transposes                      (R = 16)
     int pr = 0, pt = 0;
     int l, i, j;
@@ -81,23 +81,37 @@ struct Grid {
         v += xor_lane<1>(v);
         v += xor_lane<2>(v);
         v += xor_lane<4>(v);
-        if constexpr (R == 16) v += xor_lane<8>(v);
+        if constexpr (R >= 16) v += xor_lane<8>(v);
+        if constexpr (R == 32) {       // a row is two DPP rows
+            double a = v, b = v;
+            swap_rows16(a, b);
+            v = a + b;
+        }
         return v;
     }
     // over the R row groups: threads with the same j
     __device__ __forceinline__ double sum_i(double v) {
         if constexpr (R == 8) v += xor_lane<8>(v);
-        double a = v, b = v;
-        swap_rows16(a, b);        // a = rows {0,0,2,2}, b = rows {1,1,3,3} of v
-        v = a + b;
-        a = v; b = v;
-        swap_halves32(a, b);      // a = low half twice, b = high half twice
-        v = a + b;
-        if constexpr (R == 16) {
-            double* rb = red + (pr ^= 1) * 4 * R;
-            if ((l & 63) < R) rb[(l >> 6) * R + j] = v;
+        if constexpr (R <= 16) {
+            double a = v, b = v;
+            swap_rows16(a, b);        // a = rows {0,0,2,2}, b = rows {1,1,3,3} of v
+            v = a + b;
+        }
+        {
+            double a = v, b = v;
+            swap_halves32(a, b);      // a = low half twice, b = high half twice
+            v = a + b;
+        }
+        if constexpr (R >= 16) {      // one partial per wave and column -> LDS, one barrier, everybody adds them up
+            constexpr int NW = R * R / 64;
+            double* rb = red + (pr ^= 1) * NW * R;
+            if ((l & 63) < R) rb[j * NW + (l >> 6)] = v;
             __syncthreads();
-            v = (rb[j] + rb[R + j]) + (rb[2 * R + j] + rb[3 * R + j]);
+            const double2* r2 = reinterpret_cast<const double2*>(rb + j * NW);
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW / 2; ++q) { const double2 u = r2[q]; s0 += u.x; s1 += u.y; }
+            v = s0 + s1;
         }
         return v;
     }
@@ -146,7 +160,7 @@ __device__ __forceinline__ double dot_rows(const double* xs, const double* ys, i
     const double2* a = reinterpret_cast<const double2*>(xs + R * i);
     const double2* b = reinterpret_cast<const double2*>(ys + R * j);
     double s0 = 0.0, s1 = 0.0;
-#pragma unroll
+#pragma unroll (R >= 32 ? 4 : R / 2)   // R = 32: 64 operands in flight would not fit the 128-VGPR budget of a 16-wave workgroup
     for (int q = 0; q < R / 2; ++q) {
         const double2 u = a[q], v = b[q];
         s0 = fma(u.x, v.x, s0);
@@ -164,9 +178,9 @@ template <int R, bool COV>
 #endif
 // R = 16: a workgroup is one wave on each SIMD of a CU and a chain of barrier-separated exchanges -- latency-bound; the
 // register budget is capped so that several workgroups share a CU and fill each other's waits.
-__global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursion_wave_kernel(RecursionArgs a) {
+__global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursion_wave_kernel(RecursionArgs a) {   // R = 32: 16 waves, 128 VGPRs
     constexpr int RR = R * R;
-    constexpr int CHW = R == 16 ? 4 : kChunk8;
+    constexpr int CHW = R == 32 ? 2 : R == 16 ? 4 : kChunk8;
     extern __shared__ __attribute__((aligned(16))) double wsm[];
     double* LK = wsm;            // K = Q^-1 A, rows (constant; COV: A rows)
     double* L0 = LK + RR;
@@ -174,9 +188,9 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
     double* LJ = L1 + RR;        // J rows (backward sweep)
     Grid<R> G;
     G.prow = LJ + RR;            // (R = 8: unused, zero bytes reserved)
-    G.red = G.prow + (R == 16 ? 2 * R : 0);
-    G.tt = G.red + (R == 16 ? 2 * 4 * R : 0);
-    int* eidxS = reinterpret_cast<int*>(G.tt + (R == 16 ? 2 * RR : 0));   // [T] covariance-table entry of forward step t
+    G.red = G.prow + (R >= 16 ? 2 * R : 0);
+    G.tt = G.red + (R >= 16 ? 2 * (RR / 64) * R : 0);
+    int* eidxS = reinterpret_cast<int*>(G.tt + (R >= 16 ? 2 * RR : 0));   // [T] covariance-table entry of forward step t
     const int lane = threadIdx.x;
     const int i = lane / R, j = lane % R;
     G.l = lane; G.i = i; G.j = j;
@@ -588,6 +602,8 @@ bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
     if (a.rl != 0 && a.Rc == 0) return false;
     // Rp = 16 (state 9..16 wide: r = 4 factors with VAR(4) dynamics): a 256-thread workgroup per replicate
     if (Rpad == 16) return true;
+    // Rp = 32 (17..32: r = 8 factors with VAR(4) dynamics, AR(4) idiosyncratic terms at r = 4): 1024 threads per replicate
+    if (Rpad == 32) return a.T <= 1200;
     // Rp = 8, batch size: a wave per replicate costs ~0.85 ms per 1024 replicates (C2 shape) and scales with B; the
     // lane-group kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~3000.
     if (a.Rc == 0 && a.B > 3072) return false;
@@ -596,7 +612,7 @@ bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
 
 template <int R>
 static hipError_t launch_wave(const RecursionArgs& a, hipStream_t s) {
-    const size_t extra = R == 16 ? (2 * R + 2 * 4 * R + 2 * R * R) : 0;
+    const size_t extra = R >= 16 ? (2 * R + 2 * (R * R / 64) * R + 2 * R * R) : 0;
     const size_t lds = (4 * R * R + extra) * sizeof(double) + (size_t)a.T * sizeof(int);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (a.cov) hipLaunchKernelGGL((recursion_wave_kernel<R, true>), dim3(a.B), dim3(R * R), lds, s, a);
@@ -605,7 +621,7 @@ static hipError_t launch_wave(const RecursionArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad) {
-    return Rpad == 16 ? launch_wave<16>(a, s) : launch_wave<8>(a, s);
+    return Rpad == 32 ? launch_wave<32>(a, s) : Rpad == 16 ? launch_wave<16>(a, s) : launch_wave<8>(a, s);
 }
 
 }  // namespace dfm
