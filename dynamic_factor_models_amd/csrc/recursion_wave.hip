@@ -64,7 +64,7 @@ struct LogProd {
 // with ONE s_barrier per exchange (buffers alternate, so the next exchange's writes cannot overtake this one's reads).
 template <int R>
 struct Grid {
-    double* prow;   // [2][R]      pivot row of a sweep            (R = 16)
+    double* prow;   // [2][2][R]   the two pivot rows of a block sweep  (R >= 16)
     double* red;    // [2][R][NW]  per-wave column partial sums    (R >= 16; NW = R R / 64 waves)
     double* tt;     // [2][R][R]   transposes                      (R = 16)
     int pr = 0, pt = 0;
@@ -125,29 +125,45 @@ struct Grid {
         }
     }
     // In-place inverse of a symmetric positive definite R x R matrix (element per thread) by the symmetric sweep
-    // operator (Beaton): after sweeping every pivot the register holds -M^-1.  Returns det M = product of the pivots.
+    // operator (Beaton) with 2 x 2 BLOCK pivots: the sweeps are one dependent chain of cross-thread exchanges, and a
+    // block pivot {k, k+1} needs one exchange (both pivot rows at once) where two scalar pivots need two.  For rows /
+    // columns outside the block  B_ij = A_ij - a_i' D^-1 a_j  (a_i = A[i][k], A[i][k+1]; D the pivot block), inside
+    // B_Kj = D^-1 A_Kj and B_KK = -D^-1; after all blocks the register holds -M^-1.  Returns det M = product of det D.
     __device__ __forceinline__ double sweep_inverse(double& m) {
         double det = 1.0;
-#pragma unroll (R == 8 ? 8 : 1)       // R = 16: a real loop (16 unrolled copies in every unrolled period: 36 k instructions)
-        for (int k = 0; k < R; ++k) {
-            double piv, qj, qi;
+#pragma unroll (R == 8 ? 4 : 1)       // R >= 16: a real loop (code size)
+        for (int k = 0; k < R; k += 2) {
+            double qj0, qj1, qi0, qi1, p00, p01, p11;
             if constexpr (R == 8) {
-                piv = uniform_lane(m, 9 * k);
-                qj = __shfl(m, 8 * k + j, 64);
-                qi = __shfl(m, 8 * k + i, 64);
+                qj0 = __shfl(m, 8 * k + j, 64);
+                qj1 = __shfl(m, 8 * k + 8 + j, 64);
+                qi0 = __shfl(m, 8 * k + i, 64);
+                qi1 = __shfl(m, 8 * k + 8 + i, 64);
+                p00 = uniform_lane(m, 9 * k);
+                p01 = uniform_lane(m, 9 * k + 1);
+                p11 = uniform_lane(m, 9 * k + 9);
             } else {
-                double* pb = prow + (k & 1) * R;
+                double* pb = prow + ((k >> 1) & 1) * 2 * R;
                 if (i == k) pb[j] = m;
+                if (i == k + 1) pb[R + j] = m;
                 __syncthreads();
-                piv = pb[k]; qj = pb[j]; qi = pb[i];
+                qj0 = pb[j]; qj1 = pb[R + j]; qi0 = pb[i]; qi1 = pb[R + i];
+                p00 = pb[k]; p01 = pb[k + 1]; p11 = pb[R + k + 1];
             }
-            const double d = fast_rcp(piv);
-            det *= piv;
-            const double t = qi * d;
-            double nm = fma(-t, qj, m);
-            nm = (i == k) ? qj * d : nm;
-            nm = (j == k) ? t : nm;
-            nm = (i == k && j == k) ? -d : nm;
+            const double dd = fma(p00, p11, -p01 * p01);
+            const double rd = fast_rcp(dd);
+            det *= dd;
+            const double e00 = p11 * rd, e01 = -p01 * rd, e11 = p00 * rd;
+            const double tj0 = fma(e00, qj0, e01 * qj1), tj1 = fma(e01, qj0, e11 * qj1);
+            const double ti0 = fma(e00, qi0, e01 * qi1), ti1 = fma(e01, qi0, e11 * qi1);
+            double nm = m - fma(qi0, tj0, qi1 * tj1);
+            const bool ik0 = i == k, ik1 = i == k + 1, jk0 = j == k, jk1 = j == k + 1;
+            nm = ik0 ? tj0 : nm;
+            nm = ik1 ? tj1 : nm;
+            nm = jk0 ? ti0 : nm;
+            nm = jk1 ? ti1 : nm;
+            const double eab = ik0 ? (jk0 ? e00 : e01) : (jk0 ? e01 : e11);
+            nm = ((ik0 || ik1) && (jk0 || jk1)) ? -eab : nm;
             m = nm;
         }
         m = -m;
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
     double* LJ = L1 + RR;        // J rows (backward sweep)
     Grid<R> G;
     G.prow = LJ + RR;            // (R = 8: unused, zero bytes reserved)
-    G.red = G.prow + (R >= 16 ? 2 * R : 0);
+    G.red = G.prow + (R >= 16 ? 4 * R : 0);
     G.tt = G.red + (R >= 16 ? 2 * (RR / 64) * R : 0);
     int* eidxS = reinterpret_cast<int*>(G.tt + (R >= 16 ? 2 * RR : 0));   // [T] covariance-table entry of forward step t
     const int lane = threadIdx.x;
@@ -612,7 +628,7 @@ bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
 
 template <int R>
 static hipError_t launch_wave(const RecursionArgs& a, hipStream_t s) {
-    const size_t extra = R >= 16 ? (2 * R + 2 * (R * R / 64) * R + 2 * R * R) : 0;
+    const size_t extra = R >= 16 ? (4 * R + 2 * (R * R / 64) * R + 2 * R * R) : 0;
     const size_t lds = (4 * R * R + extra) * sizeof(double) + (size_t)a.T * sizeof(int);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     if (a.cov) hipLaunchKernelGGL((recursion_wave_kernel<R, true>), dim3(a.B), dim3(R * R), lds, s, a);
