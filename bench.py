@@ -195,6 +195,9 @@ def main():
                         kernels_ms={k: round(v, 4) for k, v in avg.items()},
                         note=("collapse_mfma_kernel = streaming collapse + the covariance workgroups and the P_smooth fill at the "
                               "front of the same grid: algorithmic bytes = panel + Lam + R read, P_smooth written" if fused else
+                              "sequential path (panel with missing cells): collapse_kernel streams the panel once, the recursion "
+                              "kernel is a chain of T dependent r x r inversions per replicate -- latency-bound, not HBM-bound"
+                              if "recursion_kernel" in avg else
                               "cov_kernel and pfill_kernel run beside the streaming collapse (forked stream); their "
                               "durations overlap it and each other's memory traffic"),
                         whole_pass=dict(bytes_per_pass=b_in + b_out,
