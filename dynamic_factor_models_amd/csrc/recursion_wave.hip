@@ -59,6 +59,12 @@ struct LogProd {
     __device__ __forceinline__ double log_value() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
 
+// LDS tiles hold R x R matrices with rows R + 2 doubles apart: the 16 lanes of one pass of a ds_read_b128 then read 16
+// different rows from 16 disjoint bank groups (at a stride of R doubles they collide 2-way at R = 8, 8-way at 16, 16-way
+// at 32), and so do the transposed 8-byte stores.
+template <int R>
+constexpr int kTileStride = R + 2;
+
 // Cross-thread plumbing of one replicate's R x R element grid (thread l = R i + j).  R = 8: one wave, everything stays in
 // registers / the LDS crossbar.  R = 16: four waves of a workgroup; what crosses waves goes through small LDS buffers
 // with ONE s_barrier per exchange (buffers alternate, so the next exchange's writes cannot overtake this one's reads).
@@ -118,10 +124,10 @@ struct Grid {
     __device__ __forceinline__ double transposed(double v) {
         if constexpr (R == 8) return __shfl(v, 8 * j + i, 64);
         else {
-            double* tb = tt + (pt ^= 1) * R * R;
-            tb[R * j + i] = v;
+            double* tb = tt + (pt ^= 1) * R * kTileStride<R>;
+            tb[kTileStride<R> * j + i] = v;
             __syncthreads();
-            return tb[l];
+            return tb[kTileStride<R> * i + j];
         }
     }
     // In-place inverse of a symmetric positive definite R x R matrix (element per thread) by the symmetric sweep
@@ -173,8 +179,8 @@ struct Grid {
 // sum_k X[i][k] Y[j][k], X and Y staged row-major in LDS
 template <int R>
 __device__ __forceinline__ double dot_rows(const double* xs, const double* ys, int i, int j) {
-    const double2* a = reinterpret_cast<const double2*>(xs + R * i);
-    const double2* b = reinterpret_cast<const double2*>(ys + R * j);
+    const double2* a = reinterpret_cast<const double2*>(xs + kTileStride<R> * i);
+    const double2* b = reinterpret_cast<const double2*>(ys + kTileStride<R> * j);
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll (R >= 32 ? 4 : R / 2)   // R = 32: 64 operands in flight would not fit the 128-VGPR budget of a 16-wave workgroup
     for (int q = 0; q < R / 2; ++q) {
@@ -199,14 +205,15 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
     constexpr int CHW = R == 32 ? 2 : R == 16 ? 4 : kChunk8;
     extern __shared__ __attribute__((aligned(16))) double wsm[];
     double* LK = wsm;            // K = Q^-1 A, rows (constant; COV: A rows)
-    double* L0 = LK + RR;
-    double* L1 = L0 + RR;
-    double* LJ = L1 + RR;        // J rows (backward sweep)
+    constexpr int TS = kTileStride<R>, RT = R * TS;           // tile row stride, tile size (doubles)
+    double* L0 = LK + RT;
+    double* L1 = L0 + RT;
+    double* LJ = L1 + RT;        // J rows (backward sweep)
     Grid<R> G;
-    G.prow = LJ + RR;            // (R = 8: unused, zero bytes reserved)
+    G.prow = LJ + RT;            // (R = 8: unused, zero bytes reserved)
     G.red = G.prow + (R >= 16 ? 4 * R : 0);
     G.tt = G.red + (R >= 16 ? 2 * (RR / 64) * R : 0);
-    int* eidxS = reinterpret_cast<int*>(G.tt + (R >= 16 ? 2 * RR : 0));   // [T] covariance-table entry of forward step t
+    int* eidxS = reinterpret_cast<int*>(G.tt + (R >= 16 ? 2 * RT : 0));   // [T] covariance-table entry of forward step t
     const int lane = threadIdx.x;
     const int i = lane / R, j = lane % R;
     G.l = lane; G.i = i; G.j = j;
@@ -244,15 +251,15 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
         detQ = G.sweep_inverse(Qi);
         detP0 = G.sweep_inverse(Omf);                    // Om_f,0 = P0^-1
         // K = Qi A:  K_ij = sum_k Qi[i][k] A[k][j] = row i of Qi . row j of A'
-        L0[lane] = Qi;
-        L1[R * j + i] = Ael;                                 // A'
+        L0[TS * i + j] = Qi;
+        L1[TS * j + i] = Ael;                                 // A'
         G.sync();
         K = dot_rows<R>(L0, L1, i, j);
         G.sync();
-        LK[lane] = K;
-        L0[R * j + i] = K;                                   // K' rows = K columns
+        LK[TS * i + j] = K;
+        L0[TS * j + i] = K;                                   // K' rows = K columns
         G.sync();
-        KT = L0[lane];                                       // K_ji
+        KT = L0[TS * i + j];                                       // K_ji
         // Phi = K' A = A' Qi A:  Phi_ij = sum_k K[k][i] A[k][j] = row i of K' . row j of A'
         Phi = dot_rows<R>(L0, L1, i, j);
         G.sync();
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
         q0_part = diag ? mu0c * xi : 0.0;
         xi = G.transposed(xi);                           // column-distributed from here on
     } else {
-        LK[lane] = Ael;
+        LK[TS * i + j] = Ael;
         G.sync();
     }
     (void)K;
@@ -329,22 +336,22 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
                     const double Crow = full ? Cf : cc[s];
                     if (need_cov || !full) {  // wave-uniform; need_cov == false: the last computed step had a full row and reproduced its P_f
                         G.sync();
-                        L0[lane] = Omf;                            // P_f rows (symmetric)
+                        L0[TS * i + j] = Omf;                            // P_f rows (symmetric)
                         G.sync();
                         const double AP = dot_rows<R>(LK, L0, i, j);  // A P_f
                         G.sync();
-                        L1[lane] = AP;
-                        L0[R * j + i] = AP;                        // (A P_f)' rows = its columns
+                        L1[TS * i + j] = AP;
+                        L0[TS * j + i] = AP;                        // (A P_f)' rows = its columns
                         G.sync();
                         Omp = dot_rows<R>(L1, LK, i, j) + Qi;         // P_p = A P_f A' + Q
                         detP_cur = G.sweep_inverse(Omp);       // Om_p = P_p^-1
                         G.sync();
-                        LJ[lane] = Omp;
+                        LJ[TS * i + j] = Omp;
                         G.sync();
                         Gm = dot_rows<R>(LJ, L0, i, j);               // G = Om_p A P_f
                         Jr = dot_rows<R>(LJ, L0, j, i);               // J = G' = P_f A' Om_p
                         G.sync();
-                        L1[lane] = Jr;
+                        L1[TS * i + j] = Jr;
                         G.sync();
                         Z = Omf - dot_rows<R>(L1, L0, i, j);          // Z = P_f - J A P_f
                         double Pn = Omp + Crow;
@@ -380,10 +387,10 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
                     TOCK(p_inv);
                     TICK(p_mm);
                     G.sync();
-                    L0[lane] = Z;
+                    L0[TS * i + j] = Z;
                     G.sync();
                     Jr = dot_rows<R>(L0, LK, i, j);               // J = Z K'
-                    L1[R * j + i] = Jr;                        // J' rows = J columns
+                    L1[TS * j + i] = Jr;                        // J' rows = J columns
                     G.sync();
                     Omp = Qi - dot_rows<R>(LK, L1, i, j);         // Om_p = Qi - K J
                     ++e;
@@ -527,18 +534,18 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
                     Z = zc[s]; Jr = jc[s];
                     e_prev = ec[s];
                     G.sync();
-                    LJ[lane] = Jr;
+                    LJ[TS * i + j] = Jr;
                     G.sync();
-                    Jt = LJ[R * j + i];
+                    Jt = LJ[TS * j + i];
                 }
                 TOCK(p_stage);
                 TICK(p_bcov);
                 if (need_b || changed) {  // wave-uniform
                     G.sync();
-                    L0[lane] = Ps;
+                    L0[TS * i + j] = Ps;
                     G.sync();
                     U = dot_rows<R>(L0, LJ, i, j);                // U = P_s J' = Cov(f_{t+1}, f_t | X)
-                    L1[R * j + i] = U;                         // U' rows = U columns
+                    L1[TS * j + i] = U;                         // U' rows = U columns
                     G.sync();
                     const double pn_ = Z + dot_rows<R>(LJ, L1, i, j);   // Z + J U
                     const bool same = close_enough(pn_, Ps);
@@ -579,12 +586,12 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
             double inv = S00;
             (void)G.sweep_inverse(inv);
             G.sync();
-            L0[lane] = S10;
-            L1[lane] = inv;                                    // symmetric: rows = columns
+            L0[TS * i + j] = S10;
+            L1[TS * i + j] = inv;                                    // symmetric: rows = columns
             G.sync();
             const double An = dot_rows<R>(L0, L1, i, j);
             G.sync();
-            L1[lane] = An;
+            L1[TS * i + j] = An;
             G.sync();
             double Qn = (S11 - dot_rows<R>(L1, L0, i, j)) / (double)T;   // (A S10')_ij = row i of A . row j of S10
             Qn = 0.5 * (Qn + G.transposed(Qn));
@@ -613,27 +620,43 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
     }
 }
 
+template <int R>
+static size_t wave_lds_bytes(int T) {
+    constexpr size_t RT = (size_t)R * kTileStride<R>;
+    const size_t extra = R >= 16 ? (4 * R + 2 * (R * R / 64) * R + 2 * RT) : 0;
+    return (4 * RT + extra) * sizeof(double) + (size_t)T * sizeof(int);
+}
+
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
-    if (a.T > 12000) return false;                               // LDS: 4 bytes per period
     if (a.rl != 0 && a.Rc == 0) return false;
+    constexpr size_t cap = 150 * 1024;                            // LDS: tiles + 4 bytes per period
     // Rp = 16 (state 9..16 wide: r = 4 factors with VAR(4) dynamics): a 256-thread workgroup per replicate
-    if (Rpad == 16) return true;
+    if (Rpad == 16) return wave_lds_bytes<16>(a.T) <= cap;
     // Rp = 32 (17..32: r = 8 factors with VAR(4) dynamics, AR(4) idiosyncratic terms at r = 4): 1024 threads per replicate
-    if (Rpad == 32) return a.T <= 1200;
+    if (Rpad == 32) return wave_lds_bytes<32>(a.T) <= cap;
     // Rp = 8, batch size: a wave per replicate costs ~0.85 ms per 1024 replicates (C2 shape) and scales with B; the
     // lane-group kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~3000.
     if (a.Rc == 0 && a.B > 3072) return false;
-    return Rpad == 8;
+    return Rpad == 8 && wave_lds_bytes<8>(a.T) <= 60 * 1024;
+}
+
+template <int R, bool COV>
+static hipError_t launch_wave_cov(const RecursionArgs& a, hipStream_t s) {
+    const size_t lds = wave_lds_bytes<R>(a.T);
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&recursion_wave_kernel<R, COV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((recursion_wave_kernel<R, COV>), dim3(a.B), dim3(R * R), lds, s, a);
+    return hipGetLastError();
 }
 
 template <int R>
 static hipError_t launch_wave(const RecursionArgs& a, hipStream_t s) {
-    const size_t extra = R >= 16 ? (4 * R + 2 * (R * R / 64) * R + 2 * R * R) : 0;
-    const size_t lds = (4 * R * R + extra) * sizeof(double) + (size_t)a.T * sizeof(int);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    if (a.cov) hipLaunchKernelGGL((recursion_wave_kernel<R, true>), dim3(a.B), dim3(R * R), lds, s, a);
-    else hipLaunchKernelGGL((recursion_wave_kernel<R, false>), dim3(a.B), dim3(R * R), lds, s, a);
-    return hipGetLastError();
+    return a.cov ? launch_wave_cov<R, true>(a, s) : launch_wave_cov<R, false>(a, s);
 }
 
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad) {
