@@ -124,3 +124,42 @@ def test_lane_group_recursion_kernel_still_matches(r, monkeypatch):
         c.close()
         monkeypatch.delenv("DFM_NO_RECURSION_WAVE")
         DfmContext().close()              # resets the process-wide dispatch default
+
+
+@pytest.mark.parametrize("B,N,T,r,why", [(2, 30, 1300, 6, "long panel on the wave kernel (LDS period index)"),
+                                         (3100, 12, 20, 5, "B > 3072: lane-group kernel at Rp = 8"),
+                                         (1600, 10, 15, 3, "B > 1536: no widening of r <= 4"),
+                                         (2, 24, 40, 20, "Rp = 32 information form on Grid<32>")])
+def test_dispatch_edges_of_the_sequential_path(ctx, B, N, T, r, why):
+    import torch
+    nchk = min(B, 3)
+    reps = [ko.synth_replicate(b % nchk, N, T, r, missing=0.1) for b in range(nchk)]
+    idx = np.arange(B) % nchk
+    x = np.stack([reps[k][0] for k in idx])
+    st = {k: np.stack([reps[q][1][k] for q in idx]) for k in reps[0][1]}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_batch(t(x), *[t(st[k]) for k in ("Lam", "R", "A", "Q", "mu0", "P0")])
+    torch.cuda.synchronize()
+    for b in list(range(nchk)) + [B - 1]:
+        o = ko.kfs_pass(x[b], **reps[idx[b]][1])
+        assert abs(ll[b].item() - o["loglik"]) <= RTOL * abs(o["loglik"]), why
+        assert np.abs(f[b].cpu().numpy() - o["f_smooth"]).max() <= 1e-8 * max(1.0, np.abs(o["f_smooth"]).max()), why
+
+
+def test_companion_state_32_wide_with_large_lds(ctx):
+    """r = 8, VAR(4), T = 700: Grid<32> with more than 64 KB of dynamic LDS (tiles + period index)."""
+    import torch
+    from oracle import varp_oracle as vo
+    B, N, T, r, p = 2, 40, 700, 8, 4
+    keys = ("Lam", "R", "Avar", "Q", "mu0", "P0")
+    xs = [vo.synth_varp(b, N, T, r, p, missing=0.05) for b in range(B)]
+    qs = [vo.varp_init(np.nan_to_num(x), r, p)[0] for x in xs]
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_varp_batch(t(np.stack(xs)), *[t(np.stack([q[k] for q in qs])) for k in keys])
+    torch.cuda.synchronize()
+    for b in range(B):
+        o = vo.kfs_pass_varp(xs[b], p=p, **qs[b])
+        assert abs(ll[b].item() - o["loglik"]) <= 1e-8 * abs(o["loglik"])
+        assert np.abs(f[b].cpu().numpy() - o["f_smooth"][:, :r]).max() <= 1e-7 * np.abs(o["f_smooth"]).max()
