@@ -14,6 +14,7 @@
 //   * 1024 waves instead of 128: every SIMD of the chip walks a replicate.
 // Same inputs, scratch tables (Z_e, J_e row-major, w_t) and outputs as recursion_kernel; same memoisation of repeated
 // covariance steps.  The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
+#include <stdlib.h>
 #include "dfm_kernels.h"
 #include "dfm_smallmat.h"
 
@@ -635,8 +636,9 @@ bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
     // Rp = 32 (17..32: r = 8 factors with VAR(4) dynamics, AR(4) idiosyncratic terms at r = 4): 1024 threads per replicate
     if (Rpad == 32) return wave_lds_bytes<32>(a.T) <= cap;
     // Rp = 8, batch size: a wave per replicate costs ~0.85 ms per 1024 replicates (C2 shape) and scales with B; the
-    // lane-group kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~3000.
-    if (a.Rc == 0 && a.B > 3072) return false;
+    // lane-group kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~4000 (measured: 3.31 vs 3.32 ms at B = 4096; the wave kernel holds one wave per SIMD, 256 VGPRs, and scales linearly).
+    static const int bmax = [] { const char* v = getenv("DFM_WAVE_BMAX"); return v ? atoi(v) : 4096; }();
+    if (a.Rc == 0 && a.B > bmax) return false;
     return Rpad == 8 && wave_lds_bytes<8>(a.T) <= 60 * 1024;
 }
 

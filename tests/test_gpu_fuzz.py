@@ -127,7 +127,7 @@ def test_lane_group_recursion_kernel_still_matches(r, monkeypatch):
 
 
 @pytest.mark.parametrize("B,N,T,r,why", [(2, 30, 1300, 6, "long panel on the wave kernel (LDS period index)"),
-                                         (3100, 12, 20, 5, "B > 3072: lane-group kernel at Rp = 8"),
+                                         (4100, 12, 20, 5, "B > 4096: lane-group kernel at Rp = 8"),
                                          (1600, 10, 15, 3, "B > 1536: no widening of r <= 4"),
                                          (2, 24, 40, 20, "Rp = 32 information form on Grid<32>")])
 def test_dispatch_edges_of_the_sequential_path(ctx, B, N, T, r, why):
