@@ -116,3 +116,18 @@ def test_estimate_rejects_what_the_path_does_not_cover():
     m2 = api.DFMModel(_data(), np.ones(7), 5, 5, 1, 40, 1, 2, 1e-8, 4, 4)
     with pytest.raises(NotImplementedError):
         api.estimate(m2, api.Parametric())
+
+
+def test_parametric_argument_checks_run_before_any_device_work():
+    """factor_lags / state-width validation and the AR-idiosyncratic smoother's preconditions are host logic: they
+    must raise their own errors on a machine without a GPU (not 'no HIP device')."""
+    m = api.DFMModel(np.random.default_rng(1).standard_normal((40, 7)), np.ones(7), 5, 5, 1, 40, 0, 2, 1e-8, 4, 4)
+    with pytest.raises(ValueError, match="factor_lags"):
+        api.estimate(m, api.Parametric(), factor_lags=0)
+    with pytest.raises(ValueError, match="factor_lags"):
+        api.estimate(m, api.Parametric(), factor_lags=17)            # 2 * 17 > 32
+    with pytest.raises(ValueError, match="not estimated|no series"):
+        api.smooth_factors_ar_idio(m)                                 # nothing estimated yet
+    m8 = api.DFMModel(np.random.default_rng(2).standard_normal((60, 12)), np.ones(12), 5, 5, 1, 60, 0, 8, 1e-8, 4, 4)
+    with pytest.raises(ValueError, match="must not exceed 32"):
+        api.smooth_factors_ar_idio(m8)                                # 8 * max(4, 5) = 40

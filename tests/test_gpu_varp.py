@@ -123,3 +123,34 @@ def test_covariance_form_equals_information_form(ctx, miss):
     torch.cuda.synchronize()
     for u, v in zip(a, b):
         _close(v.cpu().numpy(), u.cpu().numpy(), 1e-10, "cov vs info")
+
+
+def test_varp_and_ar_edge_cases(ctx):
+    """Edges the reference's own tests would probe: a period with every cell missing, a single replicate, odd N, the
+    shortest panel an AR(q) model admits (T = q + 2), q = 0."""
+    import torch
+    from oracle import ar_oracle as aro
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    # VAR(2), r = 3, N odd, one period with no observation at all
+    x = vo.synth_varp(5, 27, 40, 3, 2, missing=0.05)
+    q, _ = vo.varp_init(np.nan_to_num(x), 3, 2)
+    x[11, :] = np.nan
+    f, P, ll = ctx.ks_pass_varp_batch(t(x[None]), *[t(q[k][None]) for k in KEYS])
+    o = vo.kfs_pass_varp(x, p=2, **q)
+    assert abs(ll[0].item() - o["loglik"]) <= 1e-9 * abs(o["loglik"])
+    _close(f[0].cpu().numpy(), o["f_smooth"][:, :3], 1e-9, "all-missing period")
+    # AR(3) idiosyncratic terms on T = q + 2 = 5 periods: two quasi-differenced rows
+    rng = np.random.default_rng(3)
+    N, r, qq = 12, 2, 3
+    xs = rng.standard_normal((5, N))
+    k = r * (qq + 1)
+    G0 = rng.standard_normal((k, k))
+    a = dict(Lam=rng.standard_normal((N, r)), sig2=rng.uniform(0.5, 1.5, N), rho=0.2 * rng.uniform(-1, 1, (N, qq)),
+             Avar=0.5 * np.eye(r), Q=np.eye(r), mu0=np.zeros(k), P0=G0 @ G0.T / k + np.eye(k))
+    keys = ("Lam", "sig2", "rho", "Avar", "Q", "mu0", "P0")
+    f, P, ll = ctx.ks_pass_ar_batch(t(xs[None]), *[t(a[kk][None]) for kk in keys])
+    o = aro.kfs_pass_ar(xs, **a)
+    assert f.shape == (1, 2, r)
+    assert abs(ll[0].item() - o["loglik"]) <= 1e-9 * abs(o["loglik"])
+    _close(f[0].cpu().numpy(), o["f_smooth"][:, :r], 1e-9, "shortest AR panel")
