@@ -20,7 +20,7 @@ DFM_F_MAY_HAVE_MISSING = 1
 DFM_F_SINGULAR_Q = 2
 DFM_MAX_R = 32
 ERRORS = {-1: "DFM_E_DIMS", -2: "DFM_E_R_UNSUPPORTED", -3: "DFM_E_NULL", -4: "DFM_E_MISSING",
-          -5: "DFM_E_NUMERIC", -6: "DFM_E_NO_DEVICE"}
+          -5: "DFM_E_NUMERIC", -6: "DFM_E_NO_DEVICE", -7: "DFM_E_COMM"}
 
 _PASS_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 10 + [c_uint]
 _EMSTEP_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 8 + [c_uint]
@@ -50,6 +50,12 @@ SYMBOLS = {
     "dfm_em_step_batch_dev": (c_int, _EMSTEP_ARGS),
     "dfm_em_batch_dev": (c_int, _EM_ARGS),
     "dfm_em_batch": (c_int, _EM_ARGS),
+    "dfm_em_iterate_batch_dev": (c_int, [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, c_int, ctypes.c_double]
+                                 + [c_vp] * 5 + [c_uint]),
+    "dfm_em_batch_multi": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, ctypes.c_double]
+                           + [c_vp] * 4 + [c_uint, c_vp, ctypes.c_char_p, c_int]),
+    "dfm_ks_pass_batch_multi": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 10
+                                + [c_uint, ctypes.c_char_p, c_int]),
     "dfm_ks_pass_varp_batch_dev": (c_int, _VPASS_ARGS),
     "dfm_ks_pass_varp_batch": (c_int, _VPASS_ARGS),
     "dfm_em_varp_batch_dev": (c_int, _VEM_ARGS),

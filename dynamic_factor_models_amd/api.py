@@ -147,16 +147,6 @@ def drop_missing_col(A: np.ndarray):
     return A[:, keep], keep
 
 
-def _ols_rows(y: np.ndarray, X: np.ndarray):
-    """Complete-case least squares of one series on the factors (the reference's `ols_skipmissing(...,
-    Balanced())`, dfm_functions.ipynb:242-252, no intercept): returns (b, residual variance, #rows)."""
-    ok = ~np.isnan(y)
-    Xo, yo = X[ok], y[ok]
-    b = np.linalg.lstsq(Xo, yo, rcond=None)[0]
-    e = yo - Xo @ b
-    return b, float(e @ e) / max(int(ok.sum()), 1), int(ok.sum())
-
-
 # ----------------------------------------------------------------------------- estimate!(m, ::Parametric)
 def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int = 50, tol_em: float = 1e-6,
              factor_lags: Optional[int] = None, ctx=None, lam_constr_f=None, lam_constr_fl=None):
@@ -213,13 +203,24 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
         F0 = F0[0]
         Lam = np.empty((N, r)); R = np.empty(N)
         Lam[balmask] = p0["Lam"][0]; R[balmask] = p0["R"][0]
-        for i in np.nonzero(~balmask)[0]:                               # series with gaps: complete-case OLS on F0
-            Lam[i], R[i], _ = _ols_rows(z[:, i], F0)
+        gap = np.nonzero(~balmask)[0]
+        if gap.size:                                                    # series with gaps: complete-case OLS on F0, no
+            o = ctx.ols_batch_host(F0, z[:, gap], want_resid=False)     # intercept (`ols_skipmissing`, :242-252): dfm_ols_batch
+            Lam[gap] = o["beta"]
+            R[gap] = o["ssr"] / np.maximum(o["nobs"], 1)
         if nlag == 1:
             start = dict(Lam=Lam[None], R=R[None], A=p0["A"], Q=p0["Q"], mu0=p0["mu0"], P0=p0["P0"])
-            params, path, iters, f, P = ctx.em_batch_host(z[None], start["Lam"], start["R"], start["A"], start["Q"],
-                                                          start["mu0"], start["P0"], max_iter=max_em_iter, tol=tol_em,
-                                                          may_have_missing=bool((~obs).any()))
+            from ._lib import DfmError
+            args = (z[None], start["Lam"], start["R"], start["A"], start["Q"], start["mu0"], start["P0"])
+            kw = dict(max_iter=max_em_iter, tol=tol_em, may_have_missing=bool((~obs).any()))
+            try:
+                params, path, iters, f, P = ctx.em_batch_host(*args, **kw)
+            except DfmError as err:
+                # the information-form recursion inverts Q: a PCA start on fewer than 2r + 1 periods has a rank-deficient
+                # VAR residual covariance.  Run the covariance-form recursion (DFM_F_SINGULAR_Q) instead of failing.
+                if err.code != -5:
+                    raise
+                params, path, iters, f, P = ctx.em_batch_host(*args, singular_q=True, **kw)
         else:
             # VAR(p) start (oracle/varp_oracle.py varp_init): OLS of the PCA factors on their p lags without constant
             # (dfm_ols_batch), Q = residual covariance / (T - p), z_0 ~ N(0, second moment of the stacked lags)
@@ -567,22 +568,25 @@ def smooth_factors_ar_idio(m: DFMModel, *, ctx=None):
     return dict(loglik=float(ll[0]), factor=factor, P=P[0], series=cols, inputs=inputs, mu_f=mu_f)
 
 
-def amengual_watson_test(m: DFMModel, nlag: int = 4, *, ctx=None):
+def amengual_watson_test(m: DFMModel, nper: int = 4, *, ctx=None):
     """`amengual_watson_test(m, nper)` -- dfm_functions.ipynb:734-768: the number of DYNAMIC factors.  Every
-    included series is regressed on [1, lags 1..nlag of the r estimated static factors] over all rows of the data
-    (one dfm_ols_batch call, 1 + nlag r <= 64 regressors); the ALS estimator is then run on the residual panel
-    for k = 1..r dynamic factors over rows initperiod + nlag .. lastperiod (one dfm_als_batch call, r runs on a
-    shared panel).  `m.factor` must hold the static factors (estimate_factor first).  Returns (aw_icp [r], ssr [r])."""
+    included series is regressed on [1, lags 1..p of the r estimated static factors], p = the factor VAR's
+    `nlag` (:737, :741), over all rows of the data (one dfm_ols_batch call, 1 + p r <= 64 regressors); the ALS
+    estimator is then run on the residual panel for k = 1..r dynamic factors over rows initperiod + 4 .. lastperiod
+    (:761 -- the reference hard-codes the 4 and never reads its `nper` argument; kept for signature
+    parity and ignored here too), one dfm_als_batch call, r runs on a shared panel.  `m.factor` must hold the
+    static factors (estimate_factor first).  Returns (aw_icp [r], ssr [r])."""
     r = m.nfac_t
     est = m.data[:, m.inclcode == 1]
     T_all, ns = est.shape
+    nlag = m.factor_var_model.nlag
     x = np.column_stack([np.ones(T_all), _lagmat(m.factor, range(1, nlag + 1))])
     ctx, own = _own(ctx)
     try:
         # the reference keeps a series when it has at least nt_min rows MORE than regressors (:744)
         o = ctx.ols_batch_host(x, est, nt_min=x.shape[1] + m.nt_min_factor_estimation)
         res = o["resid"]                                                   # NaN where a row was not used
-        init, last = m.initperiod + nlag, m.lastperiod
+        init, last = m.initperiod + 4, m.lastperiod
         z, _ = standardize_data(res[init - 1:last])
         T = z.shape[0]
         nobs = int((~np.isnan(z)).sum())

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libdfmhip.so")
-SOURCES = ["collapse.hip", "collapse_dma.hip", "collapse_mfma.hip", "collapse_wide.hip", "recursion.hip", "recursion_wave.hip", "fastpath.hip", "mstep.hip", "mstep_mfma.hip", "pca.hip", "als.hip", "boot.hip", "breaks.hip", "synth.hip", "capi.hip"]
+SOURCES = ["collapse.hip", "collapse_dma.hip", "collapse_mfma.hip", "collapse_wide.hip", "recursion.hip", "recursion_wave.hip", "fastpath.hip", "mstep.hip", "mstep_mfma.hip", "pca.hip", "als.hip", "boot.hip", "breaks.hip", "synth.hip", "capi.hip", "multi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -50,7 +50,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 if res.returncode:
                     raise RuntimeError(f"hipcc failed: {' '.join(cmd)}")
     if force or jobs or _stale(SO, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs, "-ldl", "-lpthread"]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode:
             sys.stderr.write(res.stdout + res.stderr)

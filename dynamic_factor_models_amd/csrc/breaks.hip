@@ -10,6 +10,10 @@
 // One lane group of R = 2k (padded) lanes per problem: lane m owns regressor m -- row m of W'W, of v, of V; rows are
 // exchanged through LDS; the last q + 1 score vectors z_t live in an LDS ring.  y and X of a series are shared by
 // all its problems (L2 / L1 hits).
+// Synchronisation: a lane group (R <= 16 lanes) never spans two waves and its LDS region is private, so every exchange
+// is fenced at WAVE level (wave_lds_sync, gj_inverse<R, true>): the problems of one workgroup belong to series of
+// different lengths T, and a workgroup barrier inside the `t < T` loops would be executed a different number of times
+// by different waves.
 #include "dfm_kernels.h"
 #include "dfm_smallmat.h"
 
@@ -61,20 +65,20 @@ __global__ __launch_bounds__(kChowThreads) void chow_kernel(ChowArgs a) {
 #pragma unroll
         for (int j = 0; j < R; ++j) G[j] = (j == m) ? 1.0 : 0.0;
     }
-    const double dk = equilibrate_rows<R>(G, Xg, m);
-    gj_inverse<R>(G, Xg, m);                 // G <- (D W'W D)^-1 row m
-    __syncthreads();
+    const double dk = equilibrate_rows<R, true>(G, Xg, m);
+    gj_inverse<R, true>(G, Xg, m);                 // G <- (D W'W D)^-1 row m
+    wave_lds_sync();
     hb[m] = h * dk;
-    __syncthreads();
+    wave_lds_sync();
     double beta = 0.0;
 #pragma unroll
     for (int j = 0; j < R; ++j) beta = fma(G[j], hb[j], beta);
     beta *= dk;
-    __syncthreads();
+    wave_lds_sync();
     hb[m] = beta;                            // coefficients, for the residuals
     // (W'W)^-1 = D Ginv D: keep it in M2 for the sandwich
     Xg[m] = dk;
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < R; ++j) M2[m * R + j] = G[j] * dk * Xg[j];
     // scores and their lagged products
@@ -89,9 +93,9 @@ __global__ __launch_bounds__(kChowThreads) void chow_kernel(ChowArgs a) {
         const double wm = (m < K2) ? ((isD && t < tau) ? 0.0 : X[(size_t)t * k + mk]) : 0.0;
         const double zt = wm * u;
         double* cur = zr + (t % (kChowMaxQ + 1)) * R;
-        __syncthreads();
+        wave_lds_sync();
         cur[m] = zt;
-        __syncthreads();
+        wave_lds_sync();
 #pragma unroll
         for (int j = 0; j < R; ++j) v[j] = fma(zt, cur[j], v[j]);                  // lag 0
         for (int l = 1; l <= q && l <= t; ++l) {
@@ -103,10 +107,10 @@ __global__ __launch_bounds__(kChowThreads) void chow_kernel(ChowArgs a) {
         }
     }
     // V = (W'W)^-1 v (W'W)^-1
-    __syncthreads();
+    wave_lds_sync();
 #pragma unroll
     for (int j = 0; j < R; ++j) M1[m * R + j] = v[j];
-    __syncthreads();
+    wave_lds_sync();
     double t1[R], Vr[R];
     {
         double gi[R];
@@ -119,12 +123,12 @@ __global__ __launch_bounds__(kChowThreads) void chow_kernel(ChowArgs a) {
     double B[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) B[j] = (m >= k && m < K2 && j >= k && j < K2) ? Vr[j] : ((j == m) ? 1.0 : 0.0);
-    const double d2 = equilibrate_rows<R>(B, Xg, m);
-    gj_inverse<R>(B, Xg, m);
-    __syncthreads();
+    const double d2 = equilibrate_rows<R, true>(B, Xg, m);
+    gj_inverse<R, true>(B, Xg, m);
+    wave_lds_sync();
     const double gam = (m >= k && m < K2) ? beta : 0.0;
     hb[m] = gam * d2;
-    __syncthreads();
+    wave_lds_sync();
     double w2 = 0.0;
 #pragma unroll
     for (int j = 0; j < R; ++j) w2 = fma(B[j], hb[j], w2);

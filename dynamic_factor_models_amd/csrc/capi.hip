@@ -181,7 +181,9 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
 int ensure_ws(dfm_handle* h, size_t bytes) {
     if (bytes <= h->ws_bytes) return 0;
     if (h->ws) {
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        // every stream this handle has launched on (the caller may have swapped streams with dfm_set_stream, and the
+        // side / post streams of the fast path) must be done with the old block before it goes back to the allocator
+        HIP_TRY(h, hipDeviceSynchronize());
         HIP_TRY(h, hipFree(h->ws));
         h->ws = nullptr;
         h->ws_bytes = 0;
@@ -209,6 +211,10 @@ int check_general_n(dfm_handle* h, int N, int r) {
                                    "tiling: N <= 1024 for r <= 8, 512 for r <= 16, 256 for r <= 32)%s");
     return 0;
 }
+
+// EM: balanced panels keep the fast-path E-step at any N (the wide collapse has no register tiling); what bounds them
+// is the loadings M-step (mstep_lam_kernel: lane = series, N <= 1024; BASELINE config 4 is N = 1000, r = 20).
+int check_em_n(dfm_handle* h, int N, int r, unsigned flags);
 
 // Embed caller parameters (factor dimension r) into the padded dimension Rp.
 __global__ void pad_params_kernel(int B, int N, int r, int Rp, int Rl, const double* Lam, const double* A,
@@ -269,6 +275,15 @@ struct EmOpts {          // all-null for a plain pass
 bool fast_eligible(const dfm_handle* h, int N, int r, unsigned flags) {
     if (h->force_general || (flags & (DFM_F_MAY_HAVE_MISSING | DFM_F_SINGULAR_Q))) return false;
     return collapse_dma_supported(pad_r(r), N) || collapse_wide_supported(pad_r(r), N);
+}
+
+int check_em_n(dfm_handle* h, int N, int r, unsigned flags) {
+    if (fast_eligible(h, N, r, flags) && !h->em_general) {
+        if (N > 1024 && !mstep_mfma_supported(pad_r(r), N))
+            return fail(h, DFM_E_DIMS, "N > 1024: the loadings M-step (one lane per series, 4 series per lane) does not cover this cross-section%s");
+        return 0;
+    }
+    return check_general_n(h, N, r);
 }
 
 // gram + cov on the side stream, beside the streaming collapse on the main stream; the batch is cut
@@ -480,12 +495,15 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
     return 0;
 }
 
-// Shared driver of dfm_em_step_batch_dev (max_iter = 1, no bookkeeping) and dfm_em_batch_dev.
+// Shared driver of dfm_em_step_batch_dev (max_iter = 1, no bookkeeping), dfm_em_batch_dev (iterations 0 .. max_iter-1,
+// stops launching once no replicate of THIS batch is active) and dfm_em_iterate_batch_dev (iteration k_first only, the
+// caller owns `active` and decides when to stop: the multi-GPU drivers).
 int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R, double* A,
            double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path, int* iters,
-           double* loglik_single, double* f_smooth, double* P_smooth, unsigned flags) {
+           double* loglik_single, double* f_smooth, double* P_smooth, unsigned flags, int k_first = 0, int k_count = -1,
+           int* active_ext = nullptr) {
     if (int rc = check_dims(h, B, T, N, r)) return rc;
-    if (int rc = check_general_n(h, N, r)) return rc;
+    if (int rc = check_em_n(h, N, r, flags)) return rc;
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
     HIP_TRY(h, hipSetDevice(h->device));
@@ -510,17 +528,18 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
     double* Psm = (!padded && P_smooth) ? P_smooth : at<double>(h, p.Psm);
     double* llbuf = loglik_single ? loglik_single : at<double>(h, p.llbuf);
     const bool book = loglik_path != nullptr;
-    int* active = book ? at<int>(h, p.active) : nullptr;
-    if (book) {
+    int* active = book ? (active_ext ? active_ext : at<int>(h, p.active)) : nullptr;
+    if (book && k_first == 0) {
         HIP_TRY(h, hipMemsetAsync(loglik_path, 0xFF, (size_t)B * max_iter * sizeof(double), h->stream));  // NaN
         HIP_TRY(h, hipMemsetAsync(iters, 0, (size_t)B * sizeof(int), h->stream));
     }
+    const int k_end = k_count < 0 ? max_iter : (k_first + k_count < max_iter ? k_first + k_count : max_iter);
     std::vector<int> act_host;
-    for (int k = 0; k < max_iter; ++k) {
+    for (int k = k_first; k < k_end; ++k) {
         EmOpts eo;
         eo.active = active; eo.iters = iters; eo.ll_path = loglik_path; eo.k = k; eo.max_iter = max_iter; eo.tol = tol;
         if (int rc = em_iteration(h, p, B, T, N, panel, LamP, R, AP, QP, mu0P, P0P, fsm, Psm, llbuf, eo)) return rc;
-        if (book && tol > 0.0 && k + 1 < max_iter) {   // stop launching once every replicate has converged
+        if (book && !active_ext && tol > 0.0 && k + 1 < k_end) {   // stop launching once every replicate has converged
             act_host.resize(B);
             HIP_TRY(h, hipMemcpyAsync(act_host.data(), active, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -784,12 +803,20 @@ int dfm_destroy(dfm_handle* h) {
 
 int dfm_set_stream(dfm_handle* h, void* stream) {
     if (!h) return DFM_E_NULL;
+    hipStream_t ns = static_cast<hipStream_t>(stream);
+    if (ns == h->stream) return 0;
+    HIP_TRY(h, hipSetDevice(h->device));
     if (h->own_stream && h->stream) {
         hipStreamSynchronize(h->stream);
         hipStreamDestroy(h->stream);
         h->own_stream = false;
+    } else {
+        // The handle has ONE workspace (bcol, wtab, tab, status, ...): work enqueued on the new stream must not start
+        // before the work already enqueued on the old one has finished with it.
+        HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(ns, h->ev_fork, 0));
     }
-    h->stream = static_cast<hipStream_t>(stream);
+    h->stream = ns;
     return 0;
 }
 
@@ -829,7 +856,15 @@ const char* dfm_last_error(const dfm_handle* h) { return h ? h->err : "null hand
 
 size_t dfm_workspace_bytes(int B, int T, int N, int r, unsigned flags) {
     if (B < 1 || T < 1 || N < 1 || r < 1 || r > DFM_MAX_R) return 0;
-    return make_plan(B, T, N, r, flags, true).total;
+    // the larger of the two plans an entry point may take for this shape: sequential (general) path, or -- balanced
+    // panels only -- the time-parallel fast path, whose `tab` ([B][T][3][Rp][Rp]) and M-step partial sums are larger
+    size_t best = make_plan(B, T, N, r, flags, true, false).total;
+    const int Rp = pad_r(r);
+    if (!(flags & (DFM_F_MAY_HAVE_MISSING | DFM_F_SINGULAR_Q)) && (collapse_dma_supported(Rp, N) || collapse_wide_supported(Rp, N))) {
+        const size_t f = make_plan(B, T, N, r, flags, true, true).total;
+        if (f > best) best = f;
+    }
+    return best;
 }
 
 int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, const double* Lam,
@@ -917,11 +952,22 @@ int dfm_em_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* pa
                   P_smooth, flags);
 }
 
+int dfm_em_iterate_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,
+                             double* A, double* Q, double* mu0, double* P0, int k, int max_iter, double tol,
+                             double* loglik_path, int* iters, int* active, double* f_smooth, double* P_smooth,
+                             unsigned flags) {
+    if (!h) return DFM_E_NULL;
+    if (!loglik_path || !iters || !active) return fail(h, DFM_E_NULL, "loglik_path / iters / active is NULL%s");
+    if (max_iter < 1 || k < 0 || k >= max_iter) return fail(h, DFM_E_DIMS, "need 0 <= k < max_iter%s");
+    return em_run(h, B, T, N, r, panel, Lam, R, A, Q, mu0, P0, max_iter, tol, loglik_path, iters, nullptr, f_smooth, P_smooth,
+                  flags, k, 1, active);
+}
+
 int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R, double* A,
                  double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path, int* iters,
                  double* f_smooth, double* P_smooth, unsigned flags) {
     if (int rc = check_dims(h, B, T, N, r)) return rc;
-    if (int rc = check_general_n(h, N, r)) return rc;
+    if (int rc = check_em_n(h, N, r, flags)) return rc;
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
@@ -1120,13 +1166,16 @@ int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doub
     const size_t d = sizeof(double);
     size_t off = 0;
     const size_t oS = take(off, (size_t)B * N * N * d), oV = take(off, (size_t)B * N * Rp * d),
-                 oY = take(off, (size_t)B * N * Rp * d), oF = take(off, (size_t)B * T * Rp * d);
+                 oY = take(off, (size_t)B * N * Rp * d), oF = take(off, (size_t)B * T * Rp * d), oSt = take(off, 256);
     if (int rc = ensure_ws(h, off)) return rc;
+    h->status_off = oSt;
+    HIP_TRY(h, hipMemsetAsync(at<int>(h, oSt), 0, sizeof(int), h->stream));
     PcaArgs pa;
     pa.B = B; pa.T = T; pa.N = N; pa.r = r; pa.max_iter = 4000;
     pa.panel = panel;
     pa.S = at<double>(h, oS); pa.V = at<double>(h, oV); pa.Y = at<double>(h, oY); pa.F = at<double>(h, oF);
     pa.Lam = Lam; pa.Rv = R; pa.A = A; pa.Q = Q; pa.mu0 = mu0; pa.P0 = P0; pa.factors = factors;
+    pa.status = at<int>(h, oSt);
     { ProfScope ps(h, K_PCA); HIP_TRY(h, launch_gram_xx(pa, h->stream)); HIP_TRY(h, launch_pca(Rp, pa, h->stream)); }
     return 0;
 }
@@ -1155,6 +1204,11 @@ int dfm_pca_init_batch(dfm_handle* h, int B, int T, int N, int r, const double* 
         if (factors) down(factors, f_d, n_f * d);
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    if (rc == 0) {
+        int st = 0;
+        (void)hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost);
+        if (st & 2) rc = fail(h, DFM_E_NUMERIC, "PCA subspace iteration did not converge (near-degenerate spectrum at the cut)%s");
     }
     (void)hipFree(buf);
     return rc;

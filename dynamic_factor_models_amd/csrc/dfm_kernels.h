@@ -165,6 +165,7 @@ struct PcaArgs {
     double* F;                  // [B][T][Rp]  scores
     double* Lam; double* Rv; double* A; double* Q; double* mu0; double* P0;   // caller's layout (r)
     double* factors;            // [B][T][r] or null
+    int* status;                // bit 1 (value 2): subspace iteration stopped at max_iter above its tolerance; or null
 };
 hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s);
 hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s);

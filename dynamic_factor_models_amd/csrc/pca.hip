@@ -250,6 +250,7 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
     // floor (or stops improving): the Ritz vectors taken afterwards are then exact to roundoff / gap
     double best = 1e300;
     int stall = 0;
+    bool converged = false;
     for (int it = 0; it < a.max_iter; ++it) {
         apply_S();
         tall_gram<R>(sH, V, Y, N, r, sred);              // H = V'S V
@@ -266,10 +267,13 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
         block_sum<2>(part, sred);
         const double rel = sqrt(part[0] / part[1]);
         orthonormalise();
-        if (rel <= 1e-14) break;
+        if (rel <= 1e-14) { converged = true; break; }
         if (rel < 0.5 * best) { best = rel; stall = 0; }
-        else if (++stall >= 8 && best < 1e-10) break;
+        else if (++stall >= 8 && best < 1e-10) { converged = true; break; }
     }
+    // max_iter exhausted above the tolerance (near-degenerate spectrum at the cut: the rate is lambda_{r+1} / lambda_r):
+    // the basis is NOT the reference's svd-based pca_score (dfm_functions.ipynb:179-183) -- say so instead of returning it
+    if (!converged && tid == 0 && a.status) atomicOr(a.status, 2);
     // Rayleigh-Ritz: H = V'SV, H = W Theta W', V <- V W (descending), sign rule of the oracle
     apply_S();
     tall_gram<R>(sH, V, Y, N, r, sred);

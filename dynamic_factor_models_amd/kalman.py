@@ -29,6 +29,7 @@ class DfmContext:
         self._lib = _lib.load()
         self.device = torch.cuda.current_device() if device is None else int(device)
         self._torch = torch
+        self._use_torch_stream = bool(use_torch_stream)
         stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else None
         h = ctypes.c_void_p()
         rc = self._lib.dfm_create(ctypes.byref(h), self.device, ctypes.c_void_p(stream))
@@ -57,6 +58,8 @@ class DfmContext:
         return ctypes.c_void_p(t.data_ptr())
 
     def _sync_stream(self):
+        if not self._use_torch_stream:      # the handle keeps the stream it created for itself
+            return
         s = self._torch.cuda.current_stream(self.device).cuda_stream
         self._lib.dfm_set_stream(self._h, ctypes.c_void_p(s))
 
@@ -174,10 +177,52 @@ class DfmContext:
         _check(self._h, rc)
         return path, iters, f, P
 
+    def em_iterate_batch(self, panel, Lam, R, A, Q, mu0, P0, k: int, max_iter: int, tol: float, path, iters, active,
+                         f=None, P=None, may_have_missing: Optional[bool] = False, singular_q: bool = False):
+        """EM iteration number k of max_iter (dfm_em_iterate_batch_dev): parameters updated in place, bookkeeping in the
+        CALLER's device tensors path [B,max_iter] f64, iters [B] i32, active [B] i32 (they persist between calls; the
+        k = 0 call initialises them).  The unit a multi-GPU driver steps: shard.em_batch_sharded."""
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        flags = self._flags(panel, may_have_missing, singular_q)
+        self._sync_stream()
+        rc = self._lib.dfm_em_iterate_batch_dev(
+            self._h, B, T, N, r, self._dev(panel, "panel"), self._dev(Lam, "Lam", (B, N, r)),
+            self._dev(R, "R", (B, N)), self._dev(A, "A", (B, r, r)), self._dev(Q, "Q", (B, r, r)),
+            self._dev(mu0, "mu0", (B, r)), self._dev(P0, "P0", (B, r, r)), int(k), int(max_iter), float(tol),
+            self._dev(path, "loglik_path", (B, max_iter)), ctypes.c_void_p(iters.data_ptr()),
+            ctypes.c_void_p(active.data_ptr()), self._dev(f, "f_smooth") if f is not None else None,
+            self._dev(P, "P_smooth") if P is not None else None, flags)
+        _check(self._h, rc)
+
     def em_batch_host(self, panel, Lam, R, A, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
-                      may_have_missing: Optional[bool] = None):
+                      may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """Host-pointer EM entry (what Julia's ccall binds).  Returns (params dict, loglik_path, iters,
         f_smooth, P_smooth); inputs are not modified."""
+        c = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
+        panel = np.ascontiguousarray(panel, dtype=np.float64)
+        Lam, R, A, Q, mu0, P0 = map(c, (Lam, R, A, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
+        path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
+        f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2))
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_em_batch(self._h, B, T, N, r, p(panel), p(Lam), p(R), p(A), p(Q), p(mu0), p(P0),
+                                    int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags)
+        _check(self._h, rc)
+        return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
+
+    # ------------------------------------------------------------------ several GPUs from one process (multi.hip)
+    @staticmethod
+    def em_batch_multi_host(ngpu, panel, Lam, R, A, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
+                            may_have_missing: Optional[bool] = None, device_ids=None):
+        """dfm_em_batch_multi: the EM loop on `ngpu` GPUs from THIS process (one host thread per GPU, library-owned
+        RCCL communicator, one all-gather of {loglik, active} per iteration) -- what the Julia host binds.  NumPy in /
+        out as em_batch_host; also returns the number of iterations every GPU ran."""
+        lib = _lib.load()
         c = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
         panel = np.ascontiguousarray(panel, dtype=np.float64)
         Lam, R, A, Q, mu0, P0 = map(c, (Lam, R, A, Q, mu0, P0))
@@ -188,11 +233,38 @@ class DfmContext:
         flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
         path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
         f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2))
-        p = lambda a: ctypes.c_void_p(a.ctypes.data)
-        rc = self._lib.dfm_em_batch(self._h, B, T, N, r, p(panel), p(Lam), p(R), p(A), p(Q), p(mu0), p(P0),
-                                    int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags)
-        _check(self._h, rc)
-        return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
+        ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
+        ran = ctypes.c_int(0)
+        err = ctypes.create_string_buffer(700)
+        p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
+        rc = lib.dfm_em_batch_multi(int(ngpu), p(ids), B, T, N, r, p(panel), p(Lam), p(R), p(A), p(Q), p(mu0), p(P0),
+                                    int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags,
+                                    ctypes.cast(ctypes.byref(ran), ctypes.c_void_p), err, 700)
+        if rc != 0:
+            raise _lib.DfmError(rc, err.value.decode())
+        return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), path, iters, f, P, ran.value
+
+    @staticmethod
+    def ks_pass_batch_multi_host(ngpu, panel, Lam, R, A, Q, mu0, P0, may_have_missing: Optional[bool] = None,
+                                 device_ids=None):
+        """dfm_ks_pass_batch_multi: the smoother pass with the replicates split over `ngpu` GPUs (no exchange)."""
+        lib = _lib.load()
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        panel, Lam, R, A, Q, mu0, P0 = map(c, (panel, Lam, R, A, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2)); ll = np.empty(B)
+        ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
+        err = ctypes.create_string_buffer(700)
+        p = lambda a: None if a is None else ctypes.c_void_p(a.ctypes.data)
+        rc = lib.dfm_ks_pass_batch_multi(int(ngpu), p(ids), B, T, N, r, p(panel), p(Lam), p(R), p(A), p(Q), p(mu0), p(P0),
+                                         p(f), p(P), p(ll), flags, err, 700)
+        if rc != 0:
+            raise _lib.DfmError(rc, err.value.decode())
+        return f, P, ll
 
     # ------------------------------------------------------------------ VAR(p) factor dynamics (companion form)
     def ks_pass_varp_batch(self, panel, Lam, R, Avar, Q, mu0, P0, want_P: bool = True,

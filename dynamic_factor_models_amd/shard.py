@@ -63,3 +63,47 @@ def em_convergence_allgather(loglik_local, active_local, B: int, group=None):
     pair = torch.stack([loglik_local.double(), active_local.double()], dim=1)
     full = allgather_replicates(pair, B, group)
     return full[:, 0], full[:, 1] != 0
+
+
+def em_batch_sharded(ctx, panel, Lam, R, A, Q, mu0, P0, B_global: int, max_iter: int = 10, tol: float = 0.0,
+                     want_smooth: bool = True, want_P: bool = True, may_have_missing=False, group=None,
+                     iterate=None):
+    """The EM loop of ONE rank of a replicate-sharded job (north_star: "the replicate batch shards
+    embarrassingly across the 8 GPUs of one node with a single RCCL allgather at the end of each EM iteration").
+
+    `panel`, `Lam`, .. `P0`: THIS rank's shard (replicates replicate_range(B_global, world, rank)), tensors on this
+    rank's device; parameters are updated in place.  Every iteration runs `iterate` -- by default
+    DfmContext.em_iterate_batch, i.e. dfm_em_iterate_batch_dev: E-step + M-step + per-replicate bookkeeping on the
+    GPU -- then em_convergence_allgather exchanges {loglik_k, active} of every replicate of the job (one collective),
+    and every rank stops at the same iteration, when no replicate anywhere is still iterating (tol > 0) or after
+    max_iter iterations.  A replicate that converged keeps the parameters that entered its last iteration, exactly as
+    dfm_em_batch_dev; a single rank (or no process group) reproduces dfm_em_batch_dev.
+
+    Returns dict(path [shard, max_iter] (NaN past iters), iters [shard] int32, f, P, loglik_global [B_global,
+    iterations] -- the gathered log-likelihoods, identical on every rank --, active_global [B_global] bool,
+    iterations).  `iterate` is injectable so that the world-size-2 gloo test can drive this very function on CPU
+    ranks with the oracle standing in for the kernel call (tests/ only)."""
+    import torch
+    if iterate is None:
+        iterate = ctx.em_iterate_batch
+    Bl, T, N = panel.shape
+    r = Lam.shape[2]
+    dev = panel.device
+    path = torch.full((Bl, max_iter), float("nan"), dtype=torch.float64, device=dev)
+    iters = torch.zeros((Bl,), dtype=torch.int32, device=dev)
+    active = torch.ones((Bl,), dtype=torch.int32, device=dev)
+    f = torch.empty((Bl, T, r), dtype=torch.float64, device=dev) if want_smooth else None
+    P = torch.empty((Bl, T, r * (r + 1) // 2), dtype=torch.float64, device=dev) if (want_smooth and want_P) else None
+    history = []
+    gact = None
+    ran = 0
+    for k in range(max_iter):
+        iterate(panel, Lam, R, A, Q, mu0, P0, k, max_iter, tol, path, iters, active, f, P,
+                may_have_missing=may_have_missing)
+        ran = k + 1
+        gll, gact = em_convergence_allgather(path[:, k], active, B_global, group)   # THE collective of the iteration
+        history.append(gll)
+        if tol > 0.0 and not bool(gact.any().item()):
+            break
+    return dict(path=path, iters=iters, f=f, P=P, loglik_global=torch.stack(history, dim=1), active_global=gact,
+                iterations=ran)

@@ -45,7 +45,8 @@ enum {
     DFM_E_NULL = -3,          /* required pointer is NULL */
     DFM_E_MISSING = -4,       /* NaN found in the panel but DFM_F_MAY_HAVE_MISSING not set */
     DFM_E_NUMERIC = -5,       /* non-finite log-likelihood in some replicate (non-PD Q/P0/...) */
-    DFM_E_NO_DEVICE = -6      /* no HIP device / extension not usable */
+    DFM_E_NO_DEVICE = -6,     /* no HIP device / extension not usable */
+    DFM_E_COMM = -7           /* multi-GPU entry points: RCCL could not be loaded or a collective failed */
 };
 
 /* flags */
@@ -74,7 +75,10 @@ int dfm_profile_enable(dfm_handle* h, int on);
 int dfm_profile_read(dfm_handle* h, int kernel_index, char* name_out, int name_cap, double* total_ms,
                      int* launches);
 
-/* Bytes of device workspace the handle will hold for a (B,T,N,r) problem (for capacity planning). */
+/* Bytes of device workspace the handle will hold for a pass / EM call on a (B,T,N,r) problem with these flags (for
+ * capacity planning; the larger of the sequential and -- for balanced panels -- the time-parallel plan).  The VAR(p),
+ * AR-idiosyncratic, PCA and synthetic-panel entry points add their own scratch on top (a quasi-differenced panel copy,
+ * [B][N][N] Gram matrices, ...). */
 size_t dfm_workspace_bytes(int B, int T, int N, int r, unsigned flags);
 
 /* --- one full Kalman-smoother pass per replicate (SURVEY.md §8(d) "pass") ---------------------
@@ -113,6 +117,37 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
                  double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol,
                  double* loglik_path, int* iters, double* f_smooth, double* P_smooth,
                  unsigned flags);
+
+/* EM iteration number k (0-based) of max_iter with the bookkeeping of dfm_em_batch_dev kept in CALLER-owned device
+ * arrays that persist between calls: loglik_path [B][max_iter] and iters [B] (both initialised by the k = 0 call) and
+ * active [B] (written by every call: 1 while the replicate keeps iterating).  dfm_em_batch_dev is this call for k = 0,
+ * 1, ... until no replicate of its batch is active; a multi-GPU driver (replicates sharded over the
+ * GPUs, no data-path collective) calls it on every shard, all-gathers {loglik_path[:, k], active} -- north_star's
+ * "single allgather at the end of each EM iteration" -- and stops when no replicate ANYWHERE is active:
+ * dynamic_factor_models_amd/shard.py em_batch_sharded (one process per GPU, torch.distributed over RCCL) and
+ * dfm_em_batch_multi below (one process, one host thread per GPU).  f_smooth / P_smooth (may be NULL) receive the
+ * smoother output of this iteration's E-step. */
+int dfm_em_iterate_batch_dev(dfm_handle* h, int B, int T, int N, int r, const double* panel, double* Lam, double* R,
+                             double* A, double* Q, double* mu0, double* P0, int k, int max_iter, double tol,
+                             double* loglik_path, int* iters, int* active, double* f_smooth, double* P_smooth,
+                             unsigned flags);
+
+/* --- the same two operations on SEVERAL GPUs of one node from ONE process (`ngpu`, `device_ids`,
+ * library-owned RCCL communicator; what `estimate!(m, ::Parametric; nrep, ngpu)` of julia/dfm_hip.jl binds).  HOST
+ * pointers, layouts as dfm_em_batch / dfm_ks_pass_batch.  GPU g of ngpu owns replicates [g B / ngpu, (g+1) B / ngpu);
+ * device_ids[ngpu] (NULL: 0 .. ngpu-1) must be distinct.  One host thread per GPU; after every EM iteration ONE
+ * ncclAllGather of {loglik, active} ([B/ngpu][2] doubles per GPU) over xGMI gives every thread the global convergence
+ * state, and all GPUs stop at the same iteration: *iterations_run (may be NULL).  RCCL is loaded at the first call
+ * with ngpu > 1 (DFM_E_COMM if that fails).  No handle: each call creates and destroys its per-GPU contexts.
+ * err[err_cap] (may be NULL) receives the message of the first failing GPU. */
+int dfm_em_batch_multi(int ngpu, const int* device_ids, int B, int T, int N, int r, const double* panel, double* Lam,
+                       double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol,
+                       double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags,
+                       int* iterations_run, char* err, int err_cap);
+int dfm_ks_pass_batch_multi(int ngpu, const int* device_ids, int B, int T, int N, int r, const double* panel,
+                            const double* Lam, const double* R, const double* A, const double* Q, const double* mu0,
+                            const double* P0, double* f_smooth, double* P_smooth, double* loglik, unsigned flags,
+                            char* err, int err_cap);
 
 /* --- VAR(p) factor dynamics ------------------------------------------------------
  *   x_t = Lam f_t + e_t,   f_t = A_1 f_{t-1} + ... + A_p f_{t-p} + eta_t,  eta_t ~ N(0, Q)

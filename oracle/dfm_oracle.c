@@ -10,7 +10,7 @@
  * ones (Shumway & Stoffer 1982; Banbura & Modugno 2014 for missing cells; collapsed observation
  * vector as in Jungbacker & Koopman 2015) -- SURVEY.md Appendix B.  The file is pinned against
  * oracle/kalman_oracle.py (itself pinned by brute-force Gaussian conditioning) in
- * tests/test_oracle_c.py.
+ * tests/test_oracle_kalman.py.
  *
  * Layout: panel x[t*N + i] (NaN = missing); Lam[i*r + k]; A, Q, P0 row-major r x r;
  * packed symmetric output: lower triangle row-major, idx(i,j) = i(i+1)/2 + j (j <= i).

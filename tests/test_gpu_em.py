@@ -111,3 +111,105 @@ def test_em_host_entry(ctx):
         np.testing.assert_allclose(path[b], opath, rtol=RTOL)
         for k in KEYS:
             assert np.abs(newp[k][b] - p[k]).max() <= RTOL * max(1.0, np.abs(p[k]).max())
+
+
+# ---- multi-GPU drivers on one GPU: the stepping entry, the torch.distributed driver and the in-library (RCCL) driver
+# are the same function of the inputs as dfm_em_batch_dev -------------------------------------------------------------
+@pytest.mark.parametrize("B,N,T,r,missing,tol", [(6, 30, 60, 2, 0.0, 2e-4), (5, 40, 50, 3, 0.1, 0.0), (4, 200, 120, 8, 0.0, 0.0)])
+def test_em_iterate_and_sharded_driver_equal_em_batch(ctx, B, N, T, r, missing, tol):
+    import torch
+    from dynamic_factor_models_amd import shard
+    max_iter = 12
+    panel, st = _start(B, N, T, r, missing)
+    ref = {k: _dev(ctx, st[k]) for k in KEYS}
+    path0, its0, f0, P0 = ctx.em_batch(_dev(ctx, panel), *[ref[k] for k in KEYS], max_iter=max_iter, tol=tol,
+                                       may_have_missing=missing > 0)
+    torch.cuda.synchronize()
+    got = {k: _dev(ctx, st[k]) for k in KEYS}
+    out = shard.em_batch_sharded(ctx, _dev(ctx, panel), *[got[k] for k in KEYS], B_global=B, max_iter=max_iter, tol=tol,
+                                 may_have_missing=missing > 0)
+    torch.cuda.synchronize()
+    assert torch.equal(out["iters"], its0)
+    assert torch.equal(torch.nan_to_num(out["path"]), torch.nan_to_num(path0))
+    for k in KEYS:
+        assert torch.equal(got[k], ref[k]), k
+    assert torch.equal(out["f"], f0) and torch.equal(out["P"], P0)
+    assert out["iterations"] == int(its0.max().item()) or tol == 0.0
+    assert out["loglik_global"].shape == (B, out["iterations"])
+    if tol > 0.0:
+        assert out["iterations"] < max_iter and not bool(out["active_global"].any())
+
+
+def test_em_batch_multi_one_gpu_equals_em_batch_host(ctx):
+    """dfm_em_batch_multi with ngpu = 1 (what the Julia host binds; RCCL not needed for one GPU) and the same through
+    ngpu = 1 of dfm_ks_pass_batch_multi."""
+    from dynamic_factor_models_amd import DfmContext
+    panel, st = _start(5, 30, 50, 3, 0.1)
+    for tol in (0.0, 1e-3):
+        p0, path0, its0, f0, P0 = ctx.em_batch_host(panel, *[st[k] for k in KEYS], max_iter=9, tol=tol)
+        p1, path1, its1, f1, P1, ran = DfmContext.em_batch_multi_host(1, panel, *[st[k] for k in KEYS], max_iter=9, tol=tol)
+        np.testing.assert_array_equal(its0, its1)
+        np.testing.assert_array_equal(np.nan_to_num(path0), np.nan_to_num(path1))
+        for k in KEYS:
+            np.testing.assert_array_equal(p0[k], p1[k])
+        np.testing.assert_array_equal(f0, f1)
+        assert ran == (9 if tol == 0.0 else its0.max())
+    f, P, ll = ctx.ks_pass_batch_host(panel, *[st[k] for k in KEYS])
+    f2, P2, ll2 = DfmContext.ks_pass_batch_multi_host(1, panel, *[st[k] for k in KEYS])
+    np.testing.assert_array_equal(ll, ll2); np.testing.assert_array_equal(f, f2); np.testing.assert_array_equal(P, P2)
+
+
+def test_em_batch_multi_argument_errors():
+    from dynamic_factor_models_amd import DfmContext, DfmError
+    panel, st = _start(2, 20, 30, 2, 0.0)
+    with pytest.raises(DfmError) as ei:
+        DfmContext.em_batch_multi_host(2, panel, *[st[k] for k in KEYS], max_iter=2, device_ids=[0, 0])
+    assert ei.value.code == -1
+    with pytest.raises(DfmError) as ei:
+        DfmContext.em_batch_multi_host(1, panel, *[st[k] for k in KEYS], max_iter=2, device_ids=[99])
+    assert ei.value.code == -1
+
+
+# ---- BASELINE config 4 (N = 1000, T = 2000, r = 20) and config 3's shard (B = 8192) through EM ------------------
+def test_config4_em_three_iterations_match_the_oracle(ctx):
+    import torch
+    B, N, T, r, iters = 2, 1000, 2000, 20, 3
+    panel, st = _start(B, N, T, r, 0.0)
+    dev = {k: _dev(ctx, st[k]) for k in KEYS}
+    path, its, f, P = ctx.em_batch(_dev(ctx, panel), *[dev[k] for k in KEYS], max_iter=iters, tol=0.0, may_have_missing=False)
+    torch.cuda.synchronize()
+    path = path.cpu().numpy(); f = f.cpu().numpy()
+    for b in range(B):
+        p, opath, out = ko.em(panel[b], {k: st[k][b] for k in KEYS}, max_iter=iters, tol=0.0)
+        np.testing.assert_allclose(path[b], opath, rtol=RTOL, err_msg=f"loglik path b={b}")
+        for k in KEYS:
+            got = dev[k][b].cpu().numpy()
+            assert np.abs(got - p[k]).max() <= RTOL * max(1.0, np.abs(p[k]).max()), (k, b, np.abs(got - p[k]).max())
+        assert np.abs(f[b] - out["f_smooth"]).max() <= RTOL * np.abs(out["f_smooth"]).max()
+
+
+def test_config3_shard_em_scattered_replicates(ctx):
+    """B = 8192 replicates (device-generated), PCA start on the device, 3 EM iterations; 12 replicates scattered over the
+    batch against the oracle's EM from the same start."""
+    import torch
+    B, N, T, r, iters = 8192, 200, 500, 8, 3
+    panel, _ = ctx.synth_panels(99, 0, B, T, N, r)
+    Lam, R, A, Q, mu0, P0, _ = ctx.pca_init_batch(panel, r, want_factors=False)
+    torch.cuda.synchronize()
+    idx = [0, 3, 4, 2047, 2048, 2051, 4096, 5000, 6143, 6144, 8188, 8191]
+    ix = torch.tensor(idx, device=panel.device)
+    start = {k: v.index_select(0, ix).cpu().numpy() for k, v in zip(KEYS, (Lam, R, A, Q, mu0, P0))}
+    xs = panel.index_select(0, ix).cpu().numpy()
+    path, its, _, _ = ctx.em_batch(panel, Lam, R, A, Q, mu0, P0, max_iter=iters, tol=0.0, want_smooth=False,
+                                   may_have_missing=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(path).all()) and bool((its == iters).all())
+    got = {k: v.index_select(0, ix).cpu().numpy() for k, v in zip(KEYS, (Lam, R, A, Q, mu0, P0))}
+    pth = path.index_select(0, ix).cpu().numpy()
+    for j in range(len(idx)):
+        p, opath, _ = ko.em(xs[j], {k: start[k][j] for k in KEYS}, max_iter=iters, tol=0.0)
+        np.testing.assert_allclose(pth[j], opath, rtol=RTOL, err_msg=f"replicate {idx[j]}")
+        for k in KEYS:
+            assert np.abs(got[k][j] - p[k]).max() <= RTOL * max(1.0, np.abs(p[k]).max()), (k, idx[j])
+    del panel
+    torch.cuda.empty_cache()

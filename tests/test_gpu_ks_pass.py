@@ -226,3 +226,107 @@ def test_config4_full_size_properties(ctx):
     torch.cuda.synchronize()
     assert torch.allclose(f2, -2.0 * f1, rtol=1e-10, atol=1e-12)
     assert torch.equal(P1, P2) and torch.equal(P1[0], P1[-1])
+
+
+# ---- BASELINE config 3's per-GPU shard: 8192 replicates on one GPU (SURVEY row g) ---------------------------------
+def _scattered(B, n, seed=3):
+    """Replicate indices spread over the batch: both ends, both sides of the boundaries of the launch rounds (at B = 8192
+    the MFMA collapse runs one period segment per replicate -- 4 replicates per workgroup, 512 resident workgroups, i.e.
+    rounds of 2048 replicates), and a seeded random rest."""
+    edge = [0, 1, 2, 3, 4, 7, 8, B - 1, B - 2, B - 4, B - 5, B - 8, B - 9]
+    for m in range(2048, B, 2048):
+        edge += [m - 5, m - 4, m - 1, m, m + 1, m + 3, m + 4]
+    rng = np.random.default_rng(seed)
+    rest = rng.choice(B, size=max(0, n - len(set(edge))), replace=False).tolist()
+    return sorted(set(i for i in edge + rest if 0 <= i < B))[: max(n, len(set(edge)))]
+
+
+def test_config3_shard_8192_replicates_against_the_oracle(ctx):
+    """B = 8192, N = 200, T = 500, r = 8 balanced (6.6 GB of panels generated on the device): >= 64 replicates scattered
+    over the batch against the C oracle at 1e-9, every log-likelihood finite, P_smooth data-independent."""
+    import torch
+    B, N, T, r = 8192, 200, 500, 8
+    panel, par = ctx.synth_panels(20160415, 0, B, T, N, r)
+    f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ll).all())
+    idx = _scattered(B, 72)
+    assert len(idx) >= 64
+    ix = torch.tensor(idx, device=panel.device)
+    h = lambda a: a.index_select(0, ix).cpu().numpy()
+    st = dict(zip(("Lam", "R", "A", "Q", "mu0", "P0"), [h(p) for p in par]))
+    ref = _oracle(h(panel), st)
+    _compare((h(f), h(P), h(ll)), ref, "B=8192 scattered replicates")
+    # same replicates in a small batch (different launch geometry: 3 segments per replicate instead of 1): same numbers
+    f2, P2, ll2 = ctx.ks_pass_batch(panel.index_select(0, ix).contiguous(), *[p.index_select(0, ix).contiguous() for p in par],
+                                    may_have_missing=False)
+    torch.cuda.synchronize()
+    _compare((f2.cpu().numpy(), P2.cpu().numpy(), ll2.cpu().numpy()), ref, "same replicates, small batch")
+    del f, P, f2, P2, panel
+    torch.cuda.empty_cache()
+
+
+def test_config3_shard_with_missing_cells(ctx):
+    """The same shard size on the sequential path (10 % of the cells missing; lane-group recursion at B > 4096)."""
+    import torch
+    B, N, T, r = 8192, 200, 500, 8
+    panel, par = ctx.synth_panels(7, 100000, B, T, N, r, missing_prob=0.1)
+    f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ll).all())
+    idx = _scattered(B, 32, seed=5)[:40]
+    ix = torch.tensor(idx, device=panel.device)
+    h = lambda a: a.index_select(0, ix).cpu().numpy()
+    st = dict(zip(("Lam", "R", "A", "Q", "mu0", "P0"), [h(p) for p in par]))
+    _compare((h(f), h(P), h(ll)), _oracle(h(panel), st), "B=8192, 10 % missing")
+    del f, P, panel
+    torch.cuda.empty_cache()
+
+
+# ---- BASELINE config 4: several DISTINCT replicates against the oracle -------------------------------------------
+def test_config4_eight_replicates_against_the_oracle(ctx):
+    B, N, T, r = 8, 1000, 2000, 20
+    panel, st = _batch(B, N, T, r, 0.0)
+    ref = _oracle(panel, st)
+    _compare(_run_dev(ctx, panel, st, may_have_missing=False), ref, "config 4, 8 distinct replicates")
+
+
+# ---- slowly converging Riccati recursion through the balanced (fixed-point detecting) path ------------------------
+def _slow_riccati(B, N, T, r, rho, Rscale, seed=11):
+    """Near-unit-root factors observed through very noisy series: C = Lam' R^-1 Lam is small, the closed-loop matrix
+    A (I - K Lam) stays close to A, and the covariance recursion needs hundreds of steps to settle (or never does
+    within T): the fast path's fixed-point cut E approaches T."""
+    rng = np.random.default_rng(seed)
+    a = np.linspace(rho, rho - 0.004 * (r - 1), r)
+    A = np.diag(a) + 1e-3 * rng.standard_normal((r, r))
+    Q = 0.02 * np.eye(r) + 0.002 * np.ones((r, r))
+    panels, sts = [], []
+    for b in range(B):
+        Lam = rng.standard_normal((N, r))
+        R = Rscale * rng.uniform(0.5, 1.5, N)
+        f = rng.standard_normal(r)
+        x = np.empty((T, N))
+        for t in range(T):
+            f = A @ f + np.linalg.cholesky(Q) @ rng.standard_normal(r)
+            x[t] = Lam @ f + np.sqrt(R) * rng.standard_normal(N)
+        panels.append(x)
+        sts.append(dict(Lam=Lam, R=R, A=A.copy(), Q=Q.copy(), mu0=0.1 * rng.standard_normal(r), P0=np.eye(r) * (1.0 + b)))
+    return np.stack(panels), {k: np.stack([s[k] for s in sts]) for k in sts[0]}
+
+
+@pytest.mark.parametrize("N,T,r,rho,Rscale", [
+    (20, 500, 4, 0.999, 1e3),      # E close to (or equal to) T: the whole pass is "transient"
+    (20, 500, 8, 0.999, 2e2),      # headline state width
+    (200, 500, 8, 0.995, 5e3),     # headline shape, MFMA collapse
+    (30, 500, 3, 0.99, 50.0),      # E of a few hundred: long transient + short steady stretch
+    (16, 120, 2, 0.9999, 1e4),     # T shorter than the convergence time
+])
+def test_slow_riccati_on_the_balanced_path(ctx, N, T, r, rho, Rscale):
+    panel, st = _slow_riccati(3, N, T, r, rho, Rscale)
+    ref = _oracle(panel, st)
+    _compare(_run_dev(ctx, panel, st, may_have_missing=False), ref, f"slow Riccati N={N} T={T} r={r} rho={rho}")
+    c = _ctx_with_env(DFM_FORCE_GENERAL=1)     # and the sequential path on the same inputs
+    try:
+        _compare(_run_dev(c, panel, st, may_have_missing=False), ref, "slow Riccati, sequential path")
+    finally:
+        c.close()

@@ -83,3 +83,24 @@ def test_synth_missing_cells(ctx):
     torch.cuda.synchronize()
     frac = float(torch.isnan(p).double().mean().item())
     assert 0.08 < frac < 0.12
+
+
+@pytest.mark.parametrize("B,N,T,r,missing,first", [(5, 60, 81, 4, 0.0, 0), (3, 200, 500, 8, 0.0, 8189), (4, 31, 40, 3, 0.15, 2 ** 33),
+                                                  (2, 20, 30, 1, 0.05, 7)])
+def test_device_generator_equals_its_host_restatement(ctx, B, N, T, r, missing, first):
+    """The panels the throughput runs use (dfm_synth_panels_dev: Philox4x32-10 keyed by (seed, global replicate index))
+    cell by cell against oracle/synth_oracle.py -- the §8(d) DGP on the Random123-pinned generator.  Differences are the
+    last bits of log / sincospi and of the summation order in the standardisation."""
+    import torch
+    from oracle import synth_oracle as so
+    seed = 20160415
+    panel, par = ctx.synth_panels(seed, first, B, T, N, r, missing_prob=missing)
+    torch.cuda.synchronize()
+    x = panel.cpu().numpy()
+    got = dict(zip(("Lam", "R", "A", "Q", "mu0", "P0"), [p.cpu().numpy() for p in par]))
+    for b in range(B):
+        xo, po = so.synth_replicate_device(seed, first + b, N, T, r, missing)
+        np.testing.assert_array_equal(np.isnan(x[b]), np.isnan(xo))          # the same cells are missing
+        np.testing.assert_allclose(np.nan_to_num(x[b]), np.nan_to_num(xo), rtol=0, atol=2e-11)
+        for k in po:
+            np.testing.assert_allclose(got[k][b], po[k], rtol=1e-11, atol=1e-12, err_msg=k)

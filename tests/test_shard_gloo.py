@@ -112,3 +112,110 @@ def test_bootstrap_draws_gather_over_gloo():
     for rank, full, med in got:
         np.testing.assert_array_equal(full, want)                       # every rank: all draws, global order
         np.testing.assert_array_equal(med, np.quantile(want, 0.5, axis=0, method="inverted_cdf"))
+
+
+# ---- the multi-GPU EM driver itself (shard.em_batch_sharded) on CPU ranks -------------------------------------
+# The kernel call (DfmContext.em_iterate_batch = dfm_em_iterate_batch_dev) is replaced by the oracle's EM step with
+# the same bookkeeping contract (include/dfm_hip.h): tests only.  What is under test is the driver: sharding, the
+# all-gather after EVERY iteration, the global stopping rule, rank-identical global state, results equal to a
+# single-rank run.
+EM_KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
+
+
+def _oracle_iterate(panel, Lam, R, A, Q, mu0, P0, k, max_iter, tol, path, iters, active, f, P, may_have_missing=False):
+    from oracle import kalman_oracle as ko
+    import torch
+    for b in range(panel.shape[0]):
+        was = True if k == 0 else bool(active[b])
+        par = dict(Lam=Lam[b].numpy(), R=R[b].numpy(), A=A[b].numpy(), Q=Q[b].numpy(), mu0=mu0[b].numpy(), P0=P0[b].numpy())
+        new, ll, out = ko.em_step(panel[b].numpy(), **par)
+        go = was
+        if was and k >= 1 and tol > 0.0:
+            llp = float(path[b, k - 1])
+            go = not ((ll - llp) / (0.5 * (abs(ll) + abs(llp))) < tol)
+        if was:
+            path[b, k] = ll
+            iters[b] = k + 1
+        active[b] = 1 if go else 0
+        if go:
+            for name, t in zip(EM_KEYS, (Lam, R, A, Q, mu0, P0)):
+                t[b] = torch.from_numpy(np.ascontiguousarray(new[name]))
+        if f is not None:
+            f[b] = torch.from_numpy(out["f_smooth"])
+        if P is not None:
+            P[b] = torch.from_numpy(ko.pack_sym(out["P_smooth"]))
+
+
+def _em_problem(B, N, T, r):
+    from oracle import kalman_oracle as ko
+    panels, starts = [], []
+    for b in range(B):
+        x, _ = ko.synth_replicate(b, N, T, r, missing=0.05 if b % 2 else 0.0)
+        p0, _ = ko.pca_init(np.nan_to_num(x), r)
+        panels.append(x); starts.append(p0)
+    return np.stack(panels), {k: np.stack([s[k] for s in starts]) for k in EM_KEYS}
+
+
+def _em_worker(rank, world, port, B, max_iter, tol, q):
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        panel, st = _em_problem(B, 12, 30, 2)
+        lo, hi = shard.replicate_range(B, world, rank)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).clone()
+        par = [t(st[k]) for k in EM_KEYS]
+        out = shard.em_batch_sharded(None, t(panel), *par, B_global=B, max_iter=max_iter, tol=tol, iterate=_oracle_iterate)
+        q.put((rank, lo, hi, out["iterations"], out["loglik_global"].numpy().copy(), out["active_global"].numpy().copy(),
+               out["path"].numpy().copy(), out["iters"].numpy().copy(), [p.numpy().copy() for p in par],
+               out["f"].numpy().copy()))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _run_em(world, B, max_iter, tol):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + 11 * world
+    procs = [ctx.Process(target=_em_worker, args=(k, world, port, B, max_iter, tol, q)) for k in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("tol", [0.0, 2e-3])
+def test_em_driver_world2_equals_single_rank(tol):
+    B, max_iter = 5, 7
+    one = _run_em(1, B, max_iter, tol)[0]
+    two = _run_em(2, B, max_iter, tol)
+    # rank-identical GLOBAL state after every iteration: the gathered {loglik, active} and the stopping iteration
+    assert two[0][3] == two[1][3] == one[3]
+    np.testing.assert_array_equal(two[0][4], two[1][4])
+    np.testing.assert_array_equal(two[0][5], two[1][5])
+    np.testing.assert_array_equal(two[0][4], one[4])            # ... and equal to the single-rank run
+    np.testing.assert_array_equal(two[0][5], one[5])
+    if tol > 0.0:
+        assert one[3] < max_iter and not one[5].any()           # stopped globally, before max_iter
+        assert len(set(one[7].tolist())) > 1                    # replicates converge at different iterations
+    else:
+        assert one[3] == max_iter
+    # per-replicate results of the shards = the single-rank results (paths, iteration counts, parameters, factors)
+    for rank, lo, hi, _, _, _, path, iters, par, f in two:
+        np.testing.assert_array_equal(path, one[6][lo:hi])
+        np.testing.assert_array_equal(iters, one[7][lo:hi])
+        for a, b in zip(par, one[8]):
+            np.testing.assert_array_equal(a, b[lo:hi])
+        np.testing.assert_array_equal(f, one[9][lo:hi])
+    # the gathered column k is the log-likelihood path of every replicate still iterating at k
+    for b in range(B):
+        n = one[7][b]
+        np.testing.assert_array_equal(one[4][b, :min(n, one[3])], one[6][b, :min(n, one[3])])
