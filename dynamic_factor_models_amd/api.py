@@ -149,7 +149,8 @@ def drop_missing_col(A: np.ndarray):
 
 # ----------------------------------------------------------------------------- estimate!(m, ::Parametric)
 def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int = 50, tol_em: float = 1e-6,
-             factor_lags: Optional[int] = None, ctx=None, lam_constr_f=None, lam_constr_fl=None):
+             factor_lags: Optional[int] = None, ctx=None, lam_constr_f=None, lam_constr_fl=None,
+             nrep: int = 0, seed: int = 20160415, ngpu: int = 1):
     """`estimate!(m::DFMModel, ::Parametric; max_em_iter, tol_em)`: PCA-initialised EM for the exact
     Gaussian state-space DFM  x_t = Lam f_t + e_t,  f_t = A f_{t-1} + eta_t  on the standardised
     estimation window (rows initperiod..lastperiod, series with inclcode == 1), fitted with the HIP
@@ -165,6 +166,11 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
     `factor_lags` = p of the factor VAR, f_t = A_1 f_{t-1} + .. + A_p f_{t-p} + eta_t; default: the model's own
     `n_factorlag` (dfm_functions.ipynb:120-146), run in the companion form `fill_matrices!` builds (:477-492)
     through dfm_em_varp_batch (r p <= 32); then M, G, seps, betahat hold [A_1 .. A_p], chol(Q), Q.
+    `nrep` > 0 (SURVEY 8(b): `estimate!(m, ::Parametric; ..., nrep, seed, ngpu)`): after the point estimate, `nrep`
+    parametric-bootstrap replicates of the standardised window are drawn from the fitted model (the window's own missing
+    pattern; NumPy generator seeded with `seed`) and re-estimated by EM in ONE batched call on `ngpu` GPUs of this node
+    (dfm_em_batch_multi: replicates sharded over the GPUs, one RCCL all-gather of {loglik, active} per EM iteration);
+    the replicate estimates land in `m.replicates`.  Needs factor_lags = 1.
     `NonParametric()` runs the reference's own estimator (ALS, loadings, VAR) on the HIP kernels of als.hip:
     see estimate_nonparametric below."""
     method = Parametric() if method is None else method
@@ -180,6 +186,8 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
     nlag = m.n_factorlag if factor_lags is None else int(factor_lags)
     if nlag < 1 or r * nlag > 32:
         raise ValueError("need 1 <= factor_lags and nfac_u * factor_lags <= 32 (DFM_MAX_R)")
+    if nrep and nlag != 1:
+        raise ValueError("bootstrap replicates (nrep > 0) need factor_lags = 1")
     incl = m.inclcode == 1
     xdata = m.data[m.initperiod - 1:m.lastperiod, :][:, incl]           # :335-336
     z, sd = standardize_data(xdata)                                     # :339
@@ -272,7 +280,33 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
     var.betahat[:] = 0.0
     c0 = 1 if var.withconst else 0
     var.betahat[c0:c0 + ka, :] = A[:, :ka].T
+    if nrep:
+        m.replicates = _bootstrap_replicates(z, params, int(nrep), int(seed), int(ngpu), max_em_iter, tol_em)
     return m.loglik_path
+
+
+def _bootstrap_replicates(z, params, nrep, seed, ngpu, max_em_iter, tol_em):
+    """`nrep` parametric-bootstrap panels from the fitted model on the standardised window z (NaN where z is NaN),
+    re-estimated from the point estimate in one dfm_em_batch_multi call (julia/dfm_hip.jl estimate!: same steps)."""
+    from .kalman import DfmContext
+    Lam, R, A, Q, mu0, P0 = (params[k][0] for k in ("Lam", "R", "A", "Q", "mu0", "P0"))
+    T, N = z.shape
+    r = Lam.shape[1]
+    rng = np.random.default_rng(seed)
+    LQ = np.linalg.cholesky(0.5 * (Q + Q.T))
+    LS = np.linalg.cholesky(0.5 * (P0 + P0.T))
+    sq = np.sqrt(R)
+    panels = np.empty((nrep, T, N))
+    for b in range(nrep):
+        f = mu0 + LS @ rng.standard_normal(r)
+        for t in range(T):
+            f = A @ f + LQ @ rng.standard_normal(r)
+            panels[b, t] = Lam @ f + sq * rng.standard_normal(N)
+    panels[:, np.isnan(z)] = np.nan
+    rep = lambda a: np.repeat(a[None], nrep, axis=0)
+    new, path, iters, _, _, ran = DfmContext.em_batch_multi_host(ngpu, panels, rep(Lam), rep(R), rep(A), rep(Q), rep(mu0),
+                                                                 rep(P0), max_iter=max_em_iter, tol=tol_em)
+    return dict(params=new, loglik_path=path, iters=iters, iterations=ran, panels=panels)
 
 
 # ============================================================================= the NON-parametric path

@@ -13,12 +13,15 @@
 #
 # NOT EXECUTED IN THE BUILD IMAGE (no Julia there): kept deliberately thin -- every numerical step is a
 # single ccall; the same sequence of calls is exercised by dynamic_factor_models_amd/api.py (tests/
-# test_gpu_api.py), which mirrors this file line by line.
+# test_gpu_api.py), which mirrors this file step by step, and tests/test_julia_shim_cpu.py parses every ccall below
+# and checks symbol, return type, argument count and argument types against include/dfm_hip.h.
 
 module DFMHip
 
 const LIB = get(ENV, "DFMHIP_LIB", joinpath(@__DIR__, "..", "dynamic_factor_models_amd", "lib", "libdfmhip.so"))
 const DFM_F_MAY_HAVE_MISSING = Cuint(1)
+const DFM_F_SINGULAR_Q = Cuint(2)
+const DFM_E_NUMERIC = Cint(-5)
 
 mutable struct Handle
     ptr::Ptr{Cvoid}
@@ -36,6 +39,15 @@ function create(device::Integer = 0)
     rc == 0 || error("libdfmhip: dfm_create failed with status $rc (no HIP device?)")
     h = Handle(ref[])
     finalizer(x -> (x.ptr != C_NULL && ccall((:dfm_destroy, LIB), Cint, (Ptr{Cvoid},), x.ptr); x.ptr = C_NULL), h)
+    return h
+end
+
+# One handle (context + device workspace) per device for the whole session: the notebook calls the estimator ~200 times
+# per table (Stock_Watson.ipynb:516, 591, 643, 893) and a handle per call would allocate and free the workspace each time.
+const HANDLES = Dict{Int,Handle}()
+function handle(device::Integer = 0)
+    h = get(HANDLES, Int(device), nothing)
+    (h === nothing || h.ptr == C_NULL) && (h = HANDLES[Int(device)] = create(device))
     return h
 end
 
@@ -73,18 +85,98 @@ function em(h::Handle, z::Matrix{Float64}, p; max_iter::Integer = 50, tol::Real 
     path = Array{Float64}(undef, max_iter, 1); iters = Array{Cint}(undef, 1)
     f = Array{Float64}(undef, r, T, 1); np = div(r * (r + 1), 2); P = Array{Float64}(undef, np, T, 1)
     flags = any(isnan, z) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    start = (copy(Lam), copy(R), copy(A), copy(Q), copy(mu0), copy(P0))
     GC.@preserve panel Lam R A Q mu0 P0 path iters f P begin
         rc = ccall((:dfm_em_batch, LIB), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cdouble, Ptr{Float64}, Ptr{Cint},
                     Ptr{Float64}, Ptr{Float64}, Cuint),
                    h.ptr, 1, T, N, r, panel, Lam, R, A, Q, mu0, P0, max_iter, tol, path, iters, f, P, flags)
+        if rc == DFM_E_NUMERIC
+            # the information-form recursion inverts Q; a PCA start on fewer than 2r + 1 periods has a rank-deficient VAR
+            # residual covariance: run the covariance-form recursion instead (as api.estimate does)
+            Lam, R, A, Q, mu0, P0 = start
+            rc = ccall((:dfm_em_batch, LIB), Cint,
+                       (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                        Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cdouble, Ptr{Float64}, Ptr{Cint},
+                        Ptr{Float64}, Ptr{Float64}, Cuint),
+                       h.ptr, 1, T, N, r, panel, Lam, R, A, Q, mu0, P0, max_iter, tol, path, iters, f, P,
+                       flags | DFM_F_SINGULAR_Q)
+        end
         check(h.ptr, rc)
     end
     k = Int(iters[1])
     return (Lam = permutedims(Lam[:, :, 1]), R = R[:, 1], A = permutedims(A[:, :, 1]), Q = permutedims(Q[:, :, 1]),
             mu0 = mu0[:, 1], P0 = permutedims(P0[:, :, 1]), loglik = path[1:k, 1], iters = k,
             factor = permutedims(f[:, :, 1]))
+end
+
+# C [b][i][k] <-> Julia: a vector of B matrices (rows x cols) -> Array (cols, rows, B), and back
+pack3(ms::Vector{Matrix{Float64}}) = cat([permutedims(m) for m in ms]...; dims = 3)
+unpack3(a::Array{Float64,3}) = [permutedims(a[:, :, b]) for b in 1:size(a, 3)]
+
+"B smoother passes in ONE call (dfm_ks_pass_batch; with ngpu > 1: dfm_ks_pass_batch_multi, replicates split over the
+GPUs): panels[b] is T x N (NaN = missing), params[b] = (Lam N x r, R, A, Q, mu0, P0).  Returns per-replicate smoothed
+factors (T x r), packed covariances (T x r(r+1)/2) and log-likelihoods."
+function ks_pass_batch(h::Handle, panels::Vector{Matrix{Float64}}, params::Vector; ngpu::Integer = 1)
+    B = length(panels); T, N = size(panels[1]); r = size(params[1].Lam, 2)
+    panel = cat([permutedims(z, (2, 1)) for z in panels]...; dims = 3)           # (N, T, B) == C [b][t][i]
+    Lam = pack3([p.Lam for p in params]); R = hcat([p.R for p in params]...)
+    A = pack3([p.A for p in params]); Q = pack3([p.Q for p in params]); P0 = pack3([p.P0 for p in params])
+    mu0 = hcat([p.mu0 for p in params]...)
+    np = div(r * (r + 1), 2)
+    f = Array{Float64}(undef, r, T, B); P = Array{Float64}(undef, np, T, B); ll = Array{Float64}(undef, B)
+    flags = any(isnan, panel) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    GC.@preserve panel Lam R A Q mu0 P0 f P ll begin
+        if ngpu <= 1
+            rc = ccall((:dfm_ks_pass_batch, LIB), Cint,
+                       (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                        Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cuint),
+                       h.ptr, B, T, N, r, panel, Lam, R, A, Q, mu0, P0, f, P, ll, flags)
+            check(h.ptr, rc)
+        else
+            err = zeros(UInt8, 700)
+            rc = ccall((:dfm_ks_pass_batch_multi, LIB), Cint,
+                       (Cint, Ptr{Cint}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                        Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cuint,
+                        Ptr{UInt8}, Cint),
+                       ngpu, C_NULL, B, T, N, r, panel, Lam, R, A, Q, mu0, P0, f, P, ll, flags, err, length(err))
+            rc == 0 || error("libdfmhip: status $rc: $(unsafe_string(pointer(err)))")
+        end
+    end
+    return (factor = unpack3(f), P = unpack3(P), loglik = ll)
+end
+
+"EM for B replicates in ONE call on `ngpu` GPUs of this node (dfm_em_batch_multi: replicates split over the GPUs, one
+host thread per GPU inside the library, ONE RCCL all-gather of {loglik, active} after every EM iteration -- SURVEY.md
+8(e)).  panels[b]: T x N, starts[b] = (Lam, R, A, Q, mu0, P0).  Returns the per-replicate estimates, log-likelihood
+paths and iteration counts."
+function em_batch(panels::Vector{Matrix{Float64}}, starts::Vector; max_iter::Integer = 50, tol::Real = 1e-6,
+                  ngpu::Integer = 1, want_smooth::Bool = false)
+    B = length(panels); T, N = size(panels[1]); r = size(starts[1].Lam, 2)
+    panel = cat([permutedims(z, (2, 1)) for z in panels]...; dims = 3)
+    Lam = pack3([p.Lam for p in starts]); R = hcat([p.R for p in starts]...)
+    A = pack3([p.A for p in starts]); Q = pack3([p.Q for p in starts]); P0 = pack3([p.P0 for p in starts])
+    mu0 = hcat([p.mu0 for p in starts]...)
+    path = Array{Float64}(undef, max_iter, B); iters = Array{Cint}(undef, B); ran = Ref{Cint}(0)
+    np = div(r * (r + 1), 2)
+    f = want_smooth ? Array{Float64}(undef, r, T, B) : Array{Float64}(undef, 0, 0, 0)
+    P = want_smooth ? Array{Float64}(undef, np, T, B) : Array{Float64}(undef, 0, 0, 0)
+    flags = any(isnan, panel) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    err = zeros(UInt8, 700)
+    GC.@preserve panel Lam R A Q mu0 P0 path iters f P err begin
+        rc = ccall((:dfm_em_batch_multi, LIB), Cint,
+                   (Cint, Ptr{Cint}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cdouble, Ptr{Float64}, Ptr{Cint}, Ptr{Float64},
+                    Ptr{Float64}, Cuint, Ptr{Cint}, Ptr{UInt8}, Cint),
+                   ngpu, C_NULL, B, T, N, r, panel, Lam, R, A, Q, mu0, P0, max_iter, tol, path, iters,
+                   want_smooth ? pointer(f) : Ptr{Float64}(C_NULL), want_smooth ? pointer(P) : Ptr{Float64}(C_NULL), flags,
+                   ran, err, length(err))
+        rc == 0 || error("libdfmhip: status $rc: $(unsafe_string(pointer(err)))")
+    end
+    return (Lam = unpack3(Lam), R = [R[:, b] for b in 1:B], A = unpack3(A), Q = unpack3(Q), mu0 = [mu0[:, b] for b in 1:B],
+            P0 = unpack3(P0), loglik = [path[1:iters[b], b] for b in 1:B], iters = Int.(iters), iterations = Int(ran[]),
+            factor = want_smooth ? unpack3(f) : nothing)
 end
 
 "EM for VAR(p) factor dynamics in companion form (dfm_em_varp_batch; include/dfm_hip.h): p.Avar is r x (r p) =
@@ -219,31 +311,48 @@ end
 
 end # module
 
+import Random
+using LinearAlgebra
+
 # ---------------------------------------------------------------------------------------------------------
-# The new method.  Same mutate-in-place convention as the reference's estimate! (dfm_functions.ipynb:530-543);
-# additionally returns the per-iteration log-likelihood vector.
+# The new method (SURVEY.md 8(b)).  Same mutate-in-place convention as the reference's estimate!
+# (dfm_functions.ipynb:530-543); additionally returns the per-iteration log-likelihood vector.
+#   nrep > 0: after the point estimate, `nrep` parametric-bootstrap replicates of the standardised window are drawn
+#   from the fitted model (same missing pattern; Julia's RNG seeded with `seed`) and re-estimated by EM IN ONE BATCHED
+#   CALL on `ngpu` GPUs (DFMHip.em_batch -> dfm_em_batch_multi: replicates sharded over the GPUs, one RCCL all-gather
+#   per EM iteration); the method then returns (loglik = ..., replicates = ...).
 function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em::Real = 1e-6,
-                   factor_lags::Integer = m.n_factorlag, device::Integer = 0, handle = nothing)
+                   factor_lags::Integer = m.n_factorlag, nrep::Integer = 0, seed::Integer = 20160415, ngpu::Integer = 1,
+                   device::Integer = 0, handle = nothing, lam_constr_f = nothing, lam_constr_fl = nothing)
+    (lam_constr_f === nothing && lam_constr_fl === nothing) ||
+        error("loading constraints are not supported on the parametric path")   # never drop them silently
     m.nfac_o == 0 || error("observed factors are not supported on the parametric path")
     r = m.nfac_u
     nlag = Int(factor_lags)
     (nlag >= 1 && r * nlag <= 32) || error("need 1 <= factor_lags and nfac_u * factor_lags <= 32")
+    (nrep == 0 || nlag == 1) || error("bootstrap replicates (nrep > 0) need factor_lags = 1")
     incl = m.inclcode .== 1
     xdata = m.data[m.initperiod:m.lastperiod, incl]                       # dfm_functions.ipynb:335-336
     xstd, xsd = standardize_data(xdata)                                   # :339
     m.fes.tss = sum(skipmissing(xstd .^ 2))                               # :342
     m.fes.nobs = count(.!ismissing.(xstd))                                # :343
+    # :357 -- a series with fewer than nt_min_factor_estimation observed periods gets no loadings in the reference's
+    # estimator: it is left out here too (api.estimate: `enough`)
+    enough = vec(sum(.!ismissing.(xstd), dims = 1)) .>= m.nt_min_factor_estimation
+    xstd = xstd[:, enough]; xsd = vec(xsd)[enough]
     z = reshape(DFMHip.nan_for_missing(xstd), size(xstd))
     xbal, balmask = drop_missing_col(xstd)                                # :345
     balmask = vec(balmask)
-    h = handle === nothing ? DFMHip.create(device) : handle
+    size(xbal, 2) >= r || error("fewer fully observed series than factors: cannot initialise by PCA")
+    h = handle === nothing ? DFMHip.handle(device) : handle               # one cached handle per device
     p0 = DFMHip.pca_init(h, Float64.(xbal), r)                            # pca_score (:179-183) + OLS start, on the GPU
     N = size(z, 2)
     Lam = Matrix{Float64}(undef, N, r); R = Vector{Float64}(undef, N)
     Lam[balmask, :] = p0.Lam; R[balmask] = p0.R
-    for i in findall(.!balmask)                                           # series with gaps: complete-case OLS (:242-252)
-        b, e, rows = ols_skipmissing(xstd[:, i], p0.F, Balanced())
-        Lam[i, :] = b; R[i] = sum(abs2, e) / count(rows)
+    gap = findall(.!balmask)
+    if !isempty(gap)                                                      # series with gaps: complete-case OLS on the PCA
+        o = DFMHip.ols(h, p0.F, z[:, gap])                                # factors (:242-252), one dfm_ols_batch call
+        Lam[gap, :] = permutedims(o.beta); R[gap] = o.ssr ./ max.(o.nobs, 1)
     end
     fit = if nlag == 1
         DFMHip.em(h, z, (Lam = Lam, R = R, A = p0.A, Q = p0.Q, mu0 = p0.mu0, P0 = p0.P0);
@@ -258,9 +367,9 @@ function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em:
                               P0 = (P0v + P0v') / 2), nlag; max_iter = max_em_iter, tol = tol_em)
     end
     m.factor[m.initperiod:m.lastperiod, :] = fit.factor                   # in place: aliases factor_var_model.y (:80, :371)
-    cols = findall(incl)
-    m.lambda[cols, :] = fit.Lam .* vec(xsd)
-    m.uar_ser[cols] = sqrt.(fit.R) .* vec(xsd)
+    cols = findall(incl)[enough]
+    m.lambda[cols, :] = fit.Lam .* xsd
+    m.uar_ser[cols] = sqrt.(fit.R) .* xsd
     m.uar_coef[cols, :] .= 0.0
     common = fit.factor * fit.Lam'
     e = [isnan(z[t, i]) ? 0.0 : z[t, i] - common[t, i] for t in 1:size(z, 1), i in 1:N]
@@ -273,24 +382,51 @@ function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em:
     var.Q[1:r, 1:r] = Matrix(1.0I, r, r)
     var.seps[:, :] = fit.Q
     var.G[1:r, 1:r] = cholesky(Symmetric(fit.Q)).L
-    return fit.loglik
+    nrep == 0 && return fit.loglik
+    # ---- parametric-bootstrap replicates, re-estimated in one batched multi-GPU call (api.estimate: same steps) ----
+    rng = Random.MersenneTwister(seed)
+    T = size(z, 1)
+    LQ = cholesky(Symmetric(fit.Q)).L
+    Sf = copy(fit.P0)                                                     # start the factor path from the fitted f_0 moments
+    LS = cholesky(Symmetric((Sf + Sf') / 2)).L
+    panels = Vector{Matrix{Float64}}(undef, nrep)
+    for b in 1:nrep
+        f = fit.mu0 + LS * randn(rng, r)
+        x = Matrix{Float64}(undef, T, N)
+        for t in 1:T
+            f = fit.A * f + LQ * randn(rng, r)
+            x[t, :] = fit.Lam * f + sqrt.(fit.R) .* randn(rng, N)
+        end
+        x[isnan.(z)] .= NaN                                               # the window's own missing pattern
+        panels[b] = x
+    end
+    start = (Lam = fit.Lam, R = fit.R, A = fit.A, Q = fit.Q, mu0 = fit.mu0, P0 = fit.P0)
+    reps = DFMHip.em_batch(panels, [start for _ in 1:nrep]; max_iter = max_em_iter, tol = tol_em, ngpu = ngpu)
+    return (loglik = fit.loglik, replicates = reps)
 end
 
 
 # ---------------------------------------------------------------------------------------------------------
 # The reference's own estimator on the GPU: same arguments and effects as `estimate_factor!(m, max_iter, computeR2)`
-# (dfm_functions.ipynb:328-382).  To run Stock_Watson.ipynb unchanged on the GPU, forward the reference's method:
-#     estimate_factor!(m::DFMModel, max_iter::Integer = 100000000, computeR2::Bool = true; lam_constr = nothing) =
-#         estimate_factor_hip!(m, max_iter, computeR2)
-function estimate_factor_hip!(m::DFMModel, max_iter::Integer = 100000000, computeR2::Bool = true; device::Integer = 0,
-                              handle = nothing)
+# (dfm_functions.ipynb:328-382), PCA start and every sweep on the GPU.  Loading constraints (`lam_constr`, used at
+# Stock_Watson.ipynb:1336-1344) are NOT implemented on the HIP path: with constraints this method hands the call to the
+# reference's own pure-Julia method when the maintainer has kept it under the name `estimate_factor_cpu!` (see
+# INTEGRATION.md for the two-line change), and raises otherwise -- it never drops them.
+function estimate_factor_hip!(m::DFMModel, max_iter::Integer = 100000000, computeR2::Bool = true; lam_constr = nothing,
+                              device::Integer = 0, handle = nothing)
+    if lam_constr !== nothing
+        isdefined(Main, :estimate_factor_cpu!) ||
+            error("estimate_factor_hip!: loading constraints are not supported on the HIP path and the reference's " *
+                  "method is not available as estimate_factor_cpu! (INTEGRATION.md)")
+        return Main.estimate_factor_cpu!(m, max_iter, computeR2; lam_constr = lam_constr)
+    end
     m.nfac_o == 0 || error("observed factors are not supported on the HIP path")
     xdata = m.data[m.initperiod:m.lastperiod, m.inclcode .== 1]           # :335-336
     xstd, _ = standardize_data(xdata)                                     # :339
     m.fes.tss = sum(skipmissing(xstd .^ 2))                               # :342
     m.fes.nobs = count(.!ismissing.(xstd))                                # :343
     xbal, _ = drop_missing_col(xstd)                                      # :345
-    h = handle === nothing ? DFMHip.create(device) : handle
+    h = handle === nothing ? DFMHip.handle(device) : handle               # cached: the notebook calls this ~200 times a table
     F0 = DFMHip.pca_init(h, Float64.(xbal), m.nfac_u).F                  # pca_score (:348)
     z = reshape(DFMHip.nan_for_missing(xstd), size(xstd))
     fit = DFMHip.als(h, z, F0; nt_min = m.nt_min_factor_estimation, max_iter = max_iter, tol = m.tol,
@@ -308,6 +444,6 @@ function bootstrap_irf_bands(varm::VARModel, H::Integer; ndraws::Integer = 10000
     first = rows[1] - varm.nlag
     y = Float64.(varm.y[first:rows[end], :])
     resid = zeros(size(y)); resid[varm.nlag+1:end, :] = Float64.(varm.resid[rows, :])
-    h = handle === nothing ? DFMHip.create(device) : handle
+    h = handle === nothing ? DFMHip.handle(device) : handle
     return DFMHip.bootstrap_irf(h, y, Float64.(varm.betahat), resid, varm.nlag, H, ndraws; seed = seed)
 end

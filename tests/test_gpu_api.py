@@ -128,3 +128,35 @@ def test_config1_stock_watson_panel_pca_plus_10_em_iterations(lags):
     np.testing.assert_allclose(path, pathe, rtol=1e-6)                     # north_star: 1e-6 relative
     f = m.factor[init - 1:last]
     assert np.abs(f - fo).max() <= 1e-6 * np.abs(fo).max()
+
+
+def test_estimate_parametric_with_bootstrap_replicates_and_short_series():
+    """`estimate(m, Parametric(); nrep, seed, ngpu)`: replicates drawn from the fitted model and re-estimated
+    in one dfm_em_batch_multi call, each against the oracle's EM on the same replicate panel from the same start; a series
+    with fewer than nt_min observed periods is left out (dfm_functions.ipynb:357) and gets no loadings."""
+    from dynamic_factor_models_amd import api
+    rng = np.random.default_rng(2)
+    T_all, ns, r = 90, 20, 2
+    x, _ = ko.synth_replicate(4, ns, T_all, r)
+    raw = 1.0 + 2.0 * x
+    raw[rng.random(raw.shape) < 0.05] = np.nan
+    raw[:, :12][np.isnan(raw[:, :12])] = 0.5
+    raw[:75, 17] = np.nan                                       # 15 observed periods < nt_min = 20
+    m = api.DFMModel(raw, np.ones(ns, dtype=int), 20, 40, 1, T_all, 0, r, 1e-8, 4, 4)
+    path = api.estimate(m, api.Parametric(), max_em_iter=6, tol_em=0.0, factor_lags=1, nrep=3, seed=77, ngpu=1)
+    assert len(path) == 6 and np.isnan(m.lambda_[17]).all() and np.isfinite(np.delete(m.lambda_, 17, axis=0)).all()
+    rep = m.replicates
+    assert rep["iterations"] == 6 and rep["panels"].shape == (3, T_all, ns - 1)
+    keep = np.delete(np.arange(ns), 17)
+    z, _ = api.standardize_data(raw[:, keep])
+    np.testing.assert_array_equal(np.isnan(rep["panels"][1]), np.isnan(z))      # the window's own missing pattern
+    start = {k: v for k, v in m.em_params.items()}
+    for b in range(3):
+        pe, pathe, _ = ko.em(rep["panels"][b], start, max_iter=6, tol=0.0)
+        np.testing.assert_allclose(rep["loglik_path"][b], pathe, rtol=1e-8)
+        for k in ("Lam", "R", "A", "Q"):
+            assert np.abs(rep["params"][k][b] - pe[k]).max() <= 1e-8 * max(1.0, np.abs(pe[k]).max()), k
+    # same seed -> same replicates; the draws are a function of (seed, fitted model) only
+    m2 = api.DFMModel(raw, np.ones(ns, dtype=int), 20, 40, 1, T_all, 0, r, 1e-8, 4, 4)
+    api.estimate(m2, api.Parametric(), max_em_iter=6, tol_em=0.0, factor_lags=1, nrep=3, seed=77)
+    np.testing.assert_array_equal(np.nan_to_num(m2.replicates["panels"]), np.nan_to_num(rep["panels"]))
