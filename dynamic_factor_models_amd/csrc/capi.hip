@@ -47,11 +47,11 @@ struct dfm_handle {
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
-                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_EM_UPDATE, K_CHOW, K_MSTEP_MFMA, K_COUNT };
+                K_COLLAPSE_DMA, K_GRAM, K_COV, K_MEANSCAN, K_PFILL, K_COLLAPSE_MFMA, K_ALS, K_OLS, K_BOOT, K_QUANT, K_COLLAPSE_WIDE, K_EM_UPDATE, K_CHOW, K_MSTEP_MFMA, K_GRAM_XX, K_PASS_FUSED, K_COUNT };
 static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_kernel", "mstep_lam_kernel",
-                                                  "mstep_solve_kernel", "pca_kernels", "synth_kernel",
+                                                  "mstep_solve_kernel", "pca_kernel", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
-                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel", "em_update_kernel", "chow_kernel", "mstep_mfma_kernel"};
+                                                  "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel", "em_update_kernel", "chow_kernel", "mstep_mfma_kernel", "gram_xx_kernel", "pass_fused_kernel"};
 
 namespace {
 
@@ -1176,7 +1176,8 @@ int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doub
     pa.S = at<double>(h, oS); pa.V = at<double>(h, oV); pa.Y = at<double>(h, oY); pa.F = at<double>(h, oF);
     pa.Lam = Lam; pa.Rv = R; pa.A = A; pa.Q = Q; pa.mu0 = mu0; pa.P0 = P0; pa.factors = factors;
     pa.status = at<int>(h, oSt);
-    { ProfScope ps(h, K_PCA); HIP_TRY(h, launch_gram_xx(pa, h->stream)); HIP_TRY(h, launch_pca(Rp, pa, h->stream)); }
+    { ProfScope ps(h, K_GRAM_XX); HIP_TRY(h, launch_gram_xx(pa, h->stream)); }
+    { ProfScope ps(h, K_PCA); HIP_TRY(h, launch_pca(Rp, pa, h->stream)); }
     return 0;
 }
 

@@ -50,12 +50,18 @@ def ks_pass(x, Lam, R, A, Q, mu0, P0):
     return dict(f_smooth=fs, P_smooth_packed=Ps, loglik=ll.value, f0_smooth=f0, P0_smooth=P0s, P_lag=Pl)
 
 
-def ks_pass_batch(panel, Lam, R, A, Q, mu0, P0, want_P=True, nthreads=0):
+def ks_pass_batch(panel, Lam, R, A, Q, mu0, P0, want_P=True, nthreads=0, out=None):
+    """`out` = (f_smooth, P_smooth, loglik) persistent C-contiguous buffers (bench.py's cpu_baseline: no allocation and
+    no first-touch page faults inside the timed region)."""
     B, T, N = panel.shape
     r = Lam.shape[2]
     panel, Lam, R, A, Q, mu0, P0 = map(_c, (panel, Lam, R, A, Q, mu0, P0))
-    fs = np.empty((B, T, r)); Ps = np.empty((B, T, r * (r + 1) // 2)) if want_P else None
-    ll = np.empty(B)
+    if out is not None:
+        fs, Ps, ll = out
+        assert fs.flags.c_contiguous and ll.flags.c_contiguous and (Ps is None or Ps.flags.c_contiguous)
+    else:
+        fs = np.empty((B, T, r)); Ps = np.empty((B, T, r * (r + 1) // 2)) if want_P else None
+        ll = np.empty(B)
     rc = lib().dfm_oracle_ks_pass_batch(B, T, N, r, _p(panel), _p(Lam), _p(R), _p(A), _p(Q),
                                         _p(mu0), _p(P0), _p(fs), _p(Ps), _p(ll), int(nthreads))
     if rc:

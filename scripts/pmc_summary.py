@@ -54,7 +54,10 @@ for k, (tot, n) in calib.items():
         factor = (4096 * 199680) / per if per > 0 else 2.0
         cal_note = f"k_dma reads 817.9 MB per launch; FETCH_SIZE*1024 reported {per / 1e6:.1f} MB -> factor {factor:.3f}"
         break
-res = {"_calibration": dict(fetch_factor=factor, note=cal_note, unit_bytes=UNIT)}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (source_hash: bench.py quotes this file only for the source tree it was measured on)
+res = {"_calibration": dict(fetch_factor=factor, note=cal_note, unit_bytes=UNIT), "_source_hash": bench.source_hash(),
+       "_workload": os.environ.get("DFM_PMC_WORKLOAD", "pass:B1024:N200:T500:r8:m0.0")}
 for k in sorted(set(fetch) | set(write)):
     fb = fetch.get(k, [0.0, 0]); wb = write.get(k, [0.0, 0])
     f_per = fb[0] / fb[1] * UNIT * factor if fb[1] else None
