@@ -130,10 +130,14 @@ def test_em_iterate_and_sharded_driver_equal_em_batch(ctx, B, N, T, r, missing, 
                                  may_have_missing=missing > 0)
     torch.cuda.synchronize()
     assert torch.equal(out["iters"], its0)
-    assert torch.equal(torch.nan_to_num(out["path"]), torch.nan_to_num(path0))
+    # r == padded width: the same kernels on the same numbers, bit for bit.  r < padded width: dfm_em_batch_dev keeps the
+    # padding states' (decoupled) parameters across iterations while the stepping entry re-embeds every iteration, and the
+    # 2 x 2 block pivots of the sweep inverse round a real state together with a padding state: equal to rounding.
+    same = torch.equal if r in (2, 4, 8, 16, 32) and missing == 0.0 else (lambda a, b: torch.allclose(a, b, rtol=1e-11, atol=1e-13))
+    assert same(torch.nan_to_num(out["path"]), torch.nan_to_num(path0))
     for k in KEYS:
-        assert torch.equal(got[k], ref[k]), k
-    assert torch.equal(out["f"], f0) and torch.equal(out["P"], P0)
+        assert same(got[k], ref[k]), k
+    assert same(out["f"], f0) and same(out["P"], P0)
     assert out["iterations"] == int(its0.max().item()) or tol == 0.0
     assert out["loglik_global"].shape == (B, out["iterations"])
     if tol > 0.0:
@@ -149,10 +153,11 @@ def test_em_batch_multi_one_gpu_equals_em_batch_host(ctx):
         p0, path0, its0, f0, P0 = ctx.em_batch_host(panel, *[st[k] for k in KEYS], max_iter=9, tol=tol)
         p1, path1, its1, f1, P1, ran = DfmContext.em_batch_multi_host(1, panel, *[st[k] for k in KEYS], max_iter=9, tol=tol)
         np.testing.assert_array_equal(its0, its1)
-        np.testing.assert_array_equal(np.nan_to_num(path0), np.nan_to_num(path1))
+        # r = 3 is padded to 4: the stepping entry re-embeds the parameters every iteration (equal to rounding, see above)
+        np.testing.assert_allclose(np.nan_to_num(path0), np.nan_to_num(path1), rtol=1e-11)
         for k in KEYS:
-            np.testing.assert_array_equal(p0[k], p1[k])
-        np.testing.assert_array_equal(f0, f1)
+            np.testing.assert_allclose(p0[k], p1[k], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(f0, f1, rtol=1e-10, atol=1e-12)
         assert ran == (9 if tol == 0.0 else its0.max())
     f, P, ll = ctx.ks_pass_batch_host(panel, *[st[k] for k in KEYS])
     f2, P2, ll2 = DfmContext.ks_pass_batch_multi_host(1, panel, *[st[k] for k in KEYS])
