@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <new>
+#include <string>
 #include <vector>
 
 #include "dfm_kernels.h"
@@ -37,8 +38,12 @@ struct dfm_handle {
     bool em_general = false;               // DFM_EM_GENERAL=1: EM of balanced panels on the general path too (diagnostics)
     bool fuse_gram = false;                // DFM_FUSE_GRAM=1: Gram matrices inside cov_kernel instead of gram_kernel (slower: its
                                            // per-series loads are dependent round trips, ~5 us each beside the collapse)
+    int pass_fused = 0;                    // DFM_PASS_FUSED=1: the balanced pass at Rp = 8 as ONE launch (pass_fused.hip)
+    int pass_nsw = 0;                      // DFM_PASS_NSW: stream waves per workgroup of that launch (0 = automatic)
+    bool cov_wave = false;                 // DFM_COV_WAVE=1: one-wave-per-replicate covariance recursion on the separate-launch path
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    std::string prof_file;                 // DFM_PF_PROF_FILE with DFM_SCAN_ABL=256: phase stamps of the fused pass
     char err[512] = {0};
     // optional per-kernel timing (bench.py roofline leg): event pairs on the launch stream
     bool profiling = false;
@@ -358,6 +363,30 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     // overlap buys at B = 1024, so the default is one sub-batch; DFM_SUBBATCH keeps the knob for big batches.
     int S = h->subbatch > 0 ? h->subbatch : 1;
     if (S > B) S = B;
+    if (S == 1 && h->pass_fused && use_mfma && pass_fused_supported(p.Rp, T, N) && h->collapse_variant == 0) {
+        // ONE launch: persistent workgroups, b_t / w_t and the covariance tables never leave the chip (pass_fused.hip)
+        fa.Lam = pp.Lam; fa.Rv = Rv;
+        if (h->scan_abl & 256) {                                  // phase stamps of every replicate -> scol; readable through the
+            ca.scol = at<double>(h, p.scol);                      // workspace dump below (diagnostics)
+            if (const char* f = getenv("DFM_PF_PROF_FILE")) h->prof_file = f;
+        }
+        const int nsw = pass_fused_pick_nsw(T, N, h->pass_nsw);
+        { ProfScope ps(h, K_PASS_FUSED); HIP_TRY(h, launch_pass_fused(ca, fa, nsw, h->num_cu, h->stream)); }
+        if ((h->scan_abl & 256) && !h->prof_file.empty()) {       // diagnostics: dump the stamps of this pass (synchronises)
+            std::vector<double> st((size_t)B * T);
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            HIP_TRY(h, hipMemcpy(st.data(), ca.scol, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+            if (FILE* fp = fopen(h->prof_file.c_str(), "w")) {
+                for (int bb = 0; bb < B; ++bb) {
+                    fprintf(fp, "%d", bb);
+                    for (int k = 0; k < 30; ++k) fprintf(fp, " %.0f", st[(size_t)bb * T + k]);
+                    fprintf(fp, "\n");
+                }
+                fclose(fp);
+            }
+        }
+        return em_update();
+    }
     if (S == 1 && use_mfma && !fuse_gram && !h->no_fuse_cov && collapse_mfma_fuses_cov(p.Rp, N)) {
         // ONE stream, two launches: [Gram + covariance workgroups + P_smooth fill | streaming collapse] -> scan.
         // The covariance waves sit at the front of the collapse grid (resident first, no cross-stream events).
@@ -377,7 +406,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }   // 12 us, alone
         HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-        { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
+        { ProfScope ps(h, K_COV); HIP_TRY(h, (h->cov_wave && p.Rp == 8 && !fuse_gram) ? launch_cov_wave(fa, h->stream) : launch_cov(p.Rp, fa, h->stream)); }
         { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA, h->side); HIP_TRY(h, use_wide ? launch_collapse_wide(p.Rp, ca, h->side) : launch_collapse_dma(p.Rp, ca, h->side, cvariant)); }
         HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
         if (!h->no_pfill && P_smooth) {   // the data-independent rows of P_smooth, beside the collapse
@@ -781,6 +810,9 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_SUBBATCH")) h->subbatch = atoi(v);
     if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
+    if (const char* v = getenv("DFM_PASS_FUSED")) h->pass_fused = atoi(v);
+    if (const char* v = getenv("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
+    if (const char* v = getenv("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;
     return 0;
 }

@@ -153,6 +153,12 @@ hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
 bool cov_fuses_gram(int Rpad, int N);   // launch_cov with a.Lam != nullptr is supported for this shape
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);
 hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s);   // the P_smooth fill of meanscan (then run it with abl bit 0)
+// The whole balanced pass in one launch (pass_fused.hip: persistent workgroups, stream / covariance / scan waves) and the
+// one-wave-per-replicate covariance recursion as a drop-in for launch_cov (Rp = 8, Cfull / ldfull from gram_kernel).
+bool pass_fused_supported(int Rpad, int T, int N);
+int pass_fused_pick_nsw(int T, int N, int want);            // stream waves per workgroup (<= 7) that fit the 160 KB of LDS
+hipError_t launch_pass_fused(const CollapseArgs& a, const FastArgs& fa, int nsw, int num_cu, hipStream_t s);
+hipError_t launch_cov_wave(const FastArgs& a, hipStream_t s);
 int fast_chunk_len(int Rpad, int T);
 int fast_stead_mats(int Rpad);
 
