@@ -38,8 +38,9 @@ struct dfm_handle {
     bool em_general = false;               // DFM_EM_GENERAL=1: EM of balanced panels on the general path too (diagnostics)
     bool fuse_gram = false;                // DFM_FUSE_GRAM=1: Gram matrices inside cov_kernel instead of gram_kernel (slower: its
                                            // per-series loads are dependent round trips, ~5 us each beside the collapse)
-    int pass_fused = 0;                    // DFM_PASS_FUSED=1: the balanced pass at Rp = 8 as ONE launch (pass_fused.hip)
+    int pass_fused = 1;                    // the balanced pass at Rp = 8 as ONE launch (pass_fused.hip); DFM_PASS_FUSED=0: two launches
     int pass_nsw = 0;                      // DFM_PASS_NSW: stream waves per workgroup of that launch (0 = automatic)
+    int pass_ncov = 0;                     // DFM_PASS_NCOV: covariance waves per workgroup of that launch (0 = automatic)
     bool cov_wave = false;                 // DFM_COV_WAVE=1: one-wave-per-replicate covariance recursion on the separate-launch path
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -370,8 +371,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
             ca.scol = at<double>(h, p.scol);                      // workspace dump below (diagnostics)
             if (const char* f = getenv("DFM_PF_PROF_FILE")) h->prof_file = f;
         }
-        const int nsw = pass_fused_pick_nsw(T, N, h->pass_nsw);
-        { ProfScope ps(h, K_PASS_FUSED); HIP_TRY(h, launch_pass_fused(ca, fa, nsw, h->num_cu, h->stream)); }
+        { ProfScope ps(h, K_PASS_FUSED); HIP_TRY(h, launch_pass_fused(ca, fa, h->pass_nsw, h->pass_ncov, h->num_cu, h->stream)); }
         if ((h->scan_abl & 256) && !h->prof_file.empty()) {       // diagnostics: dump the stamps of this pass (synchronises)
             std::vector<double> st((size_t)B * T);
             HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -379,7 +379,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
             if (FILE* fp = fopen(h->prof_file.c_str(), "w")) {
                 for (int bb = 0; bb < B; ++bb) {
                     fprintf(fp, "%d", bb);
-                    for (int k = 0; k < 30; ++k) fprintf(fp, " %.0f", st[(size_t)bb * T + k]);
+                    for (int k = 0; k < 40; ++k) fprintf(fp, " %.0f", st[(size_t)bb * T + k]);
                     fprintf(fp, "\n");
                 }
                 fclose(fp);
@@ -812,6 +812,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
     if (const char* v = getenv("DFM_PASS_FUSED")) h->pass_fused = atoi(v);
     if (const char* v = getenv("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
+    if (const char* v = getenv("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
     if (const char* v = getenv("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;
     return 0;
@@ -923,6 +924,7 @@ static int post_check(dfm_handle* h, const double* loglik_host, int B) {
     int st = 0;
     HIP_TRY(h, hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost));
     if (st & 1) return fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
+    if (st & 4) return fail(h, DFM_E_NUMERIC, "one-launch pass: a bounded wait between its waves ran out (results invalid)%s");
     for (int b = 0; b < B; ++b)
         if (!isfinite(loglik_host[b])) return fail(h, DFM_E_NUMERIC, "non-finite log-likelihood (Q or P0 not positive definite?)%s");
     return 0;

@@ -20,6 +20,7 @@ namespace dfm {
 
 constexpr int kCov8TileDoubles = 8 * kTileStride<8>;              // one staged 8 x 8 matrix (rows 10 doubles apart)
 constexpr int kCov8ScratchDoubles = 5 * kCov8TileDoubles + 64;    // L0, L1, LP (Psi' rows), LJ, spare + the Gram matrix
+constexpr int kCov8Keep = 8;                                      // transient steps whose Z_e, J_e stay in registers
 
 struct Cov8Dst {                 // every matrix row-major [8][8] = indexed by the lane
     double* tab;                 // entries e < tab_cap: tab + e * 3 * 64 = {Z_e, J_e, G_e}
@@ -82,6 +83,12 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
     LogProd detprod;                                            // prod over the E distinct steps of det(Om_f + Phi)
     double detM_last = 1.0;
     int E = 0;
+    // Z_e, J_e of the first kCov8Keep steps stay in registers for the backward sweep (one element per lane each): read
+    // back from the table they cost a global round trip per distinct step -- 5 to 8 us each beside streaming waves
+    double Zk[kCov8Keep], Jk[kCov8Keep];
+#pragma unroll
+    for (int u = 0; u < kCov8Keep; ++u) { Zk[u] = 0.0; Jk[u] = 0.0; }
+    double Zlast = 0.0, Jlast = 0.0, Glast = 0.0;               // entry E - 1 = the steady matrices
     for (int e = 0;; ++e) {
         double Z = Omf + Phi;
         const double detM = G.sweep_inverse(Z);                 // Z = (Om_f + Phi)^-1
@@ -96,6 +103,12 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
         const bool gsame = __all(close_enough(Omf_new, Omf));
         double* te = (e < o.tab_cap ? o.tab : o.tab_over) + (size_t)e * 3 * 64;
         te[lane] = Z; te[64 + lane] = Jr; te[128 + lane] = Gm;
+#pragma unroll
+        for (int u = 0; u < kCov8Keep; ++u) {
+            Zk[u] = (u == e) ? Z : Zk[u];
+            Jk[u] = (u == e) ? Jr : Jk[u];
+        }
+        Zlast = Z; Jlast = Jr; Glast = Gm;
         E = e + 1;
         detprod.mul(detM);
         detM_last = detM;
@@ -129,8 +142,18 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
     while (t >= 0) {
         const int e = t < ts ? t : ts;
         if (e != cur_e) {                                       // wave-uniform
-            const double* te = (e < o.tab_cap ? o.tab : o.tab_over) + (size_t)e * 3 * 64;
-            Zc = te[lane]; Jc = te[64 + lane];
+            if (e == ts) {
+                Zc = Zlast; Jc = Jlast;
+            } else if (e < kCov8Keep) {
+#pragma unroll
+                for (int u = 0; u < kCov8Keep; ++u) {
+                    Zc = (u == e) ? Zk[u] : Zc;
+                    Jc = (u == e) ? Jk[u] : Jc;
+                }
+            } else {
+                const double* te = (e < o.tab_cap ? o.tab : o.tab_over) + (size_t)e * 3 * 64;
+                Zc = te[lane]; Jc = te[64 + lane];
+            }
             cur_e = e;
             LJ[TS * i + j] = Jc;
         }
@@ -165,27 +188,29 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
 
     // ---------------- steady Z, J, G and the powers G^(L 2^k), J^(L 2^k) for the chunk carries ------------------
     {
-        const double* te = (ts < o.tab_cap ? o.tab : o.tab_over) + (size_t)ts * 3 * 64;
-        const double Zs = te[lane], Js = te[64 + lane], Gs = te[128 + lane];
+        const double Zs = Zlast, Js = Jlast, Gs = Glast;
         o.stead[lane] = Zs;
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {               // 0: G -> slot 2, powers 3..;  1: J -> slot 1, powers 3 + NLEV..
-            const int src = which == 0 ? 2 : 1, dst = which == 0 ? 3 : 3 + NLEV;
-            double M = which == 0 ? Gs : Js;
-            o.stead[src * 64 + lane] = M;
-            auto square = [&]() {
-                L0[TS * i + j] = M;
-                L1[TS * j + i] = M;
-                G.sync();
-                M = dot_rows<R>(L0, L1, i, j);
-                G.sync();
-            };
-            for (int l = 1; l < a.L; l <<= 1) square();         // M^L
+        o.stead[2 * 64 + lane] = Gs;
+        o.stead[1 * 64 + lane] = Js;
+        // the two power chains are independent: squared side by side (G through L0 / L1, J through LPT / LJ -- both free
+        // now), half the dependent exchanges of one chain after the other
+        double MG = Gs, MJ = Js;
+        auto square2 = [&]() {
+            L0[TS * i + j] = MG;
+            L1[TS * j + i] = MG;
+            LPT[TS * i + j] = MJ;
+            LJ[TS * j + i] = MJ;
+            G.sync();
+            MG = dot_rows<R>(L0, L1, i, j);
+            MJ = dot_rows<R>(LPT, LJ, i, j);
+            G.sync();
+        };
+        for (int l = 1; l < a.L; l <<= 1) square2();             // M^L
 #pragma unroll 1
-            for (int k = 0; k < NLEV; ++k) {
-                o.stead[(dst + k) * 64 + lane] = M;
-                if (k + 1 < NLEV) square();
-            }
+        for (int k = 0; k < NLEV; ++k) {
+            o.stead[(3 + k) * 64 + lane] = MG;                   // G^(L 2^k)
+            o.stead[(3 + NLEV + k) * 64 + lane] = MJ;            // J^(L 2^k)
+            if (k + 1 < NLEV) square2();
         }
     }
 }
@@ -212,7 +237,10 @@ __device__ __forceinline__ double gram_wave8(const double* __restrict__ Lg, cons
 #pragma unroll
             for (int k = 0; k < R; ++k) W[q][e][k] = Lg[(size_t)cc * R + k] * ri;
         }
-    c_all<R, NDR, 0, true>(W, Lg, own, lane, Cs);
+    // the 36 packed entries in two halves: 18 partial sums live at a time instead of 36 (register budget of the
+    // 12-wave workgroup of pass_fused_kernel)
+    c_chunk<R, NDR, 0, 18, true>(W, Lg, own, lane, Cs);
+    c_chunk<R, NDR, 18, 18, true>(W, Lg, own, lane, Cs);
     return wave_allsum(ld);
 }
 

@@ -156,8 +156,9 @@ hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s);   // the P_
 // The whole balanced pass in one launch (pass_fused.hip: persistent workgroups, stream / covariance / scan waves) and the
 // one-wave-per-replicate covariance recursion as a drop-in for launch_cov (Rp = 8, Cfull / ldfull from gram_kernel).
 bool pass_fused_supported(int Rpad, int T, int N);
-int pass_fused_pick_nsw(int T, int N, int want);            // stream waves per workgroup (<= 7) that fit the 160 KB of LDS
-hipError_t launch_pass_fused(const CollapseArgs& a, const FastArgs& fa, int nsw, int num_cu, hipStream_t s);
+int pass_fused_pick_nsw(int T, int N, int want);            // stream waves per workgroup that fit the 160 KB of LDS (diagnostic)
+// nsw / ncov: stream / covariance waves per workgroup (0 = as many as fit)
+hipError_t launch_pass_fused(const CollapseArgs& a, const FastArgs& fa, int nsw, int ncov, int num_cu, hipStream_t s);
 hipError_t launch_cov_wave(const FastArgs& a, hipStream_t s);
 int fast_chunk_len(int Rpad, int T);
 int fast_stead_mats(int Rpad);

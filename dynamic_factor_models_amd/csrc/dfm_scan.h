@@ -42,8 +42,14 @@ __device__ __forceinline__ void chunk_prefetch(double (&cur)[kPF], const double*
 #pragma unroll
     for (int u = 0; u < kPF; ++u) {
         const int t = t0 + dir * u;
-        const bool ok = FULL ? (u < L) : (u < L && t >= tlo && t < thi);
-        cur[u] = ok ? src[(size_t)t * R + i] : 0.0;
+        if constexpr (FULL) {
+            cur[u] = (u < L) ? src[(size_t)t * R + i] : 0.0;
+        } else {   // branch-free: read a row that exists, select afterwards (no exec-masked block per operand)
+            const bool ok = u < L && t >= tlo && t < thi;
+            const int tc = t < tlo ? tlo : (t >= thi ? thi - 1 : t);
+            const double x = src[(size_t)tc * R + i];
+            cur[u] = ok ? x : 0.0;
+        }
     }
 }
 
@@ -63,7 +69,13 @@ __device__ __forceinline__ double chunk_run(const double (&Mp)[R], const double 
         for (int u = 0; u < kPF; ++u) {
             const int j = j0 + kPF + u;
             const int t = t0 + dir * j;
-            nxt[u] = (FULL ? (j < L) : valid(j)) ? src[(size_t)t * R + i] : 0.0;
+            if constexpr (FULL) {
+                nxt[u] = (j < L) ? src[(size_t)t * R + i] : 0.0;
+            } else {
+                const int tc = t < tlo ? tlo : (t >= thi ? thi - 1 : t);
+                const double x = src[(size_t)tc * R + i];
+                nxt[u] = valid(j) ? x : 0.0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < kPF; ++u) {
@@ -99,9 +111,13 @@ __device__ __forceinline__ double chunk_run(const double (&Mp)[R], const double 
 // (pw: the NLEV power matrices, in LDS).  `head` (the true state entering chunk 0) is folded into e_0.
 // Returns the state entering chunk c.
 // act = false: a thread outside the NG chunks (pass_fused_kernel's idle waves) -- it executes the barriers only.
-template <int R, int NG>
+struct BlockSync {                                            // the whole workgroup scans
+    __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+// `sync`: barrier of the threads that take part in the scan (pass_fused_kernel: four of its waves, on an LDS counter)
+template <int R, int NG, class Sync = BlockSync>
 __device__ __forceinline__ double carry_scan(double e, double head, const double* pw, int c, int i, double* sA,
-                                             double* sB, bool act = true) {
+                                             double* sB, bool act = true, Sync&& sync = Sync()) {
     constexpr int NLEV = scan_levels(R);
     double Mp[R];
     load_xperm<R>(Mp, pw, i);                                // M^L
@@ -109,11 +125,11 @@ __device__ __forceinline__ double carry_scan(double e, double head, const double
     double v = (c == 0) ? e + h : e;
     double* cur = sA;
     double* oth = sB;
-    __syncthreads();                                          // previous users of sA / sB are done
+    sync();                                                   // previous users of sA / sB are done
 #pragma unroll 1
     for (int k = 0; k < NLEV; ++k) {
         if (act) cur[c * R + i] = v;
-        __syncthreads();
+        sync();
         const int d = 1 << k;
         const double left = (act && c >= d) ? cur[(c - d) * R + i] : 0.0;
         if (k > 0) load_xperm<R>(Mp, pw + (size_t)k * R * R, i);
@@ -121,7 +137,7 @@ __device__ __forceinline__ double carry_scan(double e, double head, const double
         double* t_ = cur; cur = oth; oth = t_;
     }
     if (act) cur[c * R + i] = v;
-    __syncthreads();
+    sync();
     return (c == 0 || !act) ? head : cur[(c - 1) * R + i];
 }
 

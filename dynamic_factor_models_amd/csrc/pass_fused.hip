@@ -1,23 +1,27 @@
 // pass_fused.hip -- the whole balanced-panel Kalman-smoother pass in ONE launch (Rp = 8): persistent workgroups, one per
-// CU, each walking its replicates b = blockIdx.x, blockIdx.x + gridDim.x, ...; inside a workgroup the waves are
-// specialised:
+// CU, each walking its replicates b = blockIdx.x, blockIdx.x + gridDim.x, ...  Inside a workgroup the waves are
+// specialised and DECOUPLED -- three software-pipeline stages that hand replicates to each other through LDS flags, never
+// through a workgroup barrier:
 //
-//   waves 0 .. nsw-1  STREAM   the collapse of collapse_mfma.hip (LDS-DMA ring of period slots, contraction on
-//                              v_mfma_f64_4x4x4): wave w streams segment w of the replicate's T periods.  b_t goes to an
-//                              LDS array [T][8] instead of HBM, sum_t s_t to an LDS slot.
-//   the last wave     COV      Gram matrix C = Lam' R^-1 Lam, the data-independent covariance recursion (dfm_cov8.h: one
-//                              wave, element per lane) into LDS tables, the transient rows of P_smooth, then the
-//                              fixed-point rows of P_smooth (pure stores) -- all beside the stream of the SAME replicate.
-//   waves 0 .. 3      SCAN     after a workgroup barrier: the time-parallel mean recursion (dfm_scan.h, the code of
-//                              meanscan_kernel) with b_t / w_t in LDS: f_smooth, log-likelihood.  Before it starts, the
-//                              stream waves have already issued the first ring fill of the NEXT replicate, so the DMA
-//                              engine keeps HBM busy while the (latency-bound, ~5 us) scan runs.
+//   waves 0 .. nsw-1     STREAM  the collapse of collapse_mfma.hip (LDS-DMA ring of period slots, contraction on
+//                                v_mfma_f64_4x4x4): wave w streams segment w of the replicate's T periods.  b_t goes to
+//                                one of two LDS arrays [T][8] instead of HBM, sum_t s_t to an LDS slot.  While the scan
+//                                waves work on replicate j the stream waves are already filling the other array with
+//                                replicate j + 1, so HBM never waits for the (latency-bound) scan.
+//   the next ncov waves  COV     Gram matrix C = Lam' R^-1 Lam, the data-independent covariance recursion (dfm_cov8.h: one
+//                                wave per replicate, element per lane), the transient rows of P_smooth, then the fixed-point
+//                                rows of P_smooth (pure stores).  Nothing here depends on the panel, so these waves run
+//                                AHEAD of the stream (replicates j, j + ncov, ... each); their tables go to the
+//                                per-replicate workspace in global memory (L2-resident: written and read by the same CU).
+//   the last 4 waves     SCAN    the time-parallel mean recursion (dfm_scan.h, the algorithm of meanscan_kernel) with
+//                                b_t / w_t in LDS: f_smooth, log-likelihood.  Its internal barriers are 4-wave barriers on
+//                                an LDS counter.
 //
 // Against the two-launch pass (fused collapse launch + meanscan_kernel): no b_t round trip through HBM (33 MB written,
 // read back), no w_t scratch (33 MB + 33 MB), no second launch whose ~55 us of dependent scans ran behind the stream
-// instead of beside it, and the covariance recursion no longer holds 128 wide waves resident for 125 us.  HBM traffic is
-// the algorithmic minimum of SURVEY 8(d): every input read once, every output written once.
-// Synchronisation is two workgroup barriers per replicate -- no inter-workgroup communication, no spin-wait.
+// instead of beside it, and the covariance recursion no longer holds 128 wide waves resident for 125 us.
+// Synchronisation: monotone counters in LDS (bt_ready[buffer], scan_done, cov_done[wave]); every wait is BOUNDED (a wait
+// that does not end sets bit 2 of the status word and the whole workgroup drains).  No inter-workgroup communication.
 // The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
 #include <string.h>
 
@@ -53,10 +57,27 @@ __device__ __forceinline__ void wait_vmf() {
 __device__ __forceinline__ void wait_lgkmf() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 constexpr int kPfR = 8;
-constexpr int kPfEcap = 8;                                  // transient covariance steps kept in LDS (later ones: global tab)
+constexpr int kPfEcap = 6;                                  // transient covariance steps staged in LDS (later ones: global tab)
 constexpr int kPfNst = stead_mats(kPfR);                    // steady Z, J, G + the carry powers (256 scan threads)
 constexpr int kPfNlev = scan_levels(kPfR);
-constexpr int kPfMaxThreads = 512;
+constexpr int kPfScanWaves = kScanThreads / 64;             // 4
+constexpr int kPfMaxCov = 2;
+constexpr int kPfMaxWaves = 12;                             // 3 waves per SIMD: 168 VGPRs each
+constexpr int kPfMaxThreads = 64 * kPfMaxWaves;
+constexpr unsigned kPfLdsLimit = 160u * 1024u;
+
+// flags (unsigned, LDS): monotone counters
+constexpr int kFBtReady = 0;      // [2] arrivals of stream waves per b_t buffer
+constexpr int kFScanDone = 2;     // replicates (local index) whose scan is complete
+constexpr int kFCovDone = 3;      // [kPfMaxCov] replicates finished by each covariance wave
+constexpr int kFScanBar = 5;      // arrivals at the scan waves' barrier
+constexpr int kFAbort = 6;
+constexpr int kFTabReady = 7;     // replicates whose tables the mover has put into the LDS table set
+constexpr int kFCount = 64;
+
+// misc doubles (LDS)
+constexpr int kMiscXi0 = 0, kMiscLlc = 8, kMiscE = 9, kMiscVec = 16, kMiscRed = 32, kMiscSsum = 40 /* [2][8] */,
+              kMiscPs = 56 /* [36] */, kMiscDoubles = 92;
 
 // row-slot stride: as collapse_mfma.hip (4 consecutive slots start 64 bytes apart modulo 256)
 __host__ __device__ inline unsigned pf_slot_bytes(int N) {
@@ -65,39 +86,92 @@ __host__ __device__ inline unsigned pf_slot_bytes(int N) {
     return sb;
 }
 
+__device__ __forceinline__ unsigned ld_flag(const unsigned* f) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+// Bounded wait until *f >= target (counters are monotone).  false: the workgroup is draining (time-out somewhere).
+__device__ __forceinline__ bool pf_wait_ge(const unsigned* f, unsigned target, unsigned* abortf) {
+    unsigned spins = 0;
+    for (;;) {
+        if ((int)(ld_flag(f) - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 255u) == 0) {
+            if (ld_flag(abortf) != 0) return false;
+            if (spins > (1u << 23)) {                        // ~ a second: something upstream died
+                __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return false;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    return true;
+}
+// everything this wave wrote (LDS and global) is visible to the workgroup before the counter moves
+__device__ __forceinline__ void pf_signal(unsigned* f, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Barrier of the kPfScanWaves scan waves on an LDS counter (s_barrier would involve the stream / covariance waves).
+struct PfScanSync {
+    unsigned* ctr;
+    unsigned* abortf;
+    unsigned gen;          // arrivals expected once every wave has passed the next barrier
+    int lane;
+    __device__ __forceinline__ void operator()() {
+        gen += kPfScanWaves;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned spins = 0;
+        while ((int)(ld_flag(ctr) - gen) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0) {
+                if (ld_flag(abortf) != 0) break;
+                if (spins > (1u << 23)) { __hip_atomic_store(abortf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+// global loads that must not be served by the scalar cache or a stale L1 line (written by another wave of this CU)
+__device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_dev(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 }  // namespace
 
 // byte offsets into the dynamic LDS of pass_fused_kernel (computed by the host)
 struct PfLds {
-    unsigned smat;    // [kPfNst + 1][64] doubles: steady matrices, then P_T
-    unsigned ctab;    // [kPfEcap][3][64] doubles: Z_e, J_e, G_e
-    unsigned misc;    // xi0 [8] | llc [1] | pad [7] | PsInf [64] | ps packed [40] | vec [16] | red [8] | ssum [16] | ints [8]
-    unsigned covws;   // kCov8ScratchDoubles doubles
+    unsigned flags;   // kFCount unsigned
+    unsigned smat;    // [kPfNst + 1][64] doubles: steady matrices, then P_T        (scan staging)
+    unsigned ctab;    // [kPfEcap][3][64] doubles: Z_e, J_e, G_e                     (scan staging)
+    unsigned misc;    // kMiscDoubles doubles
+    unsigned covws;   // ncov x kCov8ScratchDoubles doubles
     unsigned sa, sb;  // [32][8] doubles each (carry scan)
-    unsigned bt;      // [T4][8] doubles: b_t, then w_t
+    unsigned bt;      // nbuf x [T4][8] doubles: b_t, then w_t
+    unsigned bt_stride;   // doubles between the b_t buffers
     unsigned ring;    // nsw x 8 slots x SB bytes
     unsigned total;
+    int nsw, ncov, nbuf;
 };
-constexpr int kMiscXi0 = 0, kMiscLlc = 8, kMiscPsInf = 16, kMiscPs = 80, kMiscVec = 120, kMiscRed = 136, kMiscSsum = 144,
-              kMiscInts = 160, kMiscDoubles = 164;
 
 // ------------------------------------------------------------------------------------------------------------------
-// The scan of one replicate, operands in LDS.  Called by EVERY wave of the workgroup (the barriers inside are workgroup
-// barriers); threads with act = false (tid >= 256) only keep the barrier count.  meanscan_kernel's algorithm (fastpath.hip).
+// The scan of one replicate, b_t in LDS, tables staged in LDS.  Called by the 4 scan waves (tid 0 .. 255); `sync` is their
+// barrier.  meanscan_kernel's algorithm (fastpath.hip).
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, bool act, double* bt, const double* s_tab,
-                                         const double* tab_over, const double* s_mat, const double* xi0p, const double* llcp,
-                                         int E, double* s_a, double* s_b, double* s_vec, double* s_red, const double* ssum,
-                                         int nseg, double* pslot) {
+template <class Sync>
+__device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, double* bt, const double* s_tab, const double* tab_over,
+                                         const double* s_mat, const double* xi0p, const double* llcp, int E, double* s_a,
+                                         double* s_b, double* s_vec, double* s_red, const double* ssum, int nseg, Sync& sync,
+                                         double* pslot) {
     auto mark = [&](int k) {       // diagnostics: phase stamps of thread 0 (pslot null: off)
-        if (pslot && tid == 0) { pslot[k] = (double)__builtin_amdgcn_s_memrealtime(); pslot[k + 10] = (double)__builtin_amdgcn_s_memtime(); }
+        if (pslot && tid == 0) pslot[k] = (double)__builtin_amdgcn_s_memrealtime();
     };
-    mark(10);
     constexpr int R = kPfR;
     constexpr int NG = kScanThreads / R;
     constexpr int NLEV = kPfNlev;
     constexpr int NST = kPfNst;
-    const int c = act ? tid / R : 0, i = tid % R;
+    const int c = tid / R, i = tid % R;
     const int T = a.T, r = a.r, L = a.L;
     const int ts = E - 1;
     const int nst = ts < kPfEcap ? ts : kPfEcap;              // transient steps whose tables are in LDS
@@ -113,7 +187,7 @@ __device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, bool
     double dot = 0.0;                     // lane part of sum_t xi_t' w_t
 
     // ---- forward transient: steps 0 .. ts-1 on wave 0 only (its lane groups redundantly) --------------------------
-    if (ts > 0) {                                             // (workgroup-uniform)
+    if (ts > 0) {                                             // (uniform over the scan waves)
         if (tid < 64) {
             for (int t = 0; t < ts; ++t) {
                 double Zp[R], Gp[R];
@@ -131,42 +205,37 @@ __device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, bool
             }
             if (c == 0) s_vec[i] = xi;
         }
-        __syncthreads();
+        sync();
         xi = s_vec[i];
-        __syncthreads();                  // s_vec is reused for xi_T
+        sync();                           // s_vec is reused for xi_T
     }
     // xi = xi_ts in every group.
-    mark(11);
+    mark(1);
 
     // ---- steady forward scan: steps ts .. T-1; group c owns steps ts + c L + j ------------------------------------
     {
         double Gp[R], Zp[R];
         load_xperm<R>(Gp, s_mat + 2 * R * R, i);
         double dummy = 0.0;
-        double e = 0.0;
-        if (act) {
-            if (fullf) chunk_prefetch<R, true>(cur, bt, t0f, 1, L, ts, T, i);
-            else chunk_prefetch<R, false>(cur, bt, t0f, 1, L, ts, T, i);
-            // phase 1: chunk from a zero state
-            e = fullf ? chunk_run<R, true, 0>(Gp, Gp, 0.0, cur, bt, t0f, 1, L, ts, T, i, nullptr, dummy, nullptr, r)
-                      : chunk_run<R, false, 0>(Gp, Gp, 0.0, cur, bt, t0f, 1, L, ts, T, i, nullptr, dummy, nullptr, r);
-            if (fullf) chunk_prefetch<R, true>(cur, bt, t0f, 1, L, ts, T, i);     // operands of phase 3
-            else chunk_prefetch<R, false>(cur, bt, t0f, 1, L, ts, T, i);
-        }
-        mark(12);
+        if (fullf) chunk_prefetch<R, true>(cur, bt, t0f, 1, L, ts, T, i);
+        else chunk_prefetch<R, false>(cur, bt, t0f, 1, L, ts, T, i);
+        // phase 1: chunk from a zero state
+        const double e = fullf ? chunk_run<R, true, 0>(Gp, Gp, 0.0, cur, bt, t0f, 1, L, ts, T, i, nullptr, dummy, nullptr, r)
+                               : chunk_run<R, false, 0>(Gp, Gp, 0.0, cur, bt, t0f, 1, L, ts, T, i, nullptr, dummy, nullptr, r);
+        if (fullf) chunk_prefetch<R, true>(cur, bt, t0f, 1, L, ts, T, i);     // operands of phase 3
+        else chunk_prefetch<R, false>(cur, bt, t0f, 1, L, ts, T, i);
+        mark(2);
         // phase 2: true start state of chunk c
-        const double s = carry_scan<R, NG>(e, xi, s_mat + 3 * R * R, c, i, s_a, s_b, act);
-        mark(13);
+        const double s = carry_scan<R, NG>(e, xi, s_mat + 3 * R * R, c, i, s_a, s_b, true, sync);
+        mark(3);
         // phase 3: re-run from the true start; emit w_t (in place of b_t), accumulate xi_t' w_t
-        if (act) {
-            load_xperm<R>(Zp, s_mat, i);
-            const double v = fullf ? chunk_run<R, true, 1>(Gp, Zp, s, cur, bt, t0f, 1, L, ts, T, i, bt, dot, nullptr, r)
-                                   : chunk_run<R, false, 1>(Gp, Zp, s, cur, bt, t0f, 1, L, ts, T, i, bt, dot, nullptr, r);
-            if (c == clast) s_vec[i] = v;                     // xi_T
-        }
+        load_xperm<R>(Zp, s_mat, i);
+        const double v = fullf ? chunk_run<R, true, 1>(Gp, Zp, s, cur, bt, t0f, 1, L, ts, T, i, bt, dot, nullptr, r)
+                               : chunk_run<R, false, 1>(Gp, Zp, s, cur, bt, t0f, 1, L, ts, T, i, bt, dot, nullptr, r);
+        if (c == clast) s_vec[i] = v;                         // xi_T
     }
-    mark(14);
-    __syncthreads();   // xi_T in LDS; every w_t of this replicate is written
+    mark(4);
+    sync();            // xi_T in LDS; every w_t of this replicate is written
 
     // ---- terminal + steady backward scan: steps T-1 .. ts; group c owns steps T-1 - c L - j --------------------
     double fT = 0.0;
@@ -175,7 +244,7 @@ __device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, bool
         double PTp[R];
         load_xperm<R>(PTp, s_mat + NST * R * R, i);
         fT = matvec_x<R>(PTp, xiT);
-        if (act && c == 0) {
+        if (c == 0) {
             dot = fma(xiT, fT, dot);          // the log-likelihood needs sum xi'w + xi_T' f_T
             if (i < r) fout[(size_t)(T - 1) * r + i] = fT;
         }
@@ -185,28 +254,23 @@ __device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, bool
         double Jp[R];
         load_xperm<R>(Jp, s_mat + R * R, i);
         double dummy = 0.0;
-        double e = 0.0;
-        if (act) {
-            if (fullb) chunk_prefetch<R, true>(cur, bt, t0b, -1, L, ts, T, i);
-            else chunk_prefetch<R, false>(cur, bt, t0b, -1, L, ts, T, i);
-            e = fullb ? chunk_run<R, true, 0>(Jp, Jp, 0.0, cur, bt, t0b, -1, L, ts, T, i, nullptr, dummy, nullptr, r)
-                      : chunk_run<R, false, 0>(Jp, Jp, 0.0, cur, bt, t0b, -1, L, ts, T, i, nullptr, dummy, nullptr, r);
-            if (fullb) chunk_prefetch<R, true>(cur, bt, t0b, -1, L, ts, T, i);
-            else chunk_prefetch<R, false>(cur, bt, t0b, -1, L, ts, T, i);
-        }
-        mark(15);
-        const double s = carry_scan<R, NG>(e, fT, s_mat + (size_t)(3 + NLEV) * R * R, c, i, s_a, s_b, act);
-        mark(16);
-        if (act) {
-            const double v = fullb ? chunk_run<R, true, 2>(Jp, Jp, s, cur, bt, t0b, -1, L, ts, T, i, nullptr, dummy, fout, r)
-                                   : chunk_run<R, false, 2>(Jp, Jp, s, cur, bt, t0b, -1, L, ts, T, i, nullptr, dummy, fout, r);
-            if (c == clast) s_vec[R + i] = v;
-        }
-        __syncthreads();
+        if (fullb) chunk_prefetch<R, true>(cur, bt, t0b, -1, L, ts, T, i);
+        else chunk_prefetch<R, false>(cur, bt, t0b, -1, L, ts, T, i);
+        const double e = fullb ? chunk_run<R, true, 0>(Jp, Jp, 0.0, cur, bt, t0b, -1, L, ts, T, i, nullptr, dummy, nullptr, r)
+                               : chunk_run<R, false, 0>(Jp, Jp, 0.0, cur, bt, t0b, -1, L, ts, T, i, nullptr, dummy, nullptr, r);
+        if (fullb) chunk_prefetch<R, true>(cur, bt, t0b, -1, L, ts, T, i);
+        else chunk_prefetch<R, false>(cur, bt, t0b, -1, L, ts, T, i);
+        mark(5);
+        const double s = carry_scan<R, NG>(e, fT, s_mat + (size_t)(3 + NLEV) * R * R, c, i, s_a, s_b, true, sync);
+        mark(6);
+        const double v = fullb ? chunk_run<R, true, 2>(Jp, Jp, s, cur, bt, t0b, -1, L, ts, T, i, nullptr, dummy, fout, r)
+                               : chunk_run<R, false, 2>(Jp, Jp, s, cur, bt, t0b, -1, L, ts, T, i, nullptr, dummy, fout, r);
+        if (c == clast) s_vec[R + i] = v;
+        sync();
         fb = s_vec[R + i];
     }
 
-    mark(17);
+    mark(7);
     // ---- backward transient: steps ts-1 .. 0 (wave 0 only) --------------------------------------------------------
     if (tid < 64) {
         double v = fb;
@@ -220,13 +284,12 @@ __device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, bool
         if (a.f0s && c == 0) a.f0s[(size_t)b * R + i] = v;   // E[f_0 | X] (EM)
     }
 
-    mark(18);
+    mark(8);
     // ---- log-likelihood ---------------------------------------------------------------------------------------
-    if (!act) dot = 0.0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, kWave);
-    if (act && (tid & 63) == 0) s_red[tid >> 6] = dot;
-    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = dot;
+    sync();
     if (tid == 0) {
         double d = 0.0, sq = 0.0;
 #pragma unroll
@@ -237,132 +300,216 @@ __device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, bool
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Gram matrix C = Lam' R^-1 Lam of one replicate by ONE wave on the fp64 matrix pipe, in the collapse's own operand layout:
+// lane (K, g, h, q) holds W[c][4 h + q] = lam_c,4h+q / R_c for the series c = 8 s + 4 g + K (the B operands of the stream
+// waves).  Rows i = 4 p + (0..3) of Lam' play the part of the 4 periods of a row block: the A operand of block p is
+// lam_c,4p+q -- the lane's own raw loading when p == h, its partner's (lane ^ 4) otherwise.  2 x STEPS MFMAs instead of
+// ~400 VALU instructions and two 18-value transpose-reductions; C (not symmetrised) into Cs[8][8].  Returns sum_i log R_i.
+// ------------------------------------------------------------------------------------------------------------------
+template <int STEPS, int NQ>
+__device__ __forceinline__ double gram_mfma8(const double* __restrict__ Lg, const double* __restrict__ Rg, int N, int lane,
+                                             double* Cs) {
+    constexpr int R = 8, CS = 8;
+    const int K = lane >> 4, blk = (lane >> 2) & 3, q = lane & 3;
+    const int g = blk >> 1, h = blk & 1;
+    const bool tail_clamp = (STEPS - 1) * CS + 4 * g + K >= N;
+    const int clast = tail_clamp ? N - 1 : (STEPS - 1) * CS + 4 * g + K;
+    const double* __restrict__ Lq = Lg + (4 * g + K) * R + 4 * h + q;
+    const double* __restrict__ Rq = Rg + (4 * g + K);
+    double raw[STEPS], rv[STEPS];
+#pragma unroll
+    for (int s = 0; s + 1 < STEPS; ++s) {
+        raw[s] = Lq[s * CS * R];
+        rv[s] = Rq[s * CS];
+    }
+    raw[STEPS - 1] = Lg[(size_t)clast * R + 4 * h + q];
+    rv[STEPS - 1] = Rg[clast];
+    double rl[NQ][2];                                            // the lane's own series (2 l, 2 l + 1) + 128 jq: log R
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = 2 * lane + 128 * jq + e;
+            rl[jq][e] = Rg[c < N ? c : N - 1];
+        }
+    // every load is in flight before anything is consumed: under register pressure the scheduler otherwise pairs each load
+    // with its use (a full round trip per step -- 5 to 8 us each beside the streaming waves)
+    __builtin_amdgcn_sched_barrier(0);
+    double ld = 0.0;
+#pragma unroll
+    for (int jq = 0; jq < NQ; ++jq)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = 2 * lane + 128 * jq + e;
+            ld += log(c < N ? rl[jq][e] : 1.0);                  // unconditional call: no exec-masked block per series
+        }
+    double D0 = 0.0, D1 = 0.0;
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+        const double w = (s == STEPS - 1 && tail_clamp) ? 0.0 : raw[s] * fast_rcp(rv[s]);   // the stream waves' weights exactly
+        const double other = xor_lane<4>(raw[s]);
+        const double a0 = h == 0 ? raw[s] : other;           // lam_c,q
+        const double a1 = h == 0 ? other : raw[s];           // lam_c,4+q
+        D0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, w, D0, 0, 0, 0);
+        D1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, w, D1, 0, 0, 0);
+    }
+    D0 += xor_lane<8>(D0);                                       // fold the two series groups
+    D1 += xor_lane<8>(D1);
+    if (g == 0) {                                                // lane (K, h, q): C[4 p + K][4 h + q]
+        Cs[K * R + 4 * h + q] = D0;
+        Cs[(4 + K) * R + 4 * h + q] = D1;
+    }
+    return wave_allsum(ld);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 template <int STEPS, int NDR>
-__global__ __launch_bounds__(kPfMaxThreads, 2) void pass_fused_kernel(CollapseArgs a, FastArgs fa, unsigned SB, int nsw, PfLds ly) {
+__global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs a, FastArgs fa, unsigned SB, PfLds ly) {
     constexpr int R = kPfR;
     constexpr int NB = 2, NS = 4 * NB;                       // row blocks / row slots of a wave's ring
     constexpr int CS = 8;                                    // series per MFMA step at R = 8: 2 series groups x 2 factor groups
     constexpr int NQ = NDR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_stream = wave < nsw;
-    const bool is_cov = wave == (int)(blockDim.x >> 6) - 1;   // the last wave (the workgroup has max(nsw + 1, 4) waves: the scan needs 4)
-    double* s_mat = reinterpret_cast<double*>(smem + ly.smat);
-    double* s_tab = reinterpret_cast<double*>(smem + ly.ctab);
+    const int tid_wg = threadIdx.x;
+    const int lane = tid_wg & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_wg >> 6);
+    const int nsw = ly.nsw, ncov = ly.ncov, nbuf = ly.nbuf;
+    unsigned* flags = reinterpret_cast<unsigned*>(smem + ly.flags);
     double* misc = reinterpret_cast<double*>(smem + ly.misc);
-    double* covws = reinterpret_cast<double*>(smem + ly.covws);
-    double* s_a = reinterpret_cast<double*>(smem + ly.sa);
-    double* s_b = reinterpret_cast<double*>(smem + ly.sb);
-    double* bt = reinterpret_cast<double*>(smem + ly.bt);
-    int* ints = reinterpret_cast<int*>(misc + kMiscInts);    // E, fill_lo, fill_hi
+    double* bt0 = reinterpret_cast<double*>(smem + ly.bt);
     const int N = a.N, T = a.T, B = a.B;
-    const unsigned rowB = (unsigned)N * 8u;
+    const int G = (int)gridDim.x;
 
-    // ---- stream-wave constants: lane roles of v_mfma_f64_4x4x4 (collapse_mfma.hip), segment of this wave ---------
-    const int K = lane >> 4, blk = (lane >> 2) & 3, q = lane & 3;
-    const int g = blk >> 1, h = blk & 1;
-    int tq = (T + nsw - 1) / nsw;
-    {
-        unsigned gg = rowB & 127u;
-        gg = gg == 0 ? 128u : (gg & (~gg + 1u));
-        const int m = (int)(128u / gg);
-        tq = ((tq + m - 1) / m) * m;                         // segments start on 128-byte boundaries
-    }
-    const int sw = is_stream ? wave : 0;
-    const int ta = (sw * tq < T) ? sw * tq : T;
-    const int tb = (ta + tq < T) ? ta + tq : T;
-    const int nrows = is_stream ? tb - ta : 0;
-    const int nblk = (nrows + 3) / 4;
-    const unsigned ringB = NS * SB;
-    const char* ring = smem + ly.ring + (size_t)sw * ringB;
-    const unsigned ring_lds =
-        __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_f)(smem)) + ly.ring + (unsigned)sw * ringB;
-    const unsigned lane16 = 16u * lane;
-    bool pact[NDR];                                          // lane moves 16 bytes of piece p of a row
-#pragma unroll
-    for (int p = 0; p < NDR; ++p) pact[p] = lane16 + 1024u * p < rowB;
-    const unsigned lane_off = (unsigned)q * SB + (unsigned)(4 * g + K) * 8u;
-    const bool tail_clamp = (STEPS - 1) * CS + 4 * g + K >= N;
-    const unsigned last_off = tail_clamp ? (unsigned)q * SB + (unsigned)(N - 1) * 8u : lane_off + (unsigned)(STEPS - 1) * (CS * 8u);
+    if (tid_wg < kFCount) flags[tid_wg] = 0u;
+    __syncthreads();                                         // the only workgroup barrier of the kernel
 
-    double Bw[STEPS];                                        // B operands: lam_cf / R_c for c = s CS + 4 g + K, f = 4 h + q
-    double rown[NQ][2];                                      // 1 / R of the lane's own 16-byte column pairs (s_t pass)
-    auto issue_row = [&](const char* seg, int rr, int slot) {
-        const char* src = seg + (size_t)rr * rowB + lane16;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)slot * SB);
-#pragma unroll
-        for (int p = 0; p < NDR; ++p) {
-            if (pact[p]) dma16f(src + 1024 * p, dst + 1024u * p);
-        }
-    };
-    // first ring fill + weights of replicate bb (stream waves): the fill first, the weights behind it -- a counted wait on
-    // the fill later also covers everything older
-    auto prepare = [&](int bb) {
-        const char* seg = reinterpret_cast<const char*>(a.panel + ((size_t)bb * T + ta) * N);
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl)
-            if (sl < nrows) issue_row(seg, sl, sl);
-        const double* __restrict__ Lg = a.Lam + (size_t)bb * N * R;
-        const double* __restrict__ Rg = a.Rv + (size_t)bb * N;
-        double rv[STEPS];
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int c = s * CS + 4 * g + K;
-            const int cc = c < N ? c : N - 1;
-            rv[s] = Rg[cc];
-            Bw[s] = Lg[(size_t)cc * R + 4 * h + q];
-        }
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int c = 2 * lane + 128 * jq + e;
-                rown[jq][e] = Rg[c < N ? c : N - 1];
-            }
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            const int c = s * CS + 4 * g + K;
-            Bw[s] = (c < N) ? Bw[s] * (1.0 / rv[s]) : 0.0;
-        }
-#pragma unroll
-        for (int jq = 0; jq < NQ; ++jq)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int c = 2 * lane + 128 * jq + e;
-                rown[jq][e] = (c < N) ? 1.0 / rown[jq][e] : 0.0;
-            }
-    };
-
-    int b = blockIdx.x;
-    if (is_stream && b < B && nrows > 0) prepare(b);
-
-    // DFM_SCAN_ABL bit 8: s_memrealtime stamps (10 ns ticks) of the phases of every replicate into scol[b][0..15]
-    const bool prof = (fa.abl & 256) != 0 && a.scol != nullptr && T >= 16;
+    // DFM_SCAN_ABL bit 8: s_memrealtime stamps (10 ns ticks) of the phases of every replicate into scol[b][0..31]
+    const bool prof = (fa.abl & 256) != 0 && a.scol != nullptr && T >= 40;
     auto stamp = [&](int bb, int slot) {
         if (prof && lane == 0) a.scol[(size_t)bb * T + slot] = (double)__builtin_amdgcn_s_memrealtime();
     };
-    for (; b < B; b += gridDim.x) {
-        const int bn = b + (int)gridDim.x;
-        if (wave == 0) stamp(b, 0);                               // iteration starts
-        if (is_stream) {
-            // ================= STREAM: segment [ta, tb) of replicate b -> bt[t][0..7], ssum[wave] =================
-            double qa[NQ][2];
+
+    if (wave < nsw) {
+        // ================= STREAM: segment [ta, tb) of every replicate -> bt[buf][t][0..7], ssum[buf][wave] ==========
+        // The wave's work is ONE sequence of row blocks (4 periods each) over all its replicates: the ring is re-armed
+        // with the next replicate's first rows while the last rows of the current one are consumed, so the DMA stream
+        // never drains at a replicate boundary.  Every block issues exactly 4 x NDR DMA instructions (rows past the
+        // segment repeat its last row), which keeps the counted vmcnt wait valid across boundaries.
+        const unsigned rowB = (unsigned)N * 8u;
+        // lane roles of v_mfma_f64_4x4x4 (collapse_mfma.hip)
+        const int K = lane >> 4, blk = (lane >> 2) & 3, q = lane & 3;
+        const int g = blk >> 1, h = blk & 1;
+        int tq = (T + nsw - 1) / nsw;
+        {
+            unsigned gg = rowB & 127u;
+            gg = gg == 0 ? 128u : (gg & (~gg + 1u));
+            const int m = (int)(128u / gg);
+            tq = ((tq + m - 1) / m) * m;                         // segments start on 128-byte boundaries
+        }
+        const int ta = (wave * tq < T) ? wave * tq : T;
+        const int tb = (ta + tq < T) ? ta + tq : T;
+        const int nrows = tb - ta;
+        const int nblk = (nrows + 3) / 4;
+        const unsigned ringB = NS * SB;
+        const char* ring = smem + ly.ring + (size_t)wave * ringB;
+        const unsigned ring_lds =
+            __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_f)(smem)) + ly.ring + (unsigned)wave * ringB;
+        const unsigned lane16 = 16u * lane;
+        bool pact[NDR];                                          // lane moves 16 bytes of piece p of a row
 #pragma unroll
-            for (int jq = 0; jq < NQ; ++jq) { qa[jq][0] = 0.0; qa[jq][1] = 0.0; }
-            if (nrows > 0) {
-                const char* seg = reinterpret_cast<const char*>(a.panel + ((size_t)b * T + ta) * N);
-                int issued = NS;
-                // One row block.  MODE 0: main loop (counted wait; the slots of the block are re-armed with periods that
-                // exist).  MODE 1: the block after the main loop (counted wait still valid; the last < 4 periods are
-                // issued).  MODE 2: drain.
-                auto row_block = [&](int bk, int bslot, auto mode_tag) {
-                    constexpr int MODE = decltype(mode_tag)::value;
-                    const int r0 = bk * 4;
-                    // rows < r0 + 4 have landed once at most the operations YOUNGER than their DMAs are outstanding (one
-                    // in-order vmcnt counter per wave): the re-arms of the NB - 1 row blocks in between
-                    if constexpr (MODE <= 1) wait_vmf<((NB - 1) * 4 * NDR <= 63 ? (NB - 1) * 4 * NDR : 63)>();
+        for (int p = 0; p < NDR; ++p) pact[p] = lane16 + 1024u * p < rowB;
+        const unsigned lane_off = (unsigned)q * SB + (unsigned)(4 * g + K) * 8u;
+        const bool tail_clamp = (STEPS - 1) * CS + 4 * g + K >= N;
+        const unsigned last_off = tail_clamp ? (unsigned)q * SB + (unsigned)(N - 1) * 8u : lane_off + (unsigned)(STEPS - 1) * (CS * 8u);
+        const int nrep = (B - (int)blockIdx.x + G - 1) / G;      // replicates of this workgroup
+        const int gtot = nrep * nblk;                            // row blocks of this wave
+
+        double Bw[STEPS];                                        // B operands: lam_cf / R_c for c = s CS + 4 g + K, f = 4 h + q
+        double rown[NQ][2];                                      // 1 / R of the lane's own 16-byte column pairs (s_t pass)
+        // block k of local replicate jj into ring block `bslot`: 4 rows x NDR DMA instructions, always
+        auto issue_block = [&](int jj, int k, int bslot) {
+            const char* seg = reinterpret_cast<const char*>(a.panel + ((size_t)((int)blockIdx.x + jj * G) * T + ta) * N);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int ri = 4 * k + rr;
+                ri = ri < nrows ? ri : nrows - 1;
+                const char* src = seg + (size_t)ri * rowB + lane16;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(bslot * 4 + rr) * SB);
+#pragma unroll
+                for (int p = 0; p < NDR; ++p) {
+                    if (pact[p]) dma16f(src + 1024 * p, dst + 1024u * p);
+                }
+            }
+        };
+        // weights of replicate bb: loads off one base pointer with constant offsets (no per-load address registers),
+        // reciprocal by v_rcp_f64 + two Newton steps.  Ends with vmcnt(0): the ring blocks in flight have landed too.
+        auto load_weights = [&](int bb) {
+            const double* __restrict__ Lq = a.Lam + (size_t)bb * N * R + (4 * g + K) * R + 4 * h + q;
+            const double* __restrict__ Rq = a.Rv + (size_t)bb * N + (4 * g + K);
+            const int clast = tail_clamp ? N - 1 : (STEPS - 1) * CS + 4 * g + K;
+            double rv[STEPS];
+#pragma unroll
+            for (int s = 0; s + 1 < STEPS; ++s) {
+                Bw[s] = Lq[s * CS * R];
+                rv[s] = Rq[s * CS];
+            }
+            Bw[STEPS - 1] = a.Lam[(size_t)bb * N * R + (size_t)clast * R + 4 * h + q];
+            rv[STEPS - 1] = a.Rv[(size_t)bb * N + clast];
+            const double* __restrict__ Rg = a.Rv + (size_t)bb * N;
+#pragma unroll
+            for (int jq = 0; jq < NQ; ++jq)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int c = 2 * lane + 128 * jq + e;
+                    rown[jq][e] = Rg[c < N ? c : N - 1];
+                }
+            __builtin_amdgcn_sched_barrier(0);                    // all loads in flight before the first use
+            wait_vmf<0>();
+#pragma unroll
+            for (int s = 0; s + 1 < STEPS; ++s) Bw[s] *= fast_rcp(rv[s]);
+            Bw[STEPS - 1] = tail_clamp ? 0.0 : Bw[STEPS - 1] * fast_rcp(rv[STEPS - 1]);
+#pragma unroll
+            for (int jq = 0; jq < NQ; ++jq)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int c = 2 * lane + 128 * jq + e;
+                    rown[jq][e] = (c < N) ? fast_rcp(rown[jq][e]) : 0.0;
+                }
+        };
+
+        if (gtot > 0) {
+            // prologue: the first NB blocks
+            int ij = 0, ik = 0;                                  // next block to issue
+            auto advance_issue = [&]() { ++ik; if (ik == nblk) { ik = 0; ++ij; } };
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                if (u < gtot) { issue_block(ij, ik, u); advance_issue(); }
+            }
+            int bslot = 0;
+            double qa[NQ][2];
+            double* bt = bt0;
+            int buf = 0;
+            int gidx = 0;
+            for (int j = 0; j < nrep; ++j) {
+                const int b = (int)blockIdx.x + j * G;
+                if (wave == 0) stamp(b, 0);
+                load_weights(b);                                  // (drains the vm counter)
+                buf = nbuf == 2 ? (j & 1) : 0;
+                bt = bt0 + (size_t)buf * ly.bt_stride;
+                // the b_t buffer is free once the scan of the replicate that used it last is complete
+                if (j >= nbuf) {
+                    if (!pf_wait_ge(flags + kFScanDone, (unsigned)(j - nbuf + 1), flags + kFAbort)) { wait_vmf<0>(); return; }
+                }
+                if (wave == 0) stamp(b, 1);
+                stamp(b, 32 + wave);                              // per-wave segment start / end (diagnostics)
+#pragma unroll
+                for (int jq = 0; jq < NQ; ++jq) { qa[jq][0] = 0.0; qa[jq][1] = 0.0; }
+                for (int k = 0; k < nblk; ++k, ++gidx) {
+                    const int r0 = k * 4;
+                    const bool full = r0 + 4 <= nrows;           // (wave-uniform)
+                    // rows of this block have landed once at most the DMAs of the NB - 1 YOUNGER blocks are outstanding
+                    // (one in-order vmcnt counter per wave); at the tail of the sequence there are fewer younger blocks
+                    if (gidx + NB - 1 < gtot) wait_vmf<((NB - 1) * 4 * NDR <= 63 ? (NB - 1) * 4 * NDR : 63)>();
                     else wait_vmf<0>();
                     const char* blkbase = ring + (unsigned)bslot * 4u * SB;
                     const char* pa = blkbase + lane_off;
@@ -379,22 +526,17 @@ __global__ __launch_bounds__(kPfMaxThreads, 2) void pass_fused_kernel(CollapseAr
                             xq[rr][jq] = pact[jq] ? *reinterpret_cast<const double2*>(pq + (unsigned)rr * SB + 1024u * jq)
                                                   : make_double2(0.0, 0.0);
                     wait_lgkmf();                                        // the reads are done before the slots are re-armed
-                    if constexpr (MODE == 0) {
+                    if (ij < nrep) { issue_block(ij, ik, bslot); advance_issue(); }
+                    double D = 0.0, D2 = 0.0;                            // two accumulators: half the dependent MFMA chain
 #pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) issue_row(seg, issued + rr, bslot * 4 + rr);
-                        issued += 4;
-                    } else if constexpr (MODE == 1) {
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr)
-                            if (issued + rr < nrows) issue_row(seg, issued + rr, bslot * 4 + rr);
-                        issued += 4;
+                    for (int s = 0; s < STEPS; ++s) {
+                        if ((s & 1) == 0) D = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[s], Bw[s], D, 0, 0, 0);
+                        else D2 = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[s], Bw[s], D2, 0, 0, 0);
                     }
-                    double D = 0.0;
-#pragma unroll
-                    for (int s = 0; s < STEPS; ++s) D = __builtin_amdgcn_mfma_f64_4x4x4f64(xa[s], Bw[s], D, 0, 0, 0);
+                    D += D2;
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr) {
-                        if (MODE == 0 || r0 + rr < nrows) {              // wave-uniform: rows past the segment hold stale slots
+                        if (full || r0 + rr < nrows) {                   // wave-uniform: rows past the segment repeat its last row
 #pragma unroll
                             for (int jq = 0; jq < NQ; ++jq) {
                                 qa[jq][0] = fma(xq[rr][jq].x, xq[rr][jq].x, qa[jq][0]);
@@ -406,173 +548,267 @@ __global__ __launch_bounds__(kPfMaxThreads, 2) void pass_fused_kernel(CollapseAr
                     // lane (K = period, g = 0, h, q) holds factor 4 h + q of period r0 + K: the even-q lane stores (f, f + 1)
                     const double hi = xor_lane<1>(D);
                     const int t = ta + r0 + K;
-                    if (g == 0 && (q & 1) == 0 && (MODE == 0 || t < tb))
+                    if (g == 0 && (q & 1) == 0 && t < tb)
                         *reinterpret_cast<double2*>(&bt[(size_t)t * R + 4 * h + q]) = make_double2(D, hi);
-                };
-                const int nmain = (nrows - 4 * NB) >= 4 ? (nrows - 4 * NB) / 4 : 0;
-                int bslot = 0, bk = 0;
-                for (; bk < nmain; ++bk) {
-                    row_block(bk, bslot, std::integral_constant<int, 0>{});
                     bslot = (bslot + 1 == NB) ? 0 : bslot + 1;
                 }
-                if (bk < nblk && nrows >= NS) {     // the initial fill was complete: the counted wait holds once more
-                    row_block(bk, bslot, std::integral_constant<int, 1>{});
-                    bslot = (bslot + 1 == NB) ? 0 : bslot + 1;
-                    ++bk;
-                }
-                for (; bk < nblk; ++bk) {
-                    row_block(bk, bslot, std::integral_constant<int, 2>{});
-                    bslot = (bslot + 1 == NB) ? 0 : bslot + 1;
-                }
-                wait_vmf<0>();
-            }
-            double sp = 0.0;
+                double sp = 0.0;
 #pragma unroll
-            for (int jq = 0; jq < NQ; ++jq)
+                for (int jq = 0; jq < NQ; ++jq)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) sp = fma(qa[jq][e], rown[jq][e], sp);
-            sp = wave_allsum(sp);
-            if (lane == 0) {
-                misc[kMiscSsum + wave] = nrows > 0 ? sp : 0.0;
-                if (sp != sp) atomicOr(a.status, 1);             // NaN in the panel on the balanced path
+                    for (int e = 0; e < 2; ++e) sp = fma(qa[jq][e], rown[jq][e], sp);
+                sp = wave_allsum(sp);
+                if (lane == 0) {
+                    misc[kMiscSsum + buf * 8 + wave] = sp;
+                    if (sp != sp) atomicOr(a.status, 1);             // NaN in the panel on the balanced path
+                }
+                // this wave's part of b_t is in LDS.  (The release waits for the LDS writes only in effect: the DMAs in
+                // flight belong to the next replicate, so no full vmcnt wait here -- an explicit lgkmcnt wait instead.)
+                wait_lgkmf();
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) __hip_atomic_fetch_add(flags + kFBtReady + buf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (wave == 0) stamp(b, 2);
+                if (wave == nsw - 1) stamp(b, 3);
+                stamp(b, 24 + wave);
             }
-            if (wave == 0) stamp(b, 1);                           // wave 0's segment is done
-            if (wave == nsw - 1) stamp(b, 5);                     // the last stream wave's segment is done
-            // the NEXT replicate's first ring fill and weights go out now: they land while the scan below runs
-            if (bn < B && nrows > 0) prepare(bn);
-        } else if (is_cov) {
-            // ================= COV: Gram matrix, covariance recursion, P_smooth ====================================
-            __builtin_amdgcn_s_setprio(2);
+        } else {
+            // a wave without periods (T shorter than the segments): it only keeps the arrival counts
+            for (int j = 0; j < nrep; ++j) {
+                const int buf = nbuf == 2 ? (j & 1) : 0;
+                if (j >= nbuf) {
+                    if (!pf_wait_ge(flags + kFScanDone, (unsigned)(j - nbuf + 1), flags + kFAbort)) return;
+                }
+                if (lane == 0) {
+                    misc[kMiscSsum + buf * 8 + wave] = 0.0;
+                }
+                pf_signal(flags + kFBtReady + buf, lane);
+            }
+        }
+    } else if (wave < nsw + ncov) {
+        // ================= COV: Gram matrix, covariance recursion, transient rows of P_smooth -- ahead of the stream ====
+        const int cw = wave - nsw;
+        double* ws = reinterpret_cast<double*>(smem + ly.covws) + (size_t)cw * kCov8ScratchDoubles;
+        double* Cs = ws + 5 * kCov8TileDoubles;                  // Gram matrix
+        __builtin_amdgcn_s_setprio(2);                            // a latency chain (ahead of the stream after the first replicates)
+        for (int b = (int)blockIdx.x + cw * G; b < B; b += ncov * G) {
             stamp(b, 6);
-            double* Cs = covws + 5 * kCov8TileDoubles;
-            const double ld = gram_wave8<NDR>(fa.Lam + (size_t)b * N * R, fa.Rv + (size_t)b * N, N, lane, Cs);
+            const double ld = gram_mfma8<STEPS, NDR>(fa.Lam + (size_t)b * N * R, fa.Rv + (size_t)b * N, N, lane, Cs);
             wave_lds_sync();
-            const double Cel = Cs[lane];
+            const double Cel = 0.5 * (Cs[lane] + Cs[(lane & 7) * 8 + (lane >> 3)]);   // exactly symmetric
+            wave_lds_sync();
+            __builtin_amdgcn_sched_barrier(0);
             Cov8Dst o;
-            o.tab = s_tab; o.tab_cap = kPfEcap; o.tab_over = fa.tab + (size_t)b * T * 3 * 64;
-            o.stead = s_mat; o.PT = s_mat + kPfNst * 64;
-            o.xi0 = misc + kMiscXi0; o.llc = misc + kMiscLlc; o.E = ints; o.fill = ints + 1; o.PsInf = misc + kMiscPsInf;
+            o.tab = fa.tab + (size_t)b * T * 3 * 64; o.tab_cap = T; o.tab_over = o.tab;
+            o.stead = fa.stead + (size_t)b * kPfNst * 64;
+            o.PT = fa.PT + (size_t)b * 64; o.xi0 = fa.xi0 + (size_t)b * 8; o.llc = fa.llc + b; o.E = fa.E + b;
+            o.fill = fa.fill + 2 * b; o.PsInf = fa.PsInf + (size_t)b * 64;
             o.SP11 = fa.SP11 ? fa.SP11 + (size_t)b * 64 : nullptr;
             o.SU = fa.SP11 ? fa.SU + (size_t)b * 64 : nullptr;
             o.P0s = fa.SP11 ? fa.P0s + (size_t)b * 64 : nullptr;
             stamp(b, 7);                                          // Gram done
-            cov_wave8<kPfNlev>(fa, b, Cel, ld, covws, o, lane);
+            cov_wave8<kPfNlev>(fa, b, Cel, ld, ws, o, lane);
             wave_lds_sync();
             stamp(b, 8);                                          // covariance recursion done
-            if (fa.SP11) fa.PT[(size_t)b * 64 + lane] = o.PT[lane];   // EM: em_update_kernel reads P_T from global memory
-            if (fa.P_smooth) {      // rows [lo, hi) of P_smooth equal the backward fixed point: pure 16-byte stores
-                const int npr = fa.r * (fa.r + 1) / 2;
-                double* ps = misc + kMiscPs;
-                if (lane < npr) {
-                    int ri = 0;
-                    while ((ri + 1) * (ri + 2) / 2 <= lane) ++ri;
-                    ps[lane] = o.PsInf[ri * R + (lane - ri * (ri + 1) / 2)];
-                }
-                wave_lds_sync();
-                const int lo = ints[1], hi = ints[2];
-                if (hi > lo) {
-                    double* base = fa.P_smooth + ((size_t)b * T + lo) * npr;
-                    const unsigned n = (unsigned)(hi - lo) * (unsigned)npr;
-                    const unsigned peel = ((reinterpret_cast<size_t>(base) & 15) != 0) ? 1u : 0u;
-                    if (peel && lane == 0) base[0] = ps[0];
-                    const unsigned npair = (n - peel) / 2;
-                    const unsigned step = 128u % (unsigned)npr;
-                    unsigned k = peel + 2u * lane;
-                    unsigned v = k % (unsigned)npr;
-                    for (unsigned p = lane; p < npair; p += 64) {
-                        const unsigned v1 = (v + 1 == (unsigned)npr) ? 0u : v + 1;
-                        *reinterpret_cast<double2*>(base + k) = make_double2(ps[v], ps[v1]);
-                        k += 128u;
-                        v += step;
-                        if (v >= (unsigned)npr) v -= (unsigned)npr;
-                    }
-                    if (((n - peel) & 1u) != 0 && lane == 0) base[n - 1] = ps[(n - 1) % (unsigned)npr];
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            stamp(b, 9);                                          // P_smooth fill issued
+            // the tables are complete: the scan of this replicate may start (its waves also write the fixed-point rows
+            // of P_smooth -- 144 KB of pure stores that would hold this latency chain up for 15 us)
+            pf_signal(flags + kFCovDone + cw, lane);
         }
-        __syncthreads();            // (A) b_t, sum s_t and the covariance tables of replicate b are in LDS
-        if (wave == 0) stamp(b, 2);                               // past barrier A
-        scan_lds(fa, b, tid, tid < kScanThreads, bt, s_tab, fa.tab + (size_t)b * T * 3 * 64, s_mat, misc + kMiscXi0,
-                 misc + kMiscLlc, ints[0], s_a, s_b, misc + kMiscVec, misc + kMiscRed, misc + kMiscSsum, nsw,
-                 (prof && T >= 32) ? a.scol + (size_t)b * T : nullptr);
-        if (wave == 0) stamp(b, 3);                               // scan done (wave 0)
-        __syncthreads();            // (B) the scan is done with bt / the tables: the next replicate may overwrite them
-        if (wave == 0) stamp(b, 4);
+    } else if (wave == nsw + ncov) {
+        // ================= MOVER: tables of replicate j from the workspace into LDS, one replicate ahead of the scan =====
+        // Under the streaming load a global round trip of this CU takes 5-8 us (its requests queue behind the DMA loads), and
+        // the scan group needed two of them per replicate on its critical path.  This wave takes them off it: as soon as a
+        // covariance wave has published replicate j it loads the tables into REGISTERS (one matrix element per lane: 32
+        // matrices = 64 VGPRs), waits for the scan of replicate j - 1 to release the single LDS table set, writes it and
+        // raises tab_ready.  It also writes the fixed-point rows of P_smooth (144 KB of pure stores per replicate).
+        double* s_mat = reinterpret_cast<double*>(smem + ly.smat);
+        double* s_tab = reinterpret_cast<double*>(smem + ly.ctab);
+        double* s_ps = misc + kMiscPs;
+        const int nfix0 = kPfEcap < T ? kPfEcap : T;
+        __builtin_amdgcn_s_setprio(1);
+        int b = blockIdx.x;
+        for (int j = 0; b < B; b += G, ++j) {
+            if (!pf_wait_ge(flags + kFCovDone + (j % ncov), (unsigned)(j / ncov + 1), flags + kFAbort)) break;
+            stamp(b, 4);
+            const double* stead = fa.stead + (size_t)b * kPfNst * 64;
+            const double* tab = fa.tab + (size_t)b * T * 3 * 64;
+            double ms[kPfNst + 1], mt[kPfEcap * 3];
+#pragma unroll
+            for (int k = 0; k < kPfNst; ++k) ms[k] = stead[k * 64 + lane];
+            ms[kPfNst] = fa.PT[(size_t)b * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < kPfEcap * 3; ++k) mt[k] = (k < nfix0 * 3) ? tab[k * 64 + lane] : 0.0;
+            // one batch: every load is issued before the first one is consumed (a round trip is 5-8 us here)
+            const int Ev = ld_dev(fa.E + b);
+            // xi0 [8] then llc: adjacent in neither array, so two loads under lane predicates folded into one select
+            const double xiv = ld_dev(fa.xi0 + (size_t)b * R + (lane & 7));
+            const double llv = ld_dev(fa.llc + b);
+            const int npr = fa.r * (fa.r + 1) / 2;
+            int flo = 0, fhi = 0;
+            double psv = 0.0;
+            if (fa.P_smooth) {
+                flo = ld_dev(fa.fill + 2 * b);
+                fhi = ld_dev(fa.fill + 2 * b + 1);
+                int ri = 0;                                       // packed (caller's r) copy of P_s,inf
+                const int lv = lane < npr ? lane : 0;
+                while ((ri + 1) * (ri + 2) / 2 <= lv) ++ri;
+                psv = ld_dev(fa.PsInf + (size_t)b * 64 + ri * R + (lv - ri * (ri + 1) / 2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const int E = __builtin_amdgcn_readfirstlane(Ev);
+            const double xl = lane < R ? xiv : llv;
+            const int fill_lo = __builtin_amdgcn_readfirstlane(flo), fill_hi = __builtin_amdgcn_readfirstlane(fhi);
+            // the LDS table set is free once the scan of the previous replicate is complete
+            if (j >= 1) {
+                if (!pf_wait_ge(flags + kFScanDone, (unsigned)j, flags + kFAbort)) break;
+            }
+#pragma unroll
+            for (int k = 0; k <= kPfNst; ++k) s_mat[k * 64 + lane] = ms[k];
+#pragma unroll
+            for (int k = 0; k < kPfEcap * 3; ++k) s_tab[k * 64 + lane] = mt[k];
+            if (lane <= R) misc[kMiscXi0 + lane] = xl;            // xi0 [8], then llc
+            if (lane == 0) misc[kMiscE] = (double)E;
+            pf_signal(flags + kFTabReady, lane);
+            stamp(b, 5);
+            // rows [lo, hi) of P_smooth equal the backward fixed point: fire-and-forget 16-byte stores
+            if (fill_hi > fill_lo) {
+                if (lane < npr) s_ps[lane] = psv;
+                wave_lds_sync();
+                double* base = fa.P_smooth + ((size_t)b * T + fill_lo) * npr;
+                const unsigned n = (unsigned)(fill_hi - fill_lo) * (unsigned)npr;
+                const unsigned peel = ((reinterpret_cast<size_t>(base) & 15) != 0) ? 1u : 0u;
+                if (peel && lane == 0) base[0] = s_ps[0];
+                const unsigned npair = (n - peel) / 2;
+                const unsigned step = 128u % (unsigned)npr;
+                unsigned k = peel + 2u * lane;
+                unsigned v = k % (unsigned)npr;
+                for (unsigned p = lane; p < npair; p += 64) {
+                    const unsigned v1 = (v + 1 == (unsigned)npr) ? 0u : v + 1;
+                    *reinterpret_cast<double2*>(base + k) = make_double2(s_ps[v], s_ps[v1]);
+                    k += 128u;
+                    v += step;
+                    if (v >= (unsigned)npr) v -= (unsigned)npr;
+                }
+                if (((n - peel) & 1u) != 0 && lane == 0) base[n - 1] = s_ps[(n - 1) % (unsigned)npr];
+                wave_lds_sync();
+            }
+        }
+    } else if (wave < nsw + ncov + 1 + kPfScanWaves) {
+        // ================= SCAN: the mean recursion of every replicate, one behind the stream ==========================
+        const int tid = tid_wg - 64 * (nsw + ncov + 1);
+        double* s_mat = reinterpret_cast<double*>(smem + ly.smat);
+        double* s_tab = reinterpret_cast<double*>(smem + ly.ctab);
+        double* s_a = reinterpret_cast<double*>(smem + ly.sa);
+        double* s_b = reinterpret_cast<double*>(smem + ly.sb);
+        PfScanSync sync{flags + kFScanBar, flags + kFAbort, 0u, lane};
+        __builtin_amdgcn_s_setprio(3);                            // THE latency chain of the pipeline: the stream waits for its buffers
+        int b = blockIdx.x;
+        for (int j = 0; b < B; b += G, ++j) {
+            const int buf = nbuf == 2 ? (j & 1) : 0;
+            double* bt = bt0 + (size_t)buf * ly.bt_stride;
+            if (tid == 0) stamp(b, 10);
+            if (!pf_wait_ge(flags + kFTabReady, (unsigned)(j + 1), flags + kFAbort)) break;
+            if (tid == 0) stamp(b, 11);
+            if (!pf_wait_ge(flags + kFBtReady + buf, (unsigned)(nsw * (j / nbuf + 1)), flags + kFAbort)) break;
+            if (tid == 0) stamp(b, 12);
+            const int E = __builtin_amdgcn_readfirstlane((int)misc[kMiscE]);
+            scan_lds(fa, b, tid, bt, s_tab, fa.tab + (size_t)b * T * 3 * 64, s_mat, misc + kMiscXi0, misc + kMiscLlc, E, s_a, s_b,
+                     misc + kMiscVec, misc + kMiscRed, misc + kMiscSsum + buf * 8, nsw, sync,
+                     (prof && tid == 0) ? a.scol + (size_t)b * T + 13 : nullptr);
+            sync();                       // the scan is done with bt / the table set / ssum
+            if (tid == 0) {
+                __hip_atomic_store(flags + kFScanDone, (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                stamp(b, 22);
+            }
+        }
     }
+    if (lane == 0 && ld_flag(flags + kFAbort) != 0) atomicOr(a.status, 4);   // a bounded wait ran out
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-static PfLds pf_layout(int T, int N, int nsw) {
+static PfLds pf_layout(int T, int N, int nsw, int ncov, int nbuf) {
     PfLds l;
     unsigned off = 0;
     auto take = [&](unsigned bytes) { const unsigned at = off; off += (bytes + 255u) & ~255u; return at; };
+    l.flags = take(kFCount * 4);
     l.smat = take((kPfNst + 1) * 64 * 8);
     l.ctab = take(kPfEcap * 3 * 64 * 8);
     l.misc = take(kMiscDoubles * 8);
-    l.covws = take(kCov8ScratchDoubles * 8);
+    l.covws = take((unsigned)ncov * kCov8ScratchDoubles * 8);
     l.sa = take(32 * 8 * 8);
     l.sb = take(32 * 8 * 8);
-    l.bt = take((unsigned)((T + 3) / 4 * 4) * 8 * 8);
+    const unsigned btb = (unsigned)((T + 3) / 4 * 4) * 8 * 8;
+    l.bt_stride = ((btb + 255u) & ~255u) / 8;
+    l.bt = take(l.bt_stride * 8 * (unsigned)nbuf);
     l.ring = take((unsigned)nsw * 8u * pf_slot_bytes(N));
     l.total = off;
+    l.nsw = nsw; l.ncov = ncov; l.nbuf = nbuf;
     return l;
 }
 
-int pass_fused_pick_nsw(int T, int N, int want) {
-    int nsw = want > 0 ? want : 7;
-    if (nsw > 7) nsw = 7;
-    while (nsw > 1 && T / nsw < 8) --nsw;                     // keep segments a few row blocks long
-    while (nsw > 1 && pf_layout(T, N, nsw).total > 160u * 1024u) --nsw;
-    return nsw;
+// Stream waves, covariance waves and b_t buffers that fit 160 KB of LDS and 12 waves: double-buffered b_t with as many
+// stream waves as fit (at least 3), else one buffer (the stream then waits for the scan of the previous replicate).
+static PfLds pf_pick(int T, int N, int want_nsw, int want_ncov) {
+    int ncov = want_ncov > 0 ? want_ncov : kPfMaxCov;
+    if (ncov > kPfMaxCov) ncov = kPfMaxCov;
+    int cap = kPfMaxWaves - kPfScanWaves - 1 - ncov;        // one mover wave
+    if (want_nsw > 0 && want_nsw < cap) cap = want_nsw;
+    while (cap > 1 && T / cap < 8) --cap;                     // keep segments a few row blocks long
+    for (int nbuf = 2; nbuf >= 1; --nbuf) {
+        for (int nsw = cap; nsw >= (nbuf == 2 ? (cap < 3 ? cap : 3) : 1); --nsw) {
+            const PfLds l = pf_layout(T, N, nsw, ncov, nbuf);
+            if (l.total <= kPfLdsLimit) return l;
+        }
+    }
+    PfLds none = pf_layout(T, N, 1, ncov, 1);
+    return none;
 }
 
-// Rp = 8, the shapes of the MFMA collapse (even N, 8N <= 4096, ceil(N / 8) <= 32 steps), T below the int-index and LDS limits
+int pass_fused_pick_nsw(int T, int N, int want) { return pf_pick(T, N, want, 0).nsw; }
+
+// Rp = 8, the shapes of the MFMA collapse (even N, 8N <= 4096, ceil(N / 8) <= 32 steps), T below the LDS limit
 bool pass_fused_supported(int Rpad, int T, int N) {
     if (Rpad != 8 || !collapse_mfma_supported(8, N)) return false;
     if (T < 2) return false;
-    return pf_layout(T, N, 1).total <= 160u * 1024u;
+    return pf_pick(T, N, 0, 0).total <= kPfLdsLimit;
 }
 
 template <int STEPS, int NDR>
-static hipError_t launch_pf_one(const CollapseArgs& a, const FastArgs& fa, int nsw, int num_cu, hipStream_t s) {
-    const PfLds ly = pf_layout(a.T, a.N, nsw);
-    if (ly.total > 160u * 1024u) return hipErrorInvalidValue;
+static hipError_t launch_pf_one(const CollapseArgs& a, const FastArgs& fa, int nsw, int ncov, int num_cu, hipStream_t s) {
+    const PfLds ly = pf_pick(a.T, a.N, nsw, ncov);
+    if (ly.total > kPfLdsLimit) return hipErrorInvalidValue;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_fused_kernel<STEPS, NDR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPfLdsLimit);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int grid = a.B < num_cu ? a.B : num_cu;
-    const int nwaves = nsw + 1 > kScanThreads / 64 ? nsw + 1 : kScanThreads / 64;
-    hipLaunchKernelGGL((pass_fused_kernel<STEPS, NDR>), dim3(grid), dim3(64 * nwaves), ly.total, s, a, fa, pf_slot_bytes(a.N),
-                       nsw, ly);
+    const int nwaves = ly.nsw + ly.ncov + 1 + kPfScanWaves;
+    hipLaunchKernelGGL((pass_fused_kernel<STEPS, NDR>), dim3(grid), dim3(64 * nwaves), ly.total, s, a, fa, pf_slot_bytes(a.N), ly);
     return hipGetLastError();
 }
 
 template <int S>
-static hipError_t launch_pf_pick(const CollapseArgs& a, const FastArgs& fa, int nsw, int num_cu, hipStream_t s, int steps) {
+static hipError_t launch_pf_pick(const CollapseArgs& a, const FastArgs& fa, int nsw, int ncov, int num_cu, hipStream_t s, int steps) {
     if constexpr (S > 32) {
         return hipErrorInvalidValue;
     } else {
         if (steps == S) {
             const int ndr = (a.N * 8 + 1023) / 1024;
             constexpr int lo = (8 * (S - 1) * 8 + 8 + 1023) / 1024, hi = (8 * S * 8 + 1023) / 1024;
-            if constexpr (lo <= 1 && 1 <= hi) { if (ndr == 1) return launch_pf_one<S, 1>(a, fa, nsw, num_cu, s); }
-            if constexpr (lo <= 2 && 2 <= hi) { if (ndr == 2) return launch_pf_one<S, 2>(a, fa, nsw, num_cu, s); }
-            if constexpr (lo <= 3 && 3 <= hi) { if (ndr == 3) return launch_pf_one<S, 3>(a, fa, nsw, num_cu, s); }
-            if constexpr (lo <= 4 && 4 <= hi) { if (ndr == 4) return launch_pf_one<S, 4>(a, fa, nsw, num_cu, s); }
+            if constexpr (lo <= 1 && 1 <= hi) { if (ndr == 1) return launch_pf_one<S, 1>(a, fa, nsw, ncov, num_cu, s); }
+            if constexpr (lo <= 2 && 2 <= hi) { if (ndr == 2) return launch_pf_one<S, 2>(a, fa, nsw, ncov, num_cu, s); }
+            if constexpr (lo <= 3 && 3 <= hi) { if (ndr == 3) return launch_pf_one<S, 3>(a, fa, nsw, ncov, num_cu, s); }
+            if constexpr (lo <= 4 && 4 <= hi) { if (ndr == 4) return launch_pf_one<S, 4>(a, fa, nsw, ncov, num_cu, s); }
             return hipErrorInvalidValue;
         }
-        return launch_pf_pick<S + 1>(a, fa, nsw, num_cu, s, steps);
+        return launch_pf_pick<S + 1>(a, fa, nsw, ncov, num_cu, s, steps);
     }
 }
 
-hipError_t launch_pass_fused(const CollapseArgs& a, const FastArgs& fa, int nsw, int num_cu, hipStream_t s) {
-    return launch_pf_pick<1>(a, fa, nsw, num_cu, s, (a.N + 7) / 8);
+hipError_t launch_pass_fused(const CollapseArgs& a, const FastArgs& fa, int nsw, int ncov, int num_cu, hipStream_t s) {
+    return launch_pf_pick<1>(a, fa, nsw, ncov, num_cu, s, (a.N + 7) / 8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -8,8 +8,8 @@ export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_pass_fused.py -q --maxfail=30 2>&1 | tail -70 > $OUT/pytest_fused.log
 tail -40 $OUT/pytest_fused.log
 if grep -q "passed" $OUT/pytest_fused.log; then
-  timeout 200 python bench.py --no-cpu-baseline --repeats 5 --steps 30 > $OUT/bench_two.json 2> $OUT/bench_two.err
-  for nsw in 7 6 5 4; do
+  DFM_PASS_FUSED=0 timeout 200 python bench.py --no-cpu-baseline --repeats 5 --steps 30 > $OUT/bench_two.json 2> $OUT/bench_two.err
+  for nsw in 5 4 3; do
     DFM_PASS_FUSED=1 DFM_PASS_NSW=$nsw timeout 200 python bench.py --no-cpu-baseline --repeats 5 --steps 30 > $OUT/bench_fused_$nsw.json 2> $OUT/bench_fused_$nsw.err
   done
   DFM_PASS_FUSED=1 timeout 200 python bench.py --no-cpu-baseline --repeats 5 --steps 10 --batch-per-gpu 8192 > $OUT/bench_fused_b8192.json 2> $OUT/bench_fused_b8192.err

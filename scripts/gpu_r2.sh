@@ -14,6 +14,7 @@ if [ -z "$SKIP_TESTS" ]; then
 fi
 timeout 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 if [ -z "$SKIP_EXTRA" ]; then
+  DFM_PASS_FUSED=0 timeout 300 python bench.py --no-cpu-baseline --repeats 5 > $OUT/bench_two_launch.json 2> $OUT/bench_two_launch.err
   timeout 300 python bench.py --batch-per-gpu 8192 --steps 10 --warmup 2 --repeats 5 --no-cpu-baseline > $OUT/bench_b8192.json 2> $OUT/bench_b8192.err
   timeout 300 python bench.py --N 1000 --T 2000 --r 20 --batch-per-gpu 256 --steps 5 --warmup 2 --repeats 5 --no-cpu-baseline > $OUT/bench_c4.json 2> $OUT/bench_c4.err
   timeout 300 python bench.py --mode em --steps 20 --warmup 3 --repeats 5 > $OUT/bench_em.json 2> $OUT/bench_em.err
@@ -25,7 +26,7 @@ if [ -n "$PROFILE" ]; then
   cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv 2>/dev/null
 fi
 tail -25 $OUT/pytest_gpu.log 2>/dev/null; cat $OUT/smoke.log 2>/dev/null
-for f in bench bench_b8192 bench_c4 bench_em bench_pca bench_missing10; do
+for f in bench bench_two_launch bench_b8192 bench_c4 bench_em bench_pca bench_missing10; do
   [ -f $OUT/$f.json ] && python - $OUT/$f.json <<'PY'
 import json, sys
 try:

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
-"""Phase timeline of the fused pass from the s_memrealtime stamps (DFM_SCAN_ABL=256, DFM_PF_PROF_FILE): per replicate
-[0] iteration start, [1] wave 0 segment done, [5] last stream wave done, [6] cov start, [7] Gram done, [8] recursion done,
-[9] fill issued, [2] past barrier A, [3] scan done, [4] past barrier B.  Ticks are 10 ns."""
+"""Phase timeline of the one-launch pass (pass_fused.hip) from its s_memrealtime stamps (DFM_SCAN_ABL=256,
+DFM_PF_PROF_FILE).  Per replicate (10 ns ticks):
+  stream: [0] iteration start (wave 0), [1] b_t buffer free, [2] wave 0's segment done, [3] last stream wave done
+  cov:    [6] start, [7] Gram done, [8] recursion done (tables published)
+  mover:  [4] tables of the replicate published by its covariance wave, [5] table set in LDS (tab_ready)
+  scan:   [10] start waiting, [11] tables ready, [12] b_t ready, [14..21] scan phases, [22] done (buffer released)"""
 import os, sys
 import numpy as np
 import torch
@@ -21,18 +24,28 @@ d = np.loadtxt("/tmp/pf_prof.txt")
 b = d[:, 0].astype(int); s = d[:, 1:] * 0.01   # us
 t0 = s[:, 0].min()
 ncu = min(B, 256)
-print("replicates", B, "span us", (s[:, 4].max() - t0))
-for name, a, z in [("stream wave0", 0, 1), ("stream last wave", 0, 5), ("gram", 6, 7), ("cov recursion", 7, 8), ("fill", 8, 9),
-                   ("wave0 wait at A", 1, 2), ("scan", 2, 3), ("wait at B", 3, 4), ("iteration", 0, 4)]:
+print("replicates", B, "span us", (s[:, 22].max() - t0))
+for name, a, z in [("stream: wait buffer", 0, 1), ("stream: wave 0 segment", 1, 2), ("stream: last wave - w0", 2, 3), ("cov: gram", 6, 7),
+                   ("cov: recursion", 7, 8), ("mover: load + wait set", 4, 5), ("scan: wait tables", 10, 11), ("scan: wait b_t", 11, 12),
+                   ("scan: compute", 12, 22), ("replicate: start -> scan end", 0, 22)]:
     v = s[:, z] - s[:, a]
-    print(f"{name:18s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f}")
-print("scan phases (us; [cycles]):")
-names = ["fwd transient", "fwd phase 1", "fwd carry scan", "fwd phase 3", "terminal + bwd phase 1", "bwd carry scan", "bwd phase 3", "bwd transient"]
+    print(f"{name:30s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f}")
+names = ["sync + fwd transient", "fwd phase 1", "fwd carry scan", "fwd phase 3", "terminal + bwd phase 1", "bwd carry scan", "bwd phase 3",
+         "bwd transient", "loglik + release"]
+prev = 12
+print("scan phases (us):")
 for k, nm in enumerate(names):
-    v = s[:, 11 + k] - s[:, 10 + k]; cy = (d[:, 1 + 21 + k] - d[:, 1 + 20 + k])
-    print(f"  {nm:24s} {v.mean():6.2f} us  [{cy.mean():8.0f} cycles]  -> {cy.mean() / max(v.mean(), 1e-9):6.0f} MHz")
-print("  E (transient steps) unknown here; iteration clock:", ((d[:, 1 + 28] - d[:, 1 + 20]) / np.maximum(s[:, 18] - s[:, 10], 1e-9)).mean(), "MHz")
-for rnd in range((B + ncu - 1) // ncu):
+    cur = 14 + k
+    v = s[:, cur] - s[:, prev]
+    print(f"  {nm:24s} {v.mean():6.2f}")
+    prev = cur
+nsw = int(os.environ.get("DFM_PASS_NSW", 5))
+print("per stream wave: segment duration (us) / end relative to wave 0's end")
+for w in range(nsw):
+    dur = s[:, 24 + w] - s[:, 32 + w]; rel = s[:, 24 + w] - s[:, 24]
+    print(f"  wave {w}: duration mean {dur.mean():6.2f} p10 {np.percentile(dur, 10):6.2f} p90 {np.percentile(dur, 90):6.2f}   end - end(w0) mean {rel.mean():6.2f}   start - start(w0) {(s[:, 32 + w] - s[:, 32]).mean():6.2f}")
+for rnd in range(min(8, (B + ncu - 1) // ncu)):
     sel = (b // ncu) == rnd
-    print(f"round {rnd}: start {s[sel, 0].mean() - t0:7.1f}  stream end {s[sel, 5].mean() - t0:7.1f}  cov end {s[sel, 9].mean() - t0:7.1f}  scan end {s[sel, 3].mean() - t0:7.1f}")
+    print(f"round {rnd}: stream start {s[sel, 0].mean() - t0:7.1f}  buffer free {s[sel, 1].mean() - t0:7.1f}  stream end {s[sel, 3].mean() - t0:7.1f}"
+          f"  cov start {s[sel, 6].mean() - t0:7.1f}  cov end {s[sel, 8].mean() - t0:7.1f}  scan start {s[sel, 12].mean() - t0:7.1f}  scan end {s[sel, 22].mean() - t0:7.1f}")
 c.close()
