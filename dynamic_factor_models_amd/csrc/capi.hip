@@ -40,6 +40,7 @@ struct dfm_handle {
                                            // per-series loads are dependent round trips, ~5 us each beside the collapse)
     int pass_fused = 1;                    // the balanced pass at Rp = 8 as ONE launch (pass_fused.hip); DFM_PASS_FUSED=0: two launches
     int pass_nsw = 0;                      // DFM_PASS_NSW: stream waves per workgroup of that launch (0 = automatic)
+    bool gram_xx_valu = false;             // DFM_GRAM_XX_VALU=1: X'X of the PCA start on the VALU kernel (diagnostics)
     int pass_ncov = 0;                     // DFM_PASS_NCOV: covariance waves per workgroup of that launch (0 = automatic)
     bool cov_wave = false;                 // DFM_COV_WAVE=1: one-wave-per-replicate covariance recursion on the separate-launch path
     void* ws = nullptr;
@@ -813,6 +814,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_PASS_FUSED")) h->pass_fused = atoi(v);
     if (const char* v = getenv("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
     if (const char* v = getenv("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
+    if (const char* v = getenv("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
     if (const char* v = getenv("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;
     return 0;
@@ -1210,7 +1212,7 @@ int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doub
     pa.S = at<double>(h, oS); pa.V = at<double>(h, oV); pa.Y = at<double>(h, oY); pa.F = at<double>(h, oF);
     pa.Lam = Lam; pa.Rv = R; pa.A = A; pa.Q = Q; pa.mu0 = mu0; pa.P0 = P0; pa.factors = factors;
     pa.status = at<int>(h, oSt);
-    { ProfScope ps(h, K_GRAM_XX); HIP_TRY(h, launch_gram_xx(pa, h->stream)); }
+    { ProfScope ps(h, K_GRAM_XX); HIP_TRY(h, launch_gram_xx(pa, h->stream, h->gram_xx_valu ? 1 : 0)); }
     { ProfScope ps(h, K_PCA); HIP_TRY(h, launch_pca(Rp, pa, h->stream)); }
     return 0;
 }

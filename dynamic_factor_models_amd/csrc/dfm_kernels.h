@@ -174,7 +174,7 @@ struct PcaArgs {
     double* factors;            // [B][T][r] or null
     int* status;                // bit 1 (value 2): subspace iteration stopped at max_iter above its tolerance; or null
 };
-hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s);
+hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant = 0);   // 0: matrix pipe (N <= 256), 1: VALU
 hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s);
 
 // Non-parametric estimator (als.hip): batched alternating least squares and batched complete-case OLS.

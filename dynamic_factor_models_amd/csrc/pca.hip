@@ -65,6 +65,115 @@ __global__ __launch_bounds__(kPcaThreads) void gram_xx_kernel(PcaArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// S = X'X on the fp64 matrix pipe (N <= 256).  One workgroup of 8 waves per replicate.  The panel streams through LDS in
+// blocks of 32 periods (double-buffered: the next block's global loads are in flight while this one is consumed); a 16 x 16
+// tile (bi, bj), bi <= bj, of S accumulates in 4 VGPR pairs of one wave as a chain of v_mfma_f64_16x16x4 over the periods
+// (A = 4 periods x 16 series bi, transposed; B = the same 4 periods x 16 series bj -- both operands are 8-byte LDS reads of
+// one panel row segment).  Wave w owns tiles w, w + 8, ...: at N = 200 (13 x 14 / 2 = 91 tiles) 12 accumulator tiles = 96
+// VGPRs.  Arithmetic: 91 tiles x 125 MFMAs x 64 cycles per replicate and SIMD pair -- ~0.3 ms for 1024 replicates against
+// the 0.2 ms the panel takes to stream; the VALU kernel above needed 3.1 ms.
+// v_mfma_f64_16x16x4 lane layout (measured: scripts/microbench/mfma16probe.hip): A[i][k] in lane 16 k + i; B[k][j] in lane
+// 16 k + j; D[(l / 16) + 4 v][l % 16] in register v of lane l.
+constexpr int kGxThreads = 512;
+constexpr int kGxPB = 32;                     // periods per LDS block
+typedef double gx_v4 __attribute__((ext_vector_type(4)));
+
+template <int MAXP>
+__global__ __launch_bounds__(kGxThreads) void gram_xx_mfma_kernel(PcaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double gx_lds[];
+    const int b = blockIdx.x;
+    const int N = a.N, T = a.T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double* __restrict__ X = a.panel + (size_t)b * T * N;
+    double* S = a.S + (size_t)b * N * N;
+    const int NT = (N + 15) / 16;
+    const int P = NT * (NT + 1) / 2;
+    const int ld = NT * 16 + 2;                                  // row stride of the LDS block (doubles): columns >= N are zero
+    const int k4 = lane >> 4, c16 = lane & 15;
+    // tiles of this wave
+    int tbi[MAXP], tbj[MAXP];
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) {
+        const int p = wave + 8 * m;
+        int bi = 0, rem = p < P ? p : 0;
+        while (rem >= NT - bi) { rem -= NT - bi; ++bi; }
+        tbi[m] = bi; tbj[m] = bi + rem;
+    }
+    gx_v4 acc[MAXP];
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) acc[m] = gx_v4{0.0, 0.0, 0.0, 0.0};
+    const int nblk = (T + kGxPB - 1) / kGxPB;
+    const int per_thread = (kGxPB * ld + kGxThreads - 1) / kGxThreads;   // LDS doubles each thread stages per block
+    // element e of a block: row e / ld, column e % ld
+    auto fetch = [&](int blk, int e) -> double {
+        const int rr = e / ld, cc = e - rr * ld;
+        const int t = blk * kGxPB + rr;
+        return (rr < kGxPB && cc < N && t < T) ? X[(size_t)t * N + cc] : 0.0;
+    };
+    constexpr int kStage = 8;                                    // staged doubles per thread and step
+    double* buf0 = gx_lds;
+    double* buf1 = gx_lds + (size_t)kGxPB * ld;
+    for (int e = tid; e < kGxPB * ld; e += kGxThreads) buf0[e] = fetch(0, e);
+    __syncthreads();
+    for (int blk = 0; blk < nblk; ++blk) {
+        double* cur = (blk & 1) ? buf1 : buf0;
+        double* nxt = (blk & 1) ? buf0 : buf1;
+        const bool more = blk + 1 < nblk;
+        // the compute of this block, with the next block's loads issued in slices of kStage in between the tiles
+        int e_next = tid;
+#pragma unroll
+        for (int m = 0; m < MAXP; ++m) {
+            double stage[kStage];
+            int es[kStage];
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < kStage; ++u) {
+                    es[u] = e_next;
+                    stage[u] = (e_next < kGxPB * ld) ? fetch(blk + 1, e_next) : 0.0;
+                    e_next += kGxThreads;
+                }
+            }
+            if (wave + 8 * m < P) {                              // (wave-uniform)
+                const double* pa = cur + (size_t)k4 * ld + tbi[m] * 16 + c16;
+                const double* pb = cur + (size_t)k4 * ld + tbj[m] * 16 + c16;
+#pragma unroll
+                for (int kk = 0; kk < kGxPB / 4; ++kk) {
+                    const double av = pa[(size_t)kk * 4 * ld];
+                    const double bv = pb[(size_t)kk * 4 * ld];
+                    acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[m], 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < kStage; ++u)
+                    if (es[u] < kGxPB * ld) nxt[es[u]] = stage[u];
+            }
+        }
+        if (more) {                                              // whatever the slices above did not cover
+            for (int e = e_next; e < kGxPB * ld; e += kGxThreads) nxt[e] = fetch(blk + 1, e);
+        }
+        __syncthreads();
+    }
+    (void)per_thread;
+    // store: tile (bi, bj) and its mirror
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) {
+        if (wave + 8 * m < P) {
+            const int j = tbj[m] * 16 + c16;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = tbi[m] * 16 + k4 + 4 * v;
+                if (i < N && j < N) {
+                    S[(size_t)i * N + j] = acc[m][v];
+                    S[(size_t)j * N + i] = acc[m][v];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // block-wide sum of NV values per thread -> every thread gets the totals (through LDS)
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* red /* [4][NV] */) {
@@ -234,7 +343,8 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
             double y[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) y[k] = 0.0;
-            for (int j = 0; j < N; ++j) {
+#pragma unroll 8
+            for (int j = 0; j < N; ++j) {                        // (8 independent loads of S in flight)
                 const double s = S[(size_t)j * N + i];
 #pragma unroll
                 for (int k = 0; k < R; ++k) y[k] = fma(s, V[(size_t)j * R + k], y[k]);
@@ -402,7 +512,31 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s) {
+template <int MAXP>
+static hipError_t launch_gx_mfma(const PcaArgs& a, hipStream_t s) {
+    const int NT = (a.N + 15) / 16;
+    const size_t lds = (size_t)2 * kGxPB * (NT * 16 + 2) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_xx_mfma_kernel<MAXP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gram_xx_mfma_kernel<MAXP>), dim3(a.B), dim3(kGxThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+// variant: 0 = matrix pipe where the shape allows it (N <= 256), 1 = the VALU kernel (DFM_GRAM_XX_VALU=1; N > 256)
+hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant) {
+    const int NT = (a.N + 15) / 16;
+    const int per_wave = (NT * (NT + 1) / 2 + 7) / 8;
+    if (variant == 0 && a.N <= 256) {
+        if (per_wave <= 4) return launch_gx_mfma<4>(a, s);
+        if (per_wave <= 8) return launch_gx_mfma<8>(a, s);
+        if (per_wave <= 12) return launch_gx_mfma<12>(a, s);
+        if (per_wave <= 17) return launch_gx_mfma<17>(a, s);
+    }
     hipLaunchKernelGGL(gram_xx_kernel, dim3(a.B), dim3(kPcaThreads), 0, s, a);
     return hipGetLastError();
 }
