@@ -432,15 +432,22 @@ def estimate_var(varm: VARModel, compute_matrices: bool = True, *, ctx=None):
     varm.seps = e.T @ e / (T_used - K)
     varm.resid[:] = np.nan
     varm.resid[varm.initperiod - 1 + np.nonzero(rows_ok)[0]] = e
-    if compute_matrices:                                                   # fill_matrices! (:477-492)
-        b = varm.betahat[1:].T if varm.withconst else varm.betahat.T
-        k = ns * varm.nlag
-        varm.M = np.zeros((k, k)); varm.Q = np.zeros((ns, k)); varm.G = np.zeros((k, ns))
-        varm.M[:ns] = b
-        varm.M[ns:, :-ns] = np.eye(k - ns)
-        varm.Q[:, :ns] = np.eye(ns)
-        varm.G[:ns] = np.linalg.cholesky(varm.seps)
+    if compute_matrices:
+        _fill_matrices(varm)
     return None
+
+
+def _fill_matrices(varm: VARModel):
+    """`fill_matrices!` -- dfm_functions.ipynb:477-492: companion M, selection Q, G = lower Cholesky factor of seps."""
+    ns = varm.seps.shape[0]
+    b = varm.betahat[1:].T if varm.withconst else varm.betahat.T
+    k = ns * varm.nlag
+    varm.M = np.zeros((k, k)); varm.Q = np.zeros((ns, k)); varm.G = np.zeros((k, ns))
+    varm.M[:ns] = b
+    if k > ns:
+        varm.M[ns:, :-ns] = np.eye(k - ns)
+    varm.Q[:, :ns] = np.eye(ns)
+    varm.G[:ns] = np.linalg.cholesky(varm.seps)
 
 
 def estimate_nonparametric(m: DFMModel, *, ctx=None, lam_constr_f=None, lam_constr_fl=None):
@@ -540,9 +547,9 @@ def bootstrap_irf_bands(varm: VARModel, H: int, ndraws: int = 10000, quantiles=(
     return dict(point=impulse_response(varm, range(varm.ns), H), bands=bands, draws=draws)
 
 
-def smooth_factors_ar_idio(m: DFMModel, *, ctx=None):
-    """SURVEY.md §8 f3: Kalman-smoothed factors and Gaussian log-likelihood of the parametric model with AR(n_uarlag)
-    idiosyncratic terms, assembled from what the reference's own estimator leaves in the model (`estimate!(m)`):
+def _ar_model_inputs(m: DFMModel):
+    """The parametric model with AR(n_uarlag) idiosyncratic terms assembled from what the reference's own estimator leaves
+    in the model (`estimate!(m)`):
 
         x_it = c_i + lam_i' f_t + e_it,   e_it = sum_l uar_coef[i,l] e_i,t-l + eps_it,  sd(eps_it) = uar_ser[i]   (:391-415)
         f_t  = c_f + A_1 f_{t-1} + .. + A_p f_{t-p} + eta_t,  Var(eta_t) = seps      (factor_var_model, :444-492)
@@ -552,8 +559,7 @@ def smooth_factors_ar_idio(m: DFMModel, *, ctx=None):
     dfm_ks_pass_ar_batch (quasi-differenced observation equation, state (f_t .. f_{t-m+1}), m = max(p, n_uarlag + 1),
     nfac_u * m <= 32; likelihood conditional on the first n_uarlag window rows).  z_q ~ N(0, stationary covariance of
     the companion VAR) -- or the sample second moment of the stacked factor estimates when the VAR is not stable.
-    Returns dict(loglik, factor [T_all, r] (NaN outside rows initperiod + n_uarlag .. lastperiod), P [T - q, r(r+1)/2],
-    series (column indices used), inputs (the arrays handed to the library, for the parity test))."""
+    Returns (inputs dict for the library, column indices used, factor mean mu_f, series intercepts c_i)."""
     if m.nfac_o != 0:
         raise NotImplementedError("observed factors (nfac_o > 0) are not supported (non-functional in the reference too)")
     var = m.factor_var_model
@@ -590,16 +596,61 @@ def smooth_factors_ar_idio(m: DFMModel, *, ctx=None):
         P0 = Z.T @ Z / Z.shape[0]
     P0 = 0.5 * (P0 + P0.T) + 1e-10 * np.eye(k)
     inputs = dict(x=x, Lam=lam, sig2=sig2, rho=rho, Avar=Avar, Q=np.array(var.seps), mu0=np.zeros(k), P0=P0)
+    return inputs, cols, mu_f, c_i
+
+
+def smooth_factors_ar_idio(m: DFMModel, *, ctx=None):
+    """SURVEY.md §8 f3: Kalman-smoothed factors and Gaussian log-likelihood of the parametric model with AR(n_uarlag)
+    idiosyncratic terms at the parameters the reference's own estimator leaves in the model (`_ar_model_inputs`).
+    Returns dict(loglik, factor [T_all, r] (NaN outside rows initperiod + n_uarlag .. lastperiod), P [T - q, r(r+1)/2],
+    series (column indices used), inputs (the arrays handed to the library, for the parity test))."""
+    inputs, cols, mu_f, _ = _ar_model_inputs(m)
+    r, q = m.nfac_u, m.n_uarlag
     ctx, own = _own(ctx)
     try:
-        f, P, ll = ctx.ks_pass_ar_batch_host(x[None], lam[None], sig2[None], rho[None], Avar[None], inputs["Q"][None],
-                                             inputs["mu0"][None], P0[None])
+        f, P, ll = ctx.ks_pass_ar_batch_host(inputs["x"][None], inputs["Lam"][None], inputs["sig2"][None], inputs["rho"][None],
+                                             inputs["Avar"][None], inputs["Q"][None], inputs["mu0"][None], inputs["P0"][None])
     finally:
         if own:
             ctx.close()
     factor = np.full((m.T_all if hasattr(m, "T_all") else m.data.shape[0], r), np.nan)
     factor[m.initperiod - 1 + q:m.lastperiod] = f[0] + mu_f
     return dict(loglik=float(ll[0]), factor=factor, P=P[0], series=cols, inputs=inputs, mu_f=mu_f)
+
+
+def estimate_ar_idio(m: DFMModel, *, max_em_iter: int = 20, tol_em: float = 1e-6, ctx=None):
+    """JOINT estimation of the parametric model with AR(n_uarlag) idiosyncratic terms -- the
+    re-estimation of `lambda`, `uar_coef`, `uar_ser` and the factor VAR that the reference's two-step estimator
+    (:391-415, :444-468) never does.  Started from `estimate(m, NonParametric())` (`_ar_model_inputs`: the reference's own
+    loadings, AR coefficients, innovation s.d. and VAR), iterated by ECM on the device (dfm_em_ar_batch: smoother pass of
+    the quasi-differenced model, transition step, loadings | rho, rho | loadings, sig2); the series intercepts and the
+    factor mean stay at their two-step values.  Mutates m IN PLACE like the reference's estimators: `lambda`, `uar_coef`,
+    `uar_ser` of the series used, `factor` (smoothed, rows initperiod + n_uarlag .. lastperiod), `factor_var_model`
+    (`betahat` slope rows, `seps`, `M`, `Q`, `G` through `fill_matrices`).  Returns the log-likelihood path (conditional on
+    the first n_uarlag window rows; non-decreasing)."""
+    inputs, cols, mu_f, _ = _ar_model_inputs(m)
+    var = m.factor_var_model
+    r, p, q = m.nfac_u, var.nlag, m.n_uarlag
+    ctx, own = _own(ctx)
+    try:
+        est, path, iters, f, _ = ctx.em_ar_batch_host(inputs["x"][None], inputs["Lam"][None], inputs["sig2"][None],
+                                                      inputs["rho"][None], inputs["Avar"][None], inputs["Q"][None],
+                                                      inputs["mu0"][None], inputs["P0"][None], max_iter=max_em_iter, tol=tol_em)
+    finally:
+        if own:
+            ctx.close()
+    m.lambda_[cols] = est["Lam"][0]
+    m.uar_coef[cols] = est["rho"][0]
+    m.uar_ser[cols] = np.sqrt(est["sig2"][0])
+    m.factor[m.initperiod - 1 + q:m.lastperiod] = f[0] + mu_f
+    c0 = 1 if var.withconst else 0
+    A = est["Avar"][0]
+    var.betahat[c0:c0 + r * p] = A.T
+    if var.withconst:                                            # the factor mean is held: c_f = (I - sum A_l) mu_f
+        var.betahat[0] = (np.eye(r) - sum(A[:, l * r:(l + 1) * r] for l in range(p))) @ mu_f
+    var.seps = est["Q"][0]
+    _fill_matrices(var)
+    return path[0, :int(iters[0])].copy()
 
 
 def amengual_watson_test(m: DFMModel, nper: int = 4, *, ctx=None):

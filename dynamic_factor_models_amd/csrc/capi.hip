@@ -102,7 +102,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t ms_ws = (size_t)-1; int ms_wpr = 0;   // mstep_mfma partial sums (EM on the fast path)
     bool fast;
     // covariance-form recursion (DFM_F_SINGULAR_Q) and companion states (dfm_*_varp_*): see RecursionArgs
-    bool cov = false; int Rc = 0, rl = 0, kdim = 0;
+    bool cov = false; int Rc = 0, rl = 0, kdim = 0, kb = 0, ka = 0;
     size_t total;
 };
 
@@ -464,7 +464,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
-    ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim; ra.wave = h->no_rec_wave ? 0 : 1;
+    ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim; ra.kb = p.kb; ra.ka = p.ka; ra.wave = h->no_rec_wave ? 0 : 1;
     ra.A = pp.A; ra.Q = pp.Q; ra.mu0 = pp.mu0; ra.P0 = pp.P0;
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
@@ -757,6 +757,90 @@ int ar_pass_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, cons
     }
     PaddedParams pp{LamP, AP, QP, mu0P, P0P};
     return enqueue_pass(h, p, B, Tq, N, r, xin, pp, sig2, f_smooth, P_smooth, loglik, nullptr);
+}
+
+// Joint estimation with AR(q) idiosyncratic terms by ECM (oracle/ar_oracle.py em_ar).  Per iteration: quasi-difference the
+// panel at the current rho, loadings [lam, -rho_1 lam, ..] on the companion state, smoother pass + transition CM-step (the
+// recursion kernel's epilogue: VAR(p) inside the m-lag state, RecursionArgs::ka), then the series CM-steps (mstep_ar.hip).
+int ar_em_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, const double* panel, double* Lam, double* sig2,
+              double* rho, double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+              int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
+    if (!h) return DFM_E_NULL;
+    if (nlag < 1 || q < 0) return fail(h, DFM_E_DIMS, "need p >= 1 factor lags and q >= 0 idiosyncratic lags%s");
+    if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (T <= q + 1) return fail(h, DFM_E_DIMS, "T must exceed the number of idiosyncratic lags by at least 2%s");
+    const int m = nlag > q + 1 ? nlag : q + 1, k = r * m;
+    if (k > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r * max(p, q + 1) > DFM_MAX_R (32)%s");
+    if (!mstep_ar_supported(r, q)) return fail(h, DFM_E_R_UNSUPPORTED, "joint AR estimation needs r <= 8 and q <= 4%s");
+    if (int rc = check_general_n(h, N, k)) return rc;
+    if (!panel || !Lam || !sig2 || (q > 0 && !rho) || !Avar || !Q || !mu0 || !P0 || !loglik_path || !iters)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int Tq = T - q;
+    Plan p = make_plan(B, Tq, N, k, flags | DFM_F_SINGULAR_Q, true, false);
+    p.kdim = k; p.kb = r; p.ka = r * nlag;                   // companion constraints; the observation loads on q + 1 blocks (rl = 0)
+    const size_t xoff = (p.total + 255) & ~(size_t)255;
+    if (int rc = ensure_ws(h, xoff + (size_t)B * Tq * N * sizeof(double))) return rc;
+    h->status_off = p.status;
+    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
+    const int Rk = p.Rp;
+    double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
+           *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P), *xq = at<double>(h, xoff);
+    {
+        const size_t nm = (size_t)B * Rk * Rk;
+        hipLaunchKernelGGL(companion_pad_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, h->stream, B, N, r, k,
+                           r * nlag, Rk, Rk, (const double*)nullptr, Avar, Q, mu0, P0, LamP, AP, QP, mu0P, P0P);
+        HIP_TRY(h, hipGetLastError());
+    }
+    double* fsm = at<double>(h, p.fsm);
+    double* Psm = at<double>(h, p.Psm);
+    double* llbuf = at<double>(h, p.llbuf);
+    int* active = at<int>(h, p.active);
+    HIP_TRY(h, hipMemsetAsync(loglik_path, 0xFF, (size_t)B * max_iter * sizeof(double), h->stream));  // NaN
+    HIP_TRY(h, hipMemsetAsync(iters, 0, (size_t)B * sizeof(int), h->stream));
+    const size_t np = (size_t)r * (r + 1) / 2, npk = (size_t)Rk * (Rk + 1) / 2;
+    PaddedParams pp{LamP, AP, QP, mu0P, P0P};
+    std::vector<int> act_host;
+    for (int it = 0; it < max_iter; ++it) {
+        const double* xin = panel;
+        if (q > 0) {
+            const size_t n = (size_t)B * Tq * N;
+            hipLaunchKernelGGL(quasi_diff_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B, T, N, q, panel,
+                               rho, xq);
+            HIP_TRY(h, hipGetLastError());
+            xin = xq;
+        }
+        {
+            const size_t n = (size_t)B * N * Rk;
+            hipLaunchKernelGGL(ar_loadings_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B, N, r, q, Rk, Lam,
+                               rho, LamP);
+            HIP_TRY(h, hipGetLastError());
+        }
+        EmOpts eo;
+        eo.A_out = AP; eo.Q_out = QP; eo.mu0_out = mu0P; eo.P0_out = P0P;
+        eo.active = active; eo.iters = iters; eo.ll_path = loglik_path; eo.k = it; eo.max_iter = max_iter; eo.tol = tol;
+        if (int rc = enqueue_pass(h, p, B, Tq, N, Rk, xin, pp, sig2, fsm, Psm, llbuf, &eo)) return rc;
+        ArMstepArgs ma;
+        ma.B = B; ma.T = T; ma.N = N; ma.r = r; ma.q = q; ma.Rk = Rk;
+        ma.panel = panel; ma.zsm = fsm; ma.Psm = Psm; ma.active = active; ma.Lam = Lam; ma.rho = rho; ma.sig2 = sig2;
+        { ProfScope ps(h, K_MSTEP_STATS); HIP_TRY(h, launch_mstep_ar(ma, h->stream)); }
+        if (tol > 0.0 && it + 1 < max_iter) {
+            act_host.resize(B);
+            HIP_TRY(h, hipMemcpyAsync(act_host.data(), active, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            bool any = false;
+            for (int b = 0; b < B; ++b) any = any || act_host[b] != 0;
+            if (!any) break;
+        }
+    }
+    if (int rc = copy_block(h, B, Rk, Rk, r, r * nlag, AP, Avar)) return rc;
+    if (int rc = copy_block(h, B, Rk, Rk, r, r, QP, Q)) return rc;
+    if (int rc = copy_block(h, B, Rk, Rk, k, k, P0P, P0)) return rc;
+    if (int rc = copy_block(h, B, 1, Rk, 1, k, mu0P, mu0)) return rc;
+    if (f_smooth) if (int rc = copy_block(h, (size_t)B * Tq, 1, Rk, 1, r, fsm, f_smooth)) return rc;
+    if (P_smooth) if (int rc = copy_block(h, (size_t)B * Tq, 1, (int)npk, 1, (int)np, Psm, P_smooth)) return rc;
+    return 0;
 }
 
 }  // namespace
@@ -1186,6 +1270,63 @@ int dfm_ks_pass_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }
     if (rc == 0) rc = post_check(h, loglik, B);
+    (void)hipFree(buf);
+    return rc;
+}
+
+int dfm_em_ar_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, int q, const double* panel, double* Lam, double* sig2,
+                        double* rho, double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol,
+                        double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
+    return ar_em_run(h, B, T, N, r, p, q, panel, Lam, sig2, rho, Avar, Q, mu0, P0, max_iter, tol, loglik_path, iters, f_smooth,
+                     P_smooth, flags);
+}
+
+int dfm_em_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, const double* panel, double* Lam, double* sig2,
+                    double* rho, double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                    int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
+    if (int rc = check_dims(h, B, T, N, r)) return rc;
+    if (p < 1 || q < 0 || T <= q + 1) return fail(h, DFM_E_DIMS, "need p >= 1, 0 <= q < T - 1%s");
+    const int m = p > q + 1 ? p : q + 1;
+    if (r * m > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r * max(p, q + 1) > DFM_MAX_R (32)%s");
+    if (!panel || !Lam || !sig2 || (q > 0 && !rho) || !Avar || !Q || !mu0 || !P0 || !loglik_path || !iters)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double), k = (size_t)r * m, np = (size_t)r * (r + 1) / 2, Tq = (size_t)(T - q);
+    const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_rho = (size_t)B * N * q,
+                 n_a = (size_t)B * r * r * p, n_q = (size_t)B * r * r, n_v = (size_t)B * k, n_p0 = (size_t)B * k * k,
+                 n_f = (size_t)B * Tq * r, n_P = (size_t)B * Tq * np, n_ll = (size_t)B * max_iter;
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf),
+                         (n_panel + n_lam + n_R + n_rho + n_a + n_q + n_v + n_p0 + n_f + n_P + n_ll) * d + (size_t)B * sizeof(int)));
+    double* dp = buf;
+    auto up = [&](const double* src, size_t n) -> double* {
+        double* dst = dp; dp += n;
+        if (n) (void)hipMemcpyAsync(dst, src, n * d, hipMemcpyHostToDevice, h->stream);
+        return dst;
+    };
+    double *x_d = up(panel, n_panel), *lam_d = up(Lam, n_lam), *R_d = up(sig2, n_R), *rho_d = up(rho, n_rho),
+           *A_d = up(Avar, n_a), *Q_d = up(Q, n_q), *mu_d = up(mu0, n_v), *P0_d = up(P0, n_p0);
+    double* f_d = dp; dp += n_f;
+    double* P_d = dp; dp += n_P;
+    double* ll_d = dp; dp += n_ll;
+    int* it_d = reinterpret_cast<int*>(dp);
+    int rc = ar_em_run(h, B, T, N, r, p, q, x_d, lam_d, R_d, rho_d, A_d, Q_d, mu_d, P0_d, max_iter, tol, ll_d, it_d,
+                       f_smooth ? f_d : nullptr, P_smooth ? P_d : nullptr, flags);
+    if (rc == 0) {
+        auto down = [&](void* dst, const void* src, size_t bytes) { if (bytes) (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream); };
+        down(Lam, lam_d, n_lam * d); down(sig2, R_d, n_R * d); down(rho, rho_d, n_rho * d); down(Avar, A_d, n_a * d);
+        down(Q, Q_d, n_q * d); down(mu0, mu_d, n_v * d); down(P0, P0_d, n_p0 * d); down(loglik_path, ll_d, n_ll * d);
+        down(iters, it_d, (size_t)B * sizeof(int));
+        if (f_smooth) down(f_smooth, f_d, n_f * d);
+        if (P_smooth) down(P_smooth, P_d, n_P * d);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    if (rc == 0) {
+        for (int b = 0; rc == 0 && b < B; ++b)
+            if (!isfinite(loglik_path[(size_t)b * max_iter])) rc = fail(h, DFM_E_NUMERIC, "non-finite log-likelihood%s");
+    }
     (void)hipFree(buf);
     return rc;
 }

@@ -66,6 +66,10 @@ struct RecursionArgs {
     int rl;               // > 0: observation loads on the first rl state components only; outputs / S11 in the Rc layout
     int kdim;             // > 0: companion state of width kdim = rl * p: the M-step keeps the shift rows and Q's zero blocks
     int wave;             // 1: one wave per replicate where recursion_wave.hip supports the shape (Rp = 8, information form)
+    int kb;               // > 0 with kdim: block size r of the companion state when the observation loads on MORE than the first
+                          // block (AR idiosyncratic terms: rl = 0); 0: the block is rl
+    int ka;               // > 0 with kdim: only the first ka = r p columns of the transition rows are free (a VAR(p) inside a
+                          // state that carries m > p lags); 0: all kdim columns
 };
 
 struct MstepArgs {
@@ -109,6 +113,21 @@ bool mstep_needs_dmiss(int Rpad, int N);
 bool mstep_mfma_supported(int Rpad, int N);
 size_t mstep_mfma_workspace(int B, int N, int Rpad, int wpr);
 hipError_t launch_mstep_mfma(int Rpad, const MstepArgs& a, int wpr, double* workspace, hipStream_t s);
+
+// Series block of the ECM iteration with AR(q) idiosyncratic terms (mstep_ar.hip): loadings, AR coefficients and innovation
+// variances from the smoothed moments of the companion state of the quasi-differenced model.
+struct ArMstepArgs {
+    int B, T, N, r, q, Rk;      // T: rows of the ORIGINAL panel (the moments cover its rows q .. T-1); Rk: padded state width
+    const double* panel;        // [B][T][N], NaN = missing
+    const double* zsm;          // [B][T-q][Rk]             smoothed means of z_t = (f_t, .., f_{t-m+1})
+    const double* Psm;          // [B][T-q][Rk(Rk+1)/2]     smoothed covariances, packed lower
+    const int* active;          // [B] or null
+    double* Lam;                // [B][N][r]   in / out
+    double* rho;                // [B][N][q]   in / out
+    double* sig2;               // [B][N]      in / out
+};
+bool mstep_ar_supported(int r, int q);
+hipError_t launch_mstep_ar(const ArMstepArgs& a, hipStream_t s);
 
 // Balanced-panel fast path (fastpath.hip): data-independent covariance steps (cov_kernel) and the
 // time-parallel mean recursion (meanscan_kernel).  All matrices in the padded dimension Rp.

@@ -537,13 +537,23 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
             const int kd = a.kdim;                         // > 0: companion state (f_t, .., f_{t-p+1}) of width kd
 #pragma unroll
             for (int j = 0; j < R; ++j) inv[j] = S00[j];
+            double S10m[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) S10m[j] = S10[j];
+            if (kd > 0 && a.ka > 0) {   // VAR(p) inside a wider state: A = S10[:, :ka] S00[:ka, :ka]^-1, zero beyond
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    if (i >= a.ka || j >= a.ka) inv[j] = (i == j) ? 1.0 : 0.0;
+                    if (j >= a.ka) S10m[j] = 0.0;
+                }
+            }
             (void)gj_inverse<R>(inv, X, i);
             __syncthreads();
             store_row<R>(X, i, inv);
             __syncthreads();
-            mm_rows<R>(An, S10, X);                        // A row i
+            mm_rows<R>(An, S10m, X);                       // A row i
             __syncthreads();
-            store_row<R>(X, i, S10);
+            store_row<R>(X, i, S10m);
             __syncthreads();
             mm_rowsT<R>(tmp, An, X);                       // (A S10')[i][:]
 #pragma unroll
@@ -554,10 +564,11 @@ __global__ __launch_bounds__(64) void recursion_kernel(RecursionArgs a) {
 #pragma unroll
             for (int j = 0; j < R; ++j) Qn[j] = 0.5 * (Qn[j] + X[j * R + i]);
             if (kd > 0) {   // only [A_1 .. A_p] and the innovation covariance of f_t are free (dfm_functions.ipynb:477-492)
+                const int rb = a.kb > 0 ? a.kb : rl;               // block size of the companion state
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    if (i >= rl && i < kd) An[j] = (j == i - rl) ? 1.0 : 0.0;
-                    if ((i >= rl && i < kd) || (j >= rl && j < kd)) Qn[j] = 0.0;
+                    if (i >= rb && i < kd) An[j] = (j == i - rb) ? 1.0 : 0.0;
+                    if ((i >= rb && i < kd) || (j >= rb && j < kd)) Qn[j] = 0.0;
                 }
             }
             __syncthreads();

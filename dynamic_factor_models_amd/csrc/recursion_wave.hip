@@ -430,9 +430,14 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
         if (a.A_out) {
             // A = S10 S00^-1 ;  Q = sym(S11 - A S10') / T ;  mu0 = f_0|T ;  P0 = sym(P_0|T) ;  S11^-1
             double inv = S00;
+            double S10m = S10;
+            if (a.kdim > 0 && a.ka > 0) {   // VAR(p) inside a wider state: A = S10[:, :ka] S00[:ka, :ka]^-1, zero beyond
+                if (i >= a.ka || j >= a.ka) inv = (i == j) ? 1.0 : 0.0;
+                if (j >= a.ka) S10m = 0.0;
+            }
             (void)G.sweep_inverse(inv);
             G.sync();
-            L0[TS * i + j] = S10;
+            L0[TS * i + j] = S10m;
             L1[TS * i + j] = inv;                                    // symmetric: rows = columns
             G.sync();
             const double An = dot_rows<R>(L0, L1, i, j);
@@ -444,8 +449,9 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
             double Aout = An;
             if (a.kdim > 0) {   // companion state: only [A_1 .. A_p] and the innovation covariance of f_t are free
                 const int kd = a.kdim;
-                if (i >= rl && i < kd) Aout = (j == i - rl) ? 1.0 : 0.0;
-                if ((i >= rl && i < kd) || (j >= rl && j < kd)) Qn = 0.0;
+                const int rb = a.kb > 0 ? a.kb : rl;               // block size of the companion state
+                if (i >= rb && i < kd) Aout = (j == i - rb) ? 1.0 : 0.0;
+                if ((i >= rb && i < kd) || (j >= rb && j < kd)) Qn = 0.0;
             }
             const double P0n = 0.5 * (Ps + G.transposed(Ps));
             double inv2 = S11;

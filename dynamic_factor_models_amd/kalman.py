@@ -396,6 +396,56 @@ class DfmContext:
         _check(self._h, rc)
         return f, P, ll
 
+    def em_ar_batch(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
+                    want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None):
+        """Joint ECM estimation with AR(q) idiosyncratic terms (include/dfm_hip.h: dfm_em_ar_batch_dev).  Device tensors;
+        Lam [B,N,r], sig2 [B,N], rho [B,N,q], Avar [B,r,r p], Q, mu0 [B,r m], P0 [B,r m,r m] are UPDATED IN PLACE.
+        Returns (loglik_path [B,max_iter], iters [B], f_smooth [B,T-q,r] or None, P_smooth or None)."""
+        torch = self._torch
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        p = Avar.shape[2] // r
+        q = rho.shape[2]
+        k = r * max(p, q + 1)
+        flags = self._flags(panel, may_have_missing)
+        dev = panel.device
+        path = torch.empty((B, max_iter), dtype=torch.float64, device=dev)
+        iters = torch.empty((B,), dtype=torch.int32, device=dev)
+        f = torch.empty((B, T - q, r), dtype=torch.float64, device=dev) if want_smooth else None
+        P = torch.empty((B, T - q, r * (r + 1) // 2), dtype=torch.float64, device=dev) if (want_smooth and want_P) else None
+        self._sync_stream()
+        rc = self._lib.dfm_em_ar_batch_dev(
+            self._h, B, T, N, r, p, q, self._dev(panel, "panel"), self._dev(Lam, "Lam", (B, N, r)),
+            self._dev(sig2, "sig2", (B, N)), self._dev(rho, "rho", (B, N, q)) if q else None,
+            self._dev(Avar, "Avar", (B, r, r * p)), self._dev(Q, "Q", (B, r, r)), self._dev(mu0, "mu0", (B, k)),
+            self._dev(P0, "P0", (B, k, k)), int(max_iter), float(tol), self._dev(path, "loglik_path"),
+            ctypes.c_void_p(iters.data_ptr()), self._dev(f, "f_smooth") if f is not None else None,
+            self._dev(P, "P_smooth") if P is not None else None, flags)
+        _check(self._h, rc)
+        return path, iters, f, P
+
+    def em_ar_batch_host(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
+                         may_have_missing: Optional[bool] = None):
+        """Host-pointer entry (what Julia's ccall binds).  Returns (params dict, loglik_path, iters, f_smooth, P_smooth);
+        inputs are not modified."""
+        c = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
+        panel = np.ascontiguousarray(panel, dtype=np.float64)
+        Lam, sig2, rho, Avar, Q, mu0, P0 = map(c, (Lam, sig2, rho, Avar, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        p_lag = Avar.shape[2] // r
+        q = rho.shape[2]
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
+        f = np.empty((B, T - q, r)); P = np.empty((B, T - q, r * (r + 1) // 2))
+        p = lambda a: ctypes.c_void_p(a.ctypes.data) if a.size else None
+        rc = self._lib.dfm_em_ar_batch(self._h, B, T, N, r, p_lag, q, p(panel), p(Lam), p(sig2), p(rho), p(Avar), p(Q),
+                                       p(mu0), p(P0), int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags)
+        _check(self._h, rc)
+        return dict(Lam=Lam, sig2=sig2, rho=rho, Avar=Avar, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
+
     # ------------------------------------------------------------------ PCA initialisation / synthetic panels
     def pca_init_batch(self, panel, r: int, want_factors: bool = True):
         """PCA + OLS start of EM on balanced standardised panels (device tensor [B,T,N], no NaN).

@@ -191,6 +191,23 @@ int dfm_ks_pass_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q
                          const double* Q, const double* mu0, const double* P0, double* f_smooth,
                          double* P_smooth, double* loglik, unsigned flags);
 
+/* Joint estimation of the same model: loadings, AR coefficients (the reference's `uar_coef`, dfm_functions.ipynb:305-311,
+ * 405-412), innovation variances (`uar_ser`^2), [A_1 .. A_p] and Q by ECM -- per iteration one smoother pass of the
+ * quasi-differenced model at the current rho, the transition step (a VAR(p) inside the state of max(p, q + 1) lags), then
+ * per series the loadings given rho, rho given the new loadings, and sig2 (all from the smoothed moments of the companion
+ * state).  Every conditional step maximises its block of the expected complete-data likelihood, so loglik_path
+ * [B][max_iter] (the likelihood conditional on the first q rows, at the parameters ENTERING each iteration) is
+ * non-decreasing; bookkeeping (tol, iters) as dfm_em_batch.  Parameters are updated in place; rho [B][N][q]; mu0 / P0:
+ * moments of the state at period q.  r <= 8, q <= 4, r * max(p, q + 1) <= 32; f_smooth / P_smooth (may be NULL): the
+ * T - q smoothed rows of the last E-step.  Series with fewer than r + q + 1 usable quasi-differenced cells keep their
+ * loadings / rho / sig2. */
+int dfm_em_ar_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, int q, const double* panel, double* Lam,
+                        double* sig2, double* rho, double* Avar, double* Q, double* mu0, double* P0, int max_iter,
+                        double tol, double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags);
+int dfm_em_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, const double* panel, double* Lam,
+                    double* sig2, double* rho, double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol,
+                    double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags);
+
 /* --- PCA initialisation (reference: pca_score, dfm_functions.ipynb:179-183, on the standardised
  * balanced panel, :339-348) followed by the OLS start of EM: Lam = OLS(x on F), R = residual
  * variance, A/Q = VAR(1) OLS of F, mu0 = 0, P0 = F'F/T.  Balanced panels only (no NaN). */

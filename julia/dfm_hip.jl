@@ -225,6 +225,33 @@ function ks_pass_ar(h::Handle, x::Matrix{Float64}, Lam::Matrix{Float64}, sig2::V
     return (factor = permutedims(f), P = permutedims(P), loglik = ll[1])
 end
 
+"Joint ECM estimation with AR(q) idiosyncratic terms (dfm_em_ar_batch; include/dfm_hip.h): the re-estimation of the
+reference's `lambda`, `uar_coef`, `uar_ser` (dfm_functions.ipynb:391-415) and factor VAR inside the parametric model.
+Arguments as ks_pass_ar (the start: what `estimate!(m)` left in the model).  Returns the updated parameters, the
+log-likelihood path (conditional on the first q rows; non-decreasing) and the smoothed factors of rows q+1..T."
+function em_ar(h::Handle, x::Matrix{Float64}, Lam::Matrix{Float64}, sig2::Vector{Float64}, rho::Matrix{Float64},
+               Avar::Matrix{Float64}, Q::Matrix{Float64}, mu0::Vector{Float64}, P0::Matrix{Float64};
+               max_iter::Integer = 20, tol::Real = 1e-6)
+    T, N = size(x); r = size(Lam, 2); q = size(rho, 2); p = div(size(Avar, 2), r)
+    panel = to_c_panel(x)
+    LamC = permutedims(Lam); sig = copy(sig2); rhoC = permutedims(rho); AC = permutedims(Avar); QC = permutedims(Q)
+    mu = copy(mu0); P0C = permutedims(P0)
+    path = Array{Float64}(undef, max_iter); iters = Array{Cint}(undef, 1)
+    f = Array{Float64}(undef, r, T - q); np = div(r * (r + 1), 2); P = Array{Float64}(undef, np, T - q)
+    flags = any(isnan, x) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    GC.@preserve panel LamC sig rhoC AC QC mu P0C path iters f P begin
+        rc = ccall((:dfm_em_ar_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cdouble, Ptr{Float64}, Ptr{Cint},
+                    Ptr{Float64}, Ptr{Float64}, Cuint),
+                   h.ptr, 1, T, N, r, p, q, panel, LamC, sig, rhoC, AC, QC, mu, P0C, max_iter, tol, path, iters, f, P, flags)
+        check(h.ptr, rc)
+    end
+    kk = Int(iters[1])
+    return (Lam = permutedims(LamC), sig2 = sig, rho = permutedims(rhoC), Avar = permutedims(AC), Q = permutedims(QC),
+            mu0 = mu, P0 = permutedims(P0C), loglik = path[1:kk], iters = kk, factor = permutedims(f))
+end
+
 # ---- the reference's NON-parametric estimator on the GPU (als.hip) ------------------------------------------------
 "`estimate_factor!` sweeps (dfm_functions.ipynb:352-370) for ONE run: z is the standardised T x N window (NaN =
 missing), F0 the T x r start (pca_score).  dfm_als_batch; returns factors, loadings (NaN rows: no loadings), ssr,
