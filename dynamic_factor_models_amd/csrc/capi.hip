@@ -40,6 +40,7 @@ struct dfm_handle {
                                            // per-series loads are dependent round trips, ~5 us each beside the collapse)
     int pass_fused = 1;                    // the balanced pass at Rp = 8 as ONE launch (pass_fused.hip); DFM_PASS_FUSED=0: two launches
     int pass_nsw = 0;                      // DFM_PASS_NSW: stream waves per workgroup of that launch (0 = automatic)
+    bool collapse_miss_old = false;        // DFM_COLLAPSE_MISS_OLD=1: register-streamed collapse_kernel for panels with missing cells
     bool gram_xx_valu = false;             // DFM_GRAM_XX_VALU=1: X'X of the PCA start on the VALU kernel (diagnostics)
     int pass_ncov = 0;                     // DFM_PASS_NCOV: covariance waves per workgroup of that launch (0 = automatic)
     bool cov_wave = false;                 // DFM_COV_WAVE=1: one-wave-per-replicate covariance recursion on the separate-launch path
@@ -460,7 +461,12 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ca.bcol = at<double>(h, p.bcol); ca.scol = at<double>(h, p.scol); ca.nobs = at<int>(h, p.nobs);
     ca.ldrow = at<double>(h, p.ldrow); ca.Ct = at<double>(h, p.Ct); ca.Cfull = at<double>(h, p.Cfull);
     ca.ldfull = at<double>(h, p.ldfull); ca.status = at<int>(h, p.status);
-    { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(p.Rc ? p.Rc : p.Rp, ca, h->stream)); }
+    {
+        const int Rcol = p.Rc ? p.Rc : p.Rp;
+        ProfScope ps(h, K_COLLAPSE);
+        if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream));
+        else HIP_TRY(h, launch_collapse(Rcol, ca, h->stream));
+    }
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
@@ -899,6 +905,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
     if (const char* v = getenv("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
     if (const char* v = getenv("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
+    if (const char* v = getenv("DFM_COLLAPSE_MISS_OLD")) h->collapse_miss_old = atoi(v) != 0;
     if (const char* v = getenv("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;
     return 0;

@@ -87,6 +87,9 @@ struct MstepArgs {
 };
 
 hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
+// the same contract on the LDS-DMA ring + matrix pipe (collapse_miss.hip): Rp = 8, the shapes of the MFMA collapse
+bool collapse_miss_supported(int Rpad, int N);
+hipError_t launch_collapse_miss(const CollapseArgs& a, int num_cu, hipStream_t s);
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a);
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad);
 int collapse_max_n(int Rpad);
