@@ -40,6 +40,7 @@ struct dfm_handle {
                                            // per-series loads are dependent round trips, ~5 us each beside the collapse)
     int pass_fused = 1;                    // the balanced pass at Rp = 8 as ONE launch (pass_fused.hip); DFM_PASS_FUSED=0: two launches
     int pass_nsw = 0;                      // DFM_PASS_NSW: stream waves per workgroup of that launch (0 = automatic)
+    bool wide_old = false;                 // DFM_WIDE_OLD=1: Rp = 32 balanced collapse by collapse_wide_kernel + gram_wide_kernel
     bool collapse_miss_old = false;        // DFM_COLLAPSE_MISS_OLD=1: register-streamed collapse_kernel for panels with missing cells
     bool gram_xx_valu = false;             // DFM_GRAM_XX_VALU=1: X'X of the PCA start on the VALU kernel (diagnostics)
     int pass_ncov = 0;                     // DFM_PASS_NCOV: covariance waves per workgroup of that launch (0 = automatic)
@@ -101,6 +102,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     // balanced fast path (fastpath.hip); (size_t)-1 when the plan is for the general path
     size_t f_tab, f_E, f_stead, f_xi0, f_PT, f_llc, f_fill, f_PsInf, f_ssum;
     size_t ms_ws = (size_t)-1; int ms_wpr = 0;   // mstep_mfma partial sums (EM on the fast path)
+    size_t Wwide = (size_t)-1;                     // W = lam / R of the Rp = 32 collapse (collapse_wide2.hip)
     bool fast;
     // covariance-form recursion (DFM_F_SINGULAR_Q) and companion states (dfm_*_varp_*): see RecursionArgs
     bool cov = false; int Rc = 0, rl = 0, kdim = 0, kb = 0, ka = 0;
@@ -155,6 +157,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.f_fill = take(off, (size_t)B * 2 * sizeof(int));
         p.f_PsInf = take(off, B * rr * d);
         p.f_ssum = take(off, (size_t)B * kSsumSlots * d);
+        if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, (size_t)B * N * Rp * d);
     } else {
         p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
     }
@@ -319,10 +322,21 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     // (collapse_mfma.hip), else the VALU kernel (collapse_dma.hip); DFM_COLLAPSE_VARIANT < 200 forces the latter
     // shapes outside the register tilings (or DFM_COLLAPSE_VARIANT=198): the wide kernel
     const bool use_wide = !collapse_dma_supported(p.Rp, N) || h->collapse_variant == 198;
-    if (use_wide) { fa.scol = ca.scol; fa.ntile = collapse_wide_tiles(T); }
     const bool use_mfma = !use_wide && collapse_mfma_supported(p.Rp, N) && (h->collapse_variant == 0 || h->collapse_variant >= 200);
     const int cvariant = use_mfma ? (h->collapse_variant >= 200 ? h->collapse_variant : 200)
                                   : (h->collapse_variant == 199 ? 0 : h->collapse_variant);   // 199: the VALU kernel's default
+    const bool use_wide2 = use_wide && !h->wide_old && p.Wwide != (size_t)-1 && collapse_wide2_supported(p.Rp, N);
+    if (use_wide) { fa.scol = ca.scol; fa.ntile = use_wide2 ? collapse_wide2_tiles(T) : collapse_wide_tiles(T); }
+    double* Wwide = use_wide2 ? at<double>(h, p.Wwide) : nullptr;
+    // Gram matrix (+ W for the Rp = 32 collapse) and the streaming collapse of this shape, on stream `st`
+    auto run_gram = [&](hipStream_t st) -> hipError_t {
+        if (use_wide2) return launch_wide_prep(ca, Wwide, st);
+        return gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, st) : launch_gram_wide(p.Rp, ca, st);
+    };
+    auto run_collapse = [&](const CollapseArgs& c, hipStream_t st) -> hipError_t {
+        if (use_wide2) return launch_collapse_wide2(c, Wwide, st);
+        return use_wide ? launch_collapse_wide(p.Rp, c, st) : launch_collapse_dma(p.Rp, c, st, cvariant);
+    };
     // MFMA collapse: as many period segments per replicate as the chip has resident wave slots for this batch
     // (3 workgroups x 4 waves on each CU), so that the launch is one balanced round
     int wpr = 4;
@@ -356,9 +370,9 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         return 0;
     };
     if (h->no_side) {   // diagnostics: everything in order on the main stream
-        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }
+        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, run_gram(h->stream)); }
         { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }
-        { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA); HIP_TRY(h, use_wide ? launch_collapse_wide(p.Rp, ca, h->stream) : launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
+        { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA); HIP_TRY(h, run_collapse(ca, h->stream)); }
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
         return em_update();
     }
@@ -393,7 +407,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         // ONE stream, two launches: [Gram + covariance workgroups + P_smooth fill | streaming collapse] -> scan.
         // The covariance waves sit at the front of the collapse grid (resident first, no cross-stream events).
         if (h->fused_gram) { fa.Lam = pp.Lam; fa.Rv = Rv; }   // the covariance workgroups compute their Gram matrices themselves
-        else { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }
+        else { ProfScope ps(h, K_GRAM); HIP_TRY(h, run_gram(h->stream)); }
         ca.fuse_cov = &fa;
         { ProfScope ps(h, K_COLLAPSE_MFMA); HIP_TRY(h, launch_collapse_dma(p.Rp, ca, h->stream, cvariant)); }
         ca.fuse_cov = nullptr;
@@ -405,11 +419,11 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         // The covariance kernel (128 waves, 224 VGPRs each) must be resident BEFORE the streaming collapse fills
         // every CU, or it waits for the collapse to drain (measured: 285 us instead of 90).  It therefore goes
         // first on the caller's stream, and the collapse is the forked work: its queue starts ~6 us later.
-        if (!fuse_gram) { ProfScope ps(h, K_GRAM); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->stream) : launch_gram_wide(p.Rp, ca, h->stream)); }   // 12 us, alone
+        if (!fuse_gram || use_wide2) { ProfScope ps(h, K_GRAM); HIP_TRY(h, run_gram(h->stream)); }   // 12 us, alone
         HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
         { ProfScope ps(h, K_COV); HIP_TRY(h, (h->cov_wave && p.Rp == 8 && !fuse_gram) ? launch_cov_wave(fa, h->stream) : launch_cov(p.Rp, fa, h->stream)); }
-        { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA, h->side); HIP_TRY(h, use_wide ? launch_collapse_wide(p.Rp, ca, h->side) : launch_collapse_dma(p.Rp, ca, h->side, cvariant)); }
+        { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA, h->side); HIP_TRY(h, run_collapse(ca, h->side)); }
         HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
         if (!h->no_pfill && P_smooth) {   // the data-independent rows of P_smooth, beside the collapse
             ProfScope ps(h, K_PFILL);
@@ -429,7 +443,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
     HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_fork, 0));
-    if (!fuse_gram) { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, h->side) : launch_gram_wide(p.Rp, ca, h->side)); }
+    if (!fuse_gram) { ProfScope ps(h, K_GRAM, h->side); HIP_TRY(h, run_gram(h->side)); }
     { ProfScope ps(h, K_COV, h->side); HIP_TRY(h, launch_cov(p.Rp, fa, h->side)); }
     HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
     HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));
@@ -906,6 +920,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
     if (const char* v = getenv("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
     if (const char* v = getenv("DFM_COLLAPSE_MISS_OLD")) h->collapse_miss_old = atoi(v) != 0;
+    if (const char* v = getenv("DFM_WIDE_OLD")) h->wide_old = atoi(v) != 0;
     if (const char* v = getenv("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;
     return 0;

@@ -13,7 +13,10 @@ constexpr int kScanThreads = 256;   // meanscan workgroup: 256 / R lane groups =
 __host__ __device__ constexpr int cov_threads(int R) { (void)R; return 64; }
 // levels of the carry scan over the 256 / R chunks, and matrices kept per replicate in `stead`:
 // Z, J, G, then G^(L 2^k) and J^(L 2^k), k = 0 .. levels-1
-__host__ __device__ constexpr int scan_levels(int R) { int n = 0; while ((1 << n) < kScanThreads / R) ++n; return n; }
+// Rp = 32: 512 threads = 16 time chunks (8 chunks of 256 periods made the scan of config 4 a 0.65-ms chain of 1024 dependent
+// 32 x 32 matrix-vector steps; 32 chunks would need 14 staged 8-KB matrices: over the LDS budget)
+__host__ __device__ constexpr int scan_threads(int R) { return R >= 32 ? 512 : kScanThreads; }
+__host__ __device__ constexpr int scan_levels(int R) { int n = 0; while ((1 << n) < scan_threads(R) / R) ++n; return n; }
 __host__ __device__ constexpr int stead_mats(int R) { return 3 + 2 * scan_levels(R); }
 
 // ================================================================================================
@@ -353,9 +356,9 @@ __device__ __forceinline__ void cov_body(const FastArgs& a, int wave_first, doub
 
 // Rows [lo, hi) of P_smooth equal the backward fixed point P_s,inf: element k of the range is s_ps[k % npr]
 // (packed lower triangle in the caller's r).  Plain 16-byte stores, nothing waits for them.
-__device__ __forceinline__ void fill_psmooth_rows(const FastArgs& a, int b, int tid, int nthreads, const double* s_ps) {
+__device__ __forceinline__ void fill_psmooth_range(const FastArgs& a, int b, int tid, int nthreads, const double* s_ps, int lo,
+                                                   int hi) {
     const int npr = a.r * (a.r + 1) / 2;
-    const int lo = a.fill[2 * b], hi = a.fill[2 * b + 1];
     if (hi <= lo) return;
     double* base = a.P_smooth + ((size_t)b * a.T + lo) * npr;
     const unsigned n = (unsigned)(hi - lo) * (unsigned)npr;
@@ -373,6 +376,9 @@ __device__ __forceinline__ void fill_psmooth_rows(const FastArgs& a, int b, int 
         if (v >= (unsigned)npr) v -= (unsigned)npr;
     }
     if (((n - peel) & 1u) != 0 && tid == 0) base[n - 1] = s_ps[(n - 1) % (unsigned)npr];
+}
+__device__ __forceinline__ void fill_psmooth_rows(const FastArgs& a, int b, int tid, int nthreads, const double* s_ps) {
+    fill_psmooth_range(a, b, tid, nthreads, s_ps, a.fill[2 * b], a.fill[2 * b + 1]);
 }
 
 

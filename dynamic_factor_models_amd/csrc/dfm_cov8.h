@@ -36,22 +36,22 @@ struct Cov8Dst {                 // every matrix row-major [8][8] = indexed by t
     double* SP11; double* SU; double* P0s;   // EM covariance sums [64] each, or null
 };
 
-// ONE wave (64 lanes), replicate b.  Cel = element (i, j) of C = Lam' R^-1 Lam, ldfull = sum_i log R_i.
-// wsm: kCov8ScratchDoubles doubles of LDS private to this wave.  NLEV = levels of the scan's carry tree.
-template <int NLEV>
-__device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, double ldfull, double* wsm, const Cov8Dst& o,
-                                          int lane) {
-    constexpr int R = 8, TS = kTileStride<8>;
-    Grid<8> G;
-    const int i = lane >> 3, j = lane & 7;
-    G.l = lane; G.i = i; G.j = j; G.prow = nullptr; G.red = nullptr; G.tt = nullptr;
+// R x R threads (one wave at R = 8, a workgroup of 256 / 1024 threads at R = 16 / 32), replicate b.  G: the thread grid with
+// l, i, j (and, R >= 16, its LDS exchange buffers) set.  Cel = element (i, j) of C = Lam' R^-1 Lam, ldfull = sum_i log R_i.
+// wsm: 4 tiles of R x kTileStride<R> doubles of LDS private to the replicate.  NLEV = levels of the scan's carry tree;
+// KEEP = transient steps whose Z_e, J_e stay in registers.  Matrices of Cov8Dst: row-major [R][R], element l = R i + j.
+template <int R, int NLEV, int KEEP>
+__device__ __forceinline__ void cov_grid(const FastArgs& a, int b, double Cel, double ldfull, double* wsm, const Cov8Dst& o,
+                                         Grid<R>& G) {
+    constexpr int TS = kTileStride<R>, RR = R * R, RT = R * kTileStride<R>;
+    const int lane = G.l, i = G.i, j = G.j;                  // ("lane" = thread of the grid)
     double* L0 = wsm;
-    double* L1 = L0 + kCov8TileDoubles;
-    double* LPT = L1 + kCov8TileDoubles;     // rows of Psi' = Q^-1 A   (constant)
-    double* LJ = LPT + kCov8TileDoubles;     // rows of the current J_e (backward sweep)
+    double* L1 = L0 + RT;
+    double* LPT = L1 + RT;                   // rows of Psi' = Q^-1 A   (constant)
+    double* LJ = LPT + RT;                   // rows of the current J_e (backward sweep)
     const int T = a.T, r = a.r;
     const bool diag = (i == j);
-    const size_t mo = (size_t)b * 64 + lane;
+    const size_t mo = (size_t)b * RR + lane;
 
     const double Ael = a.A[mo];
     double Qi = a.Q[mo];
@@ -83,11 +83,11 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
     LogProd detprod;                                            // prod over the E distinct steps of det(Om_f + Phi)
     double detM_last = 1.0;
     int E = 0;
-    // Z_e, J_e of the first kCov8Keep steps stay in registers for the backward sweep (one element per lane each): read
+    // Z_e, J_e of the first KEEP steps stay in registers for the backward sweep (one element per lane each): read
     // back from the table they cost a global round trip per distinct step -- 5 to 8 us each beside streaming waves
-    double Zk[kCov8Keep], Jk[kCov8Keep];
+    double Zk[KEEP], Jk[KEEP];
 #pragma unroll
-    for (int u = 0; u < kCov8Keep; ++u) { Zk[u] = 0.0; Jk[u] = 0.0; }
+    for (int u = 0; u < KEEP; ++u) { Zk[u] = 0.0; Jk[u] = 0.0; }
     double Zlast = 0.0, Jlast = 0.0, Glast = 0.0;               // entry E - 1 = the steady matrices
     for (int e = 0;; ++e) {
         double Z = Omf + Phi;
@@ -100,11 +100,11 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
         const double tmp = dot_rows<R>(LPT, L1, i, j);          // Psi' J
         const double Gm = dot_rows<R>(LPT, L0, i, j);           // G = Psi' Z   (Z symmetric to rounding)
         const double Omf_new = (Qi - tmp) + Cel;                // Om_p + C
-        const bool gsame = __all(close_enough(Omf_new, Omf));
-        double* te = (e < o.tab_cap ? o.tab : o.tab_over) + (size_t)e * 3 * 64;
-        te[lane] = Z; te[64 + lane] = Jr; te[128 + lane] = Gm;
+        const bool gsame = G.all_true(close_enough(Omf_new, Omf));
+        double* te = (e < o.tab_cap ? o.tab : o.tab_over) + (size_t)e * 3 * RR;
+        te[lane] = Z; te[RR + lane] = Jr; te[2 * RR + lane] = Gm;
 #pragma unroll
-        for (int u = 0; u < kCov8Keep; ++u) {
+        for (int u = 0; u < KEEP; ++u) {
             Zk[u] = (u == e) ? Z : Zk[u];
             Jk[u] = (u == e) ? Jr : Jk[u];
         }
@@ -144,15 +144,15 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
         if (e != cur_e) {                                       // wave-uniform
             if (e == ts) {
                 Zc = Zlast; Jc = Jlast;
-            } else if (e < kCov8Keep) {
+            } else if (e < KEEP) {
 #pragma unroll
-                for (int u = 0; u < kCov8Keep; ++u) {
+                for (int u = 0; u < KEEP; ++u) {
                     Zc = (u == e) ? Zk[u] : Zc;
                     Jc = (u == e) ? Jk[u] : Jc;
                 }
             } else {
-                const double* te = (e < o.tab_cap ? o.tab : o.tab_over) + (size_t)e * 3 * 64;
-                Zc = te[lane]; Jc = te[64 + lane];
+                const double* te = (e < o.tab_cap ? o.tab : o.tab_over) + (size_t)e * 3 * RR;
+                Zc = te[lane]; Jc = te[RR + lane];
             }
             cur_e = e;
             LJ[TS * i + j] = Jc;
@@ -163,7 +163,7 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
         L1[TS * j + i] = U;                                     // U' rows
         G.sync();
         const double Psn = Zc + dot_rows<R>(LJ, L1, i, j);      // Z + J U
-        const bool gsame = __all(close_enough(Psn, Ps));
+        const bool gsame = G.all_true(close_enough(Psn, Ps));
         const bool skip = (e == ts && t > ts && gsame);         // steps t-1 .. ts repeat this (U, P_s)
         const int plo = ts >= 1 ? ts : 1;                       // periods plo .. t-1 carry P_s,inf
         const double cu = skip ? (double)(t - ts + 1) : 1.0;
@@ -190,8 +190,8 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
     {
         const double Zs = Zlast, Js = Jlast, Gs = Glast;
         o.stead[lane] = Zs;
-        o.stead[2 * 64 + lane] = Gs;
-        o.stead[1 * 64 + lane] = Js;
+        o.stead[2 * RR + lane] = Gs;
+        o.stead[1 * RR + lane] = Js;
         // the two power chains are independent: squared side by side (G through L0 / L1, J through LPT / LJ -- both free
         // now), half the dependent exchanges of one chain after the other
         double MG = Gs, MJ = Js;
@@ -208,11 +208,20 @@ __device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, 
         for (int l = 1; l < a.L; l <<= 1) square2();             // M^L
 #pragma unroll 1
         for (int k = 0; k < NLEV; ++k) {
-            o.stead[(3 + k) * 64 + lane] = MG;                   // G^(L 2^k)
-            o.stead[(3 + NLEV + k) * 64 + lane] = MJ;            // J^(L 2^k)
+            o.stead[(3 + k) * RR + lane] = MG;                   // G^(L 2^k)
+            o.stead[(3 + NLEV + k) * RR + lane] = MJ;            // J^(L 2^k)
             if (k + 1 < NLEV) square2();
         }
     }
+}
+
+// ONE wave (64 lanes) per replicate at R = 8 (pass_fused.hip, cov_wave_kernel).  wsm: kCov8ScratchDoubles doubles of LDS.
+template <int NLEV>
+__device__ __forceinline__ void cov_wave8(const FastArgs& a, int b, double Cel, double ldfull, double* wsm, const Cov8Dst& o,
+                                          int lane) {
+    Grid<8> G;
+    G.l = lane; G.i = lane >> 3; G.j = lane & 7; G.prow = nullptr; G.red = nullptr; G.tt = nullptr;
+    cov_grid<8, NLEV, kCov8Keep>(a, b, Cel, ldfull, wsm, o, G);
 }
 
 // Gram matrix C = Lam' R^-1 Lam and sum log R of replicate b by ONE wave (lane l owns series {2l, 2l+1} + 128 q, q < NDR),

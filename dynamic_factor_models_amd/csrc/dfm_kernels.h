@@ -107,6 +107,12 @@ bool collapse_wide_supported(int Rpad, int N);
 int collapse_wide_tiles(int T);
 hipError_t launch_collapse_wide(int Rpad, const CollapseArgs& a, hipStream_t s);
 hipError_t launch_gram_wide(int Rpad, const CollapseArgs& a, hipStream_t s);
+// Rp = 32 on the LDS-DMA path (collapse_wide2.hip): launch_wide_prep writes W = lam / R ([B][N][32] workspace), Cfull and
+// ldfull (the Gram kernel's outputs); launch_collapse_wide2 then streams the panel (partials of sum_t s_t: scol[b][tile])
+bool collapse_wide2_supported(int Rpad, int N);
+int collapse_wide2_tiles(int T);
+hipError_t launch_wide_prep(const CollapseArgs& a, double* W, hipStream_t s);
+hipError_t launch_collapse_wide2(const CollapseArgs& a, const double* W, hipStream_t s);
 bool gram_supported(int Rpad, int N);       // launch_gram's register tilings
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
 hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
@@ -182,6 +188,10 @@ int pass_fused_pick_nsw(int T, int N, int want);            // stream waves per 
 // nsw / ncov: stream / covariance waves per workgroup (0 = as many as fit)
 hipError_t launch_pass_fused(const CollapseArgs& a, const FastArgs& fa, int nsw, int ncov, int num_cu, hipStream_t s);
 hipError_t launch_cov_wave(const FastArgs& a, hipStream_t s);
+// the element-per-thread covariance recursion for Rp = 16 / 32 (a workgroup of Rp x Rp threads per replicate; Cfull / ldfull
+// from the Gram kernel): what launch_cov runs for those widths unless DFM_COV_ROWS=1
+bool cov_grid_supported(int Rpad);
+hipError_t launch_cov_grid(int Rpad, const FastArgs& a, hipStream_t s);
 int fast_chunk_len(int Rpad, int T);
 int fast_stead_mats(int Rpad);
 

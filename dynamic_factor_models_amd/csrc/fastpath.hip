@@ -21,6 +21,8 @@
 // r x r matrix-vector products inside a lane group use no LDS: lane i holds M[i][i^s], s = 0..R-1,
 // and fetches x[i^s] with DPP row operations (xor_lane in dfm_device.h).
 // The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
+#include <stdlib.h>
+
 #include "dfm_cov.h"
 #include "dfm_scan.h"
 
@@ -62,12 +64,18 @@ __global__ __launch_bounds__(256) void pfill_kernel(FastArgs a) {
         s_ps[v] = a.PsInf[(size_t)b * R * R + ri * R + (v - ri * (ri + 1) / 2)];
     }
     __syncthreads();
-    fill_psmooth_rows(a, b, tid, 256, s_ps);
+    // gridDim.y slices of the row range: one workgroup per replicate cannot saturate the write bandwidth when a replicate's
+    // P_smooth is megabytes (config 4: 3.4 MB each, 256 replicates -- 1.03 ms; 8 slices: the stores of 2048 workgroups)
+    const int lo = a.fill[2 * b], hi = a.fill[2 * b + 1];
+    const int ns = (int)gridDim.y, sl = (int)blockIdx.y;
+    const long long span = hi > lo ? hi - lo : 0;
+    fill_psmooth_range(a, b, tid, 256, s_ps, lo + (int)(span * sl / ns), lo + (int)(span * (sl + 1) / ns));
 }
 
 template <int R>
 struct ScanLds {   // dynamic LDS of meanscan_kernel, in doubles
-    static constexpr int NG = kScanThreads / R;
+    static constexpr int ST = scan_threads(R);
+    static constexpr int NG = ST / R;
     static constexpr int NM = stead_mats(R) + 1;                  // steady matrices + P_T
     static constexpr int oMat = 0;
     static constexpr int oTab = oMat + NM * R * R;                // ecap(R) x (Z, J, G)
@@ -77,13 +85,14 @@ struct ScanLds {   // dynamic LDS of meanscan_kernel, in doubles
     static constexpr int oVec = oB + NG * R;
     static constexpr int oPs = oVec + 2 * R;
     static constexpr int oRed = oPs + R * (R + 1) / 2;
-    static constexpr int total = oRed + kScanThreads / 64;
+    static constexpr int total = oRed + ST / 64;
     static constexpr size_t bytes() { return (size_t)total * sizeof(double); }
 };
 
 template <int R>
-__global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
+__global__ __launch_bounds__(scan_threads(R)) void meanscan_kernel(FastArgs a) {
     using LY = ScanLds<R>;
+    constexpr int ST = scan_threads(R);
     constexpr int NG = LY::NG;
     constexpr int NLEV = scan_levels(R);
     constexpr int NST = stead_mats(R);
@@ -111,15 +120,15 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
     const int npr = r * (r + 1) / 2;
 
     // ---- one round trip to global memory for everything the sequential parts will touch ------------
-    for (int k = tid; k < NST * R * R; k += kScanThreads) s_mat[k] = stead[k];
-    for (int k = tid; k < R * R; k += kScanThreads) s_mat[NST * R * R + k] = a.PT[(size_t)b * R * R + k];
+    for (int k = tid; k < NST * R * R; k += ST) s_mat[k] = stead[k];
+    for (int k = tid; k < R * R; k += ST) s_mat[NST * R * R + k] = a.PT[(size_t)b * R * R + k];
     {   // a fixed count, so these loads do not wait for E (entries past E are never used)
         const int nfix = ecap(R) < T ? ecap(R) : T;
-        for (int k = tid; k < nfix * 3 * R * R; k += kScanThreads) s_tab[k] = tab[k];
-        for (int k = tid; k < nfix * R; k += kScanThreads) s_b0[k] = bcol[k];
+        for (int k = tid; k < nfix * 3 * R * R; k += ST) s_tab[k] = tab[k];
+        for (int k = tid; k < nfix * R; k += ST) s_b0[k] = bcol[k];
     }
     if (a.P_smooth) {
-        for (int v = tid; v < npr; v += kScanThreads) {       // packed (caller's r) copy of P_s,inf
+        for (int v = tid; v < npr; v += ST) {       // packed (caller's r) copy of P_s,inf
             int ri = 0;
             while ((ri + 1) * (ri + 2) / 2 <= v) ++ri;
             s_ps[v] = a.PsInf[(size_t)b * R * R + ri * R + (v - ri * (ri + 1) / 2)];
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
     __syncthreads();
 
     // ---- P_smooth rows inside the fixed-point range: fire-and-forget stores (unless pfill_kernel wrote them)
-    if (a.P_smooth && !(a.abl & 1)) fill_psmooth_rows(a, b, tid, kScanThreads, s_ps);
+    if (a.P_smooth && !(a.abl & 1)) fill_psmooth_rows(a, b, tid, ST, s_ps);
     if (a.abl & 2) return;
     if (a.abl & 4) return;
 
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(kScanThreads) void meanscan_kernel(FastArgs a) {
     if (tid == 0) {
         double d = 0.0, sq = 0.0;
 #pragma unroll
-        for (int w = 0; w < kScanThreads / 64; ++w) d += s_red[w];
+        for (int w = 0; w < ST / 64; ++w) d += s_red[w];
         if (a.ntile > 0) {
             for (int w = 0; w < a.ntile; ++w) sq += a.scol[(size_t)b * T + w];
         } else {
@@ -443,20 +452,22 @@ static hipError_t launch_scan_r(const FastArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((meanscan_kernel<R>), dim3(a.B), dim3(kScanThreads), lds, s, a);
+    hipLaunchKernelGGL((meanscan_kernel<R>), dim3(a.B), dim3(scan_threads(R)), lds, s, a);
     return hipGetLastError();
 }
 
 int fast_stead_mats(int Rpad) { return stead_mats(Rpad); }
 
 int fast_chunk_len(int Rpad, int T) {
-    const int ng = kScanThreads / Rpad;
+    const int ng = scan_threads(Rpad) / Rpad;
     int L = 1;
     while (L * ng < T) L <<= 1;
     return L;
 }
 
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s) {
+    static const bool rows_only = [] { const char* v = getenv("DFM_COV_ROWS"); return v && atoi(v) != 0; }();
+    if (!rows_only && a.Lam == nullptr && cov_grid_supported(Rpad)) return launch_cov_grid(Rpad, a, s);
     switch (Rpad) {
         case 2: return launch_cov_r<2>(a, s);
         case 4: return launch_cov_r<4>(a, s);
@@ -468,12 +479,18 @@ hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s) {
 }
 hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s) {
     if (!a.P_smooth) return hipSuccess;
+    // slices per replicate: enough workgroups to fill the chip, each with at least ~64 KB of rows
+    const long long bytes = (long long)a.T * (a.r * (a.r + 1) / 2) * 8;
+    int ns = (int)((2048 + a.B - 1) / a.B);
+    while (ns > 1 && bytes / ns < 65536) --ns;
+    if (ns < 1) ns = 1;
+    const dim3 grid(a.B, ns);
     switch (Rpad) {
-        case 2: hipLaunchKernelGGL((pfill_kernel<2>), dim3(a.B), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((pfill_kernel<4>), dim3(a.B), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((pfill_kernel<8>), dim3(a.B), dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((pfill_kernel<16>), dim3(a.B), dim3(256), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((pfill_kernel<32>), dim3(a.B), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pfill_kernel<2>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pfill_kernel<4>), grid, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((pfill_kernel<8>), grid, dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((pfill_kernel<16>), grid, dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((pfill_kernel<32>), grid, dim3(256), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

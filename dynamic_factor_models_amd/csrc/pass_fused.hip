@@ -834,6 +834,58 @@ __global__ __launch_bounds__(256) void cov_wave_kernel(FastArgs a) {
     cov_wave8<scan_levels(8)>(a, b, Cel, a.ldfull[b], ws, o, lane);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// cov_grid_kernel: the same element-per-thread covariance recursion for states 9..16 / 17..32 wide -- a workgroup of
+// R x R threads per replicate (dfm_grid.h: what crosses waves goes through small LDS buffers, one barrier per exchange).
+// cov_kernel (fastpath.hip) gives a replicate R lanes with a matrix ROW per lane: at R = 32 that is 64 VGPRs per matrix,
+// spills, and 1.2 ms for the ~40 dependent 32 x 32 operations of BASELINE config 4 -- longer than its streaming collapse
+// (1.13 ms), which it also slowed down to 1.86 ms by sitting beside it on a third of the CUs at priority 3.
+// ------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(R * R) void cov_grid_kernel(FastArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    constexpr int RR = R * R, RT = R * kTileStride<R>;
+    const int b = blockIdx.x, l = threadIdx.x;
+    Grid<R> G;
+    G.l = l; G.i = l / R; G.j = l % R;
+    G.prow = gsm + 4 * RT;
+    G.red = G.prow + 4 * R;
+    G.tt = G.red + 2 * (RR / 64) * R;
+    __builtin_amdgcn_s_setprio(3);
+    const double* Cf = a.Cfull + (size_t)b * RR;
+    const double Cel = 0.5 * (Cf[l] + Cf[G.j * R + G.i]);     // exactly symmetric (the matrix-pipe Gram is symmetric to rounding)
+    Cov8Dst o;
+    o.tab = a.tab + (size_t)b * a.T * 3 * RR; o.tab_cap = a.T; o.tab_over = o.tab;
+    o.stead = a.stead + (size_t)b * stead_mats(R) * RR;
+    o.PT = a.PT + (size_t)b * RR; o.xi0 = a.xi0 + (size_t)b * R; o.llc = a.llc + b; o.E = a.E + b; o.fill = a.fill + 2 * b;
+    o.PsInf = a.PsInf + (size_t)b * RR;
+    o.SP11 = a.SP11 ? a.SP11 + (size_t)b * RR : nullptr;
+    o.SU = a.SP11 ? a.SU + (size_t)b * RR : nullptr;
+    o.P0s = a.SP11 ? a.P0s + (size_t)b * RR : nullptr;
+    cov_grid<R, scan_levels(R), 4>(a, b, Cel, a.ldfull[b], gsm, o, G);
+}
+
+template <int R>
+static hipError_t launch_cov_grid_r(const FastArgs& a, hipStream_t s) {
+    constexpr int RR = R * R, RT = R * kTileStride<R>;
+    const size_t lds = (size_t)(4 * RT + 4 * R + 2 * (RR / 64) * R + 2 * RT) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cov_grid_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((cov_grid_kernel<R>), dim3(a.B), dim3(RR), lds, s, a);
+    return hipGetLastError();
+}
+bool cov_grid_supported(int Rpad) { return Rpad == 16 || Rpad == 32; }
+hipError_t launch_cov_grid(int Rpad, const FastArgs& a, hipStream_t s) {
+    if (Rpad == 16) return launch_cov_grid_r<16>(a, s);
+    if (Rpad == 32) return launch_cov_grid_r<32>(a, s);
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_cov_wave(const FastArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(cov_wave_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
