@@ -425,13 +425,32 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         { ProfScope ps(h, K_COV); HIP_TRY(h, (h->cov_wave && p.Rp == 8 && !fuse_gram) ? launch_cov_wave(fa, h->stream) : launch_cov(p.Rp, fa, h->stream)); }
         { ProfScope ps(h, use_wide ? K_COLLAPSE_WIDE : use_mfma ? K_COLLAPSE_MFMA : K_COLLAPSE_DMA, h->side); HIP_TRY(h, run_collapse(ca, h->side)); }
         HIP_TRY(h, hipEventRecord(h->ev_join, h->side));
-        if (!h->no_pfill && P_smooth) {   // the data-independent rows of P_smooth, beside the collapse
+        const bool fill = !h->no_pfill && P_smooth;
+        // Rp = 32 (config 4): the fill is 0.86 GB of stores -- beside the collapse they cost it 0.4 ms of its 1.13; beside the
+        // latency-bound scan they are free.  So: cov -> [event] ; collapse (side) -> [event] ; fill on the third stream
+        // after both, scan on the caller's stream after the collapse, join at the end.
+        const bool fill_late = fill && use_wide2;
+        if (fill && !fill_late) {         // the data-independent rows of P_smooth, beside the collapse
             ProfScope ps(h, K_PFILL);
             HIP_TRY(h, launch_pfill(p.Rp, fa, h->stream));
             fa.abl |= 1;
         }
+        if (fill_late) {
+            if (h->ev_sub.empty()) {
+                hipEvent_t e;
+                HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                h->ev_sub.push_back(e);
+            }
+            HIP_TRY(h, hipEventRecord(h->ev_sub[0], h->stream));            // cov_kernel's outputs
+            HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_sub[0], 0));
+            HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));        // ... and not before the collapse is done
+            { ProfScope ps(h, K_PFILL, h->post); HIP_TRY(h, launch_pfill(p.Rp, fa, h->post)); }
+            HIP_TRY(h, hipEventRecord(h->ev_post, h->post));
+            fa.abl |= 1;
+        }
         HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
+        if (fill_late) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_post, 0));
         return em_update();
     }
     while ((int)h->ev_sub.size() < S) {

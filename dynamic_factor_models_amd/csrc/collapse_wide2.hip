@@ -76,14 +76,20 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
     const int k4 = lane >> 4, c16 = lane & 15;
     w2_v4 acc = {0.0, 0.0, 0.0, 0.0};
     const int steps = (N + 3) / 4;
-#pragma unroll 8
-    for (int s = 0; s < steps; ++s) {
-        const int c = 4 * s + k4;
-        const bool own = c < N;
-        const int cc = own ? c : N - 1;
-        const double av = own ? L[(size_t)cc * R + 16 * it + c16] : 0.0;
-        const double bv = own ? W[(size_t)cc * R + 16 * jt + c16] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    for (int s0 = 0; s0 < steps; s0 += 8) {                  // 16 loads in flight per batch (clamped addresses, select afterwards)
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = 4 * (s0 + u) + k4;
+            const int cc = c < N ? c : N - 1;
+            av[u] = L[(size_t)cc * R + 16 * it + c16];
+            bv[u] = W[(size_t)cc * R + 16 * jt + c16];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = 4 * (s0 + u) + k4;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c < N ? av[u] : 0.0, bv[u], acc, 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v)                               // D[(l / 16) + 4 v][l % 16]

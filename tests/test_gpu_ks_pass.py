@@ -68,6 +68,14 @@ def _compare(got, ref, tag=""):
     (2, 100, 40, 20, 0.05),      # config 4's r = 20 (padded to 32)
     (2, 256, 30, 8, 0.0),        # widest N of the 2-chunk tiling
     (2, 300, 20, 8, 0.1),        # 4-chunk tiling
+    # collapse_miss.hip (Rp = 8, even N <= 224): compacted lists of missing / observed series, partial steps, short panels
+    (3, 198, 61, 8, 0.02),       # N not a multiple of 8 (a clamped MFMA tail), T = 1 mod 4
+    (3, 200, 64, 8, 0.6),        # more missing than observed: the observed list
+    (2, 200, 33, 7, 0.97),       # almost nothing observed (some periods with no cell at all)
+    (4, 26, 9, 5, 0.3),          # fewer periods than a wave's segment, r padded 5 -> 8
+    (2, 224, 40, 8, 0.1),        # widest cross-section of this kernel; (226: collapse_kernel)
+    (2, 226, 40, 8, 0.1),
+    (3, 64, 3, 8, 0.25),         # T = 3
 ])
 def test_pass_matches_oracle(ctx, B, N, T, r, missing):
     panel, st = _batch(B, N, T, r, missing)
@@ -163,6 +171,15 @@ BALANCED_SHAPES = [
     (2, 300, 37, 20),          # wide kernel, r padded to 32, T not a multiple of the 16-period tile
     (3, 31, 41, 3),            # odd N: wide kernel (8-byte loads)
     (1, 1000, 2000, 20),       # BASELINE config 4's shape (N = 1000, T = 2000, r = 20), one replicate
+    # collapse_wide2 (Rp = 32, even N): stages of 64 series / tiles of 64 periods with partial tails; cov_grid_kernel<32>
+    (2, 66, 65, 17),           # one series past a stage, one period past a tile, r padded 17 -> 32
+    (3, 130, 70, 20),          # 2 series past two stages (a partial MFMA step: 2 of 4 series)
+    (2, 64, 64, 32),           # exact stage / tile, every factor column used
+    (2, 34, 3, 24),            # a tile of 3 periods, fewer series than a stage
+    (2, 1280, 40, 20),         # the widest cross-section of the LDS 1 / R table
+    (2, 1400, 40, 20),         # beyond it: collapse_wide_kernel (round-1 path) keeps working
+    # cov_grid_kernel<16> (Rp = 16: 256 threads per replicate)
+    (3, 200, 120, 12), (2, 48, 33, 9), (2, 64, 500, 16),
 ]
 
 
