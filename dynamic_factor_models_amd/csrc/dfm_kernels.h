@@ -205,6 +205,7 @@ struct PcaArgs {
     double* Lam; double* Rv; double* A; double* Q; double* mu0; double* P0;   // caller's layout (r)
     double* factors;            // [B][T][r] or null
     int* status;                // bit 1 (value 2): subspace iteration stopped at max_iter above its tolerance; or null
+    int stop_after;             // diagnostics (DFM_PCA_STOP): > 0: pca_kernel returns after that phase (timing of the phases)
 };
 hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant = 0);   // 0: matrix pipe (N <= 256), 1: VALU
 hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s);

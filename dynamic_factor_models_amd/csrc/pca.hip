@@ -12,11 +12,14 @@
 //                    the oracle does (largest-|.| entry of each vector positive); F = X V; the r x r
 //                    moment matrices of F; the OLS / VAR solves.
 // One workgroup (256 threads) per replicate in both kernels.
+#include <stdlib.h>
+
 #include "dfm_kernels.h"
 
 namespace dfm {
 
 constexpr int kPcaThreads = 256;
+constexpr int kPcaFastThreads = 512;   // pca_iterate_lds: 8 waves, 2 per SIMD (the 128-VGPR budget of 1024 threads spills)
 
 // ---------------------------------------------------------------------------------------------
 // S = X'X.  Thread tile 4 x 4 over the upper triangle of 4 x 4 blocks; mirrored on store.
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(kGxThreads) void gram_xx_mfma_kernel(PcaArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 // block-wide sum of NV values per thread -> every thread gets the totals (through LDS)
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double* red /* [4][NV] */) {
+template <int NV, int NT = kPcaThreads>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* red /* [NT / 64][NV] */) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
 #pragma unroll
@@ -190,22 +193,27 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* red /* [4][NV
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = red[k] + red[NV + k] + red[2 * NV + k] + red[3 * NV + k];
+    for (int k = 0; k < NV; ++k) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) t += red[w * NV + k];
+        v[k] = t;
+    }
 }
 
 // M (r x r, row-major in LDS, leading dimension R) = A' B for tall A, B ([n][R] in global memory)
-template <int R>
+template <int R, int NT = kPcaThreads>
 __device__ __forceinline__ void tall_gram(double* M, const double* A, const double* Bm, int n, int r, double* red) {
     for (int p = 0; p < r; ++p) {
         double acc[R];
 #pragma unroll
         for (int q = 0; q < R; ++q) acc[q] = 0.0;
-        for (int i = threadIdx.x; i < n; i += kPcaThreads) {
+        for (int i = threadIdx.x; i < n; i += NT) {
             const double ap = A[(size_t)i * R + p];
 #pragma unroll
             for (int q = 0; q < R; ++q) acc[q] = fma(ap, Bm[(size_t)i * R + q], acc[q]);
         }
-        block_sum<R>(acc, red);
+        block_sum<R, NT>(acc, red);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int q = 0; q < R; ++q) M[p * R + q] = acc[q];
@@ -280,6 +288,66 @@ __device__ __forceinline__ void jacobi_lds(double* H, double* W, double* ev, int
     }
 }
 
+// The same cyclic Jacobi by ONE WAVE with an element of H and of W per lane (lane = R i + j, lanes >= R R idle): a rotation
+// is 6 cross-lane fetches and a few FMAs per lane instead of ~100 dependent LDS read-modify-writes of one thread (the
+// single-thread version took 3.5 of pca_kernel's 5.7 ms per 1024 replicates).  Same rotations in the same order, same
+// stopping rule and sorting.  Called by wave 0 (all 64 lanes); H, W, ev in LDS.
+template <int R>
+__device__ __forceinline__ void jacobi_wave(double* H, double* W, double* ev, int r, int lane) {
+    const int i = lane / R, j = lane % R;
+    const bool in = lane < R * R && i < r && j < r;
+    double h = in ? H[i * R + j] : 0.0;
+    double w = (lane < R * R && i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = (in && i != j) ? h * h : 0.0, dia = (in && i == j) ? h * h : 0.0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { off += __shfl_xor(off, o, kWave); dia += __shfl_xor(dia, o, kWave); }
+        if (off <= 1e-32 * dia) break;
+        for (int p = 0; p < r - 1; ++p)
+            for (int q = p + 1; q < r; ++q) {
+                const double hpq = __shfl(h, p * R + q, kWave);
+                if (hpq == 0.0) continue;                       // (wave-uniform)
+                const double hpp = __shfl(h, p * R + p, kWave), hqq = __shfl(h, q * R + q, kWave);
+                const double theta = (hqq - hpp) / (2.0 * hpq);
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+                // H <- H J : columns p and q of every row
+                {
+                    const double hip = __shfl(h, i * R + p, kWave), hiq = __shfl(h, i * R + q, kWave);
+                    if (j == p) h = c * hip - sn * hiq;
+                    else if (j == q) h = sn * hip + c * hiq;
+                }
+                // H <- J' H : rows p and q
+                {
+                    const double hpj = __shfl(h, p * R + j, kWave), hqj = __shfl(h, q * R + j, kWave);
+                    if (i == p) h = c * hpj - sn * hqj;
+                    else if (i == q) h = sn * hpj + c * hqj;
+                }
+                // W <- W J
+                {
+                    const double wip = __shfl(w, i * R + p, kWave), wiq = __shfl(w, i * R + q, kWave);
+                    if (j == p) w = c * wip - sn * wiq;
+                    else if (j == q) w = sn * wip + c * wiq;
+                }
+            }
+    }
+    if (lane < R * R) { W[lane] = w; if (i == j) ev[i] = h; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0) {
+        for (int a_ = 0; a_ < r - 1; ++a_) {                   // selection sort, descending
+            int m = a_;
+            for (int k = a_ + 1; k < r; ++k)
+                if (ev[k] > ev[m]) m = k;
+            if (m != a_) {
+                const double t = ev[a_]; ev[a_] = ev[m]; ev[m] = t;
+                for (int k = 0; k < r; ++k) { const double ww = W[k * R + a_]; W[k * R + a_] = W[k * R + m]; W[k * R + m] = ww; }
+            }
+        }
+    }
+}
+
 // Solve (leading r x r of) M Xs = Bs for Xs, M SPD, nb right-hand sides as columns of Bs; all LDS ld R;
 // M is destroyed (Cholesky).  Thread 0.
 template <int R>
@@ -299,9 +367,166 @@ __device__ __forceinline__ void spd_solve_lds(double* M, double* Bs, int r, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The subspace iteration of pca_kernel with the basis in LDS and 512 threads (R <= 8, N <= 256): the 256-thread version
+// re-read S row by row with one load in flight per thread and ran 16 two-barrier block reductions per iteration (5.7 ms per
+// 1024 replicates at N = 200: ~100 us per iteration and replicate).  Here
+//   Y = S V:   thread (part p of 2, row i) multiplies half of row i of S (8 independent coalesced loads in flight)
+//              with the rows of V (LDS broadcast reads), the partial rows meet in LDS;
+//   H = V'Y, G = Y'Y:  every row thread forms its 2 x R x R outer products, one 64-value transpose-reduce per wave and
+//              matrix, 4 partial matrices per matrix meet in LDS -- one barrier for both;
+//   residual, Cholesky of G (thread 0), V = Y L^-T per row.
+// Same arithmetic, start and stopping rule as the generic loop; leaves the orthonormal basis in V (global), returns whether
+// the residual test fired.  sH / sG: R x R LDS matrices of the caller; red: >= 32 doubles.
 template <int R>
-__global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
-    __shared__ double sH[R * R], sW[R * R], sG[R * R], sM[R * R], sev[R], sred[4 * R], sflag[2];
+__device__ __forceinline__ bool pca_iterate_lds(const PcaArgs& a, const double* __restrict__ S, double* V, double* Y, int N,
+                                                int r, double* sH, double* sG, double* red) {
+    constexpr int NT = kPcaFastThreads, NPART = NT / 256, RR = R * R;
+    extern __shared__ __attribute__((aligned(16))) double pl[];
+    double* Vs = pl;                                           // [N][R]
+    double* Ys = Vs + (size_t)N * R;                           // [N][R]
+    double* part = Ys + (size_t)N * R;                         // [NPART][N][R]; later [4 waves][2][RR] partial Gram matrices
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = tid >> 8, i = tid & 255;
+    const int H4 = (N + NPART - 1) / NPART;
+    const int j0 = p * H4, j1 = (j0 + H4 < N) ? j0 + H4 : N;
+    const bool row = i < N;
+
+    for (int e = tid; e < N * R; e += NT) Ys[e] = Y[e];        // the deterministic start
+    __syncthreads();
+    // grams[0] = A'B ... helper: G = Ys'Ys (and optionally H = Vs'Ys) into sG / sH
+    auto grams = [&](bool with_h) {
+        if (tid < 256) {
+            double y[R], v[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { y[k] = row ? Ys[(size_t)i * R + k] : 0.0; v[k] = (row && with_h) ? Vs[(size_t)i * R + k] : 0.0; }
+            // R rows of R products at a time (R values: the 128-VGPR budget of a 1024-thread workgroup has no room for R x R)
+            bool canon;
+            const int idx = reduce_index<R>(lane, canon);
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                double pg[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) pg[k] = y[q] * y[k];
+                wave_transpose_reduce<R>(pg, lane);
+                if (canon) part[(wave * 2 + 0) * RR + q * R + idx] = pg[0];
+                if (with_h) {
+                    double ph[R];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) ph[k] = v[q] * y[k];
+                    wave_transpose_reduce<R>(ph, lane);
+                    if (canon) part[(wave * 2 + 1) * RR + q * R + idx] = ph[0];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * RR) {
+            const int which = tid / RR, idx = tid % RR;
+            const double t = part[(0 * 2 + which) * RR + idx] + part[(1 * 2 + which) * RR + idx] + part[(2 * 2 + which) * RR + idx]
+                           + part[(3 * 2 + which) * RR + idx];
+            if (which == 0) sG[idx] = t; else if (with_h) sH[idx] = t;
+        }
+        __syncthreads();
+    };
+    auto orthonormalise = [&]() {                               // Vs <- Ys L^-T  with  Ys'Ys = L L'  (sG holds Ys'Ys)
+        if (tid == 0) chol_lds<R>(sG, r);
+        __syncthreads();
+        if (tid < 256 && row) {
+            double y[R], v[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { y[k] = Ys[(size_t)i * R + k]; v[k] = 0.0; }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (k < r) {
+                    double sacc = y[k];
+#pragma unroll
+                    for (int m = 0; m < R; ++m)
+                        if (m < k) sacc -= v[m] * sG[k * R + m];
+                    v[k] = sacc / sG[k * R + k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) Vs[(size_t)i * R + k] = v[k];
+        }
+        __syncthreads();
+    };
+    grams(false);
+    orthonormalise();
+    double best = 1e300;
+    int stall = 0;
+    bool converged = false;
+    for (int it = 0; it < a.max_iter; ++it) {
+        // Y = S V
+        {
+            double acc[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) acc[k] = 0.0;
+            if (row) {
+                int j = j0;
+                for (; j + 8 <= j1; j += 8) {
+                    double sv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) sv[u] = S[(size_t)(j + u) * N + i];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double* vr = Vs + (size_t)(j + u) * R;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) acc[k] = fma(sv[u], vr[k], acc[k]);
+                    }
+                }
+                for (; j < j1; ++j) {
+                    const double sv = S[(size_t)j * N + i];
+                    const double* vr = Vs + (size_t)j * R;
+#pragma unroll
+                    for (int k = 0; k < R; ++k) acc[k] = fma(sv, vr[k], acc[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) part[((size_t)p * N + i) * R + k] = acc[k];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < N * R; e += NT) {
+            double t = part[e];
+#pragma unroll
+            for (int q = 1; q < NPART; ++q) t += part[(size_t)q * N * R + e];
+            Ys[e] = t;
+        }
+        __syncthreads();
+        grams(true);                                            // sG = Y'Y, sH = V'Y = V'S V
+        // residual ||Y - V H||_F / ||Y||_F
+        double pr[2] = {0.0, 0.0};
+        if (tid < 256 && row) {
+            double y[R], v[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) { y[k] = Ys[(size_t)i * R + k]; v[k] = Vs[(size_t)i * R + k]; }
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                if (k < r) {
+                    double vh = 0.0;
+#pragma unroll
+                    for (int m = 0; m < R; ++m)
+                        if (m < r) vh = fma(v[m], sH[m * R + k], vh);
+                    const double d = y[k] - vh;
+                    pr[0] = fma(d, d, pr[0]);
+                    pr[1] = fma(y[k], y[k], pr[1]);
+                }
+            }
+        }
+        block_sum<2, NT>(pr, red);
+        const double rel = sqrt(pr[0] / pr[1]);
+        orthonormalise();
+        if (rel <= 1e-14) { converged = true; break; }
+        if (rel < 0.5 * best) { best = rel; stall = 0; }
+        else if (++stall >= 8 && best < 1e-10) { converged = true; break; }
+    }
+    for (int e = tid; e < N * R; e += NT) V[e] = Vs[e];
+    __syncthreads();
+    return converged;
+}
+
+template <int R, int NT>
+__global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
+    __shared__ double sH[R * R], sW[R * R], sG[R * R], sM[R * R], sev[R], sred[(NT / 64) * (R > 2 ? R : 2)], sflag[2];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int N = a.N, T = a.T, r = a.r;
@@ -312,7 +537,7 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
     double* F = a.F + (size_t)b * T * R;           // [T][R] scores
 
     // deterministic, replicate-independent start: a fixed hash of (i, k), columns >= r zero
-    for (int idx = tid; idx < N * R; idx += kPcaThreads) {
+    for (int idx = tid; idx < N * R; idx += NT) {
         const int i = idx / R, k = idx % R;
         unsigned hsh = (unsigned)(i * 73856093u) ^ (unsigned)((k + 1) * 19349663u);
         hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
@@ -321,10 +546,10 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
     __syncthreads();
 
     auto orthonormalise = [&]() {                   // V <- Y L^-T  with  Y'Y = L L'  (Cholesky QR)
-        tall_gram<R>(sG, Y, Y, N, r, sred);
+        tall_gram<R, NT>(sG, Y, Y, N, r, sred);
         if (tid == 0) chol_lds<R>(sG, r);
         __syncthreads();
-        for (int i = tid; i < N; i += kPcaThreads) {
+        for (int i = tid; i < N; i += NT) {
             double y[R], v[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) { y[k] = Y[(size_t)i * R + k]; v[k] = 0.0; }
@@ -339,7 +564,7 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
         __syncthreads();
     };
     auto apply_S = [&]() {                          // Y <- S V   (S symmetric: column reads are row reads)
-        for (int i = tid; i < N; i += kPcaThreads) {
+        for (int i = tid; i < N; i += NT) {
             double y[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) y[k] = 0.0;
@@ -355,17 +580,20 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
         __syncthreads();
     };
 
+    bool converged = false;
+    if constexpr (NT == kPcaFastThreads && R <= 8) {
+        converged = pca_iterate_lds<R>(a, S, V, Y, N, r, sH, sG, sred);
+    } else {
     orthonormalise();
     // iterate until the invariant-subspace residual ||S V - V (V'S V)||_F / ||S V||_F reaches the fp64
     // floor (or stops improving): the Ritz vectors taken afterwards are then exact to roundoff / gap
     double best = 1e300;
     int stall = 0;
-    bool converged = false;
     for (int it = 0; it < a.max_iter; ++it) {
         apply_S();
-        tall_gram<R>(sH, V, Y, N, r, sred);              // H = V'S V
+        tall_gram<R, NT>(sH, V, Y, N, r, sred);              // H = V'S V
         double part[2] = {0.0, 0.0};
-        for (int i = tid; i < N; i += kPcaThreads) {
+        for (int i = tid; i < N; i += NT) {
             for (int k = 0; k < r; ++k) {
                 double vh = 0.0;
                 for (int m = 0; m < r; ++m) vh = fma(V[(size_t)i * R + m], sH[m * R + k], vh);
@@ -374,26 +602,33 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
                 part[1] = fma(y, y, part[1]);
             }
         }
-        block_sum<2>(part, sred);
+        block_sum<2, NT>(part, sred);
         const double rel = sqrt(part[0] / part[1]);
         orthonormalise();
         if (rel <= 1e-14) { converged = true; break; }
         if (rel < 0.5 * best) { best = rel; stall = 0; }
         else if (++stall >= 8 && best < 1e-10) { converged = true; break; }
     }
+    }
+    if (a.stop_after == 1) return;
     // max_iter exhausted above the tolerance (near-degenerate spectrum at the cut: the rate is lambda_{r+1} / lambda_r):
     // the basis is NOT the reference's svd-based pca_score (dfm_functions.ipynb:179-183) -- say so instead of returning it
     if (!converged && tid == 0 && a.status) atomicOr(a.status, 2);
     // Rayleigh-Ritz: H = V'SV, H = W Theta W', V <- V W (descending), sign rule of the oracle
     apply_S();
-    tall_gram<R>(sH, V, Y, N, r, sred);
+    tall_gram<R, NT>(sH, V, Y, N, r, sred);
     if (tid == 0) {
         for (int i = 0; i < r; ++i)
             for (int j = 0; j < i; ++j) { const double h = 0.5 * (sH[i * R + j] + sH[j * R + i]); sH[i * R + j] = h; sH[j * R + i] = h; }
-        jacobi_lds<R>(sH, sW, sev, r);
     }
     __syncthreads();
-    for (int i = tid; i < N; i += kPcaThreads) {
+    if constexpr (R <= 8) {
+        if (tid < 64) jacobi_wave<R>(sH, sW, sev, r, tid);
+    } else {
+        if (tid == 0) jacobi_lds<R>(sH, sW, sev, r);
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += NT) {
         double v[R], w[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) { v[k] = V[(size_t)i * R + k]; w[k] = 0.0; }
@@ -406,10 +641,11 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
         for (int k = 0; k < R; ++k) Y[(size_t)i * R + k] = w[k];    // rotated basis in Y
     }
     __syncthreads();
+    if (a.stop_after == 2) return;
     // sign: largest-|.| entry of each eigenvector positive (first such entry on ties, as numpy argmax)
     for (int k = 0; k < r; ++k) {
         double best = -1.0; int bi = N;
-        for (int i = tid; i < N; i += kPcaThreads) {
+        for (int i = tid; i < N; i += NT) {
             const double av = fabs(Y[(size_t)i * R + k]);
             if (av > best) { best = av; bi = i; }
         }
@@ -424,23 +660,73 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
         __syncthreads();
         if (tid == 0) {
             double bb = sred[0]; int ii = (int)sred[1];
-            for (int w = 1; w < 4; ++w)
+            for (int w = 1; w < NT / 64; ++w)
                 if (sred[2 * w] > bb || (sred[2 * w] == bb && (int)sred[2 * w + 1] < ii)) { bb = sred[2 * w]; ii = (int)sred[2 * w + 1]; }
             sflag[0] = (Y[(size_t)ii * R + k] < 0.0) ? -1.0 : 1.0;
         }
         __syncthreads();
         const double sg = sflag[0];
-        for (int i = tid; i < N; i += kPcaThreads) V[(size_t)i * R + k] = sg * Y[(size_t)i * R + k];
+        for (int i = tid; i < N; i += NT) V[(size_t)i * R + k] = sg * Y[(size_t)i * R + k];
         __syncthreads();
     }
-    for (int idx = tid; idx < N * R; idx += kPcaThreads)
+    for (int idx = tid; idx < N * R; idx += NT)
         if (idx % R >= r) V[idx] = 0.0;
     __syncthreads();
 
+    if (a.stop_after == 3) return;
     // scores F = X V  (one wave per period, lanes over series)
-    {
+    if constexpr (R <= 8) {
+        // the lane's series (i = lane + 64 u) keep their rows of V in registers; the R sums of a period by one transpose-reduce
         const int lane = tid & 63, wave = tid >> 6;
-        for (int t = wave; t < T; t += kPcaThreads / 64) {
+        constexpr int NU = 4;                                   // N <= 256
+        if (N <= 64 * NU) {
+            double vr[NU][R];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int i = lane + 64 * u;
+#pragma unroll
+                for (int k = 0; k < R; ++k) vr[u][k] = i < N ? V[(size_t)i * R + k] : 0.0;
+            }
+            bool canon;
+            const int idx = reduce_index<R>(lane, canon);
+            for (int t = wave; t < T; t += NT / 64) {
+                double f[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) f[k] = 0.0;
+                double x[NU];
+#pragma unroll
+                for (int u = 0; u < NU; ++u) { const int i = lane + 64 * u; x[u] = i < N ? X[(size_t)t * N + i] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int k = 0; k < R; ++k) f[k] = fma(x[u], vr[u][k], f[k]);
+                wave_transpose_reduce<R>(f, lane);
+                if (canon) F[(size_t)t * R + idx] = f[0];
+            }
+        } else {
+            for (int t = wave; t < T; t += NT / 64) {
+                double f[R];
+#pragma unroll
+                for (int k = 0; k < R; ++k) f[k] = 0.0;
+                for (int i = lane; i < N; i += 64) {
+                    const double x = X[(size_t)t * N + i];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) f[k] = fma(x, V[(size_t)i * R + k], f[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) f[k] += __shfl_xor(f[k], off, kWave);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < R; ++k) F[(size_t)t * R + k] = f[k];
+                }
+            }
+        }
+    } else {
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int t = wave; t < T; t += NT / 64) {
             double f[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) f[k] = 0.0;
@@ -461,15 +747,16 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
         }
     }
     __syncthreads();
+    if (a.stop_after == 4) return;
     if (a.factors) {
-        for (int idx = tid; idx < T * r; idx += kPcaThreads) {
+        for (int idx = tid; idx < T * r; idx += NT) {
             const int t = idx / r, k = idx % r;
             a.factors[((size_t)b * T + t) * r + k] = F[(size_t)t * R + k];
         }
     }
     // Lam = V_r;  R_i = (S_ii - sum_k theta_k V_ik^2) / T, with theta_k = ||F_k||^2 (= Ritz value)
-    tall_gram<R>(sG, F, F, T, r, sred);                   // F'F
-    for (int i = tid; i < N; i += kPcaThreads) {
+    tall_gram<R, NT>(sG, F, F, T, r, sred);                   // F'F
+    for (int i = tid; i < N; i += NT) {
         double q = 0.0;
         for (int k = 0; k < r; ++k) {
             const double v = V[(size_t)i * R + k];
@@ -481,10 +768,11 @@ __global__ __launch_bounds__(kPcaThreads) void pca_kernel(PcaArgs a) {
         }
         a.Rv[(size_t)b * N + i] = (S[(size_t)i * N + i] - q) / (double)T;
     }
+    if (a.stop_after == 5) return;
     // VAR(1) of F without constant: A = (F0'F0)^-1 F0'F1 (transposed), Q = e'e / (T-1)
-    tall_gram<R>(sH, F, F, T - 1, r, sred);                       // F0'F0
-    tall_gram<R>(sW, F, F + R, T - 1, r, sred);                   // F0'F1   ([p][q] = sum_t F[t][p] F[t+1][q])
-    tall_gram<R>(sM, F + R, F + R, T - 1, r, sred);               // F1'F1
+    tall_gram<R, NT>(sH, F, F, T - 1, r, sred);                       // F0'F0
+    tall_gram<R, NT>(sW, F, F + R, T - 1, r, sred);                   // F0'F1   ([p][q] = sum_t F[t][p] F[t+1][q])
+    tall_gram<R, NT>(sM, F + R, F + R, T - 1, r, sred);               // F1'F1
     if (tid == 0) {
         double* Ao = a.A + (size_t)b * r * r;
         double* Qo = a.Q + (size_t)b * r * r;
@@ -541,13 +829,37 @@ hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant) {
     return hipGetLastError();
 }
 
+template <int R>
+static hipError_t launch_pca_fast(const PcaArgs& a, hipStream_t s) {
+    const size_t need = (size_t)(2 + kPcaFastThreads / 256) * a.N * R;   // Vs, Ys, the partial products
+    const size_t gr = (size_t)2 * a.N * R + 8 * R * R;                   // ... reused for 4 x 2 partial Gram matrices
+    const size_t lds = (need > gr ? need : gr) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pca_kernel<R, kPcaFastThreads>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   // (+ the kernel's static LDS)
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((pca_kernel<R, kPcaFastThreads>), dim3(a.B), dim3(kPcaFastThreads), lds, s, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s) {
+    static const bool slow = [] { const char* v = getenv("DFM_PCA_GENERIC"); return v && atoi(v) != 0; }();
+    if (!slow && a.N <= 256 && a.N * Rpad >= 64 && Rpad <= 8) {   // the LDS-resident iteration (1024 threads per replicate)
+        switch (Rpad) {
+            case 2: return launch_pca_fast<2>(a, s);
+            case 4: return launch_pca_fast<4>(a, s);
+            case 8: return launch_pca_fast<8>(a, s);
+        }
+    }
     switch (Rpad) {
-        case 2: hipLaunchKernelGGL((pca_kernel<2>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((pca_kernel<4>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((pca_kernel<8>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((pca_kernel<16>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((pca_kernel<32>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((pca_kernel<2, kPcaThreads>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((pca_kernel<4, kPcaThreads>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((pca_kernel<8, kPcaThreads>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((pca_kernel<16, kPcaThreads>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((pca_kernel<32, kPcaThreads>), dim3(a.B), dim3(kPcaThreads), 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
