@@ -23,6 +23,7 @@
 // Synchronisation: monotone counters in LDS (bt_ready[buffer], scan_done, cov_done[wave]); every wait is BOUNDED (a wait
 // that does not end sets bit 2 of the status word and the whole workgroup drains).  No inter-workgroup communication.
 // The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -751,7 +752,11 @@ static PfLds pf_pick(int T, int N, int want_nsw, int want_ncov) {
     int ncov = want_ncov > 0 ? want_ncov : kPfMaxCov;
     if (ncov > kPfMaxCov) ncov = kPfMaxCov;
     int cap = kPfMaxWaves - kPfScanWaves - 1 - ncov;        // one mover wave
-    if (want_nsw > 0 && want_nsw < cap) cap = want_nsw;
+    // default: one stream wave per SIMD -- a second one on a SIMD is starved by the oldest-first arbitration (its segment
+    // ends 20 us after the others') and the per-CU streaming rate is the same with 4 rings as with 5 (measured: B = 1024
+    // 0.233 vs 0.245 ms, B = 8192 1.62 vs 1.68 ms)
+    if (want_nsw <= 0) want_nsw = 4;
+    if (want_nsw < cap) cap = want_nsw;
     while (cap > 1 && T / cap < 8) --cap;                     // keep segments a few row blocks long
     for (int nbuf = 2; nbuf >= 1; --nbuf) {
         for (int nsw = cap; nsw >= (nbuf == 2 ? (cap < 3 ? cap : 3) : 1); --nsw) {
