@@ -266,7 +266,7 @@ def main():
                                 frac=ach / FP64_MATRIX_PEAK_TFLOPS, traffic=measured_traffic(dom, workload_key),
                                 avg_launch_ms=avg[dom], flops_per_launch=flops[dom],
                                 kernels_ms={k: round(v, 4) for k, v in avg.items()},
-                                note="X'X of the batch (T x N by N x N per replicate) on v_mfma_f64_4x4x4; the subspace "
+                                note="X'X of the batch (T x N by N x N per replicate) on v_mfma_f64_16x16x4; the subspace "
                                      "iteration behind it (pca_kernel) is latency-bound small-matrix work")
             else:
                 roofline = dict(bound="hbm", kernel=dom, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
