@@ -32,15 +32,14 @@ namespace dfm {
 namespace {
 
 constexpr double kLog2PiW = 1.8378770664093454835606594728112;
-#ifndef DFM_WAVE_CHW
-#define DFM_WAVE_CHW 8
-#endif
-constexpr int kChunk8 = DFM_WAVE_CHW; // periods per prefetch chunk (Rp = 8); Rp = 16 takes 4 (code size)
+// periods per prefetch chunk at Rp = 8: 8 when the batch leaves at most one wave per SIMD (the deeper prefetch hides more of
+// the chain's memory latency: 0.86 vs 1.07 ms per 1024 replicates), 4 beyond that -- 212 instead of 310 registers, so TWO
+// waves share a SIMD and fill each other's waits (B = 2048: 1.26 ms with chunks of 4, 1.72 ms in two rounds of chunks of 8)
 
 }  // namespace
 
 // COV = true: covariance-form forward step (recursion.hip, COV): Q may be singular (companion states, DFM_F_SINGULAR_Q)
-template <int R, bool COV>
+template <int R, bool COV, int CH8 = 8>
 #ifndef DFM_WG16_WAVES
 #define DFM_WG16_WAVES 2
 #endif
@@ -48,7 +47,7 @@ template <int R, bool COV>
 // register budget is capped so that several workgroups share a CU and fill each other's waits.
 __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursion_wave_kernel(RecursionArgs a) {   // R = 32: 16 waves, 128 VGPRs
     constexpr int RR = R * R;
-    constexpr int CHW = R == 32 ? 2 : R == 16 ? 4 : kChunk8;
+    constexpr int CHW = R == 32 ? 2 : R == 16 ? 4 : CH8;
     extern __shared__ __attribute__((aligned(16))) double wsm[];
     double* LK = wsm;            // K = Q^-1 A, rows (constant; COV: A rows)
     constexpr int TS = kTileStride<R>, RT = R * TS;           // tile row stride, tile size (doubles)
@@ -486,25 +485,38 @@ bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
     if (Rpad == 16) return wave_lds_bytes<16>(a.T) <= cap;
     // Rp = 32 (17..32: r = 8 factors with VAR(4) dynamics, AR(4) idiosyncratic terms at r = 4): 1024 threads per replicate
     if (Rpad == 32) return wave_lds_bytes<32>(a.T) <= cap;
-    // Rp = 8, batch size: a wave per replicate costs ~0.85 ms per 1024 replicates (C2 shape) and scales with B; the
-    // lane-group kernel packs 8 replicates in a wave and stays at its ~3 ms latency floor up to B ~ 8192 -- it wins beyond ~4000 (measured: 3.31 vs 3.32 ms at B = 4096; the wave kernel holds one wave per SIMD, 256 VGPRs, and scales linearly).
-    static const int bmax = [] { const char* v = getenv("DFM_WAVE_BMAX"); return v ? atoi(v) : 4096; }();
+    // Rp = 8, batch size: the lane-group kernel packs 8 replicates in a wave and stays at its ~3.3 ms latency floor up to
+    // B ~ 8192; a wave per replicate costs 0.86 ms per 1024 replicates while a SIMD holds one wave (chunks of 8) and 0.63 ms
+    // per 1024 once two share a SIMD (chunks of 4: 2.4 ms at B = 4096) -- it wins up to ~6000.
+    static const int bmax = [] { const char* v = getenv("DFM_WAVE_BMAX"); return v ? atoi(v) : 6144; }();
     if (a.Rc == 0 && a.B > bmax) return false;
     return Rpad == 8 && wave_lds_bytes<8>(a.T) <= 60 * 1024;
 }
 
-template <int R, bool COV>
-static hipError_t launch_wave_cov(const RecursionArgs& a, hipStream_t s) {
+template <int R, bool COV, int CH8>
+static hipError_t launch_wave_cov_ch(const RecursionArgs& a, hipStream_t s) {
     const size_t lds = wave_lds_bytes<R>(a.T);
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&recursion_wave_kernel<R, COV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&recursion_wave_kernel<R, COV, CH8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((recursion_wave_kernel<R, COV>), dim3(a.B), dim3(R * R), lds, s, a);
+    hipLaunchKernelGGL((recursion_wave_kernel<R, COV, CH8>), dim3(a.B), dim3(R * R), lds, s, a);
     return hipGetLastError();
+}
+template <int R, bool COV>
+static hipError_t launch_wave_cov(const RecursionArgs& a, hipStream_t s) {
+    if constexpr (R == 8) {
+        static const int simds = [] {
+            int dev = 0; hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 1024;
+            return pr.multiProcessorCount * 4;
+        }();
+        if (a.B > simds) return launch_wave_cov_ch<R, COV, 4>(a, s);
+    }
+    return launch_wave_cov_ch<R, COV, 8>(a, s);
 }
 
 template <int R>
