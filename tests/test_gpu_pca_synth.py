@@ -24,7 +24,10 @@ def _dev(ctx, a):
 
 
 @pytest.mark.parametrize("B,N,T,r", [(6, 200, 500, 8), (4, 40, 80, 3), (3, 139, 222, 4), (2, 64, 50, 12),
-                                     (2, 30, 41, 1), (2, 300, 60, 5)])
+                                     (2, 30, 41, 1), (2, 300, 60, 5),
+                                     # LDS-resident iteration (N <= 256, Rp <= 8) at its edges, matrix-pipe X'X with partial tiles
+                                     (3, 256, 100, 8), (2, 255, 33, 7), (3, 64, 50, 1), (2, 17, 30, 2), (2, 257, 40, 8),
+                                     (2, 33, 12, 2)])
 def test_pca_init_matches_oracle(ctx, B, N, T, r):
     import torch
     panels = np.stack([ko.synth_replicate(b, N, T, r)[0] for b in range(B)])
