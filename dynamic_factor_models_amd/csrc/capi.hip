@@ -95,6 +95,7 @@ int pad_r(int r) { return pow2_ge(r) < 2 ? 2 : pow2_ge(r); }
 
 struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     int Rp;
+    int r = 0;                                     // the caller's factor count (columns r .. Rp - 1 of the padded Lam are zero)
     size_t LamP, AP, QP, P0P, mu0P;                // padded parameters (only used when r != Rp)
     size_t bcol, scol, ldrow, nobs, Ct, Cfull, ldfull;
     size_t ZJ, wtab, status, ncov;
@@ -122,6 +123,7 @@ bool g_widen_small_r = true;
 Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = false) {
     Plan p;
     int Rp = pad_r(r);
+    p.r = r;
     p.fast = fast;
     p.cov = (flags & DFM_F_SINGULAR_Q) != 0;
     // (one wave per replicate pays while the batch leaves SIMDs idle under the lane-group kernel: measured crossover
@@ -157,7 +159,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.f_fill = take(off, (size_t)B * 2 * sizeof(int));
         p.f_PsInf = take(off, B * rr * d);
         p.f_ssum = take(off, (size_t)B * kSsumSlots * d);
-        if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, (size_t)B * N * Rp * d);
+        if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N));
     } else {
         p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
     }
@@ -334,7 +336,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         return gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, st) : launch_gram_wide(p.Rp, ca, st);
     };
     auto run_collapse = [&](const CollapseArgs& c, hipStream_t st) -> hipError_t {
-        if (use_wide2) return launch_collapse_wide2(c, Wwide, st);
+        if (use_wide2) return launch_collapse_wide2(c, Wwide, p.r, h->num_cu, st);
         return use_wide ? launch_collapse_wide(p.Rp, c, st) : launch_collapse_dma(p.Rp, c, st, cvariant);
     };
     // MFMA collapse: as many period segments per replicate as the chip has resident wave slots for this batch

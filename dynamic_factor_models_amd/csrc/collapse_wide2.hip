@@ -1,25 +1,31 @@
 // collapse_wide2.hip -- the balanced-panel collapse for Rp = 32 (BASELINE config 4: N = 1000, T = 2000, r = 20) on the
-// LDS-DMA path and `v_mfma_f64_16x16x4`.
+// LDS-DMA path and the f64 matrix pipe (`v_mfma_f64_16x16x4` for factors 0..15, `v_mfma_f64_4x4x4` for every further 4).
 //
 //     b_t = sum_i lam_i x_it / R_i   (32 padded factors)        sum_t s_t,  s_t = sum_i x_it^2 / R_i
 //
 // collapse_wide_kernel (collapse_wide.hip) loads its A operands straight from the panel -- 4 rows x 32..64 bytes per load
 // instruction -- divides by R in every step and re-reads the weights from L2 once per 16-period tile: 3.5 ms for the
 // 4.1 GB of config 4 (1.17 TB/s, 0.15 of HBM peak).  Here:
-//   * wide_prep_kernel (once per pass): W = lam / R into the workspace, C = Lam' W (32 x 32) on the matrix pipe (4 waves =
-//     the 2 x 2 tiles of 16 x 16, a chain of v_mfma_f64_16x16x4 over the series each), sum log R -- gram_wide_kernel's work
-//     (0.31 ms of scalar-indexed VALU loops) in ~0.03 ms;
-//   * collapse_wide2_kernel: one workgroup (8 waves) per tile of 64 periods x ALL series.  Panel tile AND weights stream into
-//     LDS by `global_load_lds_dwordx4` in stages of 64 series (64 rows x 512 bytes + the contiguous 64 x 32 block of W),
-//     double-buffered, one barrier per stage.  Wave (rt, half) accumulates row tile rt (16 periods) x both 16-factor tiles
-//     over its half of the stage's steps: per step of 4 series one 8-byte LDS read of A (A[i][k] = x[t0 + 16 rt + i][c + k];
-//     row pairs 1040 bytes apart), two of B (B[k][j] = W[c + k][16 ft + j]) and two MFMAs.  s_t from a duplicate-free second
-//     read of the stage (thread = row x 8-series group).  HBM sees every panel byte once; W is read once per 64-period tile
-//     (1/2 of the panel bytes; a first version with 32-period tiles and register-fed W read as many W bytes as panel
-//     bytes -- 65 MB of weights do not stay in the 4-MB L2s while 4 GB stream through them -- and ran at 2.1 ms).
-// r = 20 uses 20 of the 32 factor columns (the second factor tile is 3/4 padding): the kernel is bandwidth-bound, the matrix
-// pipe has the room.  Reference counterpart: forming Lambda' x_t in the per-period regression of x_t on Lambda
-// (dfm_functions.ipynb:271-286 called from :364).
+//   * wide_prep_kernel (once per pass): W = lam / R and 1 / R into the workspace, C = Lam' W (32 x 32) on the matrix pipe
+//     (4 waves = the 2 x 2 tiles of 16 x 16, a chain of v_mfma_f64_16x16x4 over the series each), sum log R, and the tile
+//     queue counters reset;
+//   * collapse_wide2_kernel: PERSISTENT workgroups, one per CU, 8 streaming waves + 1 scheduler wave.  An item is a tile of
+//     128 periods x ALL series of one replicate, taken from a queue (one atomic counter per XCD) by the scheduler wave one
+//     tile ahead of need -- the covariance kernel runs beside this one and holds some CUs for the first ~0.2 ms, a static
+//     split would make the whole launch wait for those CUs' shares.  The tile streams through LDS in stages of 32 series:
+//     128 rows x 256 bytes of the panel, the 32 x 32 block of W (8 KB) and 32 values of 1 / R, all by
+//     `global_load_lds_dwordx4`, three stage buffers (two in flight while one is consumed), one barrier per stage, and the
+//     stage stream runs ACROSS tile boundaries (no fill / drain per tile).  Wave w owns the 16 periods 16 w .. 16 w + 15 of
+//     the tile: per step of 4 series ONE 8-byte LDS read of A (A[i][k] = x[t0 + 16 w + i][c + k]) feeds the 16x16x4 MFMA
+//     (factors 0..15) and NX 4x4x4 MFMAs (factors 16 + 4 x ..: their A operand has the same lane layout), and s_t
+//     (x^2 / R from the same register).  r = 20 costs 80 MFMA cycles per step instead of the 128 of two 16-wide tiles.
+//   * LDS layouts are chosen so that every operand read is bank-conflict free (the first version of this kernel was LDS-bound:
+//     2-way conflicts on A and B, 4-way on a separate s_t pass): see kW2GroupB and the W swizzle.
+// HBM sees every panel byte once; W is read once per 128-period tile (1/4 of the panel bytes) and mostly from L2.
+// Reference counterpart: forming Lambda' x_t in the per-period regression of x_t on Lambda (dfm_functions.ipynb:271-286
+// called from :364).
+#include <type_traits>
+
 #include "dfm_gram.h"
 #include "dfm_kernels.h"
 
@@ -28,6 +34,9 @@ namespace dfm {
 namespace {
 
 using lds_char_ptr_w = __attribute__((address_space(3))) char*;
+using lds_cvd_ptr_w = const volatile __attribute__((address_space(3))) double*;
+// one ds_read_b64 (never merged into ds_read2_b64, never moved relative to other volatile accesses) of LDS byte address a
+__device__ __forceinline__ double lds_read64(unsigned a) { return *(lds_cvd_ptr_w)(size_t)a; }
 typedef double w2_v4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void dma16w(const void* gsrc, unsigned lds_dst) {
@@ -45,18 +54,29 @@ __device__ __forceinline__ void dma16w(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void wait_all_w() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 constexpr int kW2R = 32;          // padded factors
-constexpr int kW2Rows = 64;       // periods per workgroup tile
-constexpr int kW2Chunk = 64;      // series per stage (512 bytes of a panel row)
-constexpr unsigned kW2PairB = 1040;  // LDS bytes of a PAIR of panel rows (2 x 512 + 16: 16 consecutive rows start on different banks)
-constexpr unsigned kW2RS = kW2PairB / 2;   // average bytes per row (sizes only)
+constexpr int kW2Rows = 128;      // periods per tile
+constexpr int kW2Chunk = 32;      // series per stage (256 bytes of a panel row)
 constexpr int kW2Steps = kW2Chunk / 4;
 constexpr int kW2NBuf = 3;        // stage buffers
+// One DMA lands FOUR rows x 256 bytes back to back (16 lanes each), so rows of a group start a whole number of bank sweeps
+// apart; read side by side (A operand: 16 rows x 4 series per instruction) they would collide.  Row h of a group is
+// therefore stored ROTATED by h 16-byte units (its lane u fetches piece u - h mod 16) and groups are 1024 + 64 bytes
+// apart: the 8-byte slot of (group g, row h, series k) is 8 g + 2 h + k mod 32 -- each half-wave of an A read (16 rows x 2
+// series) covers the 32 slots exactly once.
+constexpr unsigned kW2GroupB = 1088;
+constexpr unsigned kW2PanelB = (kW2Rows / 4) * kW2GroupB;          // 34816
+constexpr unsigned kW2WB = kW2Chunk * kW2R * 8;                    // 8192: W block of the stage
+constexpr unsigned kW2StageB = kW2PanelB + kW2WB + kW2Chunk * 8;   // + 1 / R of the stage's series
+constexpr int kW2Compute = 8;      // consumer waves (16 periods of the tile each)
+constexpr int kW2Producers = 4;    // LDS-DMA waves; one more wave is the scheduler
+constexpr int kW2Threads = 64 * (kW2Compute + kW2Producers + 1);
+constexpr int kW2Ring = 8;        // published items (ring)
 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
 // W = lam / R, C = Lam' W, sum log R.  One workgroup of 4 waves per replicate.
-__global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* Wout) {
+__global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, int npad, int* ctr) {
     constexpr int R = kW2R;
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,7 +84,14 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
     const double* __restrict__ L = a.Lam + (size_t)b * N * R;
     const double* __restrict__ Rv = a.Rv + (size_t)b * N;
     double* W = Wout + (size_t)b * N * R;
-    for (int e = tid; e < N * R; e += 256) W[e] = L[e] / Rv[e / R];
+    // stored with the two 16-column halves of ODD series swapped (column f of series c at f ^ 16 (c & 1)): the B operand of
+    // a step reads 4 consecutive series x 16 columns, and two series 256 bytes apart would meet on the same banks
+    for (int e = tid; e < N * R; e += 256) {
+        const int c = e / R;
+        W[e ^ (16 * (c & 1))] = L[e] / Rv[c];
+    }
+    for (int c = tid; c < npad; c += 256) rinv_out[(size_t)b * npad + c] = c < N ? 1.0 / Rv[c] : 0.0;   // (0 past N: padding of the last stage)
+    if (b == 0 && tid < 8) ctr[tid] = 0;                      // tile queues of the collapse that follows on this stream
     double ld = 0.0;
     for (int c = tid; c < N; c += 256) ld += log(Rv[c]);
     ld = wave_allsum(ld);
@@ -83,7 +110,7 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
             const int c = 4 * (s0 + u) + k4;
             const int cc = c < N ? c : N - 1;
             av[u] = L[(size_t)cc * R + 16 * it + c16];
-            bv[u] = W[(size_t)cc * R + 16 * jt + c16];
+            bv[u] = W[(size_t)cc * R + ((16 * jt + c16) ^ (16 * (cc & 1)))];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -97,164 +124,337 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// One workgroup of 8 waves per tile of 64 periods.  Stage = 64 series: 64 panel rows x 512 bytes + the 64 x 32 block of W
-// (16 KB), both by LDS-DMA, double-buffered (98 KB).  Wave rt (0..3) x half (0..1): row tile rt, the stage's steps of its
-// half (8 of 16) for BOTH factor tiles -- the two halves of a row tile are summed at the end through LDS.  Per step: one
-// 8-byte LDS read of A, two of B, two MFMAs.
-__global__ __launch_bounds__(512) void collapse_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall, int ntile) {
+// Streaming collapse (see the head of the file).  NX = 4-factor groups past the first 16 (1..3), or 4 = a second 16-wide tile.
+// Workgroup -> tiles: `xcd_map` (B >= 16): workgroups are dealt to the 8 XCDs round-robin, so workgroup g sits on XCD g % 8;
+// XCD x takes items from queue x = tiles of replicates x, x + 8, ... in order: its CUs work on ONE replicate at a time and
+// that replicate's 256 KB of W stay in that L2.  Small batches: one queue over the flat tile list.
+template <int NX, bool DIAG>
+__global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall,
+                                                                   const double* __restrict__ rinvAll, int npad, int* ctr,
+                                                                   int ntile, int xcd_map, int abl_) {
     constexpr int R = kW2R;
+    constexpr int N4 = NX < 4 ? NX : 0;                       // 4x4x4 groups
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr unsigned kStageB = kW2Rows * kW2RS + kW2Chunk * R * 8;                 // panel rows | W block
-    double* rinvS = reinterpret_cast<double*>(smem + kW2NBuf * kStageB);             // [nch * kW2Chunk]: 1 / R of every series (0 past N)
-    double* redS = rinvS + ((a.N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;             // [8]
+    const int abl = DIAG ? abl_ : 0;                          // DFM_W2_ABL (diagnostics, wrong results): compiled out of the product kernel
+    const int N = a.N, T = a.T, B = a.B;
+    const int nch = (N + kW2Chunk - 1) / kW2Chunk;
+    double* redS = reinterpret_cast<double*>(smem + kW2NBuf * kW2StageB);   // [2][8]: s_t partials of the waves, by tile parity
+    volatile int* itemq = reinterpret_cast<volatile int*>(redS + 16);       // [kW2Ring]: published items (-1 = the queue is empty)
+    const unsigned itemq_lds = (unsigned)(size_t)(lds_char_ptr_w)(smem) + kW2NBuf * kW2StageB + 16 * 8;
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(redS + 32);   // DIAG, abl & 256: [64 stages][4] of workgroup 0, wave 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = (int)blockIdx.x / ntile, tile = (int)blockIdx.x % ntile;
-    const int N = a.N, T = a.T;
-    const int t0 = tile * kW2Rows;
-    const int rt = wave >> 1, half = wave & 1;
-    const int k4 = lane >> 4, c16 = lane & 15;
-    const unsigned rowB = (unsigned)N * 8u;
-    const char* Xb = reinterpret_cast<const char*>(a.panel + (size_t)b * T * N);
-    const char* Wb = reinterpret_cast<const char*>(Wall + (size_t)b * N * R);
-    const double* __restrict__ Rv = a.Rv + (size_t)b * N;
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_w)(smem));
-    const int nch = (N + kW2Chunk - 1) / kW2Chunk;
-    const unsigned wbytes = (unsigned)N * R * 8u;
+    const int xcd = (int)blockIdx.x & 7;
+    auto valid_item = [&](int kk) { return (xcd_map ? (kk / ntile) * 8 + xcd : kk / ntile) < B; };
+    auto decode = [&](int kk, int& b, int& tile) {
+        b = xcd_map ? (kk / ntile) * 8 + xcd : kk / ntile;
+        tile = kk % ntile;
+    };
+    auto read_item = [&](int idx) {
+        return __builtin_amdgcn_readfirstlane(*(const volatile __attribute__((address_space(3))) int*)(size_t)(itemq_lds + 4u * (unsigned)(idx & (kW2Ring - 1))));
+    };
 
-    // stage ch -> buffer bsel: wave w brings in panel rows 8 w .. 8 w + 7 (512 bytes each: lanes 0..31) and 2 KB of the W
-    // block (2 DMAs of 1 KB: the block is contiguous in memory)
-    auto issue_dma = [&](int ch, int bsel) {
-        const unsigned sbase = lds0 + (unsigned)bsel * kStageB;
-        const unsigned colB = (unsigned)ch * (kW2Chunk * 8u) + 16u * (lane & 31);
-        const bool act = colB < rowB;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {                      // one DMA moves two rows: lanes 0..31 row 2 rr, lanes 32..63 row 2 rr + 1
-            const int row = wave * 8 + 2 * rr + (lane >> 5);
-            int t = t0 + row;
-            t = t < T ? t : T - 1;
-            const char* src = Xb + (size_t)t * rowB + colB;
-            // LDS destination of lane l = base + 16 l: rows kW2RS apart need one base per row pair with the second row at +512
-            // -> rows are laid out in PAIRS: pair p at p * 2 * kW2RS', row stride inside the pair 512 bytes
-            const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + (unsigned)(wave * 4 + rr) * kW2PairB);
-            if (act) dma16w(src, dst);
+    // Every role passes the SAME barriers: one after the set-up, one per stage that exists, one at the end.
+    if (wave == kW2Compute + kW2Producers) {
+        // ---- scheduler wave: publishes item n before the barrier after which a producer can first ask for it (the issue cursor
+        // enters item (q + 3) / nch after barrier q), half a tile early so that the atomic's latency is never waited for.
+        int fetched = 0, nvalid = 0;
+        bool ended = false;
+        auto publish_upto = [&](int target) {
+            while (fetched <= target && !ended) {
+                int kk = 0;
+                if (lane == 0) kk = atomicAdd(&ctr[xcd_map ? xcd : 0], 1);
+                kk = __builtin_amdgcn_readfirstlane(kk);
+                const bool ok = valid_item(kk);
+                if (lane == 0) itemq[fetched & (kW2Ring - 1)] = ok ? kk : -1;
+                ++fetched;
+                if (ok) ++nvalid; else ended = true;
+            }
+        };
+        publish_upto((3 + nch / 2) / nch);
+        __syncthreads();
+        for (int q = 0; q / nch < nvalid; ++q) {              // stage q exists (its item was published long ago)
+            publish_upto((q + 3 + nch / 2) / nch);
+            __syncthreads();
         }
-        const unsigned woff = (unsigned)ch * (kW2Chunk * R * 8u) + (unsigned)wave * 2048u + 16u * lane;
+        __syncthreads();
+        return;
+    }
+
+    // no NaN bit patterns in columns / rows the DMAs of a partial stage do not write: zero the buffers once
+    for (int e = tid; e < kW2NBuf * (int)kW2StageB / 8; e += 64 * (kW2Compute + kW2Producers)) reinterpret_cast<double*>(smem)[e] = 0.0;
+    __syncthreads();                                          // (and the scheduler's first items are published)
+
+    if (wave >= kW2Compute) {
+        // ---- producer waves: ALL the LDS-DMA of the kernel.  A DMA instruction costs its wave 60-190 issue cycles; six per stage
+        // in each streaming wave made the consumer loop issue-bound (1.3 us per stage against 0.27 us of MFMA).  Producer p
+        // brings in rows 32 p .. 32 p + 31 of the stage (8 DMAs of 4 rows x 256 bytes), 2 KB of the W block, and (p = 0) the
+        // stage's 1 / R: a FIXED number of DMAs per stage -- the row DMAs have lane 0 active in every stage, the others are
+        // unconditional -- so "stage q has landed" is a counted wait that leaves stage q + 1 outstanding.  (A wave that skipped
+        // a DMA of the partial last stage would wait for too few of the stage before it.)
+        const int pw = wave - kW2Compute;
+        __builtin_amdgcn_s_setprio(3);                        // few instructions, all on the critical path of the stream
+        const unsigned rowB = (unsigned)N * 8u;
+        const unsigned wbytes = (unsigned)N * R * 8u;
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_w)(smem));
+        auto issue_dma = [&](int b, int t0, int ch, int bsel) {
+            if (abl & 32) return;                             // (diagnostics: compute only)
+            const char* Xb = reinterpret_cast<const char*>(a.panel + (size_t)b * T * N);
+            const char* Wb = reinterpret_cast<const char*>(Wall + (size_t)b * N * R);
+            const char* Rb = reinterpret_cast<const char*>(rinvAll + (size_t)b * npad);
+            const unsigned sbase = lds0 + (unsigned)bsel * kW2StageB;
+            const int h = lane >> 4;                          // row of the group; its lane u fetches piece (u - h) mod 16
+            const unsigned colB = (unsigned)ch * (kW2Chunk * 8u) + 16u * (unsigned)((lane - h) & 15);
+            const bool act = colB < rowB;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const unsigned o = woff + 1024u * u;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2Rows * kW2RS + (unsigned)wave * 2048u + 1024u * u);
-            if (o < wbytes) dma16w(Wb + o, dst);
+            for (int k = 0; k < 8; ++k) {
+                int t = t0 + 32 * pw + 4 * k + h;
+                t = t < T ? t : T - 1;
+                const char* src = Xb + (size_t)t * rowB + colB;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + (unsigned)(pw * 8 + k) * kW2GroupB);
+                if (act) dma16w(src, dst);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {   // past the end of W -- the last, partial stage -- the lanes re-read its last 16 bytes; those rows only ever meet a zeroed A
+                const unsigned o = (unsigned)ch * kW2WB + (unsigned)(2 * pw + u) * 1024u + 16u * lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + (unsigned)(2 * pw + u) * 1024u);
+                dma16w(Wb + (o < wbytes ? o : wbytes - 16u), dst);
+            }
+            if (pw == 0) {                  // 1 / R of the stage's 32 series (the table is padded with zeros to a whole stage)
+                const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + kW2WB);
+                if (lane < 16) dma16w(Rb + (size_t)ch * (kW2Chunk * 8u) + 16u * lane, dst);
+            }
+        };
+        int ii = 0, ich = 0, ikk = read_item(0), ib = 0, itile = 0;   // issue cursor: the next stage to request
+        if (ikk >= 0) decode(ikk, ib, itile);
+        auto issue_next = [&](int bsel) {
+            issue_dma(ib, itile * kW2Rows, ich, bsel);
+            if (++ich == nch) {
+                ich = 0;
+                ikk = read_item(++ii);
+                if (ikk >= 0) decode(ikk, ib, itile);
+            }
+        };
+        bool more = ikk >= 0, v1 = false;                     // stage q exists; stage q + 1 exists (and has been requested)
+        if (more) {
+            issue_next(0);
+            v1 = ikk >= 0;
+            if (v1) issue_next(1);
+        }
+        int bsel = 0;
+        while (more) {
+            if (!v1) wait_all_w();
+            else if (pw == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            __syncthreads();                                  // stage q has landed; every consumer is done with stage q - 1
+            const bool v2 = ikk >= 0;                         // stage q + 2 exists: into the buffer stage q - 1 used
+            if (v2) issue_next(bsel == 0 ? 2 : bsel - 1);
+            bsel = bsel == 2 ? 0 : bsel + 1;
+            more = v1;
+            v1 = v2;
+        }
+        __syncthreads();
+        return;
+    }
+
+    // ---- consumer waves: wave w owns periods 16 w .. 16 w + 15 of the tile
+    int qstamp = 0;
+    auto stamp = [&](int k) {
+        if constexpr (DIAG) {
+            if ((abl & 256) && blockIdx.x == 0 && threadIdx.x == 0 && qstamp < 64) stamps[qstamp * 4 + k] = __builtin_amdgcn_s_memrealtime();
         }
     };
-    // no NaN bit patterns in columns / rows the DMAs of a partial stage do not write: zero the buffers once
-    for (int e = tid; e < kW2NBuf * (int)kStageB / 8; e += 512) reinterpret_cast<double*>(smem)[e] = 0.0;
-    __syncthreads();
-    // THREE stage buffers: two stages are in flight while one is consumed (with two, the workgroup's 49 KB burst per barrier
-    // left HBM idle half of the time: 2.07 ms).  Every wave issues exactly 6 DMAs per stage except in the last, partial one
-    // (which has no younger stage), so "stage ch has landed" is a counted wait that leaves stage ch + 1 outstanding.
-    issue_dma(0, 0);
-    if (nch > 1) issue_dma(1, 1);
-    for (int c = tid; c < nch * kW2Chunk; c += 512) rinvS[c] = c < N ? 1.0 / Rv[c] : 0.0;   // (no register load may sit between the
-                                                                                             // DMAs of the loop: one vmcnt order)
-    w2_v4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const int k4 = lane >> 4, c16 = lane & 15;
+    const unsigned ldsc = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_w)(smem));
+    int ci = 0, ch = 0, bsel = 0, cb = 0, ctile = 0;          // consume cursor
+    bool more;
+    {
+        const int kk0 = read_item(0);
+        more = kk0 >= 0;
+        if (more) decode(kk0, cb, ctile);
+    }
+    typedef double w2_v4 __attribute__((ext_vector_type(4)));
+    w2_v4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // factors 0..15: even / odd steps
+    w2_v4 accb = {0.0, 0.0, 0.0, 0.0};                                // NX == 4: factors 16..31
+    double acc4[N4 > 0 ? N4 : 1];
+#pragma unroll
+    for (int x = 0; x < (N4 > 0 ? N4 : 1); ++x) acc4[x] = 0.0;
     double qs = 0.0;
-    const int srow = tid >> 3, scg = tid & 7;                 // s_t pass: thread = (row 0..63, group of 8 series)
-    // A operand of this lane: row 16 rt + c16 of the tile -> pair (16 rt + c16) / 2, slot (16 rt + c16) % 2
-    const unsigned arow = (unsigned)((16 * rt + c16) >> 1) * kW2PairB + (unsigned)((16 * rt + c16) & 1) * 512u;
-    const unsigned srowoff = (unsigned)(srow >> 1) * kW2PairB + (unsigned)(srow & 1) * 512u;
-    int bsel = 0;
-    for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else wait_all_w();
-        __syncthreads();                                      // stage ch (panel rows, W block, 1 / R) is ready
-        const int bnew = bsel == 0 ? 2 : bsel - 1;            // buffer of stage ch + 2 = the one stage ch - 1 used
-        if (ch + 2 < nch) issue_dma(ch + 2, bnew);
-        const char* stage = smem + (size_t)bsel * kStageB;
-        const char* pa = stage + arow + (size_t)(half * (kW2Steps / 2) * 4 + k4) * 8;
-        const char* pb = stage + kW2Rows * kW2RS + (size_t)(half * (kW2Steps / 2) * 4 + k4) * (R * 8) + (size_t)c16 * 8;
-        const int cfirst = ch * kW2Chunk + half * (kW2Steps / 2) * 4 + k4;   // series of this lane's k in step 0
+    // A operand of this lane: row 16 w + c16 of the tile -> group 4 w + c16 / 4, row h = c16 % 4 of the group; series j of the
+    // stage at byte (8 j + 16 h) mod 256 of the row (only steps 6 and 7 can wrap)
+    const unsigned ah = (unsigned)(c16 & 3);
+    const unsigned arow = (unsigned)(4 * wave + (c16 >> 2)) * kW2GroupB + ah * 256u;
+    const unsigned arot = 8u * k4 + 16u * ah;
+    const unsigned a_lo = arow + arot;                        // steps 0 .. 5: + 32 s
+    const unsigned a_6 = arow + ((arot + 192u) & 255u), a_7 = arow + ((arot + 224u) & 255u);
+    // B operands: W[series 4 s + k4][f], odd series with their 16-column halves swapped
+    const unsigned bsw = 16u * (k4 & 1);
+    const unsigned b16 = (unsigned)k4 * (R * 8u) + (((unsigned)c16) ^ bsw) * 8u;             // f = c16
+    const unsigned b16b = (unsigned)k4 * (R * 8u) + ((16u + c16) ^ bsw) * 8u;                // f = 16 + c16 (NX == 4)
+    const unsigned b4 = (unsigned)k4 * (R * 8u) + ((16u + (lane & 3)) ^ bsw) * 8u;           // f = 16 + q (+ 4 x)
+
+    // finished tile: its results wait in registers / redS until the next barrier has passed
+    int pend_b = -1, pend_t0 = 0, pend_par = 0, pend_tile = 0;
+    w2_v4 pacc = {0.0, 0.0, 0.0, 0.0}, paccb = {0.0, 0.0, 0.0, 0.0};
+    double pacc4[N4 > 0 ? N4 : 1];
+    auto flush_pending = [&]() {
+        if (pend_b < 0) return;
+        double* out = a.bcol + ((size_t)pend_b * T + pend_t0 + 16 * wave) * R;
 #pragma unroll
-        for (int s = 0; s < kW2Steps / 2; ++s) {
-            double av = *reinterpret_cast<const double*>(pa + s * 32);
-            av = (cfirst + 4 * s < N) ? av : 0.0;             // the last stage may be partial: its stale columns / W rows count for nothing
-            const double b0 = *reinterpret_cast<const double*>(pb + s * (4 * R * 8));
-            const double b1 = *reinterpret_cast<const double*>(pb + s * (4 * R * 8) + 128);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, acc1, 0, 0, 0);
-        }
-        {   // s_t: 8 cells of one row per thread
-            const char* ps = stage + srowoff + (size_t)scg * 64;
-            const double* pr = rinvS + ch * kW2Chunk + scg * 8;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double2 x = *reinterpret_cast<const double2*>(ps + u * 16);
-                const double2 ri = *reinterpret_cast<const double2*>(pr + u * 2);
-                qs = fma(x.x * ri.x, x.x, qs);
-                qs = fma(x.y * ri.y, x.y, qs);
+        for (int v = 0; v < 4; ++v) {                         // 16x16x4: D[(l / 16) + 4 v][l % 16]
+            const int row = k4 + 4 * v;
+            if (pend_t0 + 16 * wave + row < T) {
+                out[(size_t)row * R + c16] = pacc[v];
+                if (NX == 4) out[(size_t)row * R + 16 + c16] = paccb[v];
             }
         }
+        if (NX < 4) {                                         // 4x4x4: block (l / 4) % 4, D[row = l / 16][col = l % 4] -> period 4 blk + l / 16
+            const int row = 4 * ((lane >> 2) & 3) + k4;
+            if (pend_t0 + 16 * wave + row < T) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)                   // (the padding columns past 16 + 4 NX are zero)
+                    out[(size_t)row * R + 16 + 4 * x + (lane & 3)] = x < N4 ? pacc4[x < N4 ? x : 0] : 0.0;
+            }
+        }
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) tot += redS[pend_par * 8 + w];
+            a.scol[(size_t)pend_b * T + pend_tile] = tot;
+            if (tot != tot) atomicOr(a.status, 1);            // NaN in the panel on the balanced path
+        }
+        pend_b = -1;
+    };
+
+    while (more) {
+        stamp(0);
+        __syncthreads();                                      // stage q is ready (the producers waited for it)
+        stamp(1);
+        flush_pending();
+        stamp(2);
+        const int bsel_cur = bsel;
+        const int cfirst = ch * kW2Chunk + k4;                // series of this lane's k in step 0
+        if (!(abl & 4)) {
+            // Operands four steps ahead of their MFMAs.  The reads are VOLATILE so that the compiler neither merges pairs of them
+            // into ds_read2_b64 (half the LDS rate, 32-bank groups of 16 lanes: the layouts above are conflict-free for
+            // ds_read_b64's two groups of 32 lanes over 64 banks) nor sinks them back next to their use.
+            double av[kW2Steps], bv[kW2Steps], ri[kW2Steps], bvb[NX == 4 ? kW2Steps : 1], b4v[N4 > 0 ? N4 : 1][kW2Steps];
+            const unsigned st = ldsc + (unsigned)bsel_cur * kW2StageB, wo = st + kW2PanelB, ro = wo + kW2WB + 8u * k4;
+            auto load_step = [&](int s) {
+                av[s] = lds_read64(st + (s == 6 ? a_6 : s == 7 ? a_7 : a_lo + 32u * s));
+                bv[s] = lds_read64(wo + b16 + s * (4 * R * 8));
+                if (NX == 4) bvb[NX == 4 ? s : 0] = lds_read64(wo + b16b + s * (4 * R * 8));
+#pragma unroll
+                for (int x = 0; x < N4; ++x) b4v[x][s] = lds_read64(wo + b4 + s * (4 * R * 8) + x * 32);
+                ri[s] = lds_read64(ro + 32u * s);
+            };
+#pragma unroll
+            for (int s = 0; s < 4; ++s) load_step(s);
+#pragma unroll
+            for (int s = 0; s < kW2Steps; ++s) {
+                if (s + 4 < kW2Steps) load_step(s + 4);
+                const double a_ = (cfirst + 4 * s < N) ? av[s] : 0.0;   // the last stage may be partial: its stale columns / W rows count for nothing
+                if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[s], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[s], acc0, 0, 0, 0);
+                if (NX == 4) accb = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bvb[NX == 4 ? s : 0], accb, 0, 0, 0);
+#pragma unroll
+                for (int x = 0; x < N4; ++x) acc4[x] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b4v[x][s], acc4[x], 0, 0, 0);
+                qs = fma(a_ * ri[s], a_, qs);                 // s_t = sum_i x_it^2 / R_i from the same register
+            }
+        }
+        stamp(3);
+        ++qstamp;
         bsel = bsel == 2 ? 0 : bsel + 1;
-    }
-    // the two halves of a row tile meet in LDS (the stage buffers are free now)
-    __syncthreads();
-    double* xch = reinterpret_cast<double*>(smem);            // [4 row tiles][2 factor tiles][4][64]
-    if (half == 1) {
+        if (++ch == nch) {                                    // the tile is complete: park b_t and the s_t partial
+            pend_b = cb; pend_t0 = ctile * kW2Rows; pend_tile = ctile; pend_par = ci & 1;
+            pacc = acc0 + acc1; paccb = accb;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            xch[((rt * 2 + 0) * 4 + v) * 64 + lane] = acc0[v];
-            xch[((rt * 2 + 1) * 4 + v) * 64 + lane] = acc1[v];
+            for (int x = 0; x < (N4 > 0 ? N4 : 1); ++x) { pacc4[x] = acc4[x]; acc4[x] = 0.0; }
+            acc0 = w2_v4{0.0, 0.0, 0.0, 0.0}; acc1 = acc0; accb = acc0;
+            if (pend_t0 + 16 * wave + c16 >= T) qs = 0.0;     // this lane's row is past the end of the sample (it repeats row T - 1)
+            qs = wave_allsum(qs);
+            if (lane == 0) redS[pend_par * 8 + wave] = qs;
+            qs = 0.0;
+            ch = 0;
+            const int ckk = read_item(++ci);                  // (published at least two barriers ago)
+            more = ckk >= 0;
+            if (more) decode(ckk, cb, ctile);
         }
     }
     __syncthreads();
-    if (half == 0) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {                         // D[(l / 16) + 4 v][l % 16]
-            const int t = t0 + rt * 16 + k4 + 4 * v;
-            if (t < T) {
-                double* out = a.bcol + ((size_t)b * T + t) * R;
-                out[c16] = acc0[v] + xch[((rt * 2 + 0) * 4 + v) * 64 + lane];
-                out[16 + c16] = acc1[v] + xch[((rt * 2 + 1) * 4 + v) * 64 + lane];
-            }
+    flush_pending();
+    if constexpr (DIAG) {
+        if ((abl & 256) && blockIdx.x == 0 && tid == 0) {     // 100 MHz ticks relative to the first stamp: barrier-begin, barrier-end, stores-end, compute-end
+            for (int q = 0; q < (qstamp < 64 ? qstamp : 64); ++q)
+                printf("W2STAMP %d %llu %llu %llu %llu\n", q, stamps[q * 4] - stamps[0], stamps[q * 4 + 1] - stamps[0],
+                       stamps[q * 4 + 2] - stamps[0], stamps[q * 4 + 3] - stamps[0]);
         }
-    }
-    // sum over the tile's valid periods of s_t
-    if (t0 + srow >= T) qs = 0.0;
-    qs = wave_allsum(qs);
-    if (lane == 0) redS[wave] = qs;
-    __syncthreads();
-    if (tid == 0) {
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) tot += redS[w];
-        a.scol[(size_t)b * T + tile] = tot;
-        if (tot != tot) atomicOr(a.status, 1);               // NaN in the panel on the balanced path
     }
 }
 
 int collapse_wide2_tiles(int T) { return (T + kW2Rows - 1) / kW2Rows; }
-bool collapse_wide2_supported(int Rpad, int N) { return Rpad == 32 && (N % 2) == 0 && N >= 2 && N <= 1280; }   // 1 / R table in LDS beside the three stages
-
-hipError_t launch_wide_prep(const CollapseArgs& a, double* W, hipStream_t s) {
-    hipLaunchKernelGGL(wide_prep_kernel, dim3(a.B), dim3(256), 0, s, a, W);
-    return hipGetLastError();
+bool collapse_wide2_supported(int Rpad, int N) { return Rpad == 32 && (N % 2) == 0 && N >= 2; }
+// workspace of the Rp = 32 collapse: W [B][N][32] | 1 / R [B][npad] | 8 queue counters
+size_t collapse_wide2_ws_bytes(int B, int N) {
+    const size_t npad = (size_t)((N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
+    return ((size_t)B * N * kW2R + (size_t)B * npad) * sizeof(double) + 64;
 }
 
-hipError_t launch_collapse_wide2(const CollapseArgs& a, const double* W, hipStream_t s) {
-    const int ntile = collapse_wide2_tiles(a.T);
-    const size_t stage = (size_t)kW2Rows * kW2RS + (size_t)kW2Chunk * kW2R * 8;
-    size_t lds = kW2NBuf * stage + (size_t)(((a.N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk + 8) * sizeof(double);
-    const size_t xch = (size_t)4 * 2 * 4 * 64 * sizeof(double);
-    if (lds < xch) lds = xch;
+namespace {
+struct W2Ws { double* W; double* rinv; int* ctr; int npad; };
+W2Ws w2_ws(const CollapseArgs& a, double* ws) {
+    W2Ws w;
+    w.npad = ((a.N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
+    w.W = ws;
+    w.rinv = ws + (size_t)a.B * a.N * kW2R;
+    w.ctr = reinterpret_cast<int*>(w.rinv + (size_t)a.B * w.npad);
+    return w;
+}
+template <int NX, bool DIAG>
+hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel<NX, DIAG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(collapse_wide2_kernel, dim3((unsigned)((long long)a.B * ntile)), dim3(512), lds, s, a, W, ntile);
+    hipLaunchKernelGGL((collapse_wide2_kernel<NX, DIAG>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl);
     return hipGetLastError();
+}
+template <int NX>
+hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s) {
+    return abl ? launch_w2v<NX, true>(a, w, G, lds, ntile, xcd_map, abl, s) : launch_w2v<NX, false>(a, w, G, lds, ntile, xcd_map, 0, s);
+}
+}  // namespace
+
+hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, hipStream_t s) {
+    const W2Ws w = w2_ws(a, ws);
+    hipLaunchKernelGGL(wide_prep_kernel, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.npad, w.ctr);
+    return hipGetLastError();
+}
+
+// r = the caller's factor count (columns r .. 31 of Lam are zero padding)
+hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int r, int num_cu, hipStream_t s) {
+    const W2Ws w = w2_ws(a, ws);
+    const int ntile = collapse_wide2_tiles(a.T);
+    const size_t lds = (size_t)kW2NBuf * kW2StageB + 32 * sizeof(double) + 64 * 4 * sizeof(unsigned long long);   // stages | redS, itemq | DIAG stamps
+    static const int xcd_env = [] { const char* v = getenv("DFM_WIDE_XCD"); return v ? atoi(v) : -1; }();
+    const int xcd_map = xcd_env >= 0 ? (xcd_env != 0) : (a.B >= 16);
+    static const int abl = [] { const char* v = getenv("DFM_W2_ABL"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
+    // one persistent workgroup per CU (130 KB of LDS each), a multiple of 8 so that every XCD has the same number
+    const long long NT = (long long)a.B * ntile;
+    int G = num_cu > 0 ? num_cu : 256;
+    G = (G / 8) * 8;
+    if (G < 8) G = 8;
+    if (!xcd_map && NT < G) G = (int)NT;
+    const int nx = r <= 16 ? 1 : (r + 3 - 16) / 4;            // 4-factor groups past the first 16; 4 = a second 16-wide tile
+    switch (nx) {
+        case 1: return launch_w2<1>(a, w, G, lds, ntile, xcd_map, abl, s);
+        case 2: return launch_w2<2>(a, w, G, lds, ntile, xcd_map, abl, s);
+        case 3: return launch_w2<3>(a, w, G, lds, ntile, xcd_map, abl, s);
+        default: return launch_w2<4>(a, w, G, lds, ntile, xcd_map, abl, s);
+    }
 }
 
 }  // namespace dfm

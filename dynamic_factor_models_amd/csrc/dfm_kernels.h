@@ -111,8 +111,9 @@ hipError_t launch_gram_wide(int Rpad, const CollapseArgs& a, hipStream_t s);
 // ldfull (the Gram kernel's outputs); launch_collapse_wide2 then streams the panel (partials of sum_t s_t: scol[b][tile])
 bool collapse_wide2_supported(int Rpad, int N);
 int collapse_wide2_tiles(int T);
-hipError_t launch_wide_prep(const CollapseArgs& a, double* W, hipStream_t s);
-hipError_t launch_collapse_wide2(const CollapseArgs& a, const double* W, hipStream_t s);
+size_t collapse_wide2_ws_bytes(int B, int N);    // W [B][N][32] | 1 / R [B][N padded to 32] | tile queue counters
+hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, hipStream_t s);
+hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int r, int num_cu, hipStream_t s);
 bool gram_supported(int Rpad, int N);       // launch_gram's register tilings
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
 hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
