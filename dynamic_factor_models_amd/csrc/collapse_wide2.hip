@@ -54,7 +54,13 @@ __device__ __forceinline__ void dma16w(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void wait_all_w() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 constexpr int kW2R = 32;          // padded factors
-constexpr int kW2Rows = 128;      // periods per tile
+#ifndef DFM_W2_ROWS
+#define DFM_W2_ROWS 128
+#endif
+// periods per tile: 128 -> 130 KB of LDS per workgroup, one per CU.  (64 -> 79 KB, two per CU, or one beside a 60-KB workgroup
+// of the covariance kernel that runs next to this launch: measured slower -- 1.29 ms against 1.04 with the covariance
+// kernel beside it, which itself went from 0.20 to 0.34 ms; alone 0.88 against 0.86.)
+constexpr int kW2Rows = DFM_W2_ROWS;
 constexpr int kW2Chunk = 32;      // series per stage (256 bytes of a panel row)
 constexpr int kW2Steps = kW2Chunk / 4;
 constexpr int kW2NBuf = 3;        // stage buffers
@@ -67,8 +73,10 @@ constexpr unsigned kW2GroupB = 1088;
 constexpr unsigned kW2PanelB = (kW2Rows / 4) * kW2GroupB;          // 34816
 constexpr unsigned kW2WB = kW2Chunk * kW2R * 8;                    // 8192: W block of the stage
 constexpr unsigned kW2StageB = kW2PanelB + kW2WB + kW2Chunk * 8;   // + 1 / R of the stage's series
-constexpr int kW2Compute = 8;      // consumer waves (16 periods of the tile each)
-constexpr int kW2Producers = 4;    // LDS-DMA waves; one more wave is the scheduler
+constexpr int kW2Compute = kW2Rows / 16;    // consumer waves (16 periods of the tile each)
+constexpr int kW2Producers = kW2Rows / 32;  // LDS-DMA waves (32 rows + their share of W each); one more wave is the scheduler
+constexpr int kW2WPieces = 8 / kW2Producers;                       // 1-KB DMAs of the W block per producer
+constexpr int kW2PerStage = 8 + kW2WPieces;                        // DMAs per producer and stage (+ 1 for producer 0: 1 / R)
 constexpr int kW2Threads = 64 * (kW2Compute + kW2Producers + 1);
 constexpr int kW2Ring = 8;        // published items (ring)
 
@@ -215,9 +223,9 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
                 if (act) dma16w(src, dst);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {   // past the end of W -- the last, partial stage -- the lanes re-read its last 16 bytes; those rows only ever meet a zeroed A
-                const unsigned o = (unsigned)ch * kW2WB + (unsigned)(2 * pw + u) * 1024u + 16u * lane;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + (unsigned)(2 * pw + u) * 1024u);
+            for (int u = 0; u < kW2WPieces; ++u) {   // past the end of W -- the last, partial stage -- the lanes re-read its last 16 bytes; those rows only ever meet a zeroed A
+                const unsigned o = (unsigned)ch * kW2WB + (unsigned)(kW2WPieces * pw + u) * 1024u + 16u * lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + (unsigned)(kW2WPieces * pw + u) * 1024u);
                 dma16w(Wb + (o < wbytes ? o : wbytes - 16u), dst);
             }
             if (pw == 0) {                  // 1 / R of the stage's 32 series (the table is padded with zeros to a whole stage)
@@ -244,8 +252,8 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
         int bsel = 0;
         while (more) {
             if (!v1) wait_all_w();
-            else if (pw == 0) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (pw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2PerStage + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2PerStage) : "memory");
             __syncthreads();                                  // stage q has landed; every consumer is done with stage q - 1
             const bool v2 = ikk >= 0;                         // stage q + 2 exists: into the buffer stage q - 1 used
             if (v2) issue_next(bsel == 0 ? 2 : bsel - 1);
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
         if (tid == 0) {
             double tot = 0.0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) tot += redS[pend_par * 8 + w];
+            for (int w = 0; w < kW2Compute; ++w) tot += redS[pend_par * 8 + w];
             a.scol[(size_t)pend_b * T + pend_tile] = tot;
             if (tot != tot) atomicOr(a.status, 1);            // NaN in the panel on the balanced path
         }
@@ -444,7 +452,7 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int r, int n
     static const int abl = [] { const char* v = getenv("DFM_W2_ABL"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
     // one persistent workgroup per CU (130 KB of LDS each), a multiple of 8 so that every XCD has the same number
     const long long NT = (long long)a.B * ntile;
-    int G = num_cu > 0 ? num_cu : 256;
+    int G = (num_cu > 0 ? num_cu : 256) * (kW2Rows <= 64 ? 2 : 1);   // as many as fit the LDS of every CU
     G = (G / 8) * 8;
     if (G < 8) G = 8;
     if (!xcd_map && NT < G) G = (int)NT;

@@ -459,7 +459,7 @@ static hipError_t launch_scan_r(const FastArgs& a, hipStream_t s) {
 int fast_stead_mats(int Rpad) { return stead_mats(Rpad); }
 
 int fast_chunk_len(int Rpad, int T) {
-    const int ng = scan_threads(Rpad) / Rpad;
+    const int ng = scan_groups(Rpad);
     int L = 1;
     while (L * ng < T) L <<= 1;
     return L;
@@ -501,7 +501,7 @@ hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s) {
         case 4: return launch_scan_r<4>(a, s);
         case 8: return launch_scan_r<8>(a, s);
         case 16: return launch_scan_r<16>(a, s);
-        case 32: return launch_scan_r<32>(a, s);
+        case 32: return launch_meanscan32(a, s);          // scan_mfma32.hip (128 chunks; meanscan_kernel's lane groups hold 16)
         default: return hipErrorInvalidValue;
     }
 }
