@@ -162,6 +162,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N));
     } else {
         p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
+        if (p.Rc == 0 && Rp == 32 && N > collapse_max_n(32) && collapse_wide2_supported(32, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N));
     }
     p.wtab = take(off, (size_t)B * T * Rp * d);
     p.status = take(off, 256);
@@ -218,10 +219,13 @@ int check_dims(dfm_handle* h, int B, int T, int N, int r) {
     return 0;
 }
 // panels with missing cells (and EM) go through collapse_kernel's register tiling
-int check_general_n(dfm_handle* h, int N, int r) {
+// plain = the factor model itself (loadings as wide as the state): at Rp = 32 cross-sections beyond the register tiling take
+// the streaming collapse of config 4 in its variant for missing cells (collapse_wide2.hip)
+int check_general_n(dfm_handle* h, int N, int r, bool plain = false) {
+    if (plain && pad_r(r) == 32 && collapse_wide2_supported(32, N)) return 0;
     if (N > collapse_max_n(pad_r(r)))
         return fail(h, DFM_E_DIMS, "N too large for this r on the path with missing cells / EM (collapse kernel register "
-                                   "tiling: N <= 1024 for r <= 8, 512 for r <= 16, 256 for r <= 32)%s");
+                                   "tiling: N <= 1024 for r <= 8, 512 for r <= 16; r > 16: 256, or any even N for the plain model)%s");
     return 0;
 }
 
@@ -296,7 +300,7 @@ int check_em_n(dfm_handle* h, int N, int r, unsigned flags) {
             return fail(h, DFM_E_DIMS, "N > 1024: the loadings M-step (one lane per series, 4 series per lane) does not cover this cross-section%s");
         return 0;
     }
-    return check_general_n(h, N, r);
+    return check_general_n(h, N, r, true);
 }
 
 // gram + cov on the side stream, beside the streaming collapse on the main stream; the batch is cut
@@ -500,7 +504,12 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
         const int Rcol = p.Rc ? p.Rc : p.Rp;
         ProfScope ps(h, K_COLLAPSE);
         if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream));
-        else HIP_TRY(h, launch_collapse(Rcol, ca, h->stream));
+        else if (p.Wwide != (size_t)-1 && N > collapse_max_n(Rcol)) {   // Rp = 32 beyond the register tiling (config 4 with missing cells)
+            double* W = at<double>(h, p.Wwide);
+            HIP_TRY(h, launch_wide_prep(ca, W, h->stream));
+            HIP_TRY(h, launch_collapse_wide2(ca, W, p.r, h->num_cu, h->stream));
+            HIP_TRY(h, launch_ct_miss_wide(ca, W, h->stream));
+        } else HIP_TRY(h, launch_collapse(Rcol, ca, h->stream));
     }
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -1037,7 +1046,7 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0 || !f_smooth || !loglik)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (!fast_eligible(h, N, r, flags))
-        if (int rc = check_general_n(h, N, r)) return rc;
+        if (int rc = check_general_n(h, N, r, true)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const Plan p = make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags));
     if (int rc = ensure_ws(h, p.total)) return rc;

@@ -72,7 +72,7 @@ constexpr int kW2NBuf = 3;        // stage buffers
 constexpr unsigned kW2GroupB = 1088;
 constexpr unsigned kW2PanelB = (kW2Rows / 4) * kW2GroupB;          // 34816
 constexpr unsigned kW2WB = kW2Chunk * kW2R * 8;                    // 8192: W block of the stage
-constexpr unsigned kW2StageB = kW2PanelB + kW2WB + kW2Chunk * 8;   // + 1 / R of the stage's series
+constexpr unsigned kW2StageB = kW2PanelB + kW2WB + 2 * kW2Chunk * 8;   // + 1 / R and (panels with missing cells) log R of the stage's series
 constexpr int kW2Compute = kW2Rows / 16;    // consumer waves (16 periods of the tile each)
 constexpr int kW2Producers = kW2Rows / 32;  // LDS-DMA waves (32 rows + their share of W each); one more wave is the scheduler
 constexpr int kW2WPieces = 8 / kW2Producers;                       // 1-KB DMAs of the W block per producer
@@ -84,7 +84,7 @@ constexpr int kW2Ring = 8;        // published items (ring)
 
 // ------------------------------------------------------------------------------------------------------------------
 // W = lam / R, C = Lam' W, sum log R.  One workgroup of 4 waves per replicate.
-__global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, int npad, int* ctr) {
+__global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, double* logr_out, int npad, int* ctr) {
     constexpr int R = kW2R;
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
         const int c = e / R;
         W[e ^ (16 * (c & 1))] = L[e] / Rv[c];
     }
-    for (int c = tid; c < npad; c += 256) rinv_out[(size_t)b * npad + c] = c < N ? 1.0 / Rv[c] : 0.0;   // (0 past N: padding of the last stage)
+    for (int c = tid; c < npad; c += 256) {                   // (0 past N: padding of the last stage)
+        rinv_out[(size_t)b * npad + c] = c < N ? 1.0 / Rv[c] : 0.0;
+        logr_out[(size_t)b * npad + c] = c < N ? log(Rv[c]) : 0.0;
+    }
     if (b == 0 && tid < 8) ctr[tid] = 0;                      // tile queues of the collapse that follows on this stream
     double ld = 0.0;
     for (int c = tid; c < N; c += 256) ld += log(Rv[c]);
@@ -136,10 +139,14 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
 // Workgroup -> tiles: `xcd_map` (B >= 16): workgroups are dealt to the 8 XCDs round-robin, so workgroup g sits on XCD g % 8;
 // XCD x takes items from queue x = tiles of replicates x, x + 8, ... in order: its CUs work on ONE replicate at a time and
 // that replicate's 256 KB of W stay in that L2.  Small batches: one queue over the flat tile list.
-template <int NX, bool DIAG>
+// MODE 0: balanced panel (sum_t s_t per tile -> scol[b][tile]); 1: the same with the DFM_W2_ABL diagnostics compiled in;
+// 2: panel with missing cells -- NaN operands count as 0 (b_t, s_t over the observed cells), per period s_t -> scol[b][t],
+// n_t -> nobs[b][t] and, where cells are missing, log det R_t -> ldrow[b][t]; C_t of those periods: ct_miss_wide_kernel.
+template <int NX, int MODE>
 __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall,
                                                                    const double* __restrict__ rinvAll, int npad, int* ctr,
                                                                    int ntile, int xcd_map, int abl_) {
+    constexpr bool DIAG = MODE == 1, MISS = MODE == 2;
     constexpr int R = kW2R;
     constexpr int N4 = NX < 4 ? NX : 0;                       // 4x4x4 groups
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,6 +238,10 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
             if (pw == 0) {                  // 1 / R of the stage's 32 series (the table is padded with zeros to a whole stage)
                 const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + kW2WB);
                 if (lane < 16) dma16w(Rb + (size_t)ch * (kW2Chunk * 8u) + 16u * lane, dst);
+                if (MISS) {                 // ... and log R (the table follows the 1 / R table of the whole batch)
+                    const char* Lb = Rb + (size_t)B * npad * 8u;
+                    if (lane < 16) dma16w(Lb + (size_t)ch * (kW2Chunk * 8u) + 16u * lane, dst + kW2Chunk * 8u);
+                }
             }
         };
         int ii = 0, ich = 0, ikk = read_item(0), ib = 0, itile = 0;   // issue cursor: the next stage to request
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
         int bsel = 0;
         while (more) {
             if (!v1) wait_all_w();
-            else if (pw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2PerStage + 1) : "memory");
+            else if (pw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2PerStage + (MISS ? 2 : 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2PerStage) : "memory");
             __syncthreads();                                  // stage q has landed; every consumer is done with stage q - 1
             const bool v2 = ikk >= 0;                         // stage q + 2 exists: into the buffer stage q - 1 used
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
     double acc4[N4 > 0 ? N4 : 1];
 #pragma unroll
     for (int x = 0; x < (N4 > 0 ? N4 : 1); ++x) acc4[x] = 0.0;
-    double qs = 0.0;
+    double qs = 0.0, nmis = 0.0, lmis = 0.0;                  // MISS: missing cells of this lane's row (count, sum of log R)
     // A operand of this lane: row 16 w + c16 of the tile -> group 4 w + c16 / 4, row h = c16 % 4 of the group; series j of the
     // stage at byte (8 j + 16 h) mod 256 of the row (only steps 6 and 7 can wrap)
     const unsigned ah = (unsigned)(c16 & 3);
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
                     out[(size_t)row * R + 16 + 4 * x + (lane & 3)] = x < N4 ? pacc4[x < N4 ? x : 0] : 0.0;
             }
         }
-        if (tid == 0) {
+        if (!MISS && tid == 0) {
             double tot = 0.0;
 #pragma unroll
             for (int w = 0; w < kW2Compute; ++w) tot += redS[pend_par * 8 + w];
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
             // Operands four steps ahead of their MFMAs.  The reads are VOLATILE so that the compiler neither merges pairs of them
             // into ds_read2_b64 (half the LDS rate, 32-bank groups of 16 lanes: the layouts above are conflict-free for
             // ds_read_b64's two groups of 32 lanes over 64 banks) nor sinks them back next to their use.
-            double av[kW2Steps], bv[kW2Steps], ri[kW2Steps], bvb[NX == 4 ? kW2Steps : 1], b4v[N4 > 0 ? N4 : 1][kW2Steps];
+            double av[kW2Steps], bv[kW2Steps], ri[kW2Steps], lr[MISS ? kW2Steps : 1], bvb[NX == 4 ? kW2Steps : 1], b4v[N4 > 0 ? N4 : 1][kW2Steps];
             const unsigned st = ldsc + (unsigned)bsel_cur * kW2StageB, wo = st + kW2PanelB, ro = wo + kW2WB + 8u * k4;
             auto load_step = [&](int s) {
                 av[s] = lds_read64(st + (s == 6 ? a_6 : s == 7 ? a_7 : a_lo + 32u * s));
@@ -355,13 +366,20 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
 #pragma unroll
                 for (int x = 0; x < N4; ++x) b4v[x][s] = lds_read64(wo + b4 + s * (4 * R * 8) + x * 32);
                 ri[s] = lds_read64(ro + 32u * s);
+                if (MISS) lr[MISS ? s : 0] = lds_read64(ro + kW2Chunk * 8u + 32u * s);
             };
 #pragma unroll
             for (int s = 0; s < 4; ++s) load_step(s);
 #pragma unroll
             for (int s = 0; s < kW2Steps; ++s) {
                 if (s + 4 < kW2Steps) load_step(s + 4);
-                const double a_ = (cfirst + 4 * s < N) ? av[s] : 0.0;   // the last stage may be partial: its stale columns / W rows count for nothing
+                double a_ = (cfirst + 4 * s < N) ? av[s] : 0.0;   // the last stage may be partial: its stale columns / W rows count for nothing
+                if (MISS) {                                   // a missing cell: no contribution to b_t and s_t; counted for n_t, log det R_t
+                    const bool nanv = a_ != a_;
+                    a_ = nanv ? 0.0 : a_;
+                    nmis += nanv ? 1.0 : 0.0;
+                    lmis += nanv ? lr[MISS ? s : 0] : 0.0;
+                }
                 if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[s], acc1, 0, 0, 0);
                 else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[s], acc0, 0, 0, 0);
                 if (NX == 4) accb = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bvb[NX == 4 ? s : 0], accb, 0, 0, 0);
@@ -379,9 +397,23 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
 #pragma unroll
             for (int x = 0; x < (N4 > 0 ? N4 : 1); ++x) { pacc4[x] = acc4[x]; acc4[x] = 0.0; }
             acc0 = w2_v4{0.0, 0.0, 0.0, 0.0}; acc1 = acc0; accb = acc0;
-            if (pend_t0 + 16 * wave + c16 >= T) qs = 0.0;     // this lane's row is past the end of the sample (it repeats row T - 1)
-            qs = wave_allsum(qs);
-            if (lane == 0) redS[pend_par * 8 + wave] = qs;
+            if (MISS) {                                       // per period: fold the four series classes k4 of the row
+                qs += __shfl_xor(qs, 16, 64); qs += __shfl_xor(qs, 32, 64);
+                nmis += __shfl_xor(nmis, 16, 64); nmis += __shfl_xor(nmis, 32, 64);
+                lmis += __shfl_xor(lmis, 16, 64); lmis += __shfl_xor(lmis, 32, 64);
+                const int t = pend_t0 + 16 * wave + c16;
+                if (k4 == 0 && t < T) {
+                    const size_t o = (size_t)cb * T + t;
+                    a.scol[o] = qs;
+                    a.nobs[o] = N - (int)nmis;
+                    if (nmis > 0.0) a.ldrow[o] = a.ldfull[cb] - lmis;
+                }
+                nmis = 0.0; lmis = 0.0;
+            } else {
+                if (pend_t0 + 16 * wave + c16 >= T) qs = 0.0; // this lane's row is past the end of the sample (it repeats row T - 1)
+                qs = wave_allsum(qs);
+                if (lane == 0) redS[pend_par * 8 + wave] = qs;
+            }
             qs = 0.0;
             ch = 0;
             const int ckk = read_item(++ci);                  // (published at least two barriers ago)
@@ -400,45 +432,140 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Panels with missing cells at Rp = 32: C_t = C - sum over the MISSING series i of lam_i lam_i' / R_i (packed lower triangle,
+// 528 entries) for every period that has a missing cell.  One workgroup of 16 waves per (replicate, 16 periods): wave w owns
+// period t0 + w and lane l the packed entries l, l + 64, ... (9 per lane).  A 16-bit mask per series says in which of the 16
+// periods it is missing; the series stream through LDS in stages of 32 (W = lam / R and lam, 8 KB each) and a wave adds
+// w_ij lam_ik of the series missing in ITS period -- one ballot per stage finds them, the work is 18 LDS reads and 9 FMAs per
+// lane for one series in ten at 10 % missing.  (Thread = entry with all 16 periods per thread repeats the per-series control
+// flow in 9 waves: 41 ms for config 4 against ~8 ms this way; the dense form -- (16 x N) masks times (N x 528) products on
+// the matrix pipe -- is ~17 x the collapse's MFMA work.)
+constexpr int kCtP = 16;
+constexpr int kCtThreads = 64 * kCtP;
+constexpr int kCtQ = (kW2R * (kW2R + 1) / 2 + 63) / 64;       // packed entries per lane: 9
+__global__ __launch_bounds__(kCtThreads) void ct_miss_wide_kernel(CollapseArgs a, const double* __restrict__ Wall, int ntile16) {
+    constexpr int R = kW2R, NP = R * (R + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, T = a.T;
+    const int npad = ((N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
+    double* Ws = reinterpret_cast<double*>(smem);             // [32][32] W (stored layout: odd series with their halves swapped)
+    double* Ls = Ws + kW2Chunk * R;                           // [32][32] lam
+    unsigned short* mask = reinterpret_cast<unsigned short*>(Ls + kW2Chunk * R);   // [npad]
+    unsigned* anyS = reinterpret_cast<unsigned*>(mask + npad);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.x / ntile16, t0 = ((int)blockIdx.x % ntile16) * kCtP;
+    const double* __restrict__ X = a.panel + (size_t)b * T * N;
+    if (tid == 0) *anyS = 0u;
+    __syncthreads();
+    unsigned many = 0u;
+    for (int i = tid; i < npad; i += kCtThreads) {
+        unsigned m = 0u;
+        if (i < N) {
+#pragma unroll
+            for (int t = 0; t < kCtP; ++t) {
+                const int tt = t0 + t < T ? t0 + t : T - 1;
+                const double x = X[(size_t)tt * N + i];
+                m |= (x != x && t0 + t < T) ? (1u << t) : 0u;
+            }
+        }
+        mask[i] = (unsigned short)m;
+        many |= m;
+    }
+    if (many) atomicOr(anyS, many);
+    __syncthreads();
+    const unsigned tilemask = *anyS;                          // periods of the tile with a missing cell
+    if (tilemask == 0u) return;
+    const bool mine = (tilemask >> wave) & 1u;                // (wave-uniform) this wave's period has a missing cell
+    // packed entries of this lane: v = lane + 64 q -> (j, k), k <= j; offsets into a stage row
+    int oj[kCtQ], ok[kCtQ];
+#pragma unroll
+    for (int q = 0; q < kCtQ; ++q) {
+        int v = lane + 64 * q;
+        v = v < NP ? v : NP - 1;
+        int j = 0;
+        while ((j + 1) * (j + 2) / 2 <= v) ++j;
+        oj[q] = j;
+        ok[q] = v - j * (j + 1) / 2;
+    }
+    double E[kCtQ];
+#pragma unroll
+    for (int q = 0; q < kCtQ; ++q) E[q] = 0.0;
+    const double* __restrict__ Wb = Wall + (size_t)b * N * R;
+    const double* __restrict__ Lb = a.Lam + (size_t)b * N * R;
+    const int nch = npad / kW2Chunk;
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();
+        for (int q = tid; q < kW2Chunk * R; q += kCtThreads) {
+            const int c = ch * kW2Chunk + q / R;
+            Ws[q] = c < N ? Wb[(size_t)ch * kW2Chunk * R + q] : 0.0;
+            Ls[q] = c < N ? Lb[(size_t)ch * kW2Chunk * R + q] : 0.0;
+        }
+        __syncthreads();
+        if (!mine) continue;
+        // the stage's series that are missing in this wave's period: one mask read per lane, one ballot, then only those
+        unsigned long long bits = __ballot(lane < kW2Chunk && ((mask[ch * kW2Chunk + (lane & (kW2Chunk - 1))] >> wave) & 1u) != 0u);
+#pragma unroll 1
+        while (bits != 0ull) {
+            const int ii = __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            const int sw = 16 * (ii & 1);                     // (stage start is a multiple of 32: parity of ii = parity of the series)
+#pragma unroll
+            for (int q = 0; q < kCtQ; ++q) E[q] = fma(Ws[ii * R + (oj[q] ^ sw)], Ls[ii * R + ok[q]], E[q]);
+        }
+    }
+    if (mine) {
+        const int t = t0 + wave;
+#pragma unroll
+        for (int q = 0; q < kCtQ; ++q) {
+            const int v = lane + 64 * q;
+            if (v < NP) a.Ct[((size_t)b * T + t) * NP + v] = a.Cfull[(size_t)b * R * R + oj[q] * R + ok[q]] - E[q];
+        }
+    }
+}
+
 int collapse_wide2_tiles(int T) { return (T + kW2Rows - 1) / kW2Rows; }
 bool collapse_wide2_supported(int Rpad, int N) { return Rpad == 32 && (N % 2) == 0 && N >= 2; }
 // workspace of the Rp = 32 collapse: W [B][N][32] | 1 / R [B][npad] | 8 queue counters
 size_t collapse_wide2_ws_bytes(int B, int N) {
     const size_t npad = (size_t)((N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
-    return ((size_t)B * N * kW2R + (size_t)B * npad) * sizeof(double) + 64;
+    return ((size_t)B * N * kW2R + 2 * (size_t)B * npad) * sizeof(double) + 64;   // W | 1 / R | log R | counters
 }
 
 namespace {
-struct W2Ws { double* W; double* rinv; int* ctr; int npad; };
+struct W2Ws { double* W; double* rinv; double* logr; int* ctr; int npad; };
 W2Ws w2_ws(const CollapseArgs& a, double* ws) {
     W2Ws w;
     w.npad = ((a.N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
     w.W = ws;
     w.rinv = ws + (size_t)a.B * a.N * kW2R;
-    w.ctr = reinterpret_cast<int*>(w.rinv + (size_t)a.B * w.npad);
+    w.logr = w.rinv + (size_t)a.B * w.npad;                   // (the kernel finds it behind the 1 / R table)
+    w.ctr = reinterpret_cast<int*>(w.logr + (size_t)a.B * w.npad);
     return w;
 }
-template <int NX, bool DIAG>
+template <int NX, int MODE>
 hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel<NX, DIAG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel<NX, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((collapse_wide2_kernel<NX, DIAG>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl);
+    hipLaunchKernelGGL((collapse_wide2_kernel<NX, MODE>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl);
     return hipGetLastError();
 }
 template <int NX>
 hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s) {
-    return abl ? launch_w2v<NX, true>(a, w, G, lds, ntile, xcd_map, abl, s) : launch_w2v<NX, false>(a, w, G, lds, ntile, xcd_map, 0, s);
+    if (a.nobs != nullptr) return launch_w2v<NX, 2>(a, w, G, lds, ntile, xcd_map, 0, s);   // panel with missing cells
+    return abl ? launch_w2v<NX, 1>(a, w, G, lds, ntile, xcd_map, abl, s) : launch_w2v<NX, 0>(a, w, G, lds, ntile, xcd_map, 0, s);
 }
 }  // namespace
 
 hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, hipStream_t s) {
     const W2Ws w = w2_ws(a, ws);
-    hipLaunchKernelGGL(wide_prep_kernel, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.npad, w.ctr);
+    hipLaunchKernelGGL(wide_prep_kernel, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr);
     return hipGetLastError();
 }
 
@@ -463,6 +590,18 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int r, int n
         case 3: return launch_w2<3>(a, w, G, lds, ntile, xcd_map, abl, s);
         default: return launch_w2<4>(a, w, G, lds, ntile, xcd_map, abl, s);
     }
+}
+
+// C_t of the periods with missing cells (a.Ct, packed; the other periods keep Cfull): after launch_wide_prep, beside or after
+// the collapse (it reads the panel itself)
+hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, hipStream_t s) {
+    static const int skip = [] { const char* v = getenv("DFM_CT_SKIP"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
+    if (skip) return hipSuccess;
+    const W2Ws w = w2_ws(a, ws);
+    const int ntile16 = (a.T + kCtP - 1) / kCtP;
+    const size_t lds = (size_t)2 * kW2Chunk * kW2R * sizeof(double) + (size_t)w.npad * sizeof(unsigned short) + 16;
+    hipLaunchKernelGGL(ct_miss_wide_kernel, dim3((unsigned)((long long)a.B * ntile16)), dim3(kCtThreads), lds, s, a, w.W, ntile16);
+    return hipGetLastError();
 }
 
 }  // namespace dfm

@@ -50,6 +50,7 @@ KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
     (3, 139, 222, 4, 0.05, 10),   # config 1 shape: 10 EM iterations
     (2, 60, 50, 12, 0.1, 3),      # r padded to 16: global Dmiss accumulators
     (2, 300, 40, 5, 0.1, 3),      # N > 256: two series per lane
+    (2, 300, 60, 20, 0.1, 2),     # Rp = 32 beyond the register tiling, missing cells: collapse_wide2 (missing-cell variant) + C_t kernel
 ])
 def test_em_path_and_params_match_oracle(ctx, B, N, T, r, missing, iters):
     import torch

@@ -76,6 +76,14 @@ def _compare(got, ref, tag=""):
     (2, 224, 40, 8, 0.1),        # widest cross-section of this kernel; (226: collapse_kernel)
     (2, 226, 40, 8, 0.1),
     (3, 64, 3, 8, 0.25),         # T = 3
+    # Rp = 32 beyond collapse_kernel's register tiling (N > 256): collapse_wide2 in its variant for missing cells (NaN -> 0 on the
+    # matrix pipe, per-period s_t / n_t / log det R_t) + ct_miss_wide_kernel (C_t of the periods with a missing cell)
+    (2, 300, 40, 20, 0.1),       # tiles of 16 periods: 2 full + 8; stages of 32 series: 9 full + 12
+    (3, 1000, 130, 20, 0.1),     # config 4's cross-section with missing cells; one tile of 128 periods + 2
+    (2, 258, 33, 17, 0.3),       # just past the tiling's limit, r padded 17 -> 32
+    (2, 400, 20, 32, 0.05),      # every factor column in use
+    (2, 512, 70, 25, 0.002),     # most periods complete (they keep C_full), a few with one missing cell
+    (2, 260, 18, 20, 0.97),      # almost nothing observed
 ])
 def test_pass_matches_oracle(ctx, B, N, T, r, missing):
     panel, st = _batch(B, N, T, r, missing)
@@ -171,13 +179,20 @@ BALANCED_SHAPES = [
     (2, 300, 37, 20),          # wide kernel, r padded to 32, T not a multiple of the 16-period tile
     (3, 31, 41, 3),            # odd N: wide kernel (8-byte loads)
     (1, 1000, 2000, 20),       # BASELINE config 4's shape (N = 1000, T = 2000, r = 20), one replicate
-    # collapse_wide2 (Rp = 32, even N): stages of 64 series / tiles of 64 periods with partial tails; cov_grid_kernel<32>
-    (2, 66, 65, 17),           # one series past a stage, one period past a tile, r padded 17 -> 32
-    (3, 130, 70, 20),          # 2 series past two stages (a partial MFMA step: 2 of 4 series)
-    (2, 64, 64, 32),           # exact stage / tile, every factor column used
-    (2, 34, 3, 24),            # a tile of 3 periods, fewer series than a stage
-    (2, 1280, 40, 20),         # the widest cross-section of the LDS 1 / R table
-    (2, 1400, 40, 20),         # beyond it: collapse_wide_kernel (round-1 path) keeps working
+    # collapse_wide2 (Rp = 32, even N): stages of 32 series / tiles of 128 periods with partial tails, 16x16x4 + NX 4x4x4
+    # MFMAs for r = 17..28, two 16x16x4 for r = 29..32; cov_grid_kernel<32>; meanscan32_kernel (128 chunks of L steps)
+    (2, 66, 65, 17),           # 2 series past two stages, r padded 17 -> 32 (NX = 1)
+    (3, 130, 70, 20),          # 2 series past four stages (a partial MFMA step: 2 of 4 series)
+    (2, 64, 64, 32),           # exact stages, every factor column used (NX = 4)
+    (2, 34, 3, 24),            # a tile of 3 periods, NX = 2, scan chunks of one step (most of them empty)
+    (2, 1280, 40, 20),
+    (2, 1400, 40, 20),
+    (17, 96, 130, 21),         # XCD-ordered tile queues with B not a multiple of 8; one full tile + 2 periods; NX = 2
+    (9, 250, 300, 25),         # one flat tile queue (B < 16); NX = 3; three tiles; scan chunks of 4 steps
+    (3, 62, 129, 29),          # NX = 4 with padding columns; stages of 32 + 30 series
+    (2, 40, 5, 18),            # T far below the 128 chunks of the scan
+    (2, 101, 45, 20),          # odd N: collapse_wide_kernel (8-byte loads) feeding the matrix-pipe scan
+    (20, 34, 260, 32),         # uneven replicate counts per XCD queue (8 + 8 + 4), r = 32
     # cov_grid_kernel<16> (Rp = 16: 256 threads per replicate)
     (3, 200, 120, 12), (2, 48, 33, 9), (2, 64, 500, 16),
 ]
@@ -337,6 +352,8 @@ def _slow_riccati(B, N, T, r, rho, Rscale, seed=11):
     (200, 500, 8, 0.995, 5e3),     # headline shape, MFMA collapse
     (30, 500, 3, 0.99, 50.0),      # E of a few hundred: long transient + short steady stretch
     (16, 120, 2, 0.9999, 1e4),     # T shorter than the convergence time
+    (40, 300, 20, 0.995, 2e2),     # Rp = 32: a long transient on wave 0 of meanscan32_kernel, then its chunked scans
+    (40, 150, 18, 0.9999, 1e4),    # Rp = 32 with no steady stretch at all
 ])
 def test_slow_riccati_on_the_balanced_path(ctx, N, T, r, rho, Rscale):
     panel, st = _slow_riccati(3, N, T, r, rho, Rscale)
