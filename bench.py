@@ -77,15 +77,17 @@ def source_hash():
 def measured_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes (scripts/gpu_profile.sh -> profiles/r02/
     pmc_traffic.json), ONLY when that file was produced by exactly this source tree on this workload; else None."""
-    path = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-        if d.get("_source_hash") != source_hash() or d.get("_workload") != workload_key:
-            return None
-        return d.get(kernel, {}).get("hbm_bytes_per_launch")
-    except Exception:  # noqa: BLE001
-        return None
+    for name in ("pmc_traffic.json", "pmc_traffic_c4.json"):      # headline workload; BASELINE config 4
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02", name)) as fh:
+                d = json.load(fh)
+            if d.get("_source_hash") == source_hash() and d.get("_workload") == workload_key:
+                for k in (kernel, kernel.replace("collapse_wide_kernel", "collapse_wide2_kernel")):   # (profile scope -> rocprof name)
+                    if k in d:
+                        return d[k].get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            pass
+    return None
 
 
 def cpu_baseline(panel_host, params_host, target_seconds=12.0):

@@ -54,6 +54,43 @@ def test_random_balanced_pass(ctx, B, N, T, r):
     assert np.abs(P.cpu().numpy() - Po).max() <= RTOL * np.abs(Po).max()
 
 
+def _shapes32(seed, n):
+    """r = 17 .. 32 (state padded to 32): the streaming collapse of config 4 (persistent workgroups, tiles of 128 periods,
+    stages of 32 series, 1 .. 4 column groups past the first 16), the matrix-pipe scan (128 chunks), and -- with missing
+    cells -- their variants for NaN panels plus the C_t kernel (N > 256) or collapse_kernel (N <= 256)."""
+    g = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        r = int(g.integers(17, 33))
+        N = int(g.integers(r + 2, 700))
+        if g.random() < 0.8:
+            N += N & 1                                   # mostly even (LDS-DMA kernels), some odd (8-byte-load kernels)
+        T = int(g.integers(3, 330))
+        B = int(g.integers(1, 20))
+        miss = float(g.choice([0.0, 0.0, 0.05, 0.3]))
+        out.append((B, N, T, r, miss))
+    return out
+
+
+@pytest.mark.parametrize("B,N,T,r,miss", _shapes32(32, 16))
+def test_random_wide_state_pass(ctx, B, N, T, r, miss):
+    import torch
+    if miss > 0 and (N & 1) and N > 256:
+        pytest.skip("odd N beyond the register tiling with missing cells: not covered (DESIGN.md known limits)")
+    reps = [ko.synth_replicate(b, N, T, r, seed=ko.SEED0 + 13 * N + T, missing=miss) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    st = {k: np.stack([p[k] for _, p in reps]) for k in reps[0][1]}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_batch(t(panel), t(st["Lam"]), t(st["R"]), t(st["A"]), t(st["Q"]), t(st["mu0"]), t(st["P0"]),
+                                 may_have_missing=miss > 0)
+    torch.cuda.synchronize()
+    fo, Po, llo = co.ks_pass_batch(panel, st["Lam"], st["R"], st["A"], st["Q"], st["mu0"], st["P0"])
+    np.testing.assert_allclose(ll.cpu().numpy(), llo, rtol=RTOL)
+    assert np.abs(f.cpu().numpy() - fo).max() <= RTOL * np.abs(fo).max()
+    assert np.abs(P.cpu().numpy() - Po).max() <= RTOL * np.abs(Po).max()
+
+
 @pytest.mark.parametrize("B,N,T,r", _shapes(7, 10))
 def test_random_balanced_em(ctx, B, N, T, r):
     import torch
