@@ -288,48 +288,56 @@ __device__ __forceinline__ void jacobi_lds(double* H, double* W, double* ev, int
     }
 }
 
-// The same cyclic Jacobi by ONE WAVE with an element of H and of W per lane (lane = R i + j, lanes >= R R idle): a rotation
-// is 6 cross-lane fetches and a few FMAs per lane instead of ~100 dependent LDS read-modify-writes of one thread (the
-// single-thread version took 3.5 of pca_kernel's 5.7 ms per 1024 replicates).  Same rotations in the same order, same
-// stopping rule and sorting.  Called by wave 0 (all 64 lanes); H, W, ev in LDS.
+// Jacobi eigen-decomposition by ONE WAVE with an element of H and of W per lane (lane = R i + j, lanes >= R R idle): cross-lane
+// fetches and a few FMAs per lane instead of ~100 dependent LDS read-modify-writes of one thread (the single-thread version
+// took 3.5 of pca_kernel's 5.7 ms per 1024 replicates).  Same rotation formula, stopping rule and sorting as jacobi_lds; the
+// ORDER of the rotations differs (parallel ordering, below) -- the decomposition it converges to is the same up to the sign
+// and order conventions the caller fixes afterwards.  Called by wave 0 (all 64 lanes); H, W, ev in LDS.
 template <int R>
 __device__ __forceinline__ void jacobi_wave(double* H, double* W, double* ev, int r, int lane) {
-    const int i = lane / R, j = lane % R;
+    const int le = lane < R * R ? lane : 0;                     // (idle lanes shadow lane 0: valid indices, results unused)
+    const int i = le / R, j = le % R;
     const bool in = lane < R * R && i < r && j < r;
     double h = in ? H[i * R + j] : 0.0;
     double w = (lane < R * R && i == j) ? 1.0 : 0.0;
+    // PARALLEL ordering: a round rotates R / 2 disjoint index pairs at once (round-robin schedule: index R - 1 stays, the
+    // others move round a circle of R - 1), R - 1 rounds per sweep; every lane computes the rotation of its column's pair and
+    // of its row's pair itself, from the H of the start of the round (disjoint pairs: J'HJ with J the product of the R / 2
+    // rotations).  The cyclic one-pair-at-a-time form was a chain of 28 x (9 dependent ds_bpermute + a divide and two square
+    // roots) per sweep on one wave while seven wait: 0.24 ms of the 0.75 ms a replicate's start takes.
+    constexpr int RM = R - 1;
+    auto partner = [&](int x, int t) { return x == RM ? t : (x == t ? RM : (2 * t - x + 2 * RM) % RM); };
+    auto rot = [&](int p, int q, double& c, double& sn) {   // rotation of pair (p < q) from the current h (lane-dependent p, q)
+        const int pc = p < R ? p : 0, qc = q < R ? q : 0;
+        const double hpq = __shfl(h, pc * R + qc, kWave);
+        const double hpp = __shfl(h, pc * R + pc, kWave), hqq = __shfl(h, qc * R + qc, kWave);
+        const bool act = q < r && hpq != 0.0;
+        const double theta = (hqq - hpp) / (2.0 * (act ? hpq : 1.0));
+        const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cc = 1.0 / sqrt(tt * tt + 1.0);
+        c = act ? cc : 1.0;
+        sn = act ? tt * cc : 0.0;
+    };
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = (in && i != j) ? h * h : 0.0, dia = (in && i == j) ? h * h : 0.0;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) { off += __shfl_xor(off, o, kWave); dia += __shfl_xor(dia, o, kWave); }
         if (off <= 1e-32 * dia) break;
-        for (int p = 0; p < r - 1; ++p)
-            for (int q = p + 1; q < r; ++q) {
-                const double hpq = __shfl(h, p * R + q, kWave);
-                if (hpq == 0.0) continue;                       // (wave-uniform)
-                const double hpp = __shfl(h, p * R + p, kWave), hqq = __shfl(h, q * R + q, kWave);
-                const double theta = (hqq - hpp) / (2.0 * hpq);
-                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
-                // H <- H J : columns p and q of every row
-                {
-                    const double hip = __shfl(h, i * R + p, kWave), hiq = __shfl(h, i * R + q, kWave);
-                    if (j == p) h = c * hip - sn * hiq;
-                    else if (j == q) h = sn * hip + c * hiq;
-                }
-                // H <- J' H : rows p and q
-                {
-                    const double hpj = __shfl(h, p * R + j, kWave), hqj = __shfl(h, q * R + j, kWave);
-                    if (i == p) h = c * hpj - sn * hqj;
-                    else if (i == q) h = sn * hpj + c * hqj;
-                }
-                // W <- W J
-                {
-                    const double wip = __shfl(w, i * R + p, kWave), wiq = __shfl(w, i * R + q, kWave);
-                    if (j == p) w = c * wip - sn * wiq;
-                    else if (j == q) w = sn * wip + c * wiq;
-                }
-            }
+        for (int t = 0; t < (RM > 0 ? RM : 1); ++t) {
+            const int pj = partner(j, t), pi = partner(i, t);
+            double cc, sc, cr, sr;
+            rot(j < pj ? j : pj, j < pj ? pj : j, cc, sc);      // the pair of this lane's column
+            rot(i < pi ? i : pi, i < pi ? pi : i, cr, sr);      // ... and of its row
+            // H <- H J : columns p and q of every row (own = h_ip for the lower index: c own - s partner; else s partner + c own)
+            const double hc = __shfl(h, i * R + pj, kWave);
+            h = j < pj ? cc * h - sc * hc : sc * hc + cc * h;
+            // H <- J' H : rows p and q
+            const double hr = __shfl(h, pi * R + j, kWave);
+            h = i < pi ? cr * h - sr * hr : sr * hr + cr * h;
+            // W <- W J
+            const double wc = __shfl(w, i * R + pj, kWave);
+            w = j < pj ? cc * w - sc * wc : sc * wc + cc * w;
+        }
     }
     if (lane < R * R) { W[lane] = w; if (i == j) ev[i] = h; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -455,14 +463,26 @@ __device__ __forceinline__ bool pca_iterate_lds(const PcaArgs& a, const double* 
     double best = 1e300;
     int stall = 0;
     bool converged = false;
-    for (int it = 0; it < a.max_iter; ++it) {
-        // Y = S V
+    auto apply_S_lds = [&]() {                                  // Ys = S Vs
         {
             double acc[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) acc[k] = 0.0;
             if (row) {
                 int j = j0;
+                // (S comes from L2 every iteration -- 320 KB per replicate do not fit LDS: the batches keep 20, then 8 loads of a
+                // column in flight; with 8 only, the ten dependent round trips were most of the 60 us an iteration took)
+                for (; j + 20 <= j1; j += 20) {
+                    double sv[20];
+#pragma unroll
+                    for (int u = 0; u < 20; ++u) sv[u] = S[(size_t)(j + u) * N + i];
+#pragma unroll
+                    for (int u = 0; u < 20; ++u) {
+                        const double* vr = Vs + (size_t)(j + u) * R;
+#pragma unroll
+                        for (int k = 0; k < R; ++k) acc[k] = fma(sv[u], vr[k], acc[k]);
+                    }
+                }
                 for (; j + 8 <= j1; j += 8) {
                     double sv[8];
 #pragma unroll
@@ -492,6 +512,9 @@ __device__ __forceinline__ bool pca_iterate_lds(const PcaArgs& a, const double* 
             Ys[e] = t;
         }
         __syncthreads();
+    };
+    for (int it = 0; it < a.max_iter; ++it) {
+        apply_S_lds();
         grams(true);                                            // sG = Y'Y, sH = V'Y = V'S V
         // residual ||Y - V H||_F / ||Y||_F
         double pr[2] = {0.0, 0.0};
@@ -519,6 +542,10 @@ __device__ __forceinline__ bool pca_iterate_lds(const PcaArgs& a, const double* 
         if (rel < 0.5 * best) { best = rel; stall = 0; }
         else if (++stall >= 8 && best < 1e-10) { converged = true; break; }
     }
+    // H = V'S V of the FINAL basis for the Rayleigh-Ritz step of the caller, still from LDS (the caller's generic product
+    // reads V from global memory: 0.31 ms per replicate, as long as the whole iteration)
+    apply_S_lds();
+    grams(true);
     for (int e = tid; e < N * R; e += NT) V[e] = Vs[e];
     __syncthreads();
     return converged;
@@ -615,8 +642,10 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
     // the basis is NOT the reference's svd-based pca_score (dfm_functions.ipynb:179-183) -- say so instead of returning it
     if (!converged && tid == 0 && a.status) atomicOr(a.status, 2);
     // Rayleigh-Ritz: H = V'SV, H = W Theta W', V <- V W (descending), sign rule of the oracle
-    apply_S();
-    tall_gram<R, NT>(sH, V, Y, N, r, sred);
+    if constexpr (!(NT == kPcaFastThreads && R <= 8)) {       // (the fast path left H in sH)
+        apply_S();
+        tall_gram<R, NT>(sH, V, Y, N, r, sred);
+    }
     if (tid == 0) {
         for (int i = 0; i < r; ++i)
             for (int j = 0; j < i; ++j) { const double h = 0.5 * (sH[i * R + j] + sH[j * R + i]); sH[i * R + j] = h; sH[j * R + i] = h; }
