@@ -103,6 +103,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     // balanced fast path (fastpath.hip); (size_t)-1 when the plan is for the general path
     size_t f_tab, f_E, f_stead, f_xi0, f_PT, f_llc, f_fill, f_PsInf, f_ssum;
     size_t ms_ws = (size_t)-1; int ms_wpr = 0;   // mstep_mfma partial sums (EM on the fast path)
+    size_t mw_ws = (size_t)-1;                     // mstep_wide: Sxf, Sxx of the Rp = 32 loadings step (EM on the fast path)
     size_t Wwide = (size_t)-1;                     // W = lam / R of the Rp = 32 collapse (collapse_wide2.hip)
     bool fast;
     // covariance-form recursion (DFM_F_SINGULAR_Q) and companion states (dfm_*_varp_*): see RecursionArgs
@@ -187,6 +188,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
             p.ms_wpr = w;
             p.ms_ws = take(off, mstep_mfma_workspace(B, N, Rp, w));
         }
+        if (fast && mstep_wide_supported(Rp, N)) p.mw_ws = take(off, mstep_wide_workspace(B, N));
     }
     p.total = off;
     return p;
@@ -567,6 +569,11 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
     if (p.fast && p.ms_ws != (size_t)-1 && !h->no_mstep_mfma) {   // balanced panel: second panel read on the matrix pipe
         ProfScope ps(h, K_MSTEP_MFMA);
         HIP_TRY(h, launch_mstep_mfma(Rp, ma, p.ms_wpr, at<double>(h, p.ms_ws), h->stream));
+        return 0;
+    }
+    if (p.fast && p.mw_ws != (size_t)-1 && !h->no_mstep_mfma) {   // ... Rp = 32 (config 4): the same on the streaming machinery of its collapse
+        ProfScope ps(h, K_MSTEP_MFMA);
+        HIP_TRY(h, launch_mstep_wide(ma, at<double>(h, p.mw_ws), p.r, h->num_cu, h->stream));
         return 0;
     }
     if (ma.Dmiss)

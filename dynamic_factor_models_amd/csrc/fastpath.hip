@@ -280,19 +280,24 @@ __global__ __launch_bounds__(scan_threads(R)) void meanscan_kernel(FastArgs a) {
 // S11, S11^-1 the loadings step needs, and the per-replicate EM bookkeeping -- exactly the epilogue of
 // recursion_kernel (recursion.hip), which does the same for panels with missing cells.
 // One lane group of R lanes per replicate (lane i = row i), 64 / R replicates per wave.
+__host__ __device__ constexpr int em_update_waves(int R) { return R >= 16 ? 4 : 1; }
 template <int R>
-__global__ __launch_bounds__(64) void em_update_kernel(EmUpdArgs a) {
-    // one WAVE per replicate: lane (i = l % R, slice = l / R) sums row i of f_t f_t' and f_t f_{t-1}' over the
-    // periods t = slice (mod 64 / R) -- independent loads, 64 / R times fewer dependent steps than one lane group
-    // per replicate -- then the slices are folded with xor-shuffles and every slice runs the (tiny) epilogue
-    // redundantly on its own LDS region; slice 0 writes.
+__global__ __launch_bounds__(64 * em_update_waves(R)) void em_update_kernel(EmUpdArgs a) {
+    // NW waves per replicate (1 for Rp <= 8; 4 for the wide states, where one wave walked T / 2 periods of 64 dependent FMAs per
+    // lane: 0.79 ms per EM iteration of config 4): lane (i = l % R, slice = NW-wave x l / R) sums row i of f_t f_t' and
+    // f_t f_{t-1}' over the periods t = slice (mod NW 64 / R) -- independent loads -- then the slices are folded with
+    // xor-shuffles, the waves through LDS (every wave adds the NW partial sums in the same order), and every slice runs the
+    // (tiny) epilogue redundantly on its own LDS region; slice 0 of wave 0 writes.
     constexpr int GPW = 64 / R;
-    __shared__ double Xs[GPW * (R * R + 2 * R)];
-    const int lane = threadIdx.x;
+    constexpr int NW = em_update_waves(R);
+    extern __shared__ __attribute__((aligned(16))) double ems[];
+    double* Xs = ems;                                        // [NW * GPW][R * R + 2 R]
+    double* red = ems + NW * GPW * (R * R + 2 * R);          // NW > 1: [NW][2][R * R]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / R, i = lane % R;
     const int b = blockIdx.x;
-    const bool live = (g == 0);
-    double* X = Xs + g * (R * R + 2 * R);
+    const bool live = (g == 0 && wave == 0);
+    double* X = Xs + (wave * GPW + g) * (R * R + 2 * R);
     const int T = a.T;
     const size_t o = (size_t)b * R * R + (size_t)i * R;
     const double* __restrict__ f = a.fsm + (size_t)b * T * R;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(64) void em_update_kernel(EmUpdArgs a) {
 #pragma unroll
     for (int j = 0; j < R; ++j) { M11[j] = 0.0; M10[j] = 0.0; }
 #pragma unroll 2
-    for (int t = g; t < T; t += GPW) {
+    for (int t = wave * GPW + g; t < T; t += NW * GPW) {
         double cur[R], prev[R];
         const double* pp = (t == 0) ? f0 : f + (size_t)(t - 1) * R;
 #pragma unroll
@@ -320,6 +325,20 @@ __global__ __launch_bounds__(64) void em_update_kernel(EmUpdArgs a) {
         for (int j = 0; j < R; ++j) {
             M11[j] += __shfl_xor(M11[j], off, kWave);
             M10[j] += __shfl_xor(M10[j], off, kWave);
+        }
+    }
+    if constexpr (NW > 1) {
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) { red[(wave * 2 + 0) * R * R + i * R + j] = M11[j]; red[(wave * 2 + 1) * R * R + i * R + j] = M10[j]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            double s1 = 0.0, s0 = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { s1 += red[(w * 2 + 0) * R * R + i * R + j]; s0 += red[(w * 2 + 1) * R * R + i * R + j]; }
+            M11[j] = s1; M10[j] = s0;
         }
     }
     const double f0i = f0[i];
@@ -397,7 +416,16 @@ __global__ __launch_bounds__(64) void em_update_kernel(EmUpdArgs a) {
 
 template <int R>
 static hipError_t launch_em_update_r(const EmUpdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((em_update_kernel<R>), dim3(a.B), dim3(64), 0, s, a);
+    constexpr int NW = em_update_waves(R), GPW = 64 / R;
+    const size_t lds = ((size_t)NW * GPW * (R * R + 2 * R) + (NW > 1 ? (size_t)NW * 2 * R * R : 0)) * sizeof(double);
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&em_update_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((em_update_kernel<R>), dim3(a.B), dim3(64 * NW), lds, s, a);
     return hipGetLastError();
 }
 hipError_t launch_em_update(int Rpad, const EmUpdArgs& a, hipStream_t s) {

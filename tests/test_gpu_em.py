@@ -50,6 +50,9 @@ KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
     (3, 139, 222, 4, 0.05, 10),   # config 1 shape: 10 EM iterations
     (2, 60, 50, 12, 0.1, 3),      # r padded to 16: global Dmiss accumulators
     (2, 300, 40, 5, 0.1, 3),      # N > 256: two series per lane
+    (3, 130, 70, 20, 0.0, 3),     # balanced, Rp = 32: mstep_wide (2 series blocks, the second partial; 3 stages of 32 periods, the last of 6)
+    (17, 66, 90, 25, 0.0, 2),     # ... XCD-ordered item queues with B not a multiple of 8, 3 column groups past the first 16
+    (2, 260, 110, 32, 0.0, 2),    # ... every factor column in use (two 16-wide tiles)
     (2, 300, 60, 20, 0.1, 2),     # Rp = 32 beyond the register tiling, missing cells: collapse_wide2 (missing-cell variant) + C_t kernel
 ])
 def test_em_path_and_params_match_oracle(ctx, B, N, T, r, missing, iters):
