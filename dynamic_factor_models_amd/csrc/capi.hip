@@ -160,10 +160,10 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.f_fill = take(off, (size_t)B * 2 * sizeof(int));
         p.f_PsInf = take(off, B * rr * d);
         p.f_ssum = take(off, (size_t)B * kSsumSlots * d);
-        if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N));
+        if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, Rp));
     } else {
         p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
-        if (p.Rc == 0 && Rp == 32 && N > collapse_max_n(32) && collapse_wide2_supported(32, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N));
+        if (p.Rc == 0 && Rp == 32 && N > collapse_max_n(32) && collapse_wide2_supported(32, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, 32));
     }
     p.wtab = take(off, (size_t)B * T * Rp * d);
     p.status = take(off, 256);
@@ -329,7 +329,9 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     // collapse kernel of the balanced path: contraction on the matrix pipe where the shape allows it
     // (collapse_mfma.hip), else the VALU kernel (collapse_dma.hip); DFM_COLLAPSE_VARIANT < 200 forces the latter
     // shapes outside the register tilings (or DFM_COLLAPSE_VARIANT=198): the wide kernel
-    const bool use_wide = !collapse_dma_supported(p.Rp, N) || h->collapse_variant == 198;
+    // Rp = 16 | 32 with an even N: the streaming collapse of collapse_wide2.hip (Rp = 16 used to take the VALU kernel: 1.4-2.1 TB/s)
+    const bool prefer_wide2 = !h->wide_old && h->collapse_variant == 0 && p.Wwide != (size_t)-1 && collapse_wide2_supported(p.Rp, N);
+    const bool use_wide = prefer_wide2 || !collapse_dma_supported(p.Rp, N) || h->collapse_variant == 198;
     const bool use_mfma = !use_wide && collapse_mfma_supported(p.Rp, N) && (h->collapse_variant == 0 || h->collapse_variant >= 200);
     const int cvariant = use_mfma ? (h->collapse_variant >= 200 ? h->collapse_variant : 200)
                                   : (h->collapse_variant == 199 ? 0 : h->collapse_variant);   // 199: the VALU kernel's default
@@ -338,11 +340,11 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     double* Wwide = use_wide2 ? at<double>(h, p.Wwide) : nullptr;
     // Gram matrix (+ W for the Rp = 32 collapse) and the streaming collapse of this shape, on stream `st`
     auto run_gram = [&](hipStream_t st) -> hipError_t {
-        if (use_wide2) return launch_wide_prep(ca, Wwide, st);
+        if (use_wide2) return launch_wide_prep(ca, Wwide, p.Rp, st);
         return gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, st) : launch_gram_wide(p.Rp, ca, st);
     };
     auto run_collapse = [&](const CollapseArgs& c, hipStream_t st) -> hipError_t {
-        if (use_wide2) return launch_collapse_wide2(c, Wwide, p.r, h->num_cu, st);
+        if (use_wide2) return launch_collapse_wide2(c, Wwide, p.Rp, p.r, h->num_cu, st);
         return use_wide ? launch_collapse_wide(p.Rp, c, st) : launch_collapse_dma(p.Rp, c, st, cvariant);
     };
     // MFMA collapse: as many period segments per replicate as the chip has resident wave slots for this batch
@@ -508,8 +510,8 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
         if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream));
         else if (p.Wwide != (size_t)-1 && N > collapse_max_n(Rcol)) {   // Rp = 32 beyond the register tiling (config 4 with missing cells)
             double* W = at<double>(h, p.Wwide);
-            HIP_TRY(h, launch_wide_prep(ca, W, h->stream));
-            HIP_TRY(h, launch_collapse_wide2(ca, W, p.r, h->num_cu, h->stream));
+            HIP_TRY(h, launch_wide_prep(ca, W, 32, h->stream));
+            HIP_TRY(h, launch_collapse_wide2(ca, W, 32, p.r, h->num_cu, h->stream));
             HIP_TRY(h, launch_ct_miss_wide(ca, W, h->stream));
         } else HIP_TRY(h, launch_collapse(Rcol, ca, h->stream));
     }

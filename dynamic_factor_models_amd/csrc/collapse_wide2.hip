@@ -53,7 +53,7 @@ __device__ __forceinline__ void dma16w(const void* gsrc, unsigned lds_dst) {
 }
 __device__ __forceinline__ void wait_all_w() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-constexpr int kW2R = 32;          // padded factors
+constexpr int kW2R = 32;          // padded factors (widest; the kernels are templates in R = 16 | 32, the stage layout is R = 32's)
 #ifndef DFM_W2_ROWS
 #define DFM_W2_ROWS 128
 #endif
@@ -75,8 +75,11 @@ constexpr unsigned kW2WB = kW2Chunk * kW2R * 8;                    // 8192: W bl
 constexpr unsigned kW2StageB = kW2PanelB + kW2WB + 2 * kW2Chunk * 8;   // + 1 / R and (panels with missing cells) log R of the stage's series
 constexpr int kW2Compute = kW2Rows / 16;    // consumer waves (16 periods of the tile each)
 constexpr int kW2Producers = kW2Rows / 32;  // LDS-DMA waves (32 rows + their share of W each); one more wave is the scheduler
-constexpr int kW2WPieces = 8 / kW2Producers;                       // 1-KB DMAs of the W block per producer
-constexpr int kW2PerStage = 8 + kW2WPieces;                        // DMAs per producer and stage (+ 1 for producer 0: 1 / R)
+template <int R> struct W2Geo {
+    static constexpr unsigned WB = kW2Chunk * R * 8;               // bytes of the stage's W block: 8 KB (R = 32), 4 KB (R = 16)
+    static constexpr int WPieces = (int)(WB / 1024) / kW2Producers;   // 1-KB DMAs of it per producer
+    static constexpr int PerStage = 8 + WPieces;                   // DMAs per producer and stage (+ 1 for producer 0: 1 / R)
+};
 constexpr int kW2Threads = 64 * (kW2Compute + kW2Producers + 1);
 constexpr int kW2Ring = 8;        // published items (ring)
 
@@ -84,8 +87,8 @@ constexpr int kW2Ring = 8;        // published items (ring)
 
 // ------------------------------------------------------------------------------------------------------------------
 // W = lam / R, C = Lam' W, sum log R.  One workgroup of 4 waves per replicate.
+template <int R>
 __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, double* logr_out, int npad, int* ctr) {
-    constexpr int R = kW2R;
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
     // a step reads 4 consecutive series x 16 columns, and two series 256 bytes apart would meet on the same banks
     for (int e = tid; e < N * R; e += 256) {
         const int c = e / R;
-        W[e ^ (16 * (c & 1))] = L[e] / Rv[c];
+        W[R == 32 ? (e ^ (16 * (c & 1))) : e] = L[e] / Rv[c];
     }
     for (int c = tid; c < npad; c += 256) {                   // (0 past N: padding of the last stage)
         rinv_out[(size_t)b * npad + c] = c < N ? 1.0 / Rv[c] : 0.0;
@@ -110,7 +113,8 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
     __syncthreads();                                         // W of this replicate is complete (and visible to this workgroup)
     if (tid == 0) a.ldfull[b] = red[0] + red[1] + red[2] + red[3];
     // tile (it, jt) of C: C[16 it + i][16 jt + j] = sum_c Lam[c][16 it + i] W[c][16 jt + j]
-    const int it = wave >> 1, jt = wave & 1;
+    if (R == 16 && wave > 0) return;                         // (R = 16: one 16 x 16 tile)
+    const int it = R == 32 ? wave >> 1 : 0, jt = R == 32 ? wave & 1 : 0;
     const int k4 = lane >> 4, c16 = lane & 15;
     w2_v4 acc = {0.0, 0.0, 0.0, 0.0};
     const int steps = (N + 3) / 4;
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
             const int c = 4 * (s0 + u) + k4;
             const int cc = c < N ? c : N - 1;
             av[u] = L[(size_t)cc * R + 16 * it + c16];
-            bv[u] = W[(size_t)cc * R + ((16 * jt + c16) ^ (16 * (cc & 1)))];
+            bv[u] = W[(size_t)cc * R + (R == 32 ? ((16 * jt + c16) ^ (16 * (cc & 1))) : c16)];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -142,12 +146,13 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
 // MODE 0: balanced panel (sum_t s_t per tile -> scol[b][tile]); 1: the same with the DFM_W2_ABL diagnostics compiled in;
 // 2: panel with missing cells -- NaN operands count as 0 (b_t, s_t over the observed cells), per period s_t -> scol[b][t],
 // n_t -> nobs[b][t] and, where cells are missing, log det R_t -> ldrow[b][t]; C_t of those periods: ct_miss_wide_kernel.
-template <int NX, int MODE>
+template <int R, int NX, int MODE>
 __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall,
                                                                    const double* __restrict__ rinvAll, int npad, int* ctr,
                                                                    int ntile, int xcd_map, int abl_) {
     constexpr bool DIAG = MODE == 1, MISS = MODE == 2;
-    constexpr int R = kW2R;
+    static_assert((R == 32 && NX >= 1 && NX <= 4) || (R == 16 && NX == 0), "R = 32: 1..4 column groups past the first 16; R = 16: none");
+    using GEO = W2Geo<R>;
     constexpr int N4 = NX < 4 ? NX : 0;                       // 4x4x4 groups
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int abl = DIAG ? abl_ : 0;                          // DFM_W2_ABL (diagnostics, wrong results): compiled out of the product kernel
@@ -230,9 +235,9 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
                 if (act) dma16w(src, dst);
             }
 #pragma unroll
-            for (int u = 0; u < kW2WPieces; ++u) {   // past the end of W -- the last, partial stage -- the lanes re-read its last 16 bytes; those rows only ever meet a zeroed A
-                const unsigned o = (unsigned)ch * kW2WB + (unsigned)(kW2WPieces * pw + u) * 1024u + 16u * lane;
-                const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + (unsigned)(kW2WPieces * pw + u) * 1024u);
+            for (int u = 0; u < GEO::WPieces; ++u) {   // past the end of W -- the last, partial stage -- the lanes re-read its last 16 bytes; those rows only ever meet a zeroed A
+                const unsigned o = (unsigned)ch * GEO::WB + (unsigned)(GEO::WPieces * pw + u) * 1024u + 16u * lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + (unsigned)(GEO::WPieces * pw + u) * 1024u);
                 dma16w(Wb + (o < wbytes ? o : wbytes - 16u), dst);
             }
             if (pw == 0) {                  // 1 / R of the stage's 32 series (the table is padded with zeros to a whole stage)
@@ -263,8 +268,8 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
         int bsel = 0;
         while (more) {
             if (!v1) wait_all_w();
-            else if (pw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2PerStage + (MISS ? 2 : 1)) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kW2PerStage) : "memory");
+            else if (pw == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GEO::PerStage + (MISS ? 2 : 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GEO::PerStage) : "memory");
             __syncthreads();                                  // stage q has landed; every consumer is done with stage q - 1
             const bool v2 = ikk >= 0;                         // stage q + 2 exists: into the buffer stage q - 1 used
             if (v2) issue_next(bsel == 0 ? 2 : bsel - 1);
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
     const unsigned a_lo = arow + arot;                        // steps 0 .. 5: + 32 s
     const unsigned a_6 = arow + ((arot + 192u) & 255u), a_7 = arow + ((arot + 224u) & 255u);
     // B operands: W[series 4 s + k4][f], odd series with their 16-column halves swapped
-    const unsigned bsw = 16u * (k4 & 1);
+    const unsigned bsw = R == 32 ? 16u * (k4 & 1) : 0u;       // (R = 16: rows of 128 bytes, slot 16 k4 + c16 -- no swizzle needed)
     const unsigned b16 = (unsigned)k4 * (R * 8u) + (((unsigned)c16) ^ bsw) * 8u;             // f = c16
     const unsigned b16b = (unsigned)k4 * (R * 8u) + ((16u + c16) ^ bsw) * 8u;                // f = 16 + c16 (NX == 4)
     const unsigned b4 = (unsigned)k4 * (R * 8u) + ((16u + (lane & 3)) ^ bsw) * 8u;           // f = 16 + q (+ 4 x)
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
                 if (NX == 4) out[(size_t)row * R + 16 + c16] = paccb[v];
             }
         }
-        if (NX < 4) {                                         // 4x4x4: block (l / 4) % 4, D[row = l / 16][col = l % 4] -> period 4 blk + l / 16
+        if (R == 32 && NX < 4) {                              // 4x4x4: block (l / 4) % 4, D[row = l / 16][col = l % 4] -> period 4 blk + l / 16
             const int row = 4 * ((lane >> 2) & 3) + k4;
             if (pend_t0 + 16 * wave + row < T) {
 #pragma unroll
@@ -526,52 +531,53 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide_kernel(CollapseArgs a
 }
 
 int collapse_wide2_tiles(int T) { return (T + kW2Rows - 1) / kW2Rows; }
-bool collapse_wide2_supported(int Rpad, int N) { return Rpad == 32 && (N % 2) == 0 && N >= 2; }
-// workspace of the Rp = 32 collapse: W [B][N][32] | 1 / R [B][npad] | 8 queue counters
-size_t collapse_wide2_ws_bytes(int B, int N) {
+bool collapse_wide2_supported(int Rpad, int N) { return (Rpad == 32 || Rpad == 16) && (N % 2) == 0 && N >= 2; }
+// workspace of the collapse: W [B][N][Rp] | 1 / R [B][npad] | log R [B][npad] | 8 queue counters
+size_t collapse_wide2_ws_bytes(int B, int N, int Rpad) {
     const size_t npad = (size_t)((N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
-    return ((size_t)B * N * kW2R + 2 * (size_t)B * npad) * sizeof(double) + 64;   // W | 1 / R | log R | counters
+    return ((size_t)B * N * Rpad + 2 * (size_t)B * npad) * sizeof(double) + 64;
 }
 
 namespace {
 struct W2Ws { double* W; double* rinv; double* logr; int* ctr; int npad; };
-W2Ws w2_ws(const CollapseArgs& a, double* ws) {
+W2Ws w2_ws(const CollapseArgs& a, double* ws, int Rpad) {
     W2Ws w;
     w.npad = ((a.N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
     w.W = ws;
-    w.rinv = ws + (size_t)a.B * a.N * kW2R;
+    w.rinv = ws + (size_t)a.B * a.N * Rpad;
     w.logr = w.rinv + (size_t)a.B * w.npad;                   // (the kernel finds it behind the 1 / R table)
     w.ctr = reinterpret_cast<int*>(w.logr + (size_t)a.B * w.npad);
     return w;
 }
-template <int NX, int MODE>
+template <int R, int NX, int MODE>
 hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel<NX, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel<R, NX, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((collapse_wide2_kernel<NX, MODE>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl);
+    hipLaunchKernelGGL((collapse_wide2_kernel<R, NX, MODE>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl);
     return hipGetLastError();
 }
 template <int NX>
 hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s) {
-    if (a.nobs != nullptr) return launch_w2v<NX, 2>(a, w, G, lds, ntile, xcd_map, 0, s);   // panel with missing cells
-    return abl ? launch_w2v<NX, 1>(a, w, G, lds, ntile, xcd_map, abl, s) : launch_w2v<NX, 0>(a, w, G, lds, ntile, xcd_map, 0, s);
+    if (a.nobs != nullptr) return launch_w2v<32, NX, 2>(a, w, G, lds, ntile, xcd_map, 0, s);   // panel with missing cells
+    return abl ? launch_w2v<32, NX, 1>(a, w, G, lds, ntile, xcd_map, abl, s) : launch_w2v<32, NX, 0>(a, w, G, lds, ntile, xcd_map, 0, s);
 }
 }  // namespace
 
-hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, hipStream_t s) {
-    const W2Ws w = w2_ws(a, ws);
-    hipLaunchKernelGGL(wide_prep_kernel, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr);
+hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s) {
+    const W2Ws w = w2_ws(a, ws, Rpad);
+    if (Rpad == 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr);
+    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr);
     return hipGetLastError();
 }
 
-// r = the caller's factor count (columns r .. 31 of Lam are zero padding)
-hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int r, int num_cu, hipStream_t s) {
-    const W2Ws w = w2_ws(a, ws);
+// r = the caller's factor count (columns r .. Rpad - 1 of Lam are zero padding)
+hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
+    const W2Ws w = w2_ws(a, ws, Rpad);
     const int ntile = collapse_wide2_tiles(a.T);
     const size_t lds = (size_t)kW2NBuf * kW2StageB + 32 * sizeof(double) + 64 * 4 * sizeof(unsigned long long);   // stages | redS, itemq | DIAG stamps
     static const int xcd_env = [] { const char* v = getenv("DFM_WIDE_XCD"); return v ? atoi(v) : -1; }();
@@ -583,6 +589,10 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int r, int n
     G = (G / 8) * 8;
     if (G < 8) G = 8;
     if (!xcd_map && NT < G) G = (int)NT;
+    if (Rpad == 16) {
+        if (a.nobs != nullptr) return hipErrorInvalidValue;  // (missing cells at Rp = 16: collapse_kernel / collapse_miss)
+        return launch_w2v<16, 0, 0>(a, w, G, lds, ntile, xcd_map, 0, s);
+    }
     const int nx = r <= 16 ? 1 : (r + 3 - 16) / 4;            // 4-factor groups past the first 16; 4 = a second 16-wide tile
     switch (nx) {
         case 1: return launch_w2<1>(a, w, G, lds, ntile, xcd_map, abl, s);
@@ -597,7 +607,7 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int r, int n
 hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, hipStream_t s) {
     static const int skip = [] { const char* v = getenv("DFM_CT_SKIP"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
     if (skip) return hipSuccess;
-    const W2Ws w = w2_ws(a, ws);
+    const W2Ws w = w2_ws(a, ws, kW2R);
     const int ntile16 = (a.T + kCtP - 1) / kCtP;
     const size_t lds = (size_t)2 * kW2Chunk * kW2R * sizeof(double) + (size_t)w.npad * sizeof(unsigned short) + 16;
     hipLaunchKernelGGL(ct_miss_wide_kernel, dim3((unsigned)((long long)a.B * ntile16)), dim3(kCtThreads), lds, s, a, w.W, ntile16);

@@ -116,9 +116,9 @@ hipError_t launch_gram_wide(int Rpad, const CollapseArgs& a, hipStream_t s);
 // ldfull (the Gram kernel's outputs); launch_collapse_wide2 then streams the panel (partials of sum_t s_t: scol[b][tile])
 bool collapse_wide2_supported(int Rpad, int N);
 int collapse_wide2_tiles(int T);
-size_t collapse_wide2_ws_bytes(int B, int N);    // W [B][N][32] | 1 / R [B][N padded to 32] | tile queue counters
-hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, hipStream_t s);
-hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int r, int num_cu, hipStream_t s);
+size_t collapse_wide2_ws_bytes(int B, int N, int Rpad);    // W [B][N][Rp] | 1 / R, log R [B][N padded to 32] | tile queue counters
+hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s);
+hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s);
 // a.nobs != nullptr selects the variant for panels with missing cells (per-period scol / nobs / ldrow); their C_t:
 hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, hipStream_t s);
 bool gram_supported(int Rpad, int N);       // launch_gram's register tilings
