@@ -16,8 +16,9 @@ __host__ __device__ constexpr int cov_threads(int R) { (void)R; return 64; }
 // Rp = 32: 512 threads = 16 time chunks (8 chunks of 256 periods made the scan of config 4 a 0.65-ms chain of 1024 dependent
 // 32 x 32 matrix-vector steps; 32 chunks would need 14 staged 8-KB matrices: over the LDS budget)
 __host__ __device__ constexpr int scan_threads(int R) { return R >= 32 ? 512 : kScanThreads; }
-// time chunks of the steady scan.  Rp = 32 runs on the matrix pipe (scan_mfma32.hip): 8 waves x 16 columns = 128 chunks
-__host__ __device__ constexpr int scan_groups(int R) { return R >= 32 ? 128 : scan_threads(R) / R; }
+// time chunks of the steady scan.  Rp = 16, 32 run on the matrix pipe (scan_mfma32.hip), 16 chunks = columns per wave: 8 waves
+// at Rp = 32; 4 at Rp = 16 (148 VGPRs: three 4-wave workgroups share a CU, an 8-wave one would have it alone)
+__host__ __device__ constexpr int scan_groups(int R) { return R >= 32 ? 128 : R == 16 ? 64 : scan_threads(R) / R; }
 __host__ __device__ constexpr int scan_levels(int R) { int n = 0; while ((1 << n) < scan_groups(R)) ++n; return n; }
 __host__ __device__ constexpr int stead_mats(int R) { return 3 + 2 * scan_levels(R); }
 

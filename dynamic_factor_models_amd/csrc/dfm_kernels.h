@@ -188,7 +188,7 @@ hipError_t launch_em_update(int Rpad, const EmUpdArgs& a, hipStream_t s);
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
 bool cov_fuses_gram(int Rpad, int N);   // launch_cov with a.Lam != nullptr is supported for this shape
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);
-hipError_t launch_meanscan32(const FastArgs& a, hipStream_t s);        // Rp = 32: the steady scans on the matrix pipe (scan_mfma32.hip)
+hipError_t launch_meanscan_mfma(int Rpad, const FastArgs& a, hipStream_t s);   // Rp = 16, 32: the steady scans on the matrix pipe (scan_mfma32.hip)
 hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s);   // the P_smooth fill of meanscan (then run it with abl bit 0)
 // The whole balanced pass in one launch (pass_fused.hip: persistent workgroups, stream / covariance / scan waves) and the
 // one-wave-per-replicate covariance recursion as a drop-in for launch_cov (Rp = 8, Cfull / ldfull from gram_kernel).

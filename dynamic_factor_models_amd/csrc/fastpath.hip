@@ -528,8 +528,8 @@ hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s) {
         case 2: return launch_scan_r<2>(a, s);
         case 4: return launch_scan_r<4>(a, s);
         case 8: return launch_scan_r<8>(a, s);
-        case 16: return launch_scan_r<16>(a, s);
-        case 32: return launch_meanscan32(a, s);          // scan_mfma32.hip (128 chunks; meanscan_kernel's lane groups hold 16)
+        case 16:
+        case 32: return launch_meanscan_mfma(Rpad, a, s);  // scan_mfma32.hip (128 chunks on the matrix pipe; meanscan_kernel's lane groups hold 16)
         default: return hipErrorInvalidValue;
     }
 }

@@ -31,52 +31,62 @@ namespace dfm {
 
 namespace {
 
-constexpr int kS3R = 32;
-constexpr int kS3Threads = 512;
-constexpr int kS3NC = scan_groups(kS3R);           // 128 chunks
-constexpr int kS3Lev = scan_levels(kS3R);          // 7
-constexpr int kS3PS = 34;                          // row stride (doubles) of the staged power matrices and of the chunk-state table:
-                                                   // 8-byte slot of (row / column j, k) = 2 j + k mod 32 -- conflict-free b64 reads
 constexpr int kS3PF = 4;                           // steps per operand prefetch block
 typedef double s3_v4 __attribute__((ext_vector_type(4)));
 
-struct S3Lds {   // doubles
-    static constexpr int oPow = 0;                                   // [kS3Lev][32][kS3PS]
-    static constexpr int oP = oPow + kS3Lev * kS3R * kS3PS;          // [128][kS3PS] chunk states
-    static constexpr int oVec = oP + kS3NC * kS3PS;                  // xi_ts | xi_T | f_T | f_b  (32 each)
-    static constexpr int oPs = oVec + 4 * kS3R;                      // packed P_s,inf
-    static constexpr int oRed = oPs + kS3R * (kS3R + 1) / 2;
+template <int R>
+struct S3Geo {
+    static constexpr int NIO = R / 16;                 // 16-row tiles of the state
+    static constexpr int NK = R / 4;                   // k-steps of a product with an R x R matrix
+    static constexpr int NC = scan_groups(R);          // chunks: 128 (R = 32), 64 (R = 16)
+    static constexpr int NT = 4 * NC;                  // threads: 16 chunks per wave
+    static constexpr int LEV = scan_levels(R);         // 7
+    // row stride (doubles) of the staged power matrices and of the chunk-state table: the 8-byte slots of (row / column j, k),
+    // j < 16, k < 2, are all different mod 32 -- conflict-free b64 reads (R = 32: 2 j + k; R = 16: 18 j + k)
+    static constexpr int PS = R + 2;
+    static constexpr int oPow = 0;                                   // [LEV][R][PS]
+    static constexpr int oP = oPow + LEV * R * PS;                   // [128][PS] chunk states
+    static constexpr int oVec = oP + NC * PS;                        // xi_ts | xi_T | f_T | f_b  (R each)
+    static constexpr int oPs = oVec + 4 * R;                         // packed P_s,inf
+    static constexpr int oRed = oPs + R * (R + 1) / 2;
     static constexpr int total = oRed + 8;
 };
 
 // State order.  The MFMA fixes which PHYSICAL row m = K + 4 v + 16 io of the state a lane (K, j) holds in register (io, v); it
-// does not care which component of the state that row is.  Row m carries component pi(m) = 8 K + 4 io + v: a lane's eight
-// registers are eight CONSECUTIVE components -- 64 contiguous bytes of b_t / w_t / f_t per lane and period (four 16-byte
-// accesses) instead of eight 8-byte accesses 32 bytes apart.  Only the matrices have to follow: A[m][n] = M[pi(m)][pi(n)].
-__device__ __forceinline__ constexpr int s3_pi(int K, int v, int io) { return 8 * K + 4 * io + v; }
+// does not care which component of the state that row is.  Row m carries component pi(m) = (R / 4) K + 4 io + v: a lane's R / 4
+// registers are CONSECUTIVE components -- 64 (R = 32) or 32 (R = 16) contiguous bytes of b_t / w_t / f_t per lane and period
+// instead of 8-byte accesses 32 bytes apart.  Only the matrices have to follow: A[m][n] = M[pi(m)][pi(n)].
+template <int R>
+__device__ __forceinline__ constexpr int s3_pi(int K, int v, int io) { return (R / 4) * K + 4 * io + v; }
 // A operand of the 16x16x4 MFMA for matrix M (row-major, row stride `ld` doubles): lane (k4 = l / 16, c16 = l % 16) holds
 // physical element (16 io + c16, 4 s + k4) in A[io][s]
-__device__ __forceinline__ void load_aop(double (&A)[2][8], const double* M, int ld, int k4, int c16) {
+template <int R>
+__device__ __forceinline__ void load_aop(double (&A)[R / 16][R / 4], const double* M, int ld, int k4, int c16) {
 #pragma unroll
-    for (int io = 0; io < 2; ++io)
+    for (int io = 0; io < R / 16; ++io)
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
-            A[io][s] = M[(size_t)s3_pi(c16 & 3, c16 >> 2, io) * ld + s3_pi(k4, s & 3, s >> 2)];
+        for (int s = 0; s < R / 4; ++s)
+            A[io][s] = M[(size_t)s3_pi<R>(c16 & 3, c16 >> 2, io) * ld + s3_pi<R>(k4, s & 3, s >> 2)];
 }
 
 // Y = M X (+ Y0): X, Y in the D layout of the MFMA (X[it][v] = element (K + 4 v + 16 it, column j) of lane (K, j))
-__device__ __forceinline__ void mm_step(const double (&A)[2][8], const s3_v4 (&X)[2], s3_v4 (&Y)[2]) {
+template <int R>
+__device__ __forceinline__ void mm_step(const double (&A)[R / 16][R / 4], const s3_v4 (&X)[R / 16], s3_v4 (&Y)[R / 16]) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < R / 4; ++s) {
 #pragma unroll
-        for (int io = 0; io < 2; ++io) Y[io] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[io][s], X[s >> 2][s & 3], Y[io], 0, 0, 0);
+        for (int io = 0; io < R / 16; ++io) Y[io] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[io][s], X[s >> 2][s & 3], Y[io], 0, 0, 0);
     }
 }
 
 }  // namespace
 
-__global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
-    constexpr int R = kS3R;
+template <int R>
+__global__ __launch_bounds__(S3Geo<R>::NT) void meanscan_mfma_kernel(FastArgs a) {
+    using S3Lds = S3Geo<R>;
+    constexpr int kS3Threads = S3Lds::NT;
+    constexpr int NIO = S3Lds::NIO, kS3Lev = S3Lds::LEV, kS3PS = S3Lds::PS, kS3NC = S3Lds::NC;
+    (void)kS3NC;
     extern __shared__ __attribute__((aligned(16))) double dsm[];
     double* s_pow = dsm + S3Lds::oPow;
     double* s_P = dsm + S3Lds::oP;
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = lane >> 4, j16 = lane & 15;                 // MFMA lane coordinates
     const int ch = 16 * wave + j16;                           // this lane's chunk (its column)
-    const int i32 = lane & 31, cg = lane >> 5;                // lane-group coordinates of the transient code (wave 0)
+    const int i32 = lane % R, cg = lane / R;                  // lane-group coordinates of the transient code (wave 0; group 0 writes)
     const int T = a.T, r = a.r, L = a.L;
     const int E = a.E[b];
     const int ts = E - 1;
@@ -150,25 +160,25 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
     // One chunked scan.  dir = +1: steps t = ts + ch L + j, operands b_t, emits w_t and xi' w;  dir = -1:
     // steps t = T - 1 - ch L - j, operands w_t, emits f.  head = s_vec offset of the start vector of chunk 0,
     // tail = offset that receives the state after the last valid step.
-    auto scan = [&](const double (&AM)[2][8], const double (&AZ)[2][8], auto fwd_tag, int head, int tail) {
+    auto scan = [&](const double (&AM)[NIO][R / 4], const double (&AZ)[NIO][R / 4], auto fwd_tag, int head, int tail) {
         constexpr bool FWD = decltype(fwd_tag)::value;
         const int t0 = FWD ? ts + ch * L : T - 1 - ch * L;
         auto step_t = [&](int j) { return FWD ? t0 + j : t0 - j; };
         auto valid_t = [&](int j) { const int t = step_t(j); return j < L && t >= ts && t < T; };
         // operands of step j in the D layout
-        auto load_u = [&](s3_v4 (&U)[2], int j) {
+        auto load_u = [&](s3_v4 (&U)[NIO], int j) {
             int t = step_t(j);
             t = t < ts ? ts : (t >= T ? T - 1 : t);           // (a row that exists; the step is skipped when invalid)
-            const double2* p = reinterpret_cast<const double2*>((FWD ? bcol : wtab) + (size_t)t * R + 8 * K);
+            const double2* p = reinterpret_cast<const double2*>((FWD ? bcol : wtab) + (size_t)t * R + (R / 4) * K);
 #pragma unroll
-            for (int io = 0; io < 2; ++io) {
+            for (int io = 0; io < NIO; ++io) {
                 const double2 x = p[2 * io], y = p[2 * io + 1];
                 U[io][0] = x.x; U[io][1] = x.y; U[io][2] = y.x; U[io][3] = y.y;
             }
         };
-        auto run = [&](s3_v4 (&X)[2], auto emit_tag) {
+        auto run = [&](s3_v4 (&X)[NIO], auto emit_tag) {
             constexpr bool EMIT = decltype(emit_tag)::value;
-            s3_v4 cur[kS3PF][2];                              // ring of operands, kS3PF steps ahead (slot u refilled once consumed)
+            s3_v4 cur[kS3PF][NIO];                              // ring of operands, kS3PF steps ahead (slot u refilled once consumed)
 #pragma unroll
             for (int u = 0; u < kS3PF; ++u) load_u(cur[u], u);
             for (int j0 = 0; j0 < L; j0 += kS3PF) {
@@ -179,12 +189,14 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
                         const bool ok = valid_t(j);
                         const int t = step_t(j);
                         if constexpr (EMIT && FWD) {          // w_t = Z xi_t, xi_t' w_t
-                            s3_v4 W[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-                            mm_step(AZ, X, W);
-                            if (ok) {
-                                double2* q = reinterpret_cast<double2*>(wtab + (size_t)t * R + 8 * K);
+                            s3_v4 W[NIO];
 #pragma unroll
-                                for (int io = 0; io < 2; ++io) {
+                            for (int io = 0; io < NIO; ++io) W[io] = s3_v4{0.0, 0.0, 0.0, 0.0};
+                            mm_step<R>(AZ, X, W);
+                            if (ok) {
+                                double2* q = reinterpret_cast<double2*>(wtab + (size_t)t * R + (R / 4) * K);
+#pragma unroll
+                                for (int io = 0; io < NIO; ++io) {
 #pragma unroll
                                     for (int v = 0; v < 4; ++v) dot = fma(X[io][v], W[io][v], dot);
                                     q[2 * io] = make_double2(W[io][0], W[io][1]);
@@ -192,20 +204,22 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
                                 }
                             }
                         }
-                        s3_v4 Y[2] = {cur[u][0], cur[u][1]};
-                        load_u(cur[u], j + kS3PF);
-                        mm_step(AM, X, Y);
+                        s3_v4 Y[NIO];
 #pragma unroll
-                        for (int io = 0; io < 2; ++io)
+                        for (int io = 0; io < NIO; ++io) Y[io] = cur[u][io];
+                        load_u(cur[u], j + kS3PF);
+                        mm_step<R>(AM, X, Y);
+#pragma unroll
+                        for (int io = 0; io < NIO; ++io)
 #pragma unroll
                             for (int v = 0; v < 4; ++v) X[io][v] = ok ? Y[io][v] : X[io][v];
                         if constexpr (EMIT && !FWD) {         // f of period t - 1
                             if (ok && t >= 1) {
 #pragma unroll
-                                for (int io = 0; io < 2; ++io)
+                                for (int io = 0; io < NIO; ++io)
 #pragma unroll
                                     for (int v = 0; v < 4; ++v) {
-                                        const int row = s3_pi(K, v, io);
+                                        const int row = s3_pi<R>(K, v, io);
                                         if (row < r) fout[(size_t)(t - 1) * r + row] = X[io][v];
                                     }
                             }
@@ -214,21 +228,21 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
                 }
             }
         };
-        auto from_vec = [&](s3_v4 (&X)[2], const double* vsrc, bool take) {
+        auto from_vec = [&](s3_v4 (&X)[NIO], const double* vsrc, bool take) {
 #pragma unroll
-            for (int io = 0; io < 2; ++io)
+            for (int io = 0; io < NIO; ++io)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) X[io][v] = take ? vsrc[s3_pi(K, v, io)] : 0.0;
+                for (int v = 0; v < 4; ++v) X[io][v] = take ? vsrc[s3_pi<R>(K, v, io)] : 0.0;
         };
         // phase 1: chunk 0 from the true start (its end state then carries the head through the scan), the others from zero
-        s3_v4 X[2];
+        s3_v4 X[NIO];
         from_vec(X, s_vec + head, ch == 0);
         run(X, std::false_type{});
         stamp();   // 3 / 7: phase 1 done
         // carry: inclusive Kogge-Stone scan of the end states, P_c += M^(L 2^k) P_(c - 2^k)
         auto put_state = [&]() {
 #pragma unroll
-            for (int io = 0; io < 2; ++io)
+            for (int io = 0; io < NIO; ++io)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) s_P[ch * kS3PS + K + 4 * v + 16 * io] = X[io][v];
         };
@@ -236,15 +250,15 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
         __syncthreads();
 #pragma unroll 1
         for (int k = 0; k < kS3Lev; ++k) {
-            double AP[2][8];
-            load_aop(AP, s_pow + (size_t)k * R * kS3PS, kS3PS, K, j16);
+            double AP[NIO][R / 4];
+            load_aop<R>(AP, s_pow + (size_t)k * R * kS3PS, kS3PS, K, j16);
             const int src = ch - (1 << k);
-            s3_v4 Bv[2];                                      // the state 2^k columns to the left, as the B operand (= D layout)
+            s3_v4 Bv[NIO];                                     // the state 2^k columns to the left, as the B operand (= D layout)
 #pragma unroll
-            for (int io = 0; io < 2; ++io)
+            for (int io = 0; io < NIO; ++io)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Bv[io][v] = src >= 0 ? s_P[(src < 0 ? 0 : src) * kS3PS + K + 4 * v + 16 * io] : 0.0;
-            mm_step(AP, Bv, X);
+            mm_step<R>(AP, Bv, X);
             __syncthreads();                                  // every wave has read the old states
             put_state();
             __syncthreads();
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
         if (ch == 0) from_vec(X, s_vec + head, true);
         else {
 #pragma unroll
-            for (int io = 0; io < 2; ++io)
+            for (int io = 0; io < NIO; ++io)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) X[io][v] = s_P[(ch - 1) * kS3PS + K + 4 * v + 16 * io];
         }
@@ -263,16 +277,16 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
         stamp();   // 5 / 9: phase 3 done
         if (ch == clast) {
 #pragma unroll
-            for (int io = 0; io < 2; ++io)
+            for (int io = 0; io < NIO; ++io)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) s_vec[tail + s3_pi(K, v, io)] = X[io][v];
+                for (int v = 0; v < 4; ++v) s_vec[tail + s3_pi<R>(K, v, io)] = X[io][v];
         }
     };
 
     {
-        double AG[2][8], AZ[2][8];
-        load_aop(AG, stead + 2 * R * R, R, K, j16);           // steady G
-        load_aop(AZ, stead, R, K, j16);                       // steady Z
+        double AG[NIO][R / 4], AZ[NIO][R / 4];
+        load_aop<R>(AG, stead + 2 * R * R, R, K, j16);           // steady G
+        load_aop<R>(AZ, stead, R, K, j16);                       // steady Z
         scan(AG, AZ, std::true_type{}, 0, R);                 // xi_ts -> ... -> xi_T
     }
     __syncthreads();   // xi_T in LDS; every w_t of this replicate is written (workgroup-visible); the G powers are done with
@@ -295,8 +309,8 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
     stamp();   // 6: terminal done
     // ---- steady backward scan: steps T - 1 .. ts ----------------------------------------------------------------------------
     {
-        double AJ[2][8];
-        load_aop(AJ, stead + R * R, R, K, j16);               // steady J
+        double AJ[NIO][R / 4];
+        load_aop<R>(AJ, stead + R * R, R, K, j16);               // steady J
         scan(AJ, AJ, std::false_type{}, 2 * R, 3 * R);
     }
     __syncthreads();
@@ -338,17 +352,24 @@ __global__ __launch_bounds__(kS3Threads) void meanscan32_kernel(FastArgs a) {
     }
 }
 
-hipError_t launch_meanscan32(const FastArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)S3Lds::total * sizeof(double);
+namespace {
+template <int R>
+hipError_t launch_scan_mfma_r(const FastArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)S3Geo<R>::total * sizeof(double);
     static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&meanscan32_kernel),
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&meanscan_mfma_kernel<R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(meanscan32_kernel, dim3(a.B), dim3(kS3Threads), lds, s, a);
+    hipLaunchKernelGGL((meanscan_mfma_kernel<R>), dim3(a.B), dim3(S3Geo<R>::NT), lds, s, a);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_meanscan_mfma(int Rpad, const FastArgs& a, hipStream_t s) {
+    return Rpad == 32 ? launch_scan_mfma_r<32>(a, s) : Rpad == 16 ? launch_scan_mfma_r<16>(a, s) : hipErrorInvalidValue;
 }
 
 }  // namespace dfm
