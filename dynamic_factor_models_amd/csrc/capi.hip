@@ -188,7 +188,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
             p.ms_wpr = w;
             p.ms_ws = take(off, mstep_mfma_workspace(B, N, Rp, w));
         }
-        if (fast && mstep_wide_supported(Rp, N)) p.mw_ws = take(off, mstep_wide_workspace(B, N));
+        if (fast && mstep_wide_supported(Rp, N)) p.mw_ws = take(off, mstep_wide_workspace(B, N, Rp));
     }
     p.total = off;
     return p;
@@ -575,7 +575,7 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
     }
     if (p.fast && p.mw_ws != (size_t)-1 && !h->no_mstep_mfma) {   // ... Rp = 32 (config 4): the same on the streaming machinery of its collapse
         ProfScope ps(h, K_MSTEP_MFMA);
-        HIP_TRY(h, launch_mstep_wide(ma, at<double>(h, p.mw_ws), p.r, h->num_cu, h->stream));
+        HIP_TRY(h, launch_mstep_wide(ma, at<double>(h, p.mw_ws), Rp, p.r, h->num_cu, h->stream));
         return 0;
     }
     if (ma.Dmiss)

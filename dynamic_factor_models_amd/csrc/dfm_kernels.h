@@ -86,11 +86,11 @@ struct MstepArgs {
     int lam_stride;
 };
 
-// balanced panels at Rp = 32 (even N): the loadings step as a second streaming pass on the matrix pipe (mstep_wide.hip);
+// balanced panels at Rp = 16 | 32 (even N): the loadings step as a second streaming pass on the matrix pipe (mstep_wide.hip);
 // ws = mstep_wide_workspace bytes; r = the caller's factor count
 bool mstep_wide_supported(int Rpad, int N);
-size_t mstep_wide_workspace(int B, int N);
-hipError_t launch_mstep_wide(const MstepArgs& a, double* ws, int r, int num_cu, hipStream_t s);
+size_t mstep_wide_workspace(int B, int N, int Rpad);
+hipError_t launch_mstep_wide(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s);
 hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
 // the same contract on the LDS-DMA ring + matrix pipe (collapse_miss.hip): Rp = 8, the shapes of the MFMA collapse
 bool collapse_miss_supported(int Rpad, int N);

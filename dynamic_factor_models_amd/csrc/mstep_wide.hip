@@ -1,5 +1,5 @@
-// mstep_wide.hip -- the loadings half of the M-step for Rp = 32 on a balanced panel (BASELINE config 4: N = 1000, T = 2000,
-// r = 20) as a second streaming pass over the panel on the f64 matrix pipe.
+// mstep_wide.hip -- the loadings half of the M-step for Rp = 32 (and 16) on a balanced panel (BASELINE config 4: N = 1000,
+// T = 2000, r = 20) as a second streaming pass over the panel on the f64 matrix pipe.
 //
 //     Sxf_i = sum_t x_it f_t|T  (32 padded factors)   Sxx_i = sum_t x_it^2      lam_i = S11^-1 Sxf_i,
 //     R_i = (Sxx_i - 2 lam_i'Sxf_i + lam_i'S11 lam_i) / T                    (Shumway-Stoffer 1982; S11, S11^-1 from em_update_kernel)
@@ -18,7 +18,7 @@
 //     the whole item -- no partial sums, no second pass;
 //   * LDS layouts free of bank conflicts: panel rows 1024 + 128 bytes apart (slot of (period k, series i) = 16 k + i mod 32),
 //     the four factor rows of a step rotated by 128 bytes per odd period.
-// mstep_finish32_kernel (thread = series) then applies S11^-1.  Reference counterpart: the regression of x_i on the factors in
+// mstep_finish_wide_kernel (thread = series) then applies S11^-1.  Rp = 16: one 16-wide factor tile, factor rows of 128 bytes.  Reference counterpart: the regression of x_i on the factors in
 // estimate_factor_loading! (dfm_functions.ipynb:386-412), here with the smoothed moments of the EM in place of PCA factors.
 #include <stdlib.h>
 
@@ -54,19 +54,23 @@ constexpr int kMwSteps = kMwPer / 4;
 constexpr int kMwNBuf = 3;
 constexpr unsigned kMwRowB = 1152;                       // LDS bytes between the panel rows of a stage (1024 + 128)
 constexpr unsigned kMwPanelB = kMwPer * kMwRowB;         // 36864
-constexpr unsigned kMwFB = kMwPer * kMwR * 8;            // 8192
+constexpr unsigned kMwFB = kMwPer * kMwR * 8;            // 8192 (R = 32; R = 16 uses half of it)
 constexpr unsigned kMwStageB = kMwPanelB + kMwFB;
 constexpr int kMwCompute = kMwSer / 16, kMwProducers = 4;
 constexpr int kMwThreads = 64 * (kMwCompute + kMwProducers + 1);
-constexpr int kMwPerStage = kMwPer / kMwProducers + (kMwFB / 1024) / kMwProducers;   // DMAs per producer and stage: 8 + 2
+template <int R> struct MwGeo {
+    static constexpr int FPieces = (kMwPer * R * 8 / 1024) / kMwProducers;            // 1-KB DMAs of the factor block per producer: 2 | 1
+    static constexpr int PerStage = kMwPer / kMwProducers + FPieces;                  // DMAs per producer and stage: 10 | 9
+};
 constexpr int kMwRing = 8;
 
 }  // namespace
 
-template <int NX>
+template <int R, int NX>
 __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, double* __restrict__ sxf, double* __restrict__ sxx,
                                                                 int* ctr, int nsb, int xcd_map) {
-    constexpr int R = kMwR;
+    static_assert((R == 32 && NX >= 1 && NX <= 4) || (R == 16 && NX == 0), "R = 32: 1..4 column groups past the first 16; R = 16: none");
+    using GEO = MwGeo<R>;
     constexpr int N4 = NX < 4 ? NX : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, T = a.T, B = a.B;
@@ -136,12 +140,19 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
                 if (act) dma16mw(src, dst);
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int piece = 2 * pw + u;
-                const int h = lane >> 4;
-                int t = t0 + 4 * piece + h;
-                t = t < T ? t : T - 1;
-                const char* src = Fb + (size_t)t * (R * 8) + 16u * (unsigned)(((lane & 15) - 8 * h) & 15);
+            for (int u = 0; u < GEO::FPieces; ++u) {
+                const int piece = GEO::FPieces * pw + u;
+                const char* src;
+                if (R == 32) {                                // a piece = the 4 periods of a step, row h rotated by 8 h units
+                    const int h = lane >> 4;
+                    int t = t0 + 4 * piece + h;
+                    t = t < T ? t : T - 1;
+                    src = Fb + (size_t)t * (R * 8) + 16u * (unsigned)(((lane & 15) - 8 * h) & 15);
+                } else {                                      // R = 16: a piece = 8 periods of 128 bytes, as they lie
+                    int t = t0 + 8 * piece + (lane >> 3);
+                    t = t < T ? t : T - 1;
+                    src = Fb + (size_t)t * (R * 8) + 16u * (unsigned)(lane & 7);
+                }
                 const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kMwPanelB + (unsigned)piece * 1024u);
                 dma16mw(src, dst);
             }
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
         int bsel = 0;
         while (more) {
             if (!v1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kMwPerStage) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GEO::PerStage) : "memory");
             __syncthreads();
             const bool v2 = ikk >= 0;
             if (v2) issue_next(bsel == 0 ? 2 : bsel - 1);
@@ -185,8 +196,9 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
     // A operand: period 4 s + k4 of the stage, series 16 w + c16 of the block
     const unsigned a_off = (unsigned)k4 * kMwRowB + (unsigned)(16 * wave + c16) * 8u;
     // B operands: factors of period 4 s + k4 (row k4 of piece s, rotated by 128 k4 bytes)
-    const unsigned f_row = kMwPanelB + (unsigned)k4 * 256u;
-    const unsigned b16 = f_row + ((8u * c16 + 128u * k4) & 255u);
+    // (R = 16: rows of 128 bytes as they lie -- slot 16 k4 + c16, no rotation needed)
+    const unsigned f_row = kMwPanelB + (unsigned)k4 * (R * 8u);
+    const unsigned b16 = R == 32 ? f_row + ((8u * c16 + 128u * k4) & 255u) : f_row + 8u * c16;
     const unsigned b16b = f_row + ((8u * (16 + c16) + 128u * k4) & 255u);
     unsigned b4[N4 > 0 ? N4 : 1];
 #pragma unroll
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
             double av[kMwSteps], bv[kMwSteps], bvb[NX == 4 ? kMwSteps : 1], b4v[N4 > 0 ? N4 : 1][kMwSteps];
             auto load_step = [&](int s) {
                 av[s] = lds_read64m(stg + a_off + (unsigned)s * (4 * kMwRowB));
-                bv[s] = lds_read64m(stg + b16 + (unsigned)s * 1024u);
+                bv[s] = lds_read64m(stg + b16 + (unsigned)s * (4u * R * 8u));
                 if (NX == 4) bvb[NX == 4 ? s : 0] = lds_read64m(stg + b16b + (unsigned)s * 1024u);
 #pragma unroll
                 for (int x = 0; x < N4; ++x) b4v[x][s] = lds_read64m(stg + b4[x] + (unsigned)s * 1024u);
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
                     if (NX == 4) out[(size_t)row * R + 16 + c16] = accb[v];
                 }
             }
-            if (NX < 4) {                                     // 4x4x4: block (l / 4) % 4, D[row = l / 16][col = l % 4] -> series 4 blk + l / 16
+            if (R == 32 && NX < 4) {                          // 4x4x4: block (l / 4) % 4, D[row = l / 16][col = l % 4] -> series 4 blk + l / 16
                 const int row = 4 * ((lane >> 2) & 3) + k4;
                 if (s0 + 16 * wave + row < N) {
 #pragma unroll
@@ -257,8 +269,8 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
 }
 
 // thread = series: lam_i = S11^-1 Sxf_i, R_i = (Sxx_i - 2 lam_i'Sxf_i + lam_i'S11 lam_i) / T
-__global__ __launch_bounds__(256) void mstep_finish32_kernel(MstepArgs a, const double* __restrict__ sxf, const double* __restrict__ sxx) {
-    constexpr int R = kMwR;
+template <int R>
+__global__ __launch_bounds__(256) void mstep_finish_wide_kernel(MstepArgs a, const double* __restrict__ sxf, const double* __restrict__ sxx) {
     __shared__ double s11[R * R], s11i[R * R];
     const int b = blockIdx.x;
     if (a.active && !a.active[b]) return;
@@ -296,29 +308,29 @@ __global__ __launch_bounds__(256) void mstep_finish32_kernel(MstepArgs a, const 
     for (int k = 0; k < R; ++k) lo[k] = lam[k];
 }
 
-bool mstep_wide_supported(int Rpad, int N) { return Rpad == 32 && (N & 1) == 0 && N >= 2; }
-// Sxf [B][N][32] | Sxx [B][N] | 8 queue counters
-size_t mstep_wide_workspace(int B, int N) { return ((size_t)B * N * kMwR + (size_t)B * N) * sizeof(double) + 64; }
+bool mstep_wide_supported(int Rpad, int N) { return (Rpad == 32 || Rpad == 16) && (N & 1) == 0 && N >= 2; }
+// Sxf [B][N][Rp] | Sxx [B][N] | 8 queue counters
+size_t mstep_wide_workspace(int B, int N, int Rpad) { return ((size_t)B * N * Rpad + (size_t)B * N) * sizeof(double) + 64; }
 
 namespace {
-template <int NX>
+template <int R, int NX>
 hipError_t launch_mw(const MstepArgs& a, double* sxf, double* sxx, int* ctr, int G, size_t lds, int nsb, int xcd_map, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_wide_kernel<NX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_wide_kernel<R, NX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((mstep_wide_kernel<NX>), dim3((unsigned)G), dim3(kMwThreads), lds, s, a, sxf, sxx, ctr, nsb, xcd_map);
+    hipLaunchKernelGGL((mstep_wide_kernel<R, NX>), dim3((unsigned)G), dim3(kMwThreads), lds, s, a, sxf, sxx, ctr, nsb, xcd_map);
     return hipGetLastError();
 }
 }  // namespace
 
-// r = the caller's factor count (columns r .. 31 of the smoothed factors are zero padding)
-hipError_t launch_mstep_wide(const MstepArgs& a, double* ws, int r, int num_cu, hipStream_t s) {
+// r = the caller's factor count (columns r .. Rpad - 1 of the smoothed factors are zero padding)
+hipError_t launch_mstep_wide(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
     double* sxf = ws;
-    double* sxx = ws + (size_t)a.B * a.N * kMwR;
+    double* sxx = ws + (size_t)a.B * a.N * Rpad;
     int* ctr = reinterpret_cast<int*>(sxx + (size_t)a.B * a.N);
     hipError_t e = hipMemsetAsync(ctr, 0, 32, s);
     if (e != hipSuccess) return e;
@@ -330,15 +342,21 @@ hipError_t launch_mstep_wide(const MstepArgs& a, double* ws, int r, int num_cu, 
     G = (G / 8) * 8;
     if (G < 8) G = 8;
     if (!xcd_map && NI < G) G = (int)NI;
+    if (Rpad == 16) {
+        e = launch_mw<16, 0>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(mstep_finish_wide_kernel<16>, dim3(a.B, (a.N + 255) / 256), dim3(256), 0, s, a, (const double*)sxf, (const double*)sxx);
+        return hipGetLastError();
+    }
     const int nx = r <= 16 ? 1 : (r + 3 - 16) / 4;
     switch (nx) {
-        case 1: e = launch_mw<1>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s); break;
-        case 2: e = launch_mw<2>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s); break;
-        case 3: e = launch_mw<3>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s); break;
-        default: e = launch_mw<4>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s); break;
+        case 1: e = launch_mw<32, 1>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s); break;
+        case 2: e = launch_mw<32, 2>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s); break;
+        case 3: e = launch_mw<32, 3>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s); break;
+        default: e = launch_mw<32, 4>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s); break;
     }
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mstep_finish32_kernel, dim3(a.B, (a.N + 255) / 256), dim3(256), 0, s, a, (const double*)sxf, (const double*)sxx);
+    hipLaunchKernelGGL(mstep_finish_wide_kernel<32>, dim3(a.B, (a.N + 255) / 256), dim3(256), 0, s, a, (const double*)sxf, (const double*)sxx);
     return hipGetLastError();
 }
 
