@@ -87,19 +87,22 @@ constexpr int kW2Ring = 8;        // published items (ring)
 
 // ------------------------------------------------------------------------------------------------------------------
 // W = lam / R, C = Lam' W, sum log R.  One workgroup of 4 waves per replicate.
+// rd = width of the caller's arrays (Lam [N][rd], Cfull [rd][rd]); rd < R (= 16) for the narrow states whose cross-section is
+// beyond the row ring of the MFMA collapse: W is padded with zero columns, the collapse computes 16 and stores rd.
 template <int R>
-__global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, double* logr_out, int npad, int* ctr) {
+__global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, double* logr_out, int npad, int* ctr, int rd) {
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N;
-    const double* __restrict__ L = a.Lam + (size_t)b * N * R;
+    const double* __restrict__ L = a.Lam + (size_t)b * N * rd;
     const double* __restrict__ Rv = a.Rv + (size_t)b * N;
     double* W = Wout + (size_t)b * N * R;
     // stored with the two 16-column halves of ODD series swapped (column f of series c at f ^ 16 (c & 1)): the B operand of
     // a step reads 4 consecutive series x 16 columns, and two series 256 bytes apart would meet on the same banks
     for (int e = tid; e < N * R; e += 256) {
         const int c = e / R;
-        W[R == 32 ? (e ^ (16 * (c & 1))) : e] = L[e] / Rv[c];
+        const int f = e % R;
+        W[R == 32 ? (e ^ (16 * (c & 1))) : e] = f < rd ? L[(size_t)c * rd + f] / Rv[c] : 0.0;
     }
     for (int c = tid; c < npad; c += 256) {                   // (0 past N: padding of the last stage)
         rinv_out[(size_t)b * npad + c] = c < N ? 1.0 / Rv[c] : 0.0;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
         for (int u = 0; u < 8; ++u) {
             const int c = 4 * (s0 + u) + k4;
             const int cc = c < N ? c : N - 1;
-            av[u] = L[(size_t)cc * R + 16 * it + c16];
+            av[u] = (16 * it + c16 < rd) ? L[(size_t)cc * rd + 16 * it + c16] : 0.0;
             bv[u] = W[(size_t)cc * R + (R == 32 ? ((16 * jt + c16) ^ (16 * (cc & 1))) : c16)];
         }
 #pragma unroll
@@ -135,7 +138,8 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v)                               // D[(l / 16) + 4 v][l % 16]
-        a.Cfull[(size_t)b * R * R + (size_t)(16 * it + k4 + 4 * v) * R + 16 * jt + c16] = acc[v];
+        if (16 * it + k4 + 4 * v < rd && 16 * jt + c16 < rd)
+            a.Cfull[(size_t)b * rd * rd + (size_t)(16 * it + k4 + 4 * v) * rd + 16 * jt + c16] = acc[v];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
 template <int R, int NX, int MODE>
 __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall,
                                                                    const double* __restrict__ rinvAll, int npad, int* ctr,
-                                                                   int ntile, int xcd_map, int abl_) {
+                                                                   int ntile, int xcd_map, int abl_, int rd) {
     constexpr bool DIAG = MODE == 1, MISS = MODE == 2;
     static_assert((R == 32 && NX >= 1 && NX <= 4) || (R == 16 && NX == 0), "R = 32: 1..4 column groups past the first 16; R = 16: none");
     using GEO = W2Geo<R>;
@@ -323,12 +327,12 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
     double pacc4[N4 > 0 ? N4 : 1];
     auto flush_pending = [&]() {
         if (pend_b < 0) return;
-        double* out = a.bcol + ((size_t)pend_b * T + pend_t0 + 16 * wave) * R;
+        double* out = a.bcol + ((size_t)pend_b * T + pend_t0 + 16 * wave) * rd;   // (rd = R except for the narrow states on R = 16)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {                         // 16x16x4: D[(l / 16) + 4 v][l % 16]
             const int row = k4 + 4 * v;
             if (pend_t0 + 16 * wave + row < T) {
-                out[(size_t)row * R + c16] = pacc[v];
+                if (R == 32 || c16 < rd) out[(size_t)row * rd + c16] = pacc[v];
                 if (NX == 4) out[(size_t)row * R + 16 + c16] = paccb[v];
             }
         }
@@ -531,11 +535,16 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide_kernel(CollapseArgs a
 }
 
 int collapse_wide2_tiles(int T) { return (T + kW2Rows - 1) / kW2Rows; }
-bool collapse_wide2_supported(int Rpad, int N) { return (Rpad == 32 || Rpad == 16) && (N % 2) == 0 && N >= 2; }
-// workspace of the collapse: W [B][N][Rp] | 1 / R [B][npad] | log R [B][npad] | 8 queue counters
+// Rp = 16 | 32 with an even N; narrower states (computed 16 wide) only where the row ring of the MFMA collapse ends (8 N > 4 KB)
+bool collapse_wide2_supported(int Rpad, int N) {
+    if ((N % 2) != 0 || N < 2) return false;
+    return Rpad == 32 || Rpad == 16 || (Rpad >= 2 && Rpad <= 8 && N * 8 > 4096);
+}
+static int w2_compute_width(int Rpad) { return Rpad < 16 ? 16 : Rpad; }
+// workspace of the collapse: W [B][N][Rk] | 1 / R [B][npad] | log R [B][npad] | 8 queue counters  (Rk = max(Rp, 16))
 size_t collapse_wide2_ws_bytes(int B, int N, int Rpad) {
     const size_t npad = (size_t)((N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
-    return ((size_t)B * N * Rpad + 2 * (size_t)B * npad) * sizeof(double) + 64;
+    return ((size_t)B * N * w2_compute_width(Rpad) + 2 * (size_t)B * npad) * sizeof(double) + 64;
 }
 
 namespace {
@@ -544,13 +553,13 @@ W2Ws w2_ws(const CollapseArgs& a, double* ws, int Rpad) {
     W2Ws w;
     w.npad = ((a.N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
     w.W = ws;
-    w.rinv = ws + (size_t)a.B * a.N * Rpad;
+    w.rinv = ws + (size_t)a.B * a.N * w2_compute_width(Rpad);
     w.logr = w.rinv + (size_t)a.B * w.npad;                   // (the kernel finds it behind the 1 / R table)
     w.ctr = reinterpret_cast<int*>(w.logr + (size_t)a.B * w.npad);
     return w;
 }
 template <int R, int NX, int MODE>
-hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s) {
+hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s, int rd = R) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel<R, NX, MODE>),
@@ -558,7 +567,7 @@ hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, i
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((collapse_wide2_kernel<R, NX, MODE>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl);
+    hipLaunchKernelGGL((collapse_wide2_kernel<R, NX, MODE>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl, rd);
     return hipGetLastError();
 }
 template <int NX>
@@ -570,8 +579,8 @@ hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, in
 
 hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s) {
     const W2Ws w = w2_ws(a, ws, Rpad);
-    if (Rpad == 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr);
-    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr);
+    if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad);
+    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, 32);
     return hipGetLastError();
 }
 
@@ -589,9 +598,9 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, in
     G = (G / 8) * 8;
     if (G < 8) G = 8;
     if (!xcd_map && NT < G) G = (int)NT;
-    if (Rpad == 16) {
-        if (a.nobs != nullptr) return hipErrorInvalidValue;  // (missing cells at Rp = 16: collapse_kernel / collapse_miss)
-        return launch_w2v<16, 0, 0>(a, w, G, lds, ntile, xcd_map, 0, s);
+    if (Rpad <= 16) {
+        if (a.nobs != nullptr) return hipErrorInvalidValue;  // (missing cells at Rp <= 16: collapse_kernel / collapse_miss)
+        return launch_w2v<16, 0, 0>(a, w, G, lds, ntile, xcd_map, 0, s, Rpad);
     }
     const int nx = r <= 16 ? 1 : (r + 3 - 16) / 4;            // 4-factor groups past the first 16; 4 = a second 16-wide tile
     switch (nx) {

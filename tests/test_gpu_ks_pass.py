@@ -193,6 +193,8 @@ BALANCED_SHAPES = [
     (2, 40, 5, 18),            # T far below the 128 chunks of the scan
     (2, 101, 45, 20),          # odd N: collapse_wide_kernel (8-byte loads) feeding the matrix-pipe scan
     (20, 34, 260, 32),         # uneven replicate counts per XCD queue (8 + 8 + 4), r = 32
+    # narrow states (Rp <= 8) with rows beyond the 4-KB row ring of the MFMA collapse: collapse_wide2 computes 16 columns, stores Rp
+    (3, 600, 130, 4), (2, 1024, 40, 2), (17, 700, 90, 7), (2, 514, 5, 8),
     # cov_grid_kernel<16> (Rp = 16: 256 threads per replicate)
     (3, 200, 120, 12), (2, 48, 33, 9), (2, 64, 500, 16),
 ]
