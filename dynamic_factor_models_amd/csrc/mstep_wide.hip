@@ -68,7 +68,8 @@ constexpr int kMwRing = 8;
 
 template <int R, int NX>
 __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, double* __restrict__ sxf, double* __restrict__ sxx,
-                                                                int* ctr, int nsb, int xcd_map) {
+                                                                int* ctr, int nsb, int xcd_map, int rd) {
+    // rd = width of the caller's arrays (fsm [T][rd], Sxf [N][rd]); rd < R (= 16) for the narrow states beyond mstep_mfma's ring
     static_assert((R == 32 && NX >= 1 && NX <= 4) || (R == 16 && NX == 0), "R = 32: 1..4 column groups past the first 16; R = 16: none");
     using GEO = MwGeo<R>;
     constexpr int N4 = NX < 4 ? NX : 0;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_mw)(smem));
         auto issue_dma = [&](int b, int sb, int st, int bsel) {
             const char* Xb = reinterpret_cast<const char*>(a.panel + (size_t)b * T * N);
-            const char* Fb = reinterpret_cast<const char*>(a.fsm + (size_t)b * T * R);
+            const char* Fb = reinterpret_cast<const char*>(a.fsm + (size_t)b * T * rd);
             const unsigned sbase = lds0 + (unsigned)bsel * kMwStageB;
             const int t0 = st * kMwPer;
             const int ser = sb * kMwSer + 2 * lane;
@@ -148,10 +149,13 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
                     int t = t0 + 4 * piece + h;
                     t = t < T ? t : T - 1;
                     src = Fb + (size_t)t * (R * 8) + 16u * (unsigned)(((lane & 15) - 8 * h) & 15);
-                } else {                                      // R = 16: a piece = 8 periods of 128 bytes, as they lie
-                    int t = t0 + 8 * piece + (lane >> 3);
-                    t = t < T ? t : T - 1;
-                    src = Fb + (size_t)t * (R * 8) + 16u * (unsigned)(lane & 7);
+                } else {                                      // R = 16: the stage's factor rows (rd x 8 bytes each) as they lie, 1 KB per piece;
+                    const size_t rowb = (size_t)rd * 8;       // past the block / the sample: the last 16 bytes again (those periods meet a zeroed A)
+                    const size_t blk = (size_t)kMwPer * rowb, lim = (size_t)T * rowb - 16;
+                    size_t o = (size_t)piece * 1024u + 16u * (unsigned)lane;
+                    o = o < blk ? o : blk - 16;
+                    o += (size_t)t0 * rowb;
+                    src = Fb + (o < lim ? o : lim);
                 }
                 const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kMwPanelB + (unsigned)piece * 1024u);
                 dma16mw(src, dst);
@@ -197,8 +201,9 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
     const unsigned a_off = (unsigned)k4 * kMwRowB + (unsigned)(16 * wave + c16) * 8u;
     // B operands: factors of period 4 s + k4 (row k4 of piece s, rotated by 128 k4 bytes)
     // (R = 16: rows of 128 bytes as they lie -- slot 16 k4 + c16, no rotation needed)
-    const unsigned f_row = kMwPanelB + (unsigned)k4 * (R * 8u);
-    const unsigned b16 = R == 32 ? f_row + ((8u * c16 + 128u * k4) & 255u) : f_row + 8u * c16;
+    const unsigned f_row = kMwPanelB + (unsigned)k4 * (unsigned)(rd * 8);
+    const unsigned b16 = R == 32 ? f_row + ((8u * c16 + 128u * k4) & 255u) : f_row + 8u * (c16 < rd ? c16 : 0);
+    const bool col_ok = R == 32 || c16 < rd;
     const unsigned b16b = f_row + ((8u * (16 + c16) + 128u * k4) & 255u);
     unsigned b4[N4 > 0 ? N4 : 1];
 #pragma unroll
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
             double av[kMwSteps], bv[kMwSteps], bvb[NX == 4 ? kMwSteps : 1], b4v[N4 > 0 ? N4 : 1][kMwSteps];
             auto load_step = [&](int s) {
                 av[s] = lds_read64m(stg + a_off + (unsigned)s * (4 * kMwRowB));
-                bv[s] = lds_read64m(stg + b16 + (unsigned)s * (4u * R * 8u));
+                bv[s] = lds_read64m(stg + b16 + (unsigned)s * (4u * (unsigned)(rd * 8)));
                 if (NX == 4) bvb[NX == 4 ? s : 0] = lds_read64m(stg + b16b + (unsigned)s * 1024u);
 #pragma unroll
                 for (int x = 0; x < N4; ++x) b4v[x][s] = lds_read64m(stg + b4[x] + (unsigned)s * 1024u);
@@ -226,8 +231,9 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
             for (int s = 0; s < kMwSteps; ++s) {
                 if (s + 4 < kMwSteps) load_step(s + 4);
                 const double a_ = (ser_ok && tfirst + 4 * s < T) ? av[s] : 0.0;   // partial block / partial last stage: nothing
-                if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[s], acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[s], acc0, 0, 0, 0);
+                const double b_ = col_ok ? bv[s] : 0.0;       // (narrow states: columns past rd of the 16-wide tile)
+                if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, b_, acc0, 0, 0, 0);
                 if (NX == 4) accb = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bvb[NX == 4 ? s : 0], accb, 0, 0, 0);
 #pragma unroll
                 for (int x = 0; x < N4; ++x) acc4[x] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b4v[x][s], acc4[x], 0, 0, 0);
@@ -237,12 +243,12 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
         bsel = bsel == 2 ? 0 : bsel + 1;
         if (++st == nst) {                                    // the item is complete: Sxf rows and Sxx of its series
             const mw_v4 accs = acc0 + acc1;
-            double* out = sxf + ((size_t)b * N + s0 + 16 * wave) * R;
+            double* out = sxf + ((size_t)b * N + s0 + 16 * wave) * rd;
 #pragma unroll
             for (int v = 0; v < 4; ++v) {                     // 16x16x4: D[(l / 16) + 4 v][l % 16] -> series k4 + 4 v, factor c16
                 const int row = k4 + 4 * v;
                 if (s0 + 16 * wave + row < N) {
-                    out[(size_t)row * R + c16] = accs[v];
+                    if (col_ok) out[(size_t)row * rd + c16] = accs[v];
                     if (NX == 4) out[(size_t)row * R + 16 + c16] = accb[v];
                 }
             }
@@ -308,13 +314,17 @@ __global__ __launch_bounds__(256) void mstep_finish_wide_kernel(MstepArgs a, con
     for (int k = 0; k < R; ++k) lo[k] = lam[k];
 }
 
-bool mstep_wide_supported(int Rpad, int N) { return (Rpad == 32 || Rpad == 16) && (N & 1) == 0 && N >= 2; }
+// Rp = 16 | 32 with an even N; narrower states (computed 16 wide) where mstep_mfma's 4-KB row ring ends
+bool mstep_wide_supported(int Rpad, int N) {
+    if ((N & 1) != 0 || N < 2) return false;
+    return Rpad == 32 || Rpad == 16 || (Rpad >= 2 && Rpad <= 8 && N * 8 > 4096);
+}
 // Sxf [B][N][Rp] | Sxx [B][N] | 8 queue counters
 size_t mstep_wide_workspace(int B, int N, int Rpad) { return ((size_t)B * N * Rpad + (size_t)B * N) * sizeof(double) + 64; }
 
 namespace {
 template <int R, int NX>
-hipError_t launch_mw(const MstepArgs& a, double* sxf, double* sxx, int* ctr, int G, size_t lds, int nsb, int xcd_map, hipStream_t s) {
+hipError_t launch_mw(const MstepArgs& a, double* sxf, double* sxx, int* ctr, int G, size_t lds, int nsb, int xcd_map, hipStream_t s, int rd = R) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_wide_kernel<R, NX>),
@@ -322,7 +332,7 @@ hipError_t launch_mw(const MstepArgs& a, double* sxf, double* sxx, int* ctr, int
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((mstep_wide_kernel<R, NX>), dim3((unsigned)G), dim3(kMwThreads), lds, s, a, sxf, sxx, ctr, nsb, xcd_map);
+    hipLaunchKernelGGL((mstep_wide_kernel<R, NX>), dim3((unsigned)G), dim3(kMwThreads), lds, s, a, sxf, sxx, ctr, nsb, xcd_map, rd);
     return hipGetLastError();
 }
 }  // namespace
@@ -342,10 +352,16 @@ hipError_t launch_mstep_wide(const MstepArgs& a, double* ws, int Rpad, int r, in
     G = (G / 8) * 8;
     if (G < 8) G = 8;
     if (!xcd_map && NI < G) G = (int)NI;
-    if (Rpad == 16) {
-        e = launch_mw<16, 0>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s);
+    if (Rpad <= 16) {
+        e = launch_mw<16, 0>(a, sxf, sxx, ctr, G, lds, nsb, xcd_map, s, Rpad);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(mstep_finish_wide_kernel<16>, dim3(a.B, (a.N + 255) / 256), dim3(256), 0, s, a, (const double*)sxf, (const double*)sxx);
+        const dim3 fg(a.B, (a.N + 255) / 256);
+        switch (Rpad) {
+            case 2: hipLaunchKernelGGL(mstep_finish_wide_kernel<2>, fg, dim3(256), 0, s, a, (const double*)sxf, (const double*)sxx); break;
+            case 4: hipLaunchKernelGGL(mstep_finish_wide_kernel<4>, fg, dim3(256), 0, s, a, (const double*)sxf, (const double*)sxx); break;
+            case 8: hipLaunchKernelGGL(mstep_finish_wide_kernel<8>, fg, dim3(256), 0, s, a, (const double*)sxf, (const double*)sxx); break;
+            default: hipLaunchKernelGGL(mstep_finish_wide_kernel<16>, fg, dim3(256), 0, s, a, (const double*)sxf, (const double*)sxx); break;
+        }
         return hipGetLastError();
     }
     const int nx = r <= 16 ? 1 : (r + 3 - 16) / 4;

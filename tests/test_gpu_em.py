@@ -50,6 +50,8 @@ KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
     (3, 139, 222, 4, 0.05, 10),   # config 1 shape: 10 EM iterations
     (2, 60, 50, 12, 0.1, 3),      # r padded to 16: global Dmiss accumulators
     (2, 300, 40, 5, 0.1, 3),      # N > 256: two series per lane
+    (2, 600, 80, 4, 0.0, 3),      # balanced, narrow state, rows beyond the 4-KB ring: collapse_wide2 / mstep_wide compute 16 columns, keep 4
+    (17, 700, 60, 7, 0.0, 2),     # ... r padded 7 -> 8, XCD-ordered queues
     (3, 130, 70, 20, 0.0, 3),     # balanced, Rp = 32: mstep_wide (2 series blocks, the second partial; 3 stages of 32 periods, the last of 6)
     (17, 66, 90, 25, 0.0, 2),     # ... XCD-ordered item queues with B not a multiple of 8, 3 column groups past the first 16
     (2, 260, 110, 32, 0.0, 2),    # ... every factor column in use (two 16-wide tiles)
