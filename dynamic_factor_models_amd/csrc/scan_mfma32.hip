@@ -1,4 +1,5 @@
-// scan_mfma32.hip -- the mean recursion of the balanced fast path for Rp = 32 (BASELINE config 4) on the f64 matrix pipe.
+// scan_mfma32.hip -- the mean recursion of the balanced fast path for Rp = 32 (BASELINE config 4) and Rp = 16 on the f64
+// matrix pipe (the text below says 32; Rp = 16 is one row tile, 4 k-steps, 4 waves = 64 chunks).
 //
 //     xi_{t+1} = G_t xi_t + b_t,  w_t = Z_t xi_t      forward       f_t = w_t + J_t f_{t+1}      backward
 //

@@ -180,7 +180,7 @@ BALANCED_SHAPES = [
     (3, 31, 41, 3),            # odd N: wide kernel (8-byte loads)
     (1, 1000, 2000, 20),       # BASELINE config 4's shape (N = 1000, T = 2000, r = 20), one replicate
     # collapse_wide2 (Rp = 32, even N): stages of 32 series / tiles of 128 periods with partial tails, 16x16x4 + NX 4x4x4
-    # MFMAs for r = 17..28, two 16x16x4 for r = 29..32; cov_grid_kernel<32>; meanscan32_kernel (128 chunks of L steps)
+    # MFMAs for r = 17..28, two 16x16x4 for r = 29..32; cov_grid_kernel<32>; meanscan_mfma_kernel (128 chunks of L steps)
     (2, 66, 65, 17),           # 2 series past two stages, r padded 17 -> 32 (NX = 1)
     (3, 130, 70, 20),          # 2 series past four stages (a partial MFMA step: 2 of 4 series)
     (2, 64, 64, 32),           # exact stages, every factor column used (NX = 4)
@@ -354,7 +354,7 @@ def _slow_riccati(B, N, T, r, rho, Rscale, seed=11):
     (200, 500, 8, 0.995, 5e3),     # headline shape, MFMA collapse
     (30, 500, 3, 0.99, 50.0),      # E of a few hundred: long transient + short steady stretch
     (16, 120, 2, 0.9999, 1e4),     # T shorter than the convergence time
-    (40, 300, 20, 0.995, 2e2),     # Rp = 32: a long transient on wave 0 of meanscan32_kernel, then its chunked scans
+    (40, 300, 20, 0.995, 2e2),     # Rp = 32: a long transient on wave 0 of meanscan_mfma_kernel, then its chunked scans
     (40, 150, 18, 0.9999, 1e4),    # Rp = 32 with no steady stretch at all
 ])
 def test_slow_riccati_on_the_balanced_path(ctx, N, T, r, rho, Rscale):
