@@ -86,12 +86,17 @@ constexpr int kW2Ring = 8;        // published items (ring)
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
-// W = lam / R, C = Lam' W, sum log R.  One workgroup of 4 waves per replicate.
+// W = lam / R, C = Lam' W, sum log R.  One workgroup of 16 waves per replicate: the (R / 16)^2 tiles of C x 16 / tiles slices of
+// the series (a 4-wave version ran each tile's chain over ALL series: ~30 dependent batches of loads, 0.1 ms -- a fifth of the
+// pass at r = 8 / N = 1000); the slices meet in LDS.
 // rd = width of the caller's arrays (Lam [N][rd], Cfull [rd][rd]); rd < R (= 16) for the narrow states whose cross-section is
 // beyond the row ring of the MFMA collapse: W is padded with zero columns, the collapse computes 16 and stores rd.
+constexpr int kPrepThreads = 1024;
 template <int R>
-__global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, double* logr_out, int npad, int* ctr, int rd) {
-    __shared__ double red[4];
+__global__ __launch_bounds__(kPrepThreads) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, double* logr_out, int npad, int* ctr, int rd) {
+    constexpr int NW = kPrepThreads / 64, NTILE = (R / 16) * (R / 16), NSL = NW / NTILE;
+    __shared__ double red[NW];
+    __shared__ double part[NW * 4 * 64];                      // [wave][v][lane]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = a.N;
     const double* __restrict__ L = a.Lam + (size_t)b * N * rd;
@@ -99,47 +104,62 @@ __global__ __launch_bounds__(256) void wide_prep_kernel(CollapseArgs a, double* 
     double* W = Wout + (size_t)b * N * R;
     // stored with the two 16-column halves of ODD series swapped (column f of series c at f ^ 16 (c & 1)): the B operand of
     // a step reads 4 consecutive series x 16 columns, and two series 256 bytes apart would meet on the same banks
-    for (int e = tid; e < N * R; e += 256) {
+    for (int e = tid; e < N * R; e += kPrepThreads) {
         const int c = e / R;
         const int f = e % R;
         W[R == 32 ? (e ^ (16 * (c & 1))) : e] = f < rd ? L[(size_t)c * rd + f] / Rv[c] : 0.0;
     }
-    for (int c = tid; c < npad; c += 256) {                   // (0 past N: padding of the last stage)
+    for (int c = tid; c < npad; c += kPrepThreads) {          // (0 past N: padding of the last stage)
         rinv_out[(size_t)b * npad + c] = c < N ? 1.0 / Rv[c] : 0.0;
         logr_out[(size_t)b * npad + c] = c < N ? log(Rv[c]) : 0.0;
     }
     if (b == 0 && tid < 8) ctr[tid] = 0;                      // tile queues of the collapse that follows on this stream
     double ld = 0.0;
-    for (int c = tid; c < N; c += 256) ld += log(Rv[c]);
+    for (int c = tid; c < N; c += kPrepThreads) ld += log(Rv[c]);
     ld = wave_allsum(ld);
     if (lane == 0) red[wave] = ld;
-    __syncthreads();                                         // W of this replicate is complete (and visible to this workgroup)
-    if (tid == 0) a.ldfull[b] = red[0] + red[1] + red[2] + red[3];
-    // tile (it, jt) of C: C[16 it + i][16 jt + j] = sum_c Lam[c][16 it + i] W[c][16 jt + j]
-    if (R == 16 && wave > 0) return;                         // (R = 16: one 16 x 16 tile)
-    const int it = R == 32 ? wave >> 1 : 0, jt = R == 32 ? wave & 1 : 0;
+    // tile (it, jt) of C over the series of slice sl: C[16 it + i][16 jt + j] = sum_c Lam[c][16 it + i] Lam[c][16 jt + j] / R_c
+    const int tile = wave % NTILE, sl = wave / NTILE;
+    const int it = tile / (R / 16), jt = tile % (R / 16);
     const int k4 = lane >> 4, c16 = lane & 15;
     w2_v4 acc = {0.0, 0.0, 0.0, 0.0};
     const int steps = (N + 3) / 4;
-    for (int s0 = 0; s0 < steps; s0 += 8) {                  // 16 loads in flight per batch (clamped addresses, select afterwards)
-        double av[8], bv[8];
+    const int sps = (steps + NSL - 1) / NSL;
+    const int s_lo = sl * sps, s_hi = (s_lo + sps < steps) ? s_lo + sps : steps;
+    for (int s0 = s_lo; s0 < s_hi; s0 += 8) {                 // 24 loads in flight per batch (clamped addresses, select afterwards)
+        double av[8], bv[8], rv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = 4 * (s0 + u) + k4;
             const int cc = c < N ? c : N - 1;
             av[u] = (16 * it + c16 < rd) ? L[(size_t)cc * rd + 16 * it + c16] : 0.0;
-            bv[u] = W[(size_t)cc * R + (R == 32 ? ((16 * jt + c16) ^ (16 * (cc & 1))) : c16)];
+            bv[u] = (16 * jt + c16 < rd) ? L[(size_t)cc * rd + 16 * jt + c16] : 0.0;
+            rv[u] = Rv[cc];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = 4 * (s0 + u) + k4;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(c < N ? av[u] : 0.0, bv[u], acc, 0, 0, 0);
+            const bool ok = c < N && s0 + u < s_hi;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av[u] : 0.0, bv[u] / rv[u], acc, 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int v = 0; v < 4; ++v)                               // D[(l / 16) + 4 v][l % 16]
-        if (16 * it + k4 + 4 * v < rd && 16 * jt + c16 < rd)
-            a.Cfull[(size_t)b * rd * rd + (size_t)(16 * it + k4 + 4 * v) * rd + 16 * jt + c16] = acc[v];
+    for (int v = 0; v < 4; ++v) part[(wave * 4 + v) * 64 + lane] = acc[v];
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < NW; ++w) t += red[w];
+        a.ldfull[b] = t;
+    }
+    if (sl == 0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {                         // D[(l / 16) + 4 v][l % 16]
+            double t = 0.0;
+            for (int q = 0; q < NSL; ++q) t += part[((q * NTILE + tile) * 4 + v) * 64 + lane];
+            if (16 * it + k4 + 4 * v < rd && 16 * jt + c16 < rd)
+                a.Cfull[(size_t)b * rd * rd + (size_t)(16 * it + k4 + 4 * v) * rd + 16 * jt + c16] = t;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -579,8 +599,8 @@ hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, in
 
 hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s) {
     const W2Ws w = w2_ws(a, ws, Rpad);
-    if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad);
-    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(256), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, 32);
+    if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad);
+    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, 32);
     return hipGetLastError();
 }
 
