@@ -21,13 +21,15 @@ if [ -z "$SKIP_EXTRA" ]; then
   timeout 300 python bench.py --mode pca --steps 5 --warmup 1 --repeats 5 > $OUT/bench_pca.json 2> $OUT/bench_pca.err
   timeout 300 python bench.py --missing 0.1 --steps 20 --warmup 3 --repeats 5 --no-cpu-baseline > $OUT/bench_missing10.json 2> $OUT/bench_missing10.err
   timeout 300 python bench.py --N 1000 --T 2000 --r 20 --batch-per-gpu 256 --missing 0.1 --steps 3 --warmup 1 --repeats 3 --no-cpu-baseline > $OUT/bench_c4_missing10.json 2> $OUT/bench_c4_missing10.err
+  timeout 300 python bench.py --mode em --N 1000 --T 2000 --r 20 --batch-per-gpu 256 --steps 3 --warmup 1 --repeats 3 --no-cpu-baseline > $OUT/bench_c4_em.json 2> $OUT/bench_c4_em.err
+  bash $R/scripts/dbg/extra_shapes.sh $TAG > /dev/null 2>&1
 fi
 if [ -n "$PROFILE" ]; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 30 --warmup 5 --repeats 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err)
   cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv 2>/dev/null
 fi
 tail -25 $OUT/pytest_gpu.log 2>/dev/null; cat $OUT/smoke.log 2>/dev/null
-for f in bench bench_two_launch bench_b8192 bench_c4 bench_em bench_pca bench_missing10 bench_c4_missing10; do
+for f in bench bench_two_launch bench_b8192 bench_c4 bench_em bench_pca bench_missing10 bench_c4_missing10 bench_c4_em; do
   [ -f $OUT/$f.json ] && python - $OUT/$f.json <<'PY'
 import json, sys
 try:
