@@ -390,6 +390,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     // overlap buys at B = 1024, so the default is one sub-batch; DFM_SUBBATCH keeps the knob for big batches.
     int S = h->subbatch > 0 ? h->subbatch : 1;
     if (S > B) S = B;
+    if (use_wide2) S = 1;                                     // (its workspace -- W, tile queues -- is laid out for the whole batch)
     if (S == 1 && h->pass_fused && use_mfma && pass_fused_supported(p.Rp, T, N) && h->collapse_variant == 0) {
         // ONE launch: persistent workgroups, b_t / w_t and the covariance tables never leave the chip (pass_fused.hip)
         fa.Lam = pp.Lam; fa.Rv = Rv;
