@@ -82,8 +82,9 @@ __device__ __forceinline__ void mm_step(const double (&A)[R / 16][R / 4], const 
 
 }  // namespace
 
+// (R = 16: at most 128 VGPRs, so that four of the 4-wave workgroups share a CU -- 1024 replicates in one round instead of two)
 template <int R>
-__global__ __launch_bounds__(S3Geo<R>::NT) void meanscan_mfma_kernel(FastArgs a) {
+__global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma_kernel(FastArgs a) {
     using S3Lds = S3Geo<R>;
     constexpr int kS3Threads = S3Lds::NT;
     constexpr int NIO = S3Lds::NIO, kS3Lev = S3Lds::LEV, kS3PS = S3Lds::PS, kS3NC = S3Lds::NC;
