@@ -185,6 +185,8 @@ struct EmUpdArgs {               // transition M-step + EM bookkeeping after a f
     int* active; int* iters; double* ll_path; int k, max_iter; double tol;   // as RecursionArgs
 };
 hipError_t launch_em_update(int Rpad, const EmUpdArgs& a, hipStream_t s);
+bool em_update_grid_supported(int Rpad);                                     // Rp = 16, 32: element-per-thread form (em_update_grid.hip)
+hipError_t launch_em_update_grid(int Rpad, const EmUpdArgs& a, hipStream_t s);
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
 bool cov_fuses_gram(int Rpad, int N);   // launch_cov with a.Lam != nullptr is supported for this shape
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);

@@ -429,6 +429,8 @@ static hipError_t launch_em_update_r(const EmUpdArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_em_update(int Rpad, const EmUpdArgs& a, hipStream_t s) {
+    static const bool old_wide = [] { const char* v = getenv("DFM_EM_UPDATE_OLD"); return v && atoi(v) != 0; }();
+    if (!old_wide && em_update_grid_supported(Rpad)) return launch_em_update_grid(Rpad, a, s);   // em_update_grid.hip
     switch (Rpad) {
         case 2: return launch_em_update_r<2>(a, s);
         case 4: return launch_em_update_r<4>(a, s);
