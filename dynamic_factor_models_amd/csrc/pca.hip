@@ -288,6 +288,84 @@ __device__ __forceinline__ void jacobi_lds(double* H, double* W, double* ev, int
     }
 }
 
+// The same decomposition by a whole WORKGROUP for the wide states (R = 16, 32), H and W in LDS: parallel ordering (R / 2 disjoint
+// pairs per round), one thread per pair computes its rotation, then (row, pair) items apply H <- H J and W <- W J, then
+// (pair, column) items H <- J' H -- three barriers per round instead of the single thread's ~100 k dependent LDS
+// read-modify-writes per sweep (config 4: 116 ms of pca_kernel per 256 replicates).  cs: [R] doubles of LDS scratch.
+template <int R, int NT>
+__device__ __forceinline__ void jacobi_block(double* H, double* W, double* ev, double* cs, double* red, int r, int tid) {
+    constexpr int RM = R - 1, NP = R / 2;
+    // pair k of round t (round-robin: index R - 1 stays, the others move round a circle of R - 1): (t, R - 1) for k = 0, else
+    // ((t + k) mod (R - 1), (t - k) mod (R - 1)); returned as x < y
+    auto pair_of = [&](int k, int t, int& x, int& y) {
+        const int a_ = k == 0 ? t : (t + k) % RM, b_ = k == 0 ? RM : (t - k + RM) % RM;
+        x = a_ < b_ ? a_ : b_;
+        y = a_ < b_ ? b_ : a_;
+    };
+    for (int e = tid; e < R * R; e += NT) W[e] = (e / R == e % R) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double part[2] = {0.0, 0.0};                            // off-diagonal, diagonal sums of squares
+        for (int e = tid; e < R * R; e += NT) {
+            const int i = e / R, j = e % R;
+            if (i < r && j < r) { const double h = H[e]; if (i == j) part[1] = fma(h, h, part[1]); else part[0] = fma(h, h, part[0]); }
+        }
+        block_sum<2, NT>(part, red);
+        if (part[0] <= 1e-32 * part[1]) break;                  // (uniform: block_sum leaves the totals in every thread)
+        for (int t = 0; t < RM; ++t) {
+            if (tid < NP) {                                     // thread k: the rotation of pair k, from the H of the start of the round
+                int x, y;
+                pair_of(tid, t, x, y);
+                const double hpq = H[x * R + y];
+                const bool act = y < r && hpq != 0.0;
+                const double theta = (H[y * R + y] - H[x * R + x]) / (2.0 * (act ? hpq : 1.0));
+                const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cc = 1.0 / sqrt(tt * tt + 1.0);
+                cs[2 * tid] = act ? cc : 1.0;
+                cs[2 * tid + 1] = act ? tt * cc : 0.0;
+            }
+            __syncthreads();
+            for (int it = tid; it < R * NP; it += NT) {         // (row i, pair k): columns x < y of H and of W
+                const int i = it / NP, k = it % NP;
+                int x, y;
+                pair_of(k, t, x, y);
+                const double c = cs[2 * k], sn = cs[2 * k + 1];
+                const double hp = H[i * R + x], hq = H[i * R + y];
+                H[i * R + x] = c * hp - sn * hq;
+                H[i * R + y] = sn * hp + c * hq;
+                const double wp = W[i * R + x], wq = W[i * R + y];
+                W[i * R + x] = c * wp - sn * wq;
+                W[i * R + y] = sn * wp + c * wq;
+            }
+            __syncthreads();
+            for (int it = tid; it < R * NP; it += NT) {         // (pair k, column j): rows x < y of H
+                const int j = it % R, k = it / R;
+                int x, y;
+                pair_of(k, t, x, y);
+                const double c = cs[2 * k], sn = cs[2 * k + 1];
+                const double hp = H[x * R + j], hq = H[y * R + j];
+                H[x * R + j] = c * hp - sn * hq;
+                H[y * R + j] = sn * hp + c * hq;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 0; k < r; ++k) ev[k] = H[k * R + k];
+        for (int a_ = 0; a_ < r - 1; ++a_) {                   // selection sort, descending
+            int m = a_;
+            for (int k = a_ + 1; k < r; ++k)
+                if (ev[k] > ev[m]) m = k;
+            if (m != a_) {
+                const double t = ev[a_]; ev[a_] = ev[m]; ev[m] = t;
+                for (int k = 0; k < r; ++k) { const double w = W[k * R + a_]; W[k * R + a_] = W[k * R + m]; W[k * R + m] = w; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // Jacobi eigen-decomposition by ONE WAVE with an element of H and of W per lane (lane = R i + j, lanes >= R R idle): cross-lane
 // fetches and a few FMAs per lane instead of ~100 dependent LDS read-modify-writes of one thread (the single-thread version
 // took 3.5 of pca_kernel's 5.7 ms per 1024 replicates).  Same rotation formula, stopping rule and sorting as jacobi_lds; the
@@ -654,7 +732,7 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
     if constexpr (R <= 8) {
         if (tid < 64) jacobi_wave<R>(sH, sW, sev, r, tid);
     } else {
-        if (tid == 0) jacobi_lds<R>(sH, sW, sev, r);
+        jacobi_block<R, NT>(sH, sW, sev, sM, sred, r, tid);     // (sM: scratch for the rotations of a round, 2 doubles per pair)
     }
     __syncthreads();
     for (int i = tid; i < N; i += NT) {
