@@ -218,7 +218,9 @@ struct PcaArgs {
     int* status;                // bit 1 (value 2): subspace iteration stopped at max_iter above its tolerance; or null
     int stop_after;             // diagnostics (DFM_PCA_STOP): > 0: pca_kernel returns after that phase (timing of the phases)
 };
-hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant = 0);   // 0: matrix pipe (N <= 256), 1: VALU
+hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant = 0);   // 0: matrix pipe (N <= 256; even N beyond: gram_xx_wide.hip), 1: VALU
+bool gram_xx_wide_supported(int N);
+hipError_t launch_gram_xx_wide(const PcaArgs& a, hipStream_t s);
 hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s);
 
 // Non-parametric estimator (als.hip): batched alternating least squares and batched complete-case OLS.

@@ -932,6 +932,7 @@ hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant) {
         if (per_wave <= 12) return launch_gx_mfma<12>(a, s);
         if (per_wave <= 17) return launch_gx_mfma<17>(a, s);
     }
+    if (variant == 0 && gram_xx_wide_supported(a.N)) return launch_gram_xx_wide(a, s);   // even N > 256: gram_xx_wide.hip
     hipLaunchKernelGGL(gram_xx_kernel, dim3(a.B), dim3(kPcaThreads), 0, s, a);
     return hipGetLastError();
 }
