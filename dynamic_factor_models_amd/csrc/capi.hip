@@ -1415,6 +1415,7 @@ int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doub
     HIP_TRY(h, hipMemsetAsync(at<int>(h, oSt), 0, sizeof(int), h->stream));
     PcaArgs pa;
     pa.B = B; pa.T = T; pa.N = N; pa.r = r; pa.max_iter = 4000;
+    { static const int mi = [] { const char* v = getenv("DFM_PCA_MAXIT"); return v ? atoi(v) : 0; }(); if (mi > 0) pa.max_iter = mi; }   // diagnostics
     { static const int stop = [] { const char* v = getenv("DFM_PCA_STOP"); return v ? atoi(v) : 0; }(); pa.stop_after = stop; }
     pa.panel = panel;
     pa.S = at<double>(h, oS); pa.V = at<double>(h, oV); pa.Y = at<double>(h, oY); pa.F = at<double>(h, oF);

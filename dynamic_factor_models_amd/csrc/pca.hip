@@ -668,19 +668,42 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
         }
         __syncthreads();
     };
-    auto apply_S = [&]() {                          // Y <- S V   (S symmetric: column reads are row reads)
-        for (int i = tid; i < N; i += NT) {
-            double y[R];
+    // Y <- S V on the matrix pipe: wave w takes the row tiles w, w + NT / 64, ...; per step of 4 columns of S one load of A
+    // (S[k][row] = S[row][k]: 128 contiguous bytes per k) and one of B per 16-column tile of V, 8 steps in flight.  (The VALU
+    // form -- thread = row, 32 loads of V per 32 FMAs -- took 5 ms per iteration at config 4: 13 GFLOP/s per CU.)
+    typedef double pca_v4 __attribute__((ext_vector_type(4)));
+    auto apply_S = [&]() {
+        constexpr int CT = R >= 16 ? R / 16 : 1;
+        const int lane = tid & 63, wave = tid >> 6, k4 = lane >> 4, c16 = lane & 15;
+        const int nrt = (N + 15) / 16, steps = (N + 3) / 4;
+        for (int rt = wave; rt < nrt; rt += NT / 64) {
+            pca_v4 acc[CT];
 #pragma unroll
-            for (int k = 0; k < R; ++k) y[k] = 0.0;
-#pragma unroll 8
-            for (int j = 0; j < N; ++j) {                        // (8 independent loads of S in flight)
-                const double s = S[(size_t)j * N + i];
+            for (int ct = 0; ct < CT; ++ct) acc[ct] = pca_v4{0.0, 0.0, 0.0, 0.0};
+            const int row = 16 * rt + c16, rowc = row < N ? row : N - 1;
+            for (int s0 = 0; s0 < steps; s0 += 8) {
+                double av[8], bv[CT][8];
 #pragma unroll
-                for (int k = 0; k < R; ++k) y[k] = fma(s, V[(size_t)j * R + k], y[k]);
+                for (int u = 0; u < 8; ++u) {
+                    const int c = 4 * (s0 + u) + k4, cc = c < N ? c : N - 1;
+                    av[u] = S[(size_t)cc * N + rowc];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) bv[ct][u] = (16 * ct + c16 < R) ? V[(size_t)cc * R + 16 * ct + (c16 < R ? c16 : 0)] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double a_ = (4 * (s0 + u) + k4 < N) ? av[u] : 0.0;
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[ct][u], acc[ct], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int k = 0; k < R; ++k) Y[(size_t)i * R + k] = y[k];
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {                 // D[(l / 16) + 4 v][l % 16]
+                    const int rr = 16 * rt + k4 + 4 * v, col = 16 * ct + c16;
+                    if (rr < N && col < R) Y[(size_t)rr * R + col] = acc[ct][v];
+                }
         }
         __syncthreads();
     };
@@ -811,45 +834,76 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
                 if (canon) F[(size_t)t * R + idx] = f[0];
             }
         } else {
-            for (int t = wave; t < T; t += NT / 64) {
-                double f[R];
+            {   // scores on the matrix pipe: tile = 16 periods; A[i][k] = x[t0 + i][c + k] (32-byte pieces of 16 rows: the next three
+                // steps hit the same lines), B[k][j] = V[c + k][16 ct + j].  (wave per period with 32 loads of V per series: 15 ms at config 4)
+                constexpr int CT = R >= 16 ? R / 16 : 1;
+                const int lane = tid & 63, wave = tid >> 6, k4 = lane >> 4, c16 = lane & 15;
+                const int ntt = (T + 15) / 16, steps = (N + 3) / 4;
+                for (int tt = wave; tt < ntt; tt += NT / 64) {
+                    pca_v4 acc[CT];
 #pragma unroll
-                for (int k = 0; k < R; ++k) f[k] = 0.0;
-                for (int i = lane; i < N; i += 64) {
-                    const double x = X[(size_t)t * N + i];
+                    for (int ct = 0; ct < CT; ++ct) acc[ct] = pca_v4{0.0, 0.0, 0.0, 0.0};
+                    const int trow = 16 * tt + c16, trc = trow < T ? trow : T - 1;
+                    for (int s0 = 0; s0 < steps; s0 += 8) {
+                        double av[8], bv[CT][8];
 #pragma unroll
-                    for (int k = 0; k < R; ++k) f[k] = fma(x, V[(size_t)i * R + k], f[k]);
-                }
+                        for (int u = 0; u < 8; ++u) {
+                            const int c = 4 * (s0 + u) + k4, cc = c < N ? c : N - 1;
+                            av[u] = X[(size_t)trc * N + cc];
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
+                            for (int ct = 0; ct < CT; ++ct) bv[ct][u] = (16 * ct + c16 < R) ? V[(size_t)cc * R + 16 * ct + (c16 < R ? c16 : 0)] : 0.0;
+                        }
 #pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) f[k] += __shfl_xor(f[k], off, kWave);
-                }
-                if (lane == 0) {
+                        for (int u = 0; u < 8; ++u) {
+                            const double a_ = (4 * (s0 + u) + k4 < N) ? av[u] : 0.0;
 #pragma unroll
-                    for (int k = 0; k < R; ++k) F[(size_t)t * R + k] = f[k];
+                            for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[ct][u], acc[ct], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int t = 16 * tt + k4 + 4 * v, col = 16 * ct + c16;
+                            if (t < T && col < R) F[(size_t)t * R + col] = acc[ct][v];
+                        }
                 }
             }
         }
     } else {
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int t = wave; t < T; t += NT / 64) {
-            double f[R];
+        {   // scores on the matrix pipe: tile = 16 periods; A[i][k] = x[t0 + i][c + k] (32-byte pieces of 16 rows: the next three
+            // steps hit the same lines), B[k][j] = V[c + k][16 ct + j].  (wave per period with 32 loads of V per series: 15 ms at config 4)
+            constexpr int CT = R >= 16 ? R / 16 : 1;
+            const int lane = tid & 63, wave = tid >> 6, k4 = lane >> 4, c16 = lane & 15;
+            const int ntt = (T + 15) / 16, steps = (N + 3) / 4;
+            for (int tt = wave; tt < ntt; tt += NT / 64) {
+                pca_v4 acc[CT];
 #pragma unroll
-            for (int k = 0; k < R; ++k) f[k] = 0.0;
-            for (int i = lane; i < N; i += 64) {
-                const double x = X[(size_t)t * N + i];
+                for (int ct = 0; ct < CT; ++ct) acc[ct] = pca_v4{0.0, 0.0, 0.0, 0.0};
+                const int trow = 16 * tt + c16, trc = trow < T ? trow : T - 1;
+                for (int s0 = 0; s0 < steps; s0 += 8) {
+                    double av[8], bv[CT][8];
 #pragma unroll
-                for (int k = 0; k < R; ++k) f[k] = fma(x, V[(size_t)i * R + k], f[k]);
-            }
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = 4 * (s0 + u) + k4, cc = c < N ? c : N - 1;
+                        av[u] = X[(size_t)trc * N + cc];
 #pragma unroll
-            for (int k = 0; k < R; ++k) {
+                        for (int ct = 0; ct < CT; ++ct) bv[ct][u] = (16 * ct + c16 < R) ? V[(size_t)cc * R + 16 * ct + (c16 < R ? c16 : 0)] : 0.0;
+                    }
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) f[k] += __shfl_xor(f[k], off, kWave);
-            }
-            if (lane == 0) {
+                    for (int u = 0; u < 8; ++u) {
+                        const double a_ = (4 * (s0 + u) + k4 < N) ? av[u] : 0.0;
 #pragma unroll
-                for (int k = 0; k < R; ++k) F[(size_t)t * R + k] = f[k];
+                        for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[ct][u], acc[ct], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int t = 16 * tt + k4 + 4 * v, col = 16 * ct + c16;
+                        if (t < T && col < R) F[(size_t)t * R + col] = acc[ct][v];
+                    }
             }
         }
     }
