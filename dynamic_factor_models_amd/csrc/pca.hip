@@ -238,6 +238,79 @@ __device__ __forceinline__ void chol_lds(double* G, int r) {
     }
 }
 
+// tall_gram on the matrix pipe (generic path, 4 waves): M = A'B as 16 x 16 tiles, A'[p][k] = A[k][16 pt + p] and
+// B[k][q] = Bm[k][16 qt + q] straight from global memory (128 contiguous bytes per k), 8 steps in flight.  R = 32: one tile per
+// wave over all rows; R <= 16: the one tile's rows split over the waves, partial tiles summed through `part` ([NT / 64][4][64]).
+// (tall_gram above re-reads B once per column p and block-sums R values r times: ~60 us per call at config 4, two calls per
+// iteration and four in the tail.)
+template <int R, int NT>
+__device__ __forceinline__ void tall_gram_mfma(double* M, const double* A, const double* Bm, int n, double* part) {
+    typedef double tg_v4 __attribute__((ext_vector_type(4)));
+    constexpr int CT = R >= 16 ? R / 16 : 1, NW = NT / 64, NTILE = CT * CT, NSL = NW / NTILE;
+    static_assert(NSL >= 1, "one wave per tile at least");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k4 = lane >> 4, c16 = lane & 15;
+    const int tile = wave % NTILE, sl = wave / NTILE, pt = tile / CT, qt = tile % CT;
+    const int steps = (n + 3) / 4, sps = (steps + NSL - 1) / NSL;
+    const int s_lo = sl * sps, s_hi = s_lo + sps < steps ? s_lo + sps : steps;
+    const int pa = 16 * pt + c16, pb = 16 * qt + c16;
+    tg_v4 acc = {0.0, 0.0, 0.0, 0.0};
+    for (int s0 = s_lo; s0 < s_hi; s0 += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = 4 * (s0 + u) + k4, cc = c < n ? c : n - 1;
+            av[u] = pa < R ? A[(size_t)cc * R + pa] : 0.0;
+            bv[u] = pb < R ? Bm[(size_t)cc * R + pb] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = 4 * (s0 + u) + k4 < n && s0 + u < s_hi;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av[u] : 0.0, bv[u], acc, 0, 0, 0);
+        }
+    }
+    if constexpr (NSL == 1) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) M[(16 * pt + k4 + 4 * v) * R + 16 * qt + c16] = acc[v];
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[(wave * 4 + v) * 64 + lane] = acc[v];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += part[(w * 4 + v) * 64 + lane];
+                const int row = k4 + 4 * v;
+                if (row < R && c16 < R) M[row * R + c16] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// chol_lds with the rows of a column in parallel: the same operations in the same order per element (identical results), two
+// barriers per column instead of one thread walking r^3 / 3 dependent LDS operations (0.1 ms per call at r = 20)
+template <int R, int NT>
+__device__ __forceinline__ void chol_lds_par(double* G, int r) {
+    for (int j = 0; j < r; ++j) {
+        if (threadIdx.x == 0) {
+            double d = G[j * R + j];
+            for (int k = 0; k < j; ++k) d -= G[j * R + k] * G[j * R + k];
+            G[j * R + j] = sqrt(d);
+        }
+        __syncthreads();
+        const double dj = G[j * R + j];
+        for (int i = j + 1 + (int)threadIdx.x; i < r; i += NT) {
+            double s = G[i * R + j];
+            for (int k = 0; k < j; ++k) s -= G[i * R + k] * G[j * R + k];
+            G[i * R + j] = s / dj;
+        }
+        __syncthreads();
+    }
+}
+
 // Cyclic Jacobi on the symmetric r x r H (LDS, ld R); W receives the eigenvectors (columns), sorted by
 // decreasing eigenvalue; ev[k] the eigenvalues.  Thread 0.
 template <int R>
@@ -635,6 +708,12 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int N = a.N, T = a.T, r = a.r;
+    constexpr bool kFastLds = NT == kPcaFastThreads && R <= 8;      // the LDS-resident iteration (its own Gram / Cholesky code)
+    __shared__ double sPart[kFastLds || R >= 32 ? 1 : (NT / 64) * 256];   // partial tiles of tall_gram_mfma (R <= 16)
+    auto tgram = [&](double* M, const double* A_, const double* B_, int n) {
+        if constexpr (kFastLds) tall_gram<R, NT>(M, A_, B_, n, r, sred);
+        else tall_gram_mfma<R, NT>(M, A_, B_, n, sPart);
+    };
     const double* __restrict__ X = a.panel + (size_t)b * T * N;
     const double* __restrict__ S = a.S + (size_t)b * N * N;
     double* V = a.V + (size_t)b * N * R;           // [N][R] current basis (columns >= r are zero)
@@ -651,9 +730,9 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
     __syncthreads();
 
     auto orthonormalise = [&]() {                   // V <- Y L^-T  with  Y'Y = L L'  (Cholesky QR)
-        tall_gram<R, NT>(sG, Y, Y, N, r, sred);
-        if (tid == 0) chol_lds<R>(sG, r);
-        __syncthreads();
+        tgram(sG, Y, Y, N);
+        if constexpr (kFastLds) { if (tid == 0) chol_lds<R>(sG, r); __syncthreads(); }
+        else chol_lds_par<R, NT>(sG, r);
         for (int i = tid; i < N; i += NT) {
             double y[R], v[R];
 #pragma unroll
@@ -719,7 +798,7 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
     int stall = 0;
     for (int it = 0; it < a.max_iter; ++it) {
         apply_S();
-        tall_gram<R, NT>(sH, V, Y, N, r, sred);              // H = V'S V
+        tgram(sH, V, Y, N);                                  // H = V'S V
         double part[2] = {0.0, 0.0};
         for (int i = tid; i < N; i += NT) {
             for (int k = 0; k < r; ++k) {
@@ -745,7 +824,7 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
     // Rayleigh-Ritz: H = V'SV, H = W Theta W', V <- V W (descending), sign rule of the oracle
     if constexpr (!(NT == kPcaFastThreads && R <= 8)) {       // (the fast path left H in sH)
         apply_S();
-        tall_gram<R, NT>(sH, V, Y, N, r, sred);
+        tgram(sH, V, Y, N);
     }
     if (tid == 0) {
         for (int i = 0; i < r; ++i)
@@ -916,7 +995,7 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
         }
     }
     // Lam = V_r;  R_i = (S_ii - sum_k theta_k V_ik^2) / T, with theta_k = ||F_k||^2 (= Ritz value)
-    tall_gram<R, NT>(sG, F, F, T, r, sred);                   // F'F
+    tgram(sG, F, F, T);                                       // F'F
     for (int i = tid; i < N; i += NT) {
         double q = 0.0;
         for (int k = 0; k < r; ++k) {
@@ -931,9 +1010,9 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
     }
     if (a.stop_after == 5) return;
     // VAR(1) of F without constant: A = (F0'F0)^-1 F0'F1 (transposed), Q = e'e / (T-1)
-    tall_gram<R, NT>(sH, F, F, T - 1, r, sred);                       // F0'F0
-    tall_gram<R, NT>(sW, F, F + R, T - 1, r, sred);                   // F0'F1   ([p][q] = sum_t F[t][p] F[t+1][q])
-    tall_gram<R, NT>(sM, F + R, F + R, T - 1, r, sred);               // F1'F1
+    tgram(sH, F, F, T - 1);                                           // F0'F0
+    tgram(sW, F, F + R, T - 1);                                       // F0'F1   ([p][q] = sum_t F[t][p] F[t+1][q])
+    tgram(sM, F + R, F + R, T - 1);                                   // F1'F1
     if (tid == 0) {
         double* Ao = a.A + (size_t)b * r * r;
         double* Qo = a.Q + (size_t)b * r * r;
