@@ -39,13 +39,15 @@ struct LogProd {
 // at 32), and so do the transposed 8-byte stores.
 template <int R>
 constexpr int kTileStride = R + 2;
+template <int R>
+constexpr int kGridProw = 2 * (4 * R + 4);          // doubles behind Grid<R>::prow
 
 // Cross-thread plumbing of one replicate's R x R element grid (thread l = R i + j).  R = 8: one wave, everything stays in
 // registers / the LDS crossbar.  R = 16: four waves of a workgroup; what crosses waves goes through small LDS buffers
 // with ONE s_barrier per exchange (buffers alternate, so the next exchange's writes cannot overtake this one's reads).
 template <int R>
 struct Grid {
-    double* prow;   // [2][2][R]   the two pivot rows of a block sweep  (R >= 16)
+    double* prow;   // [2][4 R + 4]  the two pivot rows of a block sweep, raw and scaled, + D^-1  (R >= 16): kGridProw<R> doubles
     double* red;    // [2][R][NW]  per-wave column partial sums    (R >= 16; NW = R R / 64 waves)
     double* tt;     // [2][R][R]   transposes                      (R = 16)
     int pr = 0, pt = 0;
@@ -114,37 +116,64 @@ struct Grid {
         double det = 1.0;
 #pragma unroll (R == 8 ? 4 : 1)       // R >= 16: a real loop (code size)
         for (int k = 0; k < R; k += 2) {
-            double qj0, qj1, qi0, qi1, p00, p01, p11;
-            if constexpr (R == 8) {
-                qj0 = __shfl(m, 8 * k + j, 64);
-                qj1 = __shfl(m, 8 * k + 8 + j, 64);
-                qi0 = __shfl(m, 8 * k + i, 64);
-                qi1 = __shfl(m, 8 * k + 8 + i, 64);
-                p00 = uniform_lane(m, 9 * k);
-                p01 = uniform_lane(m, 9 * k + 1);
-                p11 = uniform_lane(m, 9 * k + 9);
-            } else {
-                double* pb = prow + ((k >> 1) & 1) * 2 * R;
-                if (i == k) pb[j] = m;
-                if (i == k + 1) pb[R + j] = m;
-                __syncthreads();
-                qj0 = pb[j]; qj1 = pb[R + j]; qi0 = pb[i]; qi1 = pb[R + i];
-                p00 = pb[k]; p01 = pb[k + 1]; p11 = pb[R + k + 1];
-            }
-            const double dd = fma(p00, p11, -p01 * p01);
-            const double rd = fast_rcp(dd);
-            det *= dd;
-            const double e00 = p11 * rd, e01 = -p01 * rd, e11 = p00 * rd;
-            const double tj0 = fma(e00, qj0, e01 * qj1), tj1 = fma(e01, qj0, e11 * qj1);
-            const double ti0 = fma(e00, qi0, e01 * qi1), ti1 = fma(e01, qi0, e11 * qi1);
-            double nm = m - fma(qi0, tj0, qi1 * tj1);
+            double nm;
             const bool ik0 = i == k, ik1 = i == k + 1, jk0 = j == k, jk1 = j == k + 1;
-            nm = ik0 ? tj0 : nm;
-            nm = ik1 ? tj1 : nm;
-            nm = jk0 ? ti0 : nm;
-            nm = jk1 ? ti1 : nm;
-            const double eab = ik0 ? (jk0 ? e00 : e01) : (jk0 ? e01 : e11);
-            nm = ((ik0 || ik1) && (jk0 || jk1)) ? -eab : nm;
+            if constexpr (R == 8) {
+                const double qj0 = __shfl(m, 8 * k + j, 64);
+                const double qj1 = __shfl(m, 8 * k + 8 + j, 64);
+                const double qi0 = __shfl(m, 8 * k + i, 64);
+                const double qi1 = __shfl(m, 8 * k + 8 + i, 64);
+                const double p00 = uniform_lane(m, 9 * k);
+                const double p01 = uniform_lane(m, 9 * k + 1);
+                const double p11 = uniform_lane(m, 9 * k + 9);
+                const double dd = fma(p00, p11, -p01 * p01);
+                const double rd = fast_rcp(dd);
+                det *= dd;
+                const double e00 = p11 * rd, e01 = -p01 * rd, e11 = p00 * rd;
+                const double tj0 = fma(e00, qj0, e01 * qj1), tj1 = fma(e01, qj0, e11 * qj1);
+                const double ti0 = fma(e00, qi0, e01 * qi1), ti1 = fma(e01, qi0, e11 * qi1);
+                nm = m - fma(qi0, tj0, qi1 * tj1);
+                nm = ik0 ? tj0 : nm;
+                nm = ik1 ? tj1 : nm;
+                nm = jk0 ? ti0 : nm;
+                nm = jk1 ? ti1 : nm;
+                const double eab = ik0 ? (jk0 ? e00 : e01) : (jk0 ? e01 : e11);
+                nm = ((ik0 || ik1) && (jk0 || jk1)) ? -eab : nm;
+            } else {
+                // R >= 16.  The pivot rows k, k + 1 are R x 2 consecutive lanes of ONE wave: that wave alone inverts the pivot
+                // block and scales its two rows (T = D^-1 A_K, lane exchanges only), publishes raw rows, scaled rows and D^-1,
+                // and after the barrier every thread needs two FMAs and a few selects.  (Every thread used to redo the block
+                // inverse and the scaling of its row's and column's pivot entries: ~50 instructions x 1024 threads per pivot --
+                // the sweep was issue-bound at ~1260 cycles per pivot on a 16-wave workgroup, 56 % of a sequential step.)
+                double* pb = prow + ((k >> 1) & 1) * (4 * R + 4);       // raw0 | raw1 | t0 | t1 | e00 e01 e11 det
+                if (ik0 || ik1) {
+                    const int base = (k * R) & 63;                      // lane of element (k, 0) in this wave
+                    const double p00 = __shfl(m, base + k, 64), p01 = __shfl(m, base + k + 1, 64), p11 = __shfl(m, base + R + k + 1, 64);
+                    const double other = __shfl_xor(m, R, 64);          // the same column of the other pivot row
+                    const double qj0 = ik0 ? m : other, qj1 = ik0 ? other : m;
+                    const double dd = fma(p00, p11, -p01 * p01);
+                    const double rd = fast_rcp(dd);
+                    const double e00 = p11 * rd, e01 = -p01 * rd, e11 = p00 * rd;
+                    const double tj0 = fma(e00, qj0, e01 * qj1), tj1 = fma(e01, qj0, e11 * qj1);
+                    pb[(ik0 ? 0 : R) + j] = m;
+                    pb[(ik0 ? 2 * R : 3 * R) + j] = ik0 ? tj0 : tj1;
+                    if (ik0 && j == 0) { pb[4 * R] = e00; pb[4 * R + 1] = e01; pb[4 * R + 2] = e11; pb[4 * R + 3] = dd; }
+                }
+                __syncthreads();
+                const double qi0 = pb[i], qi1 = pb[R + i];
+                const double tj0 = pb[2 * R + j], tj1 = pb[3 * R + j];
+                const double ti0 = pb[2 * R + i], ti1 = pb[3 * R + i];   // (the matrix stays symmetric through the sweeps)
+                det *= pb[4 * R + 3];
+                nm = m - fma(qi0, tj0, qi1 * tj1);
+                nm = ik0 ? tj0 : nm;
+                nm = ik1 ? tj1 : nm;
+                nm = jk0 ? ti0 : nm;
+                nm = jk1 ? ti1 : nm;
+                if ((ik0 || ik1) && (jk0 || jk1)) {
+                    const double e00 = pb[4 * R], e01 = pb[4 * R + 1], e11 = pb[4 * R + 2];
+                    nm = -(ik0 ? (jk0 ? e00 : e01) : (jk0 ? e01 : e11));
+                }
+            }
             m = nm;
         }
         m = -m;

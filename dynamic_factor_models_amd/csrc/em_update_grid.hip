@@ -33,7 +33,7 @@ __global__ __launch_bounds__(R * R) void em_update_grid_kernel(EmUpdArgs a) {
     double* L1 = L0 + RT;
     Grid<R> G;
     G.prow = L1 + RT;
-    G.red = G.prow + 4 * R;
+    G.red = G.prow + kGridProw<R>;
     G.tt = G.red + 2 * (RR / 64) * R;
     double* part = G.tt + 2 * RT;                             // [2][NW][4][64]
     const int l = threadIdx.x, lane = l & 63, wave = l >> 6;
@@ -144,7 +144,7 @@ namespace {
 template <int R>
 hipError_t launch_eug(const EmUpdArgs& a, hipStream_t s) {
     constexpr int RR = R * R, RT = R * kTileStride<R>, NW = RR / 64;
-    const size_t lds = (size_t)(2 * RT + 4 * R + 2 * (RR / 64) * R + 2 * RT + 2 * NW * 4 * 64) * sizeof(double);
+    const size_t lds = (size_t)(2 * RT + kGridProw<R> + 2 * (RR / 64) * R + 2 * RT + 2 * NW * 4 * 64) * sizeof(double);
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&em_update_grid_kernel<R>),

@@ -854,7 +854,7 @@ __global__ __launch_bounds__(R * R) void cov_grid_kernel(FastArgs a) {
     Grid<R> G;
     G.l = l; G.i = l / R; G.j = l % R;
     G.prow = gsm + 4 * RT;
-    G.red = G.prow + 4 * R;
+    G.red = G.prow + kGridProw<R>;
     G.tt = G.red + 2 * (RR / 64) * R;
     __builtin_amdgcn_s_setprio(3);
     const double* Cf = a.Cfull + (size_t)b * RR;
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(R * R) void cov_grid_kernel(FastArgs a) {
 template <int R>
 static hipError_t launch_cov_grid_r(const FastArgs& a, hipStream_t s) {
     constexpr int RR = R * R, RT = R * kTileStride<R>;
-    const size_t lds = (size_t)(4 * RT + 4 * R + 2 * (RR / 64) * R + 2 * RT) * sizeof(double);
+    const size_t lds = (size_t)(4 * RT + kGridProw<R> + 2 * (RR / 64) * R + 2 * RT) * sizeof(double);
     static bool attr_done = false;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cov_grid_kernel<R>),

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
     double* LJ = L1 + RT;        // J rows (backward sweep)
     Grid<R> G;
     G.prow = LJ + RT;            // (R = 8: unused, zero bytes reserved)
-    G.red = G.prow + (R >= 16 ? 4 * R : 0);
+    G.red = G.prow + (R >= 16 ? kGridProw<R> : 0);
     G.tt = G.red + (R >= 16 ? 2 * (RR / 64) * R : 0);
     int* eidxS = reinterpret_cast<int*>(G.tt + (R >= 16 ? 2 * RT : 0));   // [T] covariance-table entry of forward step t
     const int lane = threadIdx.x;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
 template <int R>
 static size_t wave_lds_bytes(int T) {
     constexpr size_t RT = (size_t)R * kTileStride<R>;
-    const size_t extra = R >= 16 ? (4 * R + 2 * (R * R / 64) * R + 2 * RT) : 0;
+    const size_t extra = R >= 16 ? (kGridProw<R> + 2 * (R * R / 64) * R + 2 * RT) : 0;
     return (4 * RT + extra) * sizeof(double) + (size_t)T * sizeof(int);
 }
 
