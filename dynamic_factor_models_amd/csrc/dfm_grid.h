@@ -22,6 +22,12 @@ __device__ __forceinline__ double fast_rcp(double x) {
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
+// the same to one rounding less of latency: r (1 + e + e^2), e = 1 - x r (cubic: 2^-23 -> 2^-69) -- three dependent FMAs
+__device__ __forceinline__ double fast_rcp3(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r, 1.0);
+    return fma(r, fma(e, e, e), r);
+}
 // running log of a product of positive numbers without a log per factor: mantissa product + exponent sum
 struct LogProd {
     double m = 1.0;
@@ -114,59 +120,52 @@ struct Grid {
     // B_Kj = D^-1 A_Kj and B_KK = -D^-1; after all blocks the register holds -M^-1.  Returns det M = product of det D.
     __device__ __forceinline__ double sweep_inverse(double& m) {
         double det = 1.0;
+        const double negI = (i == j) ? -1.0 : 0.0;
+        (void)negI;
 #pragma unroll (R == 8 ? 4 : 1)       // R >= 16: a real loop (code size)
         for (int k = 0; k < R; k += 2) {
             double nm;
-            const bool ik0 = i == k, ik1 = i == k + 1, jk0 = j == k, jk1 = j == k + 1;
-            if constexpr (R == 8) {
-                const double qj0 = __shfl(m, 8 * k + j, 64);
-                const double qj1 = __shfl(m, 8 * k + 8 + j, 64);
-                const double qi0 = __shfl(m, 8 * k + i, 64);
-                const double qi1 = __shfl(m, 8 * k + 8 + i, 64);
-                const double p00 = uniform_lane(m, 9 * k);
-                const double p01 = uniform_lane(m, 9 * k + 1);
-                const double p11 = uniform_lane(m, 9 * k + 9);
+            if constexpr (R <= 16) {
+                // B = A - a_i' adj(D) a_j / det D for every element: the exchange reads a COPY of the matrix whose pivot block is
+                // -I, so a_K = -e_K arrives folded (with A_Kj = A_iK = 0 the same expression yields D^-1 A_Kj, (D^-1 A_Ki)' and
+                // -D^-1) -- two selects per pivot instead of the fourteen that picked among five results, and the chain
+                // pivots -> det -> reciprocal runs beside exchange -> a_i' adj(D) a_j: one FMA joins them.  A wave alone on its
+                // SIMD is ISSUE-bound here (every wave64 instruction is 4+ cycles): 58 -> 38 instructions per pivot.
+                const bool iK = (i >> 1) == (k >> 1), jK = (j >> 1) == (k >> 1);
+                const double mc = (iK && jK) ? negI : m;
+                double qj0, qj1, qi0, qi1, p00, p01, p11;
+                if constexpr (R == 8) {
+                    qj0 = __shfl(mc, 8 * k + j, 64);
+                    qj1 = __shfl(mc, 8 * k + 8 + j, 64);
+                    qi0 = __shfl(mc, 8 * k + i, 64);
+                    qi1 = __shfl(mc, 8 * k + 8 + i, 64);
+                    p00 = uniform_lane(m, 9 * k);
+                    p01 = uniform_lane(m, 9 * k + 1);
+                    p11 = uniform_lane(m, 9 * k + 9);
+                } else {
+                    // four waves: the two pivot rows (and the raw pivot block) through LDS, one barrier per pivot
+                    double* pb = prow + ((k >> 1) & 1) * (4 * R + 4);
+                    if (iK) {
+                        pb[(i - k) * R + j] = mc;
+                        if (jK) pb[2 * R + 2 * (i - k) + (j - k)] = m;
+                    }
+                    __syncthreads();
+                    qj0 = pb[j]; qj1 = pb[R + j]; qi0 = pb[i]; qi1 = pb[R + i];
+                    p00 = pb[2 * R]; p01 = pb[2 * R + 1]; p11 = pb[2 * R + 3];
+                }
                 const double dd = fma(p00, p11, -p01 * p01);
-                const double rd = fast_rcp(dd);
+                const double rd = fast_rcp3(dd);
                 det *= dd;
-                const double e00 = p11 * rd, e01 = -p01 * rd, e11 = p00 * rd;
-                const double tj0 = fma(e00, qj0, e01 * qj1), tj1 = fma(e01, qj0, e11 * qj1);
-                const double ti0 = fma(e00, qi0, e01 * qi1), ti1 = fma(e01, qi0, e11 * qi1);
-                nm = m - fma(qi0, tj0, qi1 * tj1);
-                nm = ik0 ? tj0 : nm;
-                nm = ik1 ? tj1 : nm;
-                nm = jk0 ? ti0 : nm;
-                nm = jk1 ? ti1 : nm;
-                const double eab = ik0 ? (jk0 ? e00 : e01) : (jk0 ? e01 : e11);
-                nm = ((ik0 || ik1) && (jk0 || jk1)) ? -eab : nm;
-            } else if constexpr (R == 16) {
-                // four waves: every thread redoes the block inverse and the scaling of its row's and column's pivot entries from
-                // the two published rows -- one barrier and no serial phase per pivot (the split form below is 20 % slower here)
-                double* pb = prow + ((k >> 1) & 1) * (4 * R + 4);
-                if (ik0) pb[j] = m;
-                if (ik1) pb[R + j] = m;
-                __syncthreads();
-                const double qj0 = pb[j], qj1 = pb[R + j], qi0 = pb[i], qi1 = pb[R + i];
-                const double p00 = pb[k], p01 = pb[k + 1], p11 = pb[R + k + 1];
-                const double dd = fma(p00, p11, -p01 * p01);
-                const double rd = fast_rcp(dd);
-                det *= dd;
-                const double e00 = p11 * rd, e01 = -p01 * rd, e11 = p00 * rd;
-                const double tj0 = fma(e00, qj0, e01 * qj1), tj1 = fma(e01, qj0, e11 * qj1);
-                const double ti0 = fma(e00, qi0, e01 * qi1), ti1 = fma(e01, qi0, e11 * qi1);
-                nm = m - fma(qi0, tj0, qi1 * tj1);
-                nm = ik0 ? tj0 : nm;
-                nm = ik1 ? tj1 : nm;
-                nm = jk0 ? ti0 : nm;
-                nm = jk1 ? ti1 : nm;
-                const double eab = ik0 ? (jk0 ? e00 : e01) : (jk0 ? e01 : e11);
-                nm = ((ik0 || ik1) && (jk0 || jk1)) ? -eab : nm;
+                const double m0 = (iK || jK) ? 0.0 : m;
+                const double u0 = fma(p11, qj0, -p01 * qj1), u1 = fma(p00, qj1, -p01 * qj0);
+                nm = fma(-fma(qi0, u0, qi1 * u1), rd, m0);
             } else {
                 // R = 32 (16 waves).  The pivot rows k, k + 1 are R x 2 consecutive lanes of ONE wave: that wave alone inverts the pivot
                 // block and scales its two rows (T = D^-1 A_K, lane exchanges only), publishes raw rows, scaled rows and D^-1,
                 // and after the barrier every thread needs two FMAs and a few selects.  (Every thread used to redo the block
                 // inverse and the scaling of its row's and column's pivot entries: ~50 instructions x 1024 threads per pivot --
                 // the sweep was issue-bound at ~1260 cycles per pivot on a 16-wave workgroup, 56 % of a sequential step.)
+                const bool ik0 = i == k, ik1 = i == k + 1, jk0 = j == k, jk1 = j == k + 1;
                 double* pb = prow + ((k >> 1) & 1) * (4 * R + 4);       // raw0 | raw1 | t0 | t1 | e00 e01 e11 det
                 if (ik0 || ik1) {
                     const int base = (k * R) & 63;                      // lane of element (k, 0) in this wave
