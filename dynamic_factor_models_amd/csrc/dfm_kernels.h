@@ -97,6 +97,9 @@ bool collapse_miss_supported(int Rpad, int N);
 hipError_t launch_collapse_miss(const CollapseArgs& a, int num_cu, hipStream_t s);
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a);
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad);
+// Rp = 8, information form, B <= ~1.5 x the SIMD count: the replicate split over a covariance wave and a mean wave (recursion_pair.hip)
+bool recursion_pair_supported(const RecursionArgs& a);
+hipError_t launch_recursion_pair(const RecursionArgs& a, hipStream_t s);
 int collapse_max_n(int Rpad);
 // balanced panels (no NaN), even N: LDS-DMA streaming collapse (writes bcol, scol only) + Gram kernel
 bool collapse_dma_supported(int Rpad, int N);
