@@ -141,16 +141,34 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
             // DENSE: every period of the chunk has a missing cell, so every step is a new covariance step whatever the
             // steady-state test says -- the chunk runs without that test (a compare, a ballot and a branch per step on the
             // chain) and as ONE basic block, which lets the scheduler put a step's tail under the next step's first exchange
+            double qcp[CHW];
             auto step = [&](auto dense_tag, int s) {
                 constexpr bool DENSE = decltype(dense_tag)::value;
                 const int t = c * CHW + s;
-                const bool computed = DENSE || need_cov;
+                if constexpr (DENSE) {
+                    // Z_t = (Om_p,t + C_t + Phi)^-1 with  Om_p,t+1 + C_t+1 + Phi = (Qi + C_t+1 + Phi) - K J_t : the constant part is
+                    // summed beside the chain (qcp), the chain sees one subtraction between the product and the next sweep
+                    detM_cur = G.sweep_inverse(Z);
+                    G.sync();
+                    L0[TS * i + j] = Z;
+                    G.sync();
+                    Jr = dot_rows<R>(L0, LK, i, j);                // J = Z K'
+                    L1[TS * j + i] = Jr;
+                    G.sync();
+                    const double kj = dot_rows<R>(LK, L1, i, j);   // K J
+                    ++e;
+                    zb[s] = Z; jb[s] = Jr; eb[s] = e;
+                    rb[s * RR + lane] = Z;
+                    detprod.mul(detM_cur);
+                    if (s + 1 < CHW) Z = qcp[s + 1] - kj;
+                    else { Omp = Qi - kj; Omf = Omp + cc[s]; }
+                    return;
+                }
+                const bool computed = need_cov;
                 const double Omf_used = Omf;
                 if (computed) {  // wave-uniform
                     Z = Omf + Phi;
-#if !defined(PAIR_ABL) || PAIR_ABL != 1
                     detM_cur = G.sweep_inverse(Z);
-#endif
                     G.sync();
                     L0[TS * i + j] = Z;
                     G.sync();
@@ -166,13 +184,11 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
                 detprod.mul(detM_cur);
                 const bool full = (cn[s] == N);
                 const double Omf_new = Omp + (full ? Cf : cc[s]);
-                if constexpr (!DENSE) {
-                    if (computed) {
-                        const bool same = full && close_enough(Omf_new, Omf_used);
-                        need_cov = !G.all_true(same);
-                    } else {
-                        need_cov = !full;
-                    }
+                if (computed) {
+                    const bool same = full && close_enough(Omf_new, Omf_used);
+                    need_cov = !G.all_true(same);
+                } else {
+                    need_cov = !full;
                 }
                 Omf = Omf_new;
             };
@@ -180,6 +196,10 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
 #pragma unroll
             for (int s = 0; s < CHW; ++s) dense = dense && (cn[s] != N);
             if (dense && need_cov) {
+#pragma unroll
+                for (int s = 0; s < CHW; ++s) qcp[s] = Qi + (cc[s > 0 ? s - 1 : 0] + Phi);   // qcp[s]: for the step after s - 1
+                if (lane < CHW) eidxS[c * CHW + lane] = e + 1 + lane;
+                Z = Omf + Phi;
 #pragma unroll
                 for (int s = 0; s < CHW; ++s) step(std::true_type{}, s);
             } else {
@@ -415,11 +435,6 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
 #pragma unroll
         for (int s = 0; s < CHW; ++s) {
             if (s < smax) {
-#if defined(PAIR_ABL) && PAIR_ABL == 4
-                const double w = zs[s] * xi;
-                wb[s] = w; xi = KT * w + cb[s]; ssum += cs[s];
-                continue;
-#endif
                 const double w = G.sum_j(zs[s] * xi);              // w = Z xi, row-distributed
                 sum_xw = fma(xi, w, sum_xw);                       // (x_j w_i in every lane: the diagonal is picked at the end)
                 wb[s] = w;
@@ -515,12 +530,19 @@ static size_t pair_lds_bytes(int T) {
     return (4 * RT + 2 * kPairChunk * 64 + 10 * 64) * sizeof(double) + (size_t)T * sizeof(int);
 }
 
-// Rp = 8, information form, batches that leave a SIMD at most ~one replicate (beyond that the SIMDs are full of single waves
-// and the split only adds barriers).  DFM_NO_PAIR=1: never; DFM_PAIR_BMAX: the batch limit (default 1536).
+// Rp = 8, information form, batches of at most one replicate per SIMD (two waves share a SIMD then; beyond that
+// recursion_wave_kernel<8> with chunks of 4 already runs two replicates per SIMD and the split would only add barriers).
+// DFM_NO_PAIR=1: never; DFM_PAIR_BMAX: another batch limit.
 bool recursion_pair_supported(const RecursionArgs& a) {
     static const bool off = [] { const char* v = getenv("DFM_NO_PAIR"); return v && atoi(v) != 0; }();
-    static const int bmax = [] { const char* v = getenv("DFM_PAIR_BMAX"); return v ? atoi(v) : 1536; }();
+    static const int bmax = [] {
+        if (const char* v = getenv("DFM_PAIR_BMAX")) return atoi(v);
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 1024;
+        return pr.multiProcessorCount * 4;
+    }();
     if (off || a.cov || a.B > bmax) return false;
+    if (a.rl != 0 && a.Rc == 0) return false;
     return pair_lds_bytes(a.T) <= 38 * 1024;                        // four workgroups per CU
 }
 
