@@ -201,9 +201,10 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
                         Z = Omf - dot_rows<R>(L1, L0, i, j);          // Z = P_f - J A P_f
                         double Pn = Omp + Crow;
                         detM_cur = G.sweep_inverse(Pn);        // P_f' = (Om_p + C_t)^-1
-                        const bool same = full && close_enough(Pn, Omf);
+                        // (a row with missing cells is a new step whatever the test says: no ballot / barrier for it)
+                        const bool steady = full && G.all_true(close_enough(Pn, Omf));
                         Omf = Pn;
-                        need_cov = !G.all_true(same);
+                        need_cov = !steady;
                         ++e;
                         zb[s] = Z; jb[s] = Jr; eb[s] = e;
                     }
@@ -257,8 +258,7 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
                 ldsum += full ? ldfull : cl[s];                // ldrow is only written for rows with NaN
                 const double Omf_new = Omp + (full ? Cf : cc[s]);
                 if (computed) {
-                    const bool same = full && close_enough(Omf_new, Omf_used);
-                    need_cov = !G.all_true(same);
+                    need_cov = !(full && G.all_true(close_enough(Omf_new, Omf_used)));   // (no ballot / barrier for a row with missing cells)
                 } else {
                     need_cov = !full;
                 }
@@ -393,9 +393,11 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
                     L1[TS * j + i] = U;                         // U' rows = U columns
                     G.sync();
                     const double pn_ = Z + dot_rows<R>(LJ, L1, i, j);   // Z + J U
-                    const bool same = close_enough(pn_, Ps);
+                    // the test only matters when the NEXT step reuses this table entry (wave-uniform, known from the prefetch)
+                    const int e_next = s > 0 ? ec[s - 1] : en[CHW - 1];
+                    const bool reuse = (s > 0 || c > 0) && e_next == ec[s];
+                    need_b = reuse ? !G.all_true(close_enough(pn_, Ps)) : true;
                     Ps = pn_;
-                    need_b = !G.all_true(same);
                 }
                 TOCK(p_bcov);
                 TICK(p_bmean);
