@@ -31,6 +31,8 @@ struct dfm_handle {
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
     size_t status_off = 0;                 // status word of the plan used by the last call
     bool no_rec_wave = false;              // DFM_NO_RECURSION_WAVE=1: lane-group recursion_kernel also at Rp = 8 (A/B)
+    int pair_bmax = -1;                    // Rp = 8: batch limit of the covariance-wave + mean-wave pair (recursion_pair.hip); -1 = one replicate per SIMD,
+                                           // DFM_PAIR_BMAX=n; DFM_NO_PAIR=1 = 0 (never)
     bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
     bool fused_gram = true;                // DFM_FUSED_GRAM=0: gram_kernel as its own launch in front of the fused collapse launch
     bool no_fuse_cov = false;              // DFM_NO_FUSE_COV=1: cov_kernel / pfill_kernel as their own launches on a forked stream
@@ -520,6 +522,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
     ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim; ra.kb = p.kb; ra.ka = p.ka; ra.wave = h->no_rec_wave ? 0 : 1;
+    ra.pair_bmax = h->pair_bmax >= 0 ? h->pair_bmax : 4 * h->num_cu;
     ra.A = pp.A; ra.Q = pp.Q; ra.mu0 = pp.mu0; ra.P0 = pp.P0;
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
@@ -951,6 +954,8 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_NUM_CU")) { if (atoi(v) > 0) h->num_cu = atoi(v); }   // diagnostics: persistent grids sized for fewer CUs
     if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
     if (const char* v = getenv("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
+    if (const char* v = getenv("DFM_PAIR_BMAX")) h->pair_bmax = atoi(v) > 0 ? atoi(v) : 0;
+    if (const char* v = getenv("DFM_NO_PAIR")) { if (atoi(v) != 0) h->pair_bmax = 0; }
     g_widen_small_r = !h->no_rec_wave;      // process-wide: follows the most recently created handle
     if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
     if (const char* v = getenv("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;

@@ -68,6 +68,8 @@ struct RecursionArgs {
     int wave;             // 1: one wave per replicate where recursion_wave.hip supports the shape (Rp = 8, information form)
     int kb;               // > 0 with kdim: block size r of the companion state when the observation loads on MORE than the first
                           // block (AR idiosyncratic terms: rl = 0); 0: the block is rl
+    int pair_bmax;        // Rp = 8, information form: batches up to this size run as a covariance wave + a mean wave per replicate
+                          // (recursion_pair.hip); 0: never
     int ka;               // > 0 with kdim: only the first ka = r p columns of the transition rows are free (a VAR(p) inside a
                           // state that carries m > p lags); 0: all kdim columns
 };

@@ -530,18 +530,11 @@ static size_t pair_lds_bytes(int T) {
     return (4 * RT + 2 * kPairChunk * 64 + 10 * 64) * sizeof(double) + (size_t)T * sizeof(int);
 }
 
-// Rp = 8, information form, batches of at most one replicate per SIMD (two waves share a SIMD then; beyond that
-// recursion_wave_kernel<8> with chunks of 4 already runs two replicates per SIMD and the split would only add barriers).
-// DFM_NO_PAIR=1: never; DFM_PAIR_BMAX: another batch limit.
+// Rp = 8, information form, batches of at most a.pair_bmax replicates (default: one replicate per SIMD -- two waves share a
+// SIMD then; beyond that recursion_wave_kernel<8> with chunks of 4 already runs two replicates per SIMD and the split would
+// only add barriers).
 bool recursion_pair_supported(const RecursionArgs& a) {
-    static const bool off = [] { const char* v = getenv("DFM_NO_PAIR"); return v && atoi(v) != 0; }();
-    static const int bmax = [] {
-        if (const char* v = getenv("DFM_PAIR_BMAX")) return atoi(v);
-        int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 1024;
-        return pr.multiProcessorCount * 4;
-    }();
-    if (off || a.cov || a.B > bmax) return false;
+    if (a.cov || a.B > a.pair_bmax) return false;
     if (a.rl != 0 && a.Rc == 0) return false;
     return pair_lds_bytes(a.T) <= 38 * 1024;                        // four workgroups per CU
 }

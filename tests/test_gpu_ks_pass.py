@@ -237,6 +237,22 @@ def test_balanced_kernel_choices_agree(env):
         c.close()
 
 
+@pytest.mark.parametrize("env", [dict(), dict(DFM_NO_PAIR=1), dict(DFM_PAIR_BMAX=3)])
+def test_sequential_kernel_choices_agree(env):
+    """Panels with missing cells at Rp = 8: the covariance-wave + mean-wave pair (recursion_pair.hip, the default up to
+    one replicate per SIMD) and the one-wave-per-replicate kernel are the same function of the inputs -- dense chunks
+    (every period with a missing cell), mixed chunks, fully observed stretches that reach the steady state, r = 3
+    padded to the 8-wide state, T not a multiple of the chunk."""
+    c = _ctx_with_env(**env)
+    try:
+        for (B, N, T, r, miss) in [(5, 200, 500, 8, 0.1), (4, 64, 203, 8, 0.01), (6, 30, 41, 3, 0.3), (3, 120, 257, 5, 0.0005),
+                                   (2, 50, 7, 2, 0.2)]:
+            panel, st = _batch(B, N, T, r, miss)
+            _compare(_run_dev(c, panel, st, may_have_missing=True), _oracle(panel, st), f"{env} N={N} T={T} r={r} miss={miss}")
+    finally:
+        c.close()
+
+
 def test_config4_full_size_properties(ctx):
     """BASELINE config 4 at full size (N = 1000, T = 2000, r = 20, 256 replicates; 4.1 GB of panels): the
     size-independent properties of the pass -- linearity of the smoothed mean in the data (mu0 = 0), data-independent
