@@ -8,6 +8,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/device.txt; nproc >> $OUT/device.txt
+(rocm-smi --showperflevel --showclocks --showpower --showmemorypartition --showcomputepartition 2>/dev/null | grep -v '^=' | grep -v '^$') >> $OUT/device.txt
 if [ -z "$SKIP_TESTS" ]; then
   timeout 1500 python -m pytest tests -q -m gpu --maxfail=25 2>&1 | tail -60 > $OUT/pytest_gpu.log
   timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 > $OUT/smoke.log
@@ -28,6 +29,7 @@ if [ -n "$PROFILE" ]; then
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --steps 30 --warmup 5 --repeats 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err)
   cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv 2>/dev/null
 fi
+(echo '--- after the runs'; rocm-smi --showclocks --showpower 2>/dev/null | grep -v '^=' | grep -v '^$') >> $OUT/device.txt
 tail -25 $OUT/pytest_gpu.log 2>/dev/null; cat $OUT/smoke.log 2>/dev/null
 for f in bench bench_two_launch bench_b8192 bench_c4 bench_em bench_pca bench_missing10 bench_c4_missing10 bench_c4_em; do
   [ -f $OUT/$f.json ] && python - $OUT/$f.json <<'PY'
