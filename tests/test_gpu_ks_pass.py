@@ -246,7 +246,7 @@ def test_sequential_kernel_choices_agree(env):
     c = _ctx_with_env(**env)
     try:
         for (B, N, T, r, miss) in [(5, 200, 500, 8, 0.1), (4, 64, 203, 8, 0.01), (6, 30, 41, 3, 0.3), (3, 120, 257, 5, 0.0005),
-                                   (2, 50, 7, 2, 0.2)]:
+                                   (2, 50, 7, 2, 0.2), (2, 20, 5750, 8, 0.05), (2, 20, 5770, 8, 0.05)]:   # (5760 periods: the pair kernel's LDS limit)
             panel, st = _batch(B, N, T, r, miss)
             _compare(_run_dev(c, panel, st, may_have_missing=True), _oracle(panel, st), f"{env} N={N} T={T} r={r} miss={miss}")
     finally:
