@@ -246,13 +246,33 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
             }
         }
 
-        // ---- backward: P_t|T, sum P, sum U
+        // ---- backward: P_t|T = Z_t + J_t P_t+1|T J_t', sum P, sum U (U = P_t+1|T J_t' = Cov(f_t+1, f_t | X)) on the matrix pipe.
+        // The matrices move to the D layout of v_mfma_f64_4x4x4 (four 4 x 4 blocks: lane l = element (4 dI + (l >> 4),
+        // 4 dJ + (l & 3)) of block (dI, dJ) = bits 3, 2 of l), in which an 8 x 8 product is two MFMAs whose result lands where
+        // the next product wants it: the A operand X[4 dI + (l & 3)][4 K + (l >> 4)] is one ds_bpermute of X, the B operand
+        // Y[4 K + (l >> 4)][4 dJ + (l & 3)] is Y of lane l with bit 3 := K (one DPP row_ror:8 and a select).  The operands of
+        // J_t do not depend on the chain.  (The LDS-tile products cost ~50 instructions and three LDS round trips per step.)
+        const int dI = (lane >> 3) & 1, dJ = (lane >> 2) & 1, lo2 = lane & 3, hi2 = lane >> 4;
+        const int di = 4 * dI + hi2, dj = lane & 7;
+        const int eD = 8 * di + dj;                                // row-major index of this lane's element
+        const int srcA0 = hi2 | (dI << 3) | (lo2 << 4), srcA1 = srcA0 | 4;   // lanes of X[4 dI + lo2][4 K + hi2], K = 0, 1
+        const int srcT0 = hi2 | (dJ << 3) | (lo2 << 4), srcT1 = srcT0 | 4;   // lanes of X[4 dJ + lo2][4 K + hi2]: B operand of X'
+        const bool hiHalf = (lane & 8) != 0;
+        auto ror8 = [&](double v) {                               // value of lane l ^ 8
+            int lo = __double2loint(v), hi = __double2hiint(v);
+            lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, false);
+            hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false);
+            return __hiloint2double(hi, lo);
+        };
+        const bool inLd = di < rl && dj < rl;
         auto emitP = [&](int trow, double P) {
-            if (i >= r) return;
-            if (a.P_smooth && j <= i) a.P_smooth[((size_t)b * T + trow) * npr + i * (i + 1) / 2 + j] = inL ? P : (i == j ? 1.0 : 0.0);
+            if (di >= r) return;
+            if (a.P_smooth && dj <= di) a.P_smooth[((size_t)b * T + trow) * npr + di * (di + 1) / 2 + dj] = inLd ? P : (di == dj ? 1.0 : 0.0);
         };
         const double PsT = Ps;
-        double S11c = Ps, S10c = 0.0, U = 0.0;
+        double PsD = __shfl(Ps, eD, 64);
+        double S11c = PsD, S10c = 0.0, U = 0.0;
+        double jA0 = 0.0, jA1 = 0.0, jT0 = 0.0, jT1 = 0.0;
         double zc[CHW], zn[CHW], jc[CHW], jn[CHW];
         int ec[CHW], en[CHW];
         auto issue_bwd = [&](int c) {
@@ -262,15 +282,15 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
                 t = t < T ? t : T - 1;
                 const int ee = eidxS[t];
                 en[s] = ee;
-                zn[s] = ZJ[((size_t)ee * 2 + 0) * RR + lane];
-                jn[s] = ZJ[((size_t)ee * 2 + 1) * RR + lane];
+                zn[s] = ZJ[((size_t)ee * 2 + 0) * RR + eD];
+                jn[s] = ZJ[((size_t)ee * 2 + 1) * RR + eD];
             }
         };
         double pb[CHW + 1];
         int tb[CHW + 1];
 #pragma unroll
         for (int s = 0; s <= CHW; ++s) { pb[s] = 0.0; tb[s] = -1; }
-        pb[CHW] = Ps; tb[CHW] = T - 1;
+        pb[CHW] = PsD; tb[CHW] = T - 1;
         auto flush_bwd = [&]() {
 #pragma unroll
             for (int s = 0; s <= CHW; ++s) {
@@ -287,37 +307,37 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
             flush_bwd();
             if (c - 1 >= 0) issue_bwd(c - 1);
             const int smax = (T - c * CHW) < CHW ? (T - c * CHW) : CHW;
-            // DENSE: eight distinct table entries -- every step restages J and recomputes P (always valid: the test only skips
-            // steps that would reproduce their input)
+            // DENSE: eight distinct table entries -- every step takes its own J and recomputes P (always valid: the test only
+            // skips steps that would reproduce their input)
             auto step = [&](auto dense_tag, int s) {
                 constexpr bool DENSE = decltype(dense_tag)::value;
                 const int t = c * CHW + s;
                 const bool changed = DENSE || ec[s] != e_prev;     // wave-uniform
                 if (changed) {
-                    Z = zc[s]; Jr = jc[s];
+                    Z = zc[s];
                     e_prev = ec[s];
-                    G.sync();
-                    LJ[TS * i + j] = Jr;
+                    jA0 = __shfl(jc[s], srcA0, 64); jA1 = __shfl(jc[s], srcA1, 64);
+                    jT0 = __shfl(jc[s], srcT0, 64); jT1 = __shfl(jc[s], srcT1, 64);
                 }
                 if (DENSE || need_b || changed) {  // wave-uniform
-                    G.sync();
-                    L0[TS * i + j] = Ps;
-                    G.sync();
-                    U = dot_rows<R>(L0, LJ, i, j);                 // U = P_s J' = Cov(f_{t+1}, f_t | X)
-                    L1[TS * j + i] = U;
-                    G.sync();
-                    const double pn_ = Z + dot_rows<R>(LJ, L1, i, j);   // Z + J U
+                    const double pA0 = __shfl(PsD, srcA0, 64), pA1 = __shfl(PsD, srcA1, 64);
+                    U = __builtin_amdgcn_mfma_f64_4x4x4f64(pA0, jT0, 0.0, 0, 0, 0);
+                    U = __builtin_amdgcn_mfma_f64_4x4x4f64(pA1, jT1, U, 0, 0, 0);          // U = P_s J'
+                    const double Ux = ror8(U);
+                    const double uB0 = hiHalf ? Ux : U, uB1 = hiHalf ? U : Ux;
+                    double pn_ = __builtin_amdgcn_mfma_f64_4x4x4f64(jA0, uB0, Z, 0, 0, 0);
+                    pn_ = __builtin_amdgcn_mfma_f64_4x4x4f64(jA1, uB1, pn_, 0, 0, 0);      // Z + J U
                     if constexpr (!DENSE) {
-                        const bool same = close_enough(pn_, Ps);
+                        const bool same = close_enough(pn_, PsD);
                         need_b = !G.all_true(same);
                     }
-                    Ps = pn_;
+                    PsD = pn_;
                 }
                 if (em) {
                     S10c += U;
-                    if (t > 0) S11c += Ps;
+                    if (t > 0) S11c += PsD;
                 }
-                if (t > 0) { pb[s] = Ps; tb[s] = t - 1; }
+                if (t > 0) { pb[s] = PsD; tb[s] = t - 1; }
             };
             if (smax == CHW && ec[CHW - 1] - ec[0] == CHW - 1) {
 #pragma unroll
@@ -329,10 +349,23 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
                     if (s < smax) step(std::false_type{}, s);
             }
         }
+        {   // back to the element layout of the forward sweep (lane 8 i + j) for the epilogue
+            const int lD = j | ((i >> 2) << 3) | ((i & 3) << 4);
+            Ps = __shfl(PsD, lD, 64);
+            S11c = __shfl(S11c, lD, 64);
+            S10c = __shfl(S10c, lD, 64);
+        }
         flush_bwd();
         PSTAMP(pt2);
 #ifdef DFM_PAIR_PROF
-        if (b == 5 && lane == 0) printf("PAIRPROF cov: fwd %llu bwd %llu (10 ns ticks)\n", pt1 - pt0, pt2 - pt1);
+        if (lane == 0) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned cu = (hw >> 8) & 15, se = (hw >> 13) & 7, simd = (hw >> 4) & 3;
+            if ((xcc & 15) == 0 && se == 0 && cu < 2)
+                printf("PAIRPROF cov b=%d xcc %u se %u cu %u simd %u: fwd %llu bwd %llu (10 ns ticks)\n", b, xcc & 15, se, cu, simd, pt1 - pt0, pt2 - pt1);
+        }
 #endif
         __syncthreads();                                           // (E1) the mean wave's sums
         if (em) {
@@ -515,7 +548,14 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
     flush_bwd();
     PSTAMP(pt2);
 #ifdef DFM_PAIR_PROF
-    if (b == 5 && lane == 0) printf("PAIRPROF mean: fwd %llu bwd %llu (10 ns ticks)\n", pt1 - pt0, pt2 - pt1);
+    if (lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned cu = (hw >> 8) & 15, se = (hw >> 13) & 7, simd = (hw >> 4) & 3;
+        if ((xcc & 15) == 0 && se == 0 && cu < 2)
+            printf("PAIRPROF mean b=%d xcc %u se %u cu %u simd %u: fwd %llu bwd %llu (10 ns ticks)\n", b, xcc & 15, se, cu, simd, pt1 - pt0, pt2 - pt1);
+    }
 #endif
     xch[5 * RR + lane] = S11m;
     xch[6 * RR + lane] = S10m;
