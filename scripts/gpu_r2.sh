@@ -9,6 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/device.txt; nproc >> $OUT/device.txt
 (rocm-smi --showperflevel --showclocks --showpower --showmemorypartition --showcomputepartition 2>/dev/null | grep -v '^=' | grep -v '^$') >> $OUT/device.txt
+[ -x $R/scripts/microbench/chainlat ] && timeout 60 $R/scripts/microbench/chainlat > $OUT/chainlat.txt 2>&1
 if [ -z "$SKIP_TESTS" ]; then
   timeout 1500 python -m pytest tests -q -m gpu --maxfail=25 2>&1 | tail -60 > $OUT/pytest_gpu.log
   timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -3 > $OUT/smoke.log
