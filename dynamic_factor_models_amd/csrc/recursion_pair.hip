@@ -12,6 +12,9 @@
 // the mean wave takes 110 of the 410 instructions off the chain and fills the covariance wave's waits on the same SIMDs.
 // Forward the mean wave runs one chunk of 8 periods behind (Z_t through a double-buffered LDS ring, one s_barrier per
 // chunk); backward the two are independent (both read the (Z_e, J_e) table) and meet once at the end.
+// The four 8 x 8 products of a period (J = Z K', K J forward; P J', Z + J U backward) run on v_mfma_f64_4x4x4 with the
+// matrices in its D layout -- operands by one ds_bpermute / a DPP row_ror:8, no LDS tiles (scripts/microbench/chainlat.hip:
+// an LDS write -> read round trip costs a lone wave 122 cycles, a ds_bpermute pair 77, every f64 instruction ~6).
 // Same inputs, scratch tables and outputs as recursion_wave_kernel<8, false>; results equal to rounding (sums are split).
 // Reference counterpart: none (dfm_functions.ipynb:21-23 declares `Parametric` only); oracle: oracle/kalman_oracle.py.
 #include <stdlib.h>
@@ -100,6 +103,38 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
         xch[1 * RR + lane] = G.transposed(xi0r);                   // column-distributed
         __syncthreads();                                           // (P) constants for the mean wave
 
+        // D layout of v_mfma_f64_4x4x4 (described at the backward sweep)
+        const int dI = (lane >> 3) & 1, dJ = (lane >> 2) & 1, lo2 = lane & 3, hi2 = lane >> 4;
+        const int di = 4 * dI + hi2, dj = lane & 7;
+        const int eD = 8 * di + dj;                                // row-major index of this lane's element
+        const int srcA0 = hi2 | (dI << 3) | (lo2 << 4), srcA1 = srcA0 | 4;   // lanes of X[4 dI + lo2][4 K + hi2], K = 0, 1
+        const int srcT0 = hi2 | (dJ << 3) | (lo2 << 4), srcT1 = srcT0 | 4;   // lanes of X[4 dJ + lo2][4 K + hi2]: B operand of X'
+        const bool hiHalf = (lane & 8) != 0;
+        auto ror8 = [&](double v) {                               // value of lane l ^ 8
+            int lo = __double2loint(v), hi = __double2hiint(v);
+            lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, false);
+            hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false);
+            return __hiloint2double(hi, lo);
+        };
+        // the two products of a step on the matrix pipe (see the backward sweep for the D layout): operands of the constant K are
+        // taken once; Z (element layout 8 i + j) gives its A operand by one ds_bpermute, K J comes back by another
+        const int srcZ0 = 8 * (4 * dI + lo2) + hi2, srcZ1 = srcZ0 + 4;        // lanes (8 i + j layout) of X[4 dI + lo2][4 K + hi2]
+        const double kB0 = __shfl(K, 8 * (4 * dJ + lo2) + hi2, 64), kB1 = __shfl(K, 8 * (4 * dJ + lo2) + 4 + hi2, 64);   // B operand of K'
+        const double kA0 = __shfl(K, srcZ0, 64), kA1 = __shfl(K, srcZ1, 64);  // A operand of K
+        const int lDij = j | ((i >> 2) << 3) | ((i & 3) << 4);                // D-layout lane of element (i, j)
+        double Jd = 0.0;                                                      // J_t in the D layout (stored at its row-major index)
+        auto products = [&](double Zel) {                                     // J = Z K' (kept in Jd); returns K J in the 8 i + j layout
+            const double zA0 = __shfl(Zel, srcZ0, 64), zA1 = __shfl(Zel, srcZ1, 64);
+            double jd = __builtin_amdgcn_mfma_f64_4x4x4f64(zA0, kB0, 0.0, 0, 0, 0);
+            jd = __builtin_amdgcn_mfma_f64_4x4x4f64(zA1, kB1, jd, 0, 0, 0);
+            Jd = jd;
+            const double jx = ror8(jd);
+            const double jB0 = hiHalf ? jx : jd, jB1 = hiHalf ? jd : jx;
+            double kj = __builtin_amdgcn_mfma_f64_4x4x4f64(kA0, jB0, 0.0, 0, 0, 0);
+            kj = __builtin_amdgcn_mfma_f64_4x4x4f64(kA1, jB1, kj, 0, 0, 0);
+            return __shfl(kj, lDij, 64);
+        };
+
         // ---- forward
         double cc[CHW], nc_[CHW];
         int cn[CHW], nn_[CHW];
@@ -125,7 +160,7 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
             for (int s = 0; s < CHW; ++s) {
                 if (eb[s] >= 0) {
                     ZJ[((size_t)eb[s] * 2 + 0) * RR + lane] = zb[s];
-                    ZJ[((size_t)eb[s] * 2 + 1) * RR + lane] = jb[s];
+                    ZJ[((size_t)eb[s] * 2 + 1) * RR + eD] = jb[s];   // (J_e is held in the D layout: lane -> element eD)
                 }
                 eb[s] = -1;
             }
@@ -149,15 +184,9 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
                     // Z_t = (Om_p,t + C_t + Phi)^-1 with  Om_p,t+1 + C_t+1 + Phi = (Qi + C_t+1 + Phi) - K J_t : the constant part is
                     // summed beside the chain (qcp), the chain sees one subtraction between the product and the next sweep
                     detM_cur = G.sweep_inverse(Z);
-                    G.sync();
-                    L0[TS * i + j] = Z;
-                    G.sync();
-                    Jr = dot_rows<R>(L0, LK, i, j);                // J = Z K'
-                    L1[TS * j + i] = Jr;
-                    G.sync();
-                    const double kj = dot_rows<R>(LK, L1, i, j);   // K J
+                    const double kj = products(Z);                 // J = Z K' (Jd), K J
                     ++e;
-                    zb[s] = Z; jb[s] = Jr; eb[s] = e;
+                    zb[s] = Z; jb[s] = Jd; eb[s] = e;
                     rb[s * RR + lane] = Z;
                     detprod.mul(detM_cur);
                     if (s + 1 < CHW) Z = qcp[s + 1] - kj;
@@ -169,15 +198,9 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
                 if (computed) {  // wave-uniform
                     Z = Omf + Phi;
                     detM_cur = G.sweep_inverse(Z);
-                    G.sync();
-                    L0[TS * i + j] = Z;
-                    G.sync();
-                    Jr = dot_rows<R>(L0, LK, i, j);                // J = Z K'
-                    L1[TS * j + i] = Jr;
-                    G.sync();
-                    Omp = Qi - dot_rows<R>(LK, L1, i, j);          // Om_p = Qi - K J
+                    Omp = Qi - products(Z);                        // J = Z K' (Jd), Om_p = Qi - K J
                     ++e;
-                    zb[s] = Z; jb[s] = Jr; eb[s] = e;
+                    zb[s] = Z; jb[s] = Jd; eb[s] = e;
                 }
                 rb[s * RR + lane] = Z;
                 if (lane == 0) eidxS[t] = e;
@@ -252,18 +275,6 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
         // the next product wants it: the A operand X[4 dI + (l & 3)][4 K + (l >> 4)] is one ds_bpermute of X, the B operand
         // Y[4 K + (l >> 4)][4 dJ + (l & 3)] is Y of lane l with bit 3 := K (one DPP row_ror:8 and a select).  The operands of
         // J_t do not depend on the chain.  (The LDS-tile products cost ~50 instructions and three LDS round trips per step.)
-        const int dI = (lane >> 3) & 1, dJ = (lane >> 2) & 1, lo2 = lane & 3, hi2 = lane >> 4;
-        const int di = 4 * dI + hi2, dj = lane & 7;
-        const int eD = 8 * di + dj;                                // row-major index of this lane's element
-        const int srcA0 = hi2 | (dI << 3) | (lo2 << 4), srcA1 = srcA0 | 4;   // lanes of X[4 dI + lo2][4 K + hi2], K = 0, 1
-        const int srcT0 = hi2 | (dJ << 3) | (lo2 << 4), srcT1 = srcT0 | 4;   // lanes of X[4 dJ + lo2][4 K + hi2]: B operand of X'
-        const bool hiHalf = (lane & 8) != 0;
-        auto ror8 = [&](double v) {                               // value of lane l ^ 8
-            int lo = __double2loint(v), hi = __double2hiint(v);
-            lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, false);
-            hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false);
-            return __hiloint2double(hi, lo);
-        };
         const bool inLd = di < rl && dj < rl;
         auto emitP = [&](int trow, double P) {
             if (di >= r) return;
