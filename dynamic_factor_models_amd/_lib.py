@@ -19,6 +19,10 @@ c_uint = ctypes.c_uint
 DFM_F_MAY_HAVE_MISSING = 1
 DFM_F_SINGULAR_Q = 2
 DFM_MAX_R = 32
+DFM_MULTI_F_FORCE_COMM = 1
+# dfm_multi_fetch `what` (enum in include/dfm_hip.h)
+(DFM_MULTI_LAM, DFM_MULTI_R, DFM_MULTI_A, DFM_MULTI_Q, DFM_MULTI_MU0, DFM_MULTI_P0, DFM_MULTI_F_SMOOTH, DFM_MULTI_P_SMOOTH,
+ DFM_MULTI_LOGLIK, DFM_MULTI_LOGLIK_PATH, DFM_MULTI_ITERS, DFM_MULTI_PANEL) = range(12)
 ERRORS = {-1: "DFM_E_DIMS", -2: "DFM_E_R_UNSUPPORTED", -3: "DFM_E_NULL", -4: "DFM_E_MISSING",
           -5: "DFM_E_NUMERIC", -6: "DFM_E_NO_DEVICE", -7: "DFM_E_COMM"}
 
@@ -41,6 +45,7 @@ SYMBOLS = {
     "dfm_destroy": (c_int, [c_vp]),
     "dfm_set_stream": (c_int, [c_vp, c_vp]),
     "dfm_synchronize": (c_int, [c_vp]),
+    "dfm_check_status": (c_int, [c_vp]),
     "dfm_last_error": (ctypes.c_char_p, [c_vp]),
     "dfm_version": (ctypes.c_char_p, []),
     "dfm_profile_enable": (c_int, [c_vp, c_int]),
@@ -53,6 +58,16 @@ SYMBOLS = {
     "dfm_em_batch": (c_int, _EM_ARGS),
     "dfm_em_iterate_batch_dev": (c_int, [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, c_int, ctypes.c_double]
                                  + [c_vp] * 5 + [c_uint]),
+    "dfm_multi_create": (c_int, [ctypes.POINTER(c_vp), c_int, c_vp, c_uint, ctypes.c_char_p, c_int]),
+    "dfm_multi_destroy": (c_int, [c_vp]),
+    "dfm_multi_ngpu": (c_int, [c_vp]),
+    "dfm_multi_has_comm": (c_int, [c_vp]),
+    "dfm_multi_last_error": (ctypes.c_char_p, [c_vp]),
+    "dfm_multi_load": (c_int, [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7),
+    "dfm_multi_synth": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_int64, c_int, c_int, c_int, c_int, ctypes.c_double, c_int]),
+    "dfm_multi_ks_pass": (c_int, [c_vp, c_int, c_uint]),
+    "dfm_multi_em": (c_int, [c_vp, c_int, ctypes.c_double, c_int, c_int, c_uint, c_vp]),
+    "dfm_multi_fetch": (c_int, [c_vp, c_int, c_vp]),
     "dfm_em_batch_multi": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, ctypes.c_double]
                            + [c_vp] * 4 + [c_uint, c_vp, ctypes.c_char_p, c_int]),
     "dfm_ks_pass_batch_multi": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 10

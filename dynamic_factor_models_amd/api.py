@@ -476,7 +476,13 @@ def bai_ng_criterion(ssr: float, nobs: int, T: int, r: int) -> float:
 def estimate_factor_numbers(m: DFMModel, nfacs, *, ctx=None, with_aw: bool = False):
     """`estimate_factor_numbers(m, nfacs)` -- dfm_functions.ipynb:698-725: the static-factor runs for every r in
     `nfacs` go through ONE dfm_als_batch call (shared panel, r_each); Bai-Ng ICp2 per r.  Returns
-    dict(bn_icp, ssr_static, tss, nobs, T, iters)."""
+    dict(bn_icp, ssr_static, tss, nobs, T, iters, factors).
+
+    with_aw: also the `amengual_watson_test` (:734-768) the reference runs inside every static run (:716-717): per static
+    count i one dfm_ols_batch (every series on [1, lags of the i factors]) and one PCA start of the residual window,
+    then ALL the dynamic runs (k = 1..i for every i) in ONE dfm_als_batch call, each run on its own residual window --
+    adds aw_icp / ssr_dynamic [max r, n runs] (NaN above the diagonal, the reference's `missing`).  julia/dfm_hip.jl
+    estimate_factor_numbers_hip is the same sequence of calls."""
     nfacs = [int(k) for k in nfacs]
     rmax = max(nfacs)
     xdata = m.data[m.initperiod - 1:m.lastperiod, :][:, m.inclcode == 1]
@@ -488,12 +494,35 @@ def estimate_factor_numbers(m: DFMModel, nfacs, *, ctx=None, with_aw: bool = Fal
         F0 = pca_start(ctx, z, rmax)                       # scores are nested: run r starts from the first r columns
         o = ctx.als_batch_host(z, np.repeat(F0[None], len(nfacs), axis=0), r_each=nfacs,
                                nt_min=m.nt_min_factor_estimation, tol=m.tol)
+        out = dict(bn_icp=np.array([bai_ng_criterion(s, nobs, T, k) for s, k in zip(o["ssr"], nfacs)]),
+                   ssr_static=o["ssr"].copy(), tss=tss, nobs=nobs, T=T, iters=o["iters"].copy(), factors=o["F"])
+        if with_aw:
+            est = m.data[:, m.inclcode == 1]
+            T_all = est.shape[0]
+            nlag = m.factor_var_model.nlag
+            init, last = m.initperiod + 4, m.lastperiod                       # :761 (the reference hard-codes the 4)
+            Tw = last - init + 1
+            zs, F0s, r_each, owner, meta = [], [], [], [], []
+            for col, i in enumerate(nfacs):
+                fac = np.full((T_all, i), np.nan)
+                fac[m.initperiod - 1:m.lastperiod] = o["F"][col][:, :i]
+                x = np.column_stack([np.ones(T_all), _lagmat(fac, range(1, nlag + 1))])
+                res = ctx.ols_batch_host(x, est, nt_min=x.shape[1] + m.nt_min_factor_estimation)["resid"]
+                zi, _ = standardize_data(res[init - 1:last])
+                Fi = np.zeros((Tw, rmax)); Fi[:, :i] = pca_start(ctx, zi, i)
+                meta.append((int((~np.isnan(zi)).sum()), zi.shape[0]))
+                for k in range(1, i + 1):
+                    zs.append(zi); F0s.append(Fi); r_each.append(k); owner.append((k, col))
+            a = ctx.als_batch_host(np.stack(zs), np.stack(F0s), r_each=r_each, nt_min=m.nt_min_factor_estimation, tol=m.tol)
+            aw = np.full((rmax, len(nfacs)), np.nan); ssr_dyn = np.full((rmax, len(nfacs)), np.nan)
+            for b, (k, col) in enumerate(owner):
+                aw[k - 1, col] = bai_ng_criterion(a["ssr"][b], meta[col][0], meta[col][1], k)
+                ssr_dyn[k - 1, col] = a["ssr"][b]
+            out.update(aw_icp=aw, ssr_dynamic=ssr_dyn)
     finally:
         if own:
             ctx.close()
-    bn = np.array([bai_ng_criterion(s, nobs, T, k) for s, k in zip(o["ssr"], nfacs)])
-    return dict(bn_icp=bn, ssr_static=o["ssr"].copy(), tss=tss, nobs=nobs, T=T, iters=o["iters"].copy(),
-                factors=o["F"])
+    return out
 
 
 def impulse_response(varm: VARModel, shock_ids, T: int) -> np.ndarray:

@@ -345,7 +345,7 @@ template <int R>
 static hipError_t launch_als_r(const AlsArgs& a, hipStream_t s) {
     const size_t lds = AlsLds<R>::doubles(a.T, a.N) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&als_kernel<R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -205,7 +205,7 @@ static hipError_t launch_boot_r(const BootArgs& a, hipStream_t s) {
     const int K = 1 + a.ns * a.p;
     const size_t lds = (size_t)NG * ((size_t)a.T * a.ns + (size_t)K * a.ns + 2 * R) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&var_boot_kernel<R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -230,7 +230,7 @@ hipError_t launch_quantiles(const QuantArgs& a, hipStream_t s) {
     while (n2 < a.B) n2 <<= 1;
     const size_t lds = (size_t)n2 * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&quantile_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -29,7 +29,7 @@ struct dfm_handle {
     int num_cu = 256;
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
-    size_t status_off = 0;                 // status word of the plan used by the last call
+    size_t status_off = (size_t)-1;        // status word of the plan used by the last call ((size_t)-1: none yet)
     bool no_rec_wave = false;              // DFM_NO_RECURSION_WAVE=1: lane-group recursion_kernel also at Rp = 8 (A/B)
     int pair_bmax = -1;                    // Rp = 8: batch limit of the covariance-wave + mean-wave pair (recursion_pair.hip); -1 = one replicate per SIMD,
                                            // DFM_PAIR_BMAX=n; DFM_NO_PAIR=1 = 0 (never)
@@ -197,6 +197,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
 }
 
 int ensure_ws(dfm_handle* h, size_t bytes) {
+    h->status_off = (size_t)-1;     // a new layout of the workspace: the caller names its status word (if it has one)
     if (bytes <= h->ws_bytes) return 0;
     if (h->ws) {
         // every stream this handle has launched on (the caller may have swapped streams with dfm_set_stream, and the
@@ -1011,11 +1012,17 @@ int dfm_set_stream(dfm_handle* h, void* stream) {
     return 0;
 }
 
+// (forward: defined with the entry points that use it)
+static int status_check(dfm_handle* h);
+
 int dfm_synchronize(dfm_handle* h) {
     if (!h) return DFM_E_NULL;
+    HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return status_check(h);
 }
+
+int dfm_check_status(dfm_handle* h) { return dfm_synchronize(h); }
 
 int dfm_profile_enable(dfm_handle* h, int on) {
     if (!h) return DFM_E_NULL;
@@ -1077,14 +1084,24 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     return enqueue_pass(h, p, B, T, N, r, panel, pp, R, f_smooth, P_smooth, loglik, nullptr);
 }
 
-// status word / log-likelihood sanity after a synchronising call
-static int post_check(dfm_handle* h, const double* loglik_host, int B) {
+// The status word of the last call's plan, read after the stream has been synchronised.  Bits: 1 = NaN in a panel that was
+// declared balanced, 2 = the PCA start's subspace iteration did not converge, 4 = a bounded wait between the waves of the
+// one-launch pass ran out (its outputs are invalid even where the log-likelihood happens to be finite).  Every synchronising
+// entry point goes through here; device-pointer callers get the same check from dfm_synchronize / dfm_check_status.
+static int status_check(dfm_handle* h) {
+    if (!h->ws || h->status_off == (size_t)-1) return 0;
     int st = 0;
     HIP_TRY(h, hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost));
-    if (st & 1) return fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
     if (st & 4) return fail(h, DFM_E_NUMERIC, "one-launch pass: a bounded wait between its waves ran out (results invalid)%s");
+    if (st & 1) return fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
+    if (st & 2) return fail(h, DFM_E_NUMERIC, "PCA subspace iteration did not converge (near-degenerate spectrum at the cut)%s");
+    return 0;
+}
+// status word + log-likelihood sanity after a synchronising call (loglik_host: stride doubles apart)
+static int post_check(dfm_handle* h, const double* loglik_host, int B, size_t stride = 1) {
+    if (int rc = status_check(h)) return rc;
     for (int b = 0; b < B; ++b)
-        if (!isfinite(loglik_host[b])) return fail(h, DFM_E_NUMERIC, "non-finite log-likelihood (Q or P0 not positive definite?)%s");
+        if (!isfinite(loglik_host[(size_t)b * stride])) return fail(h, DFM_E_NUMERIC, "non-finite log-likelihood (Q or P0 not positive definite?)%s");
     return 0;
 }
 
@@ -1194,13 +1211,7 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }
-    if (rc == 0) {
-        int st = 0;
-        (void)hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost);
-        if (st & 1) rc = fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
-        for (int b = 0; rc == 0 && b < B; ++b)
-            if (!isfinite(loglik_path[(size_t)b * max_iter])) rc = fail(h, DFM_E_NUMERIC, "non-finite log-likelihood%s");
-    }
+    if (rc == 0) rc = post_check(h, loglik_path, B, (size_t)max_iter);
     (void)hipFree(buf);
     return rc;
 }
@@ -1271,14 +1282,7 @@ static int varp_host(dfm_handle* h, int B, int T, int N, int r, int p, const dou
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }
-    if (rc == 0) {
-        int st = 0;
-        (void)hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost);
-        if (st & 1) rc = fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
-        const double* llh = em ? loglik_path : loglik;
-        for (int b = 0; rc == 0 && b < B; ++b)
-            if (!isfinite(llh[em ? (size_t)b * max_iter : (size_t)b])) rc = fail(h, DFM_E_NUMERIC, "non-finite log-likelihood%s");
-    }
+    if (rc == 0) rc = post_check(h, em ? loglik_path : loglik, B, em ? (size_t)max_iter : (size_t)1);
     (void)hipFree(buf);
     return rc;
 }
@@ -1395,10 +1399,7 @@ int dfm_em_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, con
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }
-    if (rc == 0) {
-        for (int b = 0; rc == 0 && b < B; ++b)
-            if (!isfinite(loglik_path[(size_t)b * max_iter])) rc = fail(h, DFM_E_NUMERIC, "non-finite log-likelihood%s");
-    }
+    if (rc == 0) rc = post_check(h, loglik_path, B, (size_t)max_iter);
     (void)hipFree(buf);
     return rc;
 }
@@ -1457,11 +1458,7 @@ int dfm_pca_init_batch(dfm_handle* h, int B, int T, int N, int r, const double* 
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
     }
-    if (rc == 0) {
-        int st = 0;
-        (void)hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost);
-        if (st & 2) rc = fail(h, DFM_E_NUMERIC, "PCA subspace iteration did not converge (near-degenerate spectrum at the cut)%s");
-    }
+    if (rc == 0) rc = status_check(h);
     (void)hipFree(buf);
     return rc;
 }

@@ -237,7 +237,7 @@ template <int R, int CPL2, int RB>
 static hipError_t launch_one(const CollapseArgs& a, hipStream_t s) {
     const size_t lds = ((size_t)a.N * R + 2 * (size_t)a.N + R * (R + 1) / 2 + 1) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_kernel<R, CPL2, RB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -281,7 +281,7 @@ template <int R, int CPL2, int RB, int NP, int ABL = 0, int OPT = 0>
 static hipError_t launch_dma_one(const CollapseArgs& a, hipStream_t s) {
     const size_t lds = (size_t)4 * NP * 1024;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_dma_kernel<R, CPL2, RB, NP, ABL, OPT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -504,7 +504,7 @@ static hipError_t launch_mfma_one(const CollapseArgs& a, hipStream_t s) {
             using FC = FusedCov<R>;
             if (FC::lds_bytes() > lds) lds = FC::lds_bytes();
             const int ncov = (a.B + FC::LY::GPW - 1) / FC::LY::GPW;
-            static bool attr_f = false;
+            static LdsOptIn attr_f;
             if (!attr_f && lds > 64 * 1024) {
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_mfma_kernel<R, STEPS, NB, NDR, 0, true>),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -519,7 +519,7 @@ static hipError_t launch_mfma_one(const CollapseArgs& a, hipStream_t s) {
         }
     }
     if (a.fuse_cov) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -358,7 +358,7 @@ static hipError_t launch_cm_one(const CollapseArgs& a, int num_cu, hipStream_t s
     (void)num_cu;
     const unsigned SB = miss_slot_bytes(a.N);
     const size_t lds = cm_lds_bytes(a.N);
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_miss_kernel<STEPS, NDR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -580,7 +580,7 @@ W2Ws w2_ws(const CollapseArgs& a, double* ws, int Rpad) {
 }
 template <int R, int NX, int MODE>
 hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s, int rd = R) {
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel<R, NX, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -7,6 +7,16 @@ namespace dfm {
 
 constexpr int kWave = 64;
 
+// "hipFuncSetAttribute(MaxDynamicSharedMemorySize) done" per DEVICE: the attribute belongs to the function on the current
+// device, and the multi-GPU library object (multi.hip) launches the same kernels from one process on several devices, from
+// one host thread per GPU.  Drop-in for the `static bool` flag the launchers used (`if (!flag) { ...; flag = true; }`).
+struct LdsOptIn {
+    unsigned long long mask = 0;
+    static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    bool operator!() const { return (__atomic_load_n(&mask, __ATOMIC_ACQUIRE) & bit()) == 0; }
+    LdsOptIn& operator=(bool done) { if (done) __atomic_fetch_or(&mask, bit(), __ATOMIC_RELEASE); return *this; }
+};
+
 __host__ __device__ constexpr int npack(int r) { return r * (r + 1) / 2; }
 __host__ __device__ constexpr int pow2_ge(int r) { return r <= 1 ? 1 : r <= 2 ? 2 : r <= 4 ? 4 : r <= 8 ? 8 : r <= 16 ? 16 : 32; }
 

@@ -145,7 +145,7 @@ template <int R>
 hipError_t launch_eug(const EmUpdArgs& a, hipStream_t s) {
     constexpr int RR = R * R, RT = R * kTileStride<R>, NW = RR / 64;
     const size_t lds = (size_t)(2 * RT + kGridProw<R> + 2 * (RR / 64) * R + 2 * RT + 2 * NW * 4 * 64) * sizeof(double);
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&em_update_grid_kernel<R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);

@@ -418,7 +418,7 @@ template <int R>
 static hipError_t launch_em_update_r(const EmUpdArgs& a, hipStream_t s) {
     constexpr int NW = em_update_waves(R), GPW = 64 / R;
     const size_t lds = ((size_t)NW * GPW * (R * R + 2 * R) + (NW > 1 ? (size_t)NW * 2 * R * R : 0)) * sizeof(double);
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&em_update_kernel<R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
@@ -448,7 +448,7 @@ static hipError_t launch_cov_rc(const FastArgs& a, hipStream_t s) {
     constexpr int kCovThreads = cov_threads(R);
     constexpr int per_wg = LY::GPW * (kCovThreads / 64);
     const int grid = (a.B + per_wg - 1) / per_wg;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && LY::lds_bytes() > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cov_kernel<R, CPL2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -475,7 +475,7 @@ bool cov_fuses_gram(int Rpad, int N) { return N <= 128 || (Rpad <= 16 && N <= 25
 template <int R>
 static hipError_t launch_scan_r(const FastArgs& a, hipStream_t s) {
     const size_t lds = ScanLds<R>::bytes();
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&meanscan_kernel<R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -145,7 +145,7 @@ bool gram_xx_wide_supported(int N) { return (N & 1) == 0 && N > 256; }
 hipError_t launch_gram_xx_wide(const PcaArgs& a, hipStream_t s) {
     const int nb = (a.N + kGxSer - 1) / kGxSer, npair = nb * (nb + 1) / 2;
     const size_t lds = (size_t)kGxNBuf * kGxStageB;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_xx_wide_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

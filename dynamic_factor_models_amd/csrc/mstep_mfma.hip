@@ -275,7 +275,7 @@ static hipError_t launch_ms_one(const MstepArgs& a, int wpr, double* pf, double*
     const unsigned SB = ms_slot_bytes(a.N);
     const size_t lds = (size_t)4 * (8 * SB + 2 * 4 * R * 8);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_mfma_kernel<R, STEPS, NDR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -325,7 +325,7 @@ size_t mstep_wide_workspace(int B, int N, int Rpad) { return ((size_t)B * N * Rp
 namespace {
 template <int R, int NX>
 hipError_t launch_mw(const MstepArgs& a, double* sxf, double* sxx, int* ctr, int G, size_t lds, int nsb, int xcd_map, hipStream_t s, int rd = R) {
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_wide_kernel<R, NX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

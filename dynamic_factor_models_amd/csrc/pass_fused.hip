@@ -781,7 +781,7 @@ template <int STEPS, int NDR>
 static hipError_t launch_pf_one(const CollapseArgs& a, const FastArgs& fa, int nsw, int ncov, int num_cu, hipStream_t s) {
     const PfLds ly = pf_pick(a.T, a.N, nsw, ncov);
     if (ly.total > kPfLdsLimit) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_fused_kernel<STEPS, NDR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPfLdsLimit);
@@ -874,7 +874,7 @@ template <int R>
 static hipError_t launch_cov_grid_r(const FastArgs& a, hipStream_t s) {
     constexpr int RR = R * R, RT = R * kTileStride<R>;
     const size_t lds = (size_t)(4 * RT + kGridProw<R> + 2 * (RR / 64) * R + 2 * RT) * sizeof(double);
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cov_grid_kernel<R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

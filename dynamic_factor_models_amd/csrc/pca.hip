@@ -1044,7 +1044,7 @@ template <int MAXP>
 static hipError_t launch_gx_mfma(const PcaArgs& a, hipStream_t s) {
     const int NT = (a.N + 15) / 16;
     const size_t lds = (size_t)2 * kGxPB * (NT * 16 + 2) * sizeof(double);
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_xx_mfma_kernel<MAXP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1075,7 +1075,7 @@ static hipError_t launch_pca_fast(const PcaArgs& a, hipStream_t s) {
     const size_t need = (size_t)(2 + kPcaFastThreads / 256) * a.N * R;   // Vs, Ys, the partial products
     const size_t gr = (size_t)2 * a.N * R + 8 * R * R;                   // ... reused for 4 x 2 partial Gram matrices
     const size_t lds = (need > gr ? need : gr) * sizeof(double);
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pca_kernel<R, kPcaFastThreads>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);   // (+ the kernel's static LDS)

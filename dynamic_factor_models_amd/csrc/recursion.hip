@@ -620,7 +620,7 @@ static hipError_t launch_rec(const RecursionArgs& a, hipStream_t s) {
     const int grid = (a.B + LY::GPW - 1) / LY::GPW;
     const size_t lds = LY::lds_bytes(a.T);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&recursion_kernel<R, COV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

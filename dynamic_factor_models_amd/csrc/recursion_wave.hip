@@ -498,7 +498,7 @@ bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
 template <int R, bool COV, int CH8>
 static hipError_t launch_wave_cov_ch(const RecursionArgs& a, hipStream_t s) {
     const size_t lds = wave_lds_bytes<R>(a.T);
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         // (the kernel also has 256 bytes of static LDS: 160 KB of dynamic LDS on top would be refused -- every Rp >= 16 panel
         // with T > ~1000 failed here with "invalid argument"; recursion_wave_supported caps the request at 150 KB)

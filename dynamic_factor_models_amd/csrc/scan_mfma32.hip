@@ -358,7 +358,7 @@ namespace {
 template <int R>
 hipError_t launch_scan_mfma_r(const FastArgs& a, hipStream_t s) {
     const size_t lds = (size_t)S3Geo<R>::total * sizeof(double);
-    static bool attr_done = false;
+    static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&meanscan_mfma_kernel<R>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -18,6 +18,98 @@ def _check(h, rc: int):
         raise _lib.DfmError(rc, _lib.load().dfm_last_error(h).decode())
 
 
+class DfmMulti:
+    """The library's multi-GPU object (dfm_multi, csrc/multi.hip): `ngpu` GPUs of this node driven from THIS process -- one
+    handle, stream and workspace per GPU and ONE RCCL communicator, created once; the job's replicates stay resident in
+    the GPUs' HBM between calls.  What a host without torch.distributed (Julia) uses; `bench.py --driver lib` times it.
+    force_comm: build the (1-rank) communicator also for ngpu = 1, so that the all-gather path runs on one GPU."""
+
+    def __init__(self, ngpu: int = 1, device_ids=None, force_comm: bool = False):
+        self._lib = _lib.load()
+        ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
+        h = ctypes.c_void_p()
+        err = ctypes.create_string_buffer(700)
+        rc = self._lib.dfm_multi_create(ctypes.byref(h), int(ngpu), None if ids is None else ctypes.c_void_p(ids.ctypes.data),
+                                        _lib.DFM_MULTI_F_FORCE_COMM if force_comm else 0, err, 700)
+        if rc != 0:
+            raise _lib.DfmError(rc, err.value.decode())
+        self._m = h
+        self.shape = None
+        self._max_iter = 0
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._lib.dfm_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise _lib.DfmError(rc, self._lib.dfm_multi_last_error(self._m).decode())
+
+    @property
+    def ngpu(self):
+        return self._lib.dfm_multi_ngpu(self._m)
+
+    @property
+    def has_comm(self):
+        return bool(self._lib.dfm_multi_has_comm(self._m))
+
+    def load(self, panel, Lam, R, A, Q, mu0, P0):
+        """Upload a job (NumPy, layouts of em_batch_host) to the GPUs that own its replicates."""
+        c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        panel, Lam, R, A, Q, mu0, P0 = map(c, (panel, Lam, R, A, Q, mu0, P0))
+        B, T, N = panel.shape
+        r = Lam.shape[2]
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        self._ck(self._lib.dfm_multi_load(self._m, B, T, N, r, p(panel), p(Lam), p(R), p(A), p(Q), p(mu0), p(P0)))
+        self.shape = (B, T, N, r)
+
+    def synth(self, seed: int, first_replicate: int, B: int, T: int, N: int, r: int, missing_prob: float = 0.0,
+              pca_start: bool = False):
+        """Generate the job where it lives: GPU g draws replicates first_replicate + [lo_g, hi_g) (dfm_synth_panels_dev);
+        pca_start replaces the DGP parameters by the PCA + OLS start."""
+        self._ck(self._lib.dfm_multi_synth(self._m, int(seed), int(first_replicate), B, T, N, r, float(missing_prob),
+                                           1 if pca_start else 0))
+        self.shape = (B, T, N, r)
+
+    def ks_pass(self, want_P: bool = True, may_have_missing: bool = False, singular_q: bool = False):
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
+        self._ck(self._lib.dfm_multi_ks_pass(self._m, 1 if want_P else 0, flags))
+
+    def em(self, max_iter: int = 10, tol: float = 0.0, want_smooth: bool = True, want_P: bool = True,
+           may_have_missing: bool = False, singular_q: bool = False) -> int:
+        """The EM loop on the resident job (parameters updated in place on the GPUs); returns the iterations run."""
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
+        ran = ctypes.c_int(0)
+        self._max_iter = int(max_iter)
+        self._ck(self._lib.dfm_multi_em(self._m, int(max_iter), float(tol), 1 if want_smooth else 0, 1 if want_P else 0, flags,
+                                        ctypes.cast(ctypes.byref(ran), ctypes.c_void_p)))
+        return ran.value
+
+    def fetch(self, what: str):
+        """One resident array of the whole job, global replicate order (NumPy)."""
+        B, T, N, r = self.shape
+        npk = r * (r + 1) // 2
+        table = {"Lam": (_lib.DFM_MULTI_LAM, (B, N, r), np.float64), "R": (_lib.DFM_MULTI_R, (B, N), np.float64),
+                 "A": (_lib.DFM_MULTI_A, (B, r, r), np.float64), "Q": (_lib.DFM_MULTI_Q, (B, r, r), np.float64),
+                 "mu0": (_lib.DFM_MULTI_MU0, (B, r), np.float64), "P0": (_lib.DFM_MULTI_P0, (B, r, r), np.float64),
+                 "f_smooth": (_lib.DFM_MULTI_F_SMOOTH, (B, T, r), np.float64),
+                 "P_smooth": (_lib.DFM_MULTI_P_SMOOTH, (B, T, npk), np.float64),
+                 "loglik": (_lib.DFM_MULTI_LOGLIK, (B,), np.float64),
+                 "loglik_path": (_lib.DFM_MULTI_LOGLIK_PATH, (B, self._max_iter), np.float64),
+                 "iters": (_lib.DFM_MULTI_ITERS, (B,), np.int32), "panel": (_lib.DFM_MULTI_PANEL, (B, T, N), np.float64)}
+        code, shape, dt = table[what]
+        out = np.empty(shape, dtype=dt)
+        self._ck(self._lib.dfm_multi_fetch(self._m, code, ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+
 class DfmContext:
     """One libdfmhip handle bound to a HIP device and (by default) torch's current stream."""
 
@@ -64,7 +156,12 @@ class DfmContext:
         self._lib.dfm_set_stream(self._h, ctypes.c_void_p(s))
 
     def synchronize(self):
+        """Wait for the handle's stream AND surface the status word of the last call (NaN in a panel declared balanced,
+        an expired bounded wait of the one-launch pass, PCA start not converged): the device-pointer entry points only
+        enqueue, so this is where their failures become exceptions."""
         _check(self._h, self._lib.dfm_synchronize(self._h))
+
+    check_status = synchronize
 
     def profile_enable(self, on: bool = True):
         self._sync_stream()

@@ -63,7 +63,13 @@ typedef struct dfm_handle dfm_handle;
 int dfm_create(dfm_handle** h, int device_id, void* stream);
 int dfm_destroy(dfm_handle* h);
 int dfm_set_stream(dfm_handle* h, void* stream);
+/* dfm_synchronize: wait for the handle's stream, THEN read the status word the kernels of the last call left behind --
+ * DFM_E_MISSING (NaN in a panel that was declared balanced), DFM_E_NUMERIC (a bounded wait inside the one-launch pass
+ * ran out: outputs invalid; PCA start not converged).  The "_dev" entry points only enqueue, so this is where a
+ * device-pointer caller learns that a call went wrong; the host-pointer entry points make the same check themselves.
+ * dfm_check_status is the same call under the name a reader looks for. */
 int dfm_synchronize(dfm_handle* h);
+int dfm_check_status(dfm_handle* h);
 const char* dfm_last_error(const dfm_handle* h);
 const char* dfm_version(void);
 
@@ -132,14 +138,55 @@ int dfm_em_iterate_batch_dev(dfm_handle* h, int B, int T, int N, int r, const do
                              double* loglik_path, int* iters, int* active, double* f_smooth, double* P_smooth,
                              unsigned flags);
 
-/* --- the same two operations on SEVERAL GPUs of one node from ONE process (`ngpu`, `device_ids`,
- * library-owned RCCL communicator; what `estimate!(m, ::Parametric; nrep, ngpu)` of julia/dfm_hip.jl binds).  HOST
- * pointers, layouts as dfm_em_batch / dfm_ks_pass_batch.  GPU g of ngpu owns replicates [g B / ngpu, (g+1) B / ngpu);
- * device_ids[ngpu] (NULL: 0 .. ngpu-1) must be distinct.  One host thread per GPU; after every EM iteration ONE
- * ncclAllGather of {loglik, active} ([B/ngpu][2] doubles per GPU) over xGMI gives every thread the global convergence
- * state, and all GPUs stop at the same iteration: *iterations_run (may be NULL).  RCCL is loaded at the first call
- * with ngpu > 1 (DFM_E_COMM if that fails).  No handle: each call creates and destroys its per-GPU contexts.
- * err[err_cap] (may be NULL) receives the message of the first failing GPU. */
+/* --- the same operations on SEVERAL GPUs of one node from ONE process (a library-owned object with
+ * `ngpu`, `device_ids`, per-GPU handles / streams / workspaces and ONE RCCL communicator; what
+ * `estimate!(m, ::Parametric; nrep, ngpu)` of julia/dfm_hip.jl binds -- Julia has no torch.distributed).
+ * GPU g of ngpu owns replicates [g B / ngpu, (g+1) B / ngpu) of a job (the partition of shard.py replicate_range); no
+ * data-path collective.  One host thread per GPU inside a call; after every EM iteration ONE ncclAllGather of {loglik,
+ * active} ([ceil(B/ngpu)][2] doubles per GPU) over xGMI gives every thread the global convergence state, and all GPUs stop
+ * at the same iteration.
+ *
+ * dfm_multi_create: device_ids[ngpu] (NULL: 0 .. ngpu-1) must be distinct.  The communicator (ncclCommInitAll) is created
+ * here, once, when ngpu > 1 or DFM_MULTI_F_FORCE_COMM is set (a 1-rank communicator: the exchange path of the EM loop then
+ * runs -- and is tested -- on a single GPU); RCCL is bound with dlopen at that moment (DFM_E_COMM if it cannot be).
+ * The replicates of a job live ON THE DEVICES between calls ("resident" job):
+ *   dfm_multi_load   uploads host arrays (layouts of dfm_em_batch) to their owners;
+ *   dfm_multi_synth  generates them where they live -- GPU g calls dfm_synth_panels_dev with first_replicate + lo_g, so
+ *                    BASELINE configs[2] (65 536 replicates, 52 GB of panels) never crosses PCIe; pca_start != 0 replaces
+ *                    the DGP parameters by the PCA + OLS start (dfm_pca_init_batch_dev; balanced panels only);
+ *   dfm_multi_ks_pass / dfm_multi_em  run on the resident job (EM updates the resident parameters in place);
+ *   dfm_multi_fetch  copies one resident array of the whole job back to the host, in global replicate order. */
+typedef struct dfm_multi dfm_multi;
+#define DFM_MULTI_F_FORCE_COMM 1u
+enum {  /* dfm_multi_fetch `what`; element type double unless noted */
+    DFM_MULTI_LAM = 0, DFM_MULTI_R, DFM_MULTI_A, DFM_MULTI_Q, DFM_MULTI_MU0, DFM_MULTI_P0,
+    DFM_MULTI_F_SMOOTH,    /* [B][T][r]         of the last pass / last E-step */
+    DFM_MULTI_P_SMOOTH,    /* [B][T][r(r+1)/2]  (only when the last call asked for it) */
+    DFM_MULTI_LOGLIK,      /* [B]               of the last dfm_multi_ks_pass */
+    DFM_MULTI_LOGLIK_PATH, /* [B][max_iter]     of the last dfm_multi_em */
+    DFM_MULTI_ITERS,       /* int [B]           of the last dfm_multi_em */
+    DFM_MULTI_PANEL        /* [B][T][N] */
+};
+int dfm_multi_create(dfm_multi** m, int ngpu, const int* device_ids, unsigned mflags, char* err, int err_cap);
+int dfm_multi_destroy(dfm_multi* m);
+int dfm_multi_ngpu(const dfm_multi* m);
+int dfm_multi_has_comm(const dfm_multi* m);          /* 1 when the object owns an RCCL communicator */
+const char* dfm_multi_last_error(const dfm_multi* m);
+int dfm_multi_load(dfm_multi* m, int B, int T, int N, int r, const double* panel, const double* Lam, const double* R,
+                   const double* A, const double* Q, const double* mu0, const double* P0);
+int dfm_multi_synth(dfm_multi* m, uint64_t seed, int64_t first_replicate, int B, int T, int N, int r,
+                    double missing_prob, int pca_start);
+/* One smoother pass of every resident replicate (want_P: also P_smooth).  Synchronises every GPU. */
+int dfm_multi_ks_pass(dfm_multi* m, int want_P, unsigned flags);
+/* The EM loop of dfm_em_batch on the resident job: per iteration dfm_em_iterate_batch_dev on every shard, then the
+ * all-gather; *iterations_run (may be NULL) = iterations every GPU ran.  want_smooth: keep f_smooth (and, with want_P,
+ * P_smooth) of the last E-step resident for dfm_multi_fetch. */
+int dfm_multi_em(dfm_multi* m, int max_iter, double tol, int want_smooth, int want_P, unsigned flags,
+                 int* iterations_run);
+int dfm_multi_fetch(dfm_multi* m, int what, void* dst);
+
+/* Handle-less forms (round-2 ABI, kept): create + load + run + fetch + destroy in one call.  HOST pointers, layouts as
+ * dfm_em_batch / dfm_ks_pass_batch; err[err_cap] (may be NULL) receives the message of the first failing GPU. */
 int dfm_em_batch_multi(int ngpu, const int* device_ids, int B, int T, int N, int r, const double* panel, double* Lam,
                        double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol,
                        double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags,

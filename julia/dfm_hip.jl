@@ -86,13 +86,15 @@ function em(h::Handle, z::Matrix{Float64}, p; max_iter::Integer = 50, tol::Real 
     f = Array{Float64}(undef, r, T, 1); np = div(r * (r + 1), 2); P = Array{Float64}(undef, np, T, 1)
     flags = any(isnan, z) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
     start = (copy(Lam), copy(R), copy(A), copy(Q), copy(mu0), copy(P0))
+    fallback = false
     GC.@preserve panel Lam R A Q mu0 P0 path iters f P begin
         rc = ccall((:dfm_em_batch, LIB), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cdouble, Ptr{Float64}, Ptr{Cint},
                     Ptr{Float64}, Ptr{Float64}, Cuint),
                    h.ptr, 1, T, N, r, panel, Lam, R, A, Q, mu0, P0, max_iter, tol, path, iters, f, P, flags)
-        if rc == DFM_E_NUMERIC
+        fallback = rc == DFM_E_NUMERIC
+        if fallback
             # the information-form recursion inverts Q; a PCA start on fewer than 2r + 1 periods has a rank-deficient VAR
             # residual covariance: run the covariance-form recursion instead (as api.estimate does)
             Lam, R, A, Q, mu0, P0 = start
@@ -108,7 +110,7 @@ function em(h::Handle, z::Matrix{Float64}, p; max_iter::Integer = 50, tol::Real 
     k = Int(iters[1])
     return (Lam = permutedims(Lam[:, :, 1]), R = R[:, 1], A = permutedims(A[:, :, 1]), Q = permutedims(Q[:, :, 1]),
             mu0 = mu0[:, 1], P0 = permutedims(P0[:, :, 1]), loglik = path[1:k, 1], iters = k,
-            factor = permutedims(f[:, :, 1]))
+            factor = permutedims(f[:, :, 1]), singular_q = fallback)
 end
 
 # C [b][i][k] <-> Julia: a vector of B matrices (rows x cols) -> Array (cols, rows, B), and back
@@ -147,36 +149,115 @@ function ks_pass_batch(h::Handle, panels::Vector{Matrix{Float64}}, params::Vecto
     return (factor = unpack3(f), P = unpack3(P), loglik = ll)
 end
 
-"EM for B replicates in ONE call on `ngpu` GPUs of this node (dfm_em_batch_multi: replicates split over the GPUs, one
-host thread per GPU inside the library, ONE RCCL all-gather of {loglik, active} after every EM iteration -- SURVEY.md
-8(e)).  panels[b]: T x N, starts[b] = (Lam, R, A, Q, mu0, P0).  Returns the per-replicate estimates, log-likelihood
-paths and iteration counts."
+# ---- the library's multi-GPU object (dfm_multi, csrc/multi.hip): per-GPU handles / streams / workspaces and ONE RCCL
+# communicator, created once and cached per GPU count; a job's replicates stay resident on the GPUs between calls -------
+mutable struct Multi
+    ptr::Ptr{Cvoid}
+    shape::NTuple{4,Int}      # (B, T, N, r) of the resident job
+    max_iter::Int
+end
+const DFM_MULTI_F_FORCE_COMM = Cuint(1)
+const MULTI_LAM, MULTI_R, MULTI_A, MULTI_Q, MULTI_MU0, MULTI_P0, MULTI_F_SMOOTH, MULTI_P_SMOOTH, MULTI_LOGLIK,
+      MULTI_LOGLIK_PATH, MULTI_ITERS, MULTI_PANEL = Cint.(0:11)
+
+function mcheck(m::Multi, rc::Cint)
+    rc == 0 && return nothing
+    error("libdfmhip: status $rc: " * unsafe_string(ccall((:dfm_multi_last_error, LIB), Cstring, (Ptr{Cvoid},), m.ptr)))
+end
+
+function multi_create(ngpu::Integer = 1; device_ids = nothing, force_comm::Bool = false)
+    ref = Ref{Ptr{Cvoid}}(C_NULL); err = zeros(UInt8, 700)
+    ids = device_ids === nothing ? Cint[] : Cint.(device_ids)
+    GC.@preserve ids err begin
+        rc = ccall((:dfm_multi_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint, Ptr{Cint}, Cuint, Ptr{UInt8}, Cint),
+                   ref, ngpu, device_ids === nothing ? Ptr{Cint}(C_NULL) : pointer(ids),
+                   force_comm ? DFM_MULTI_F_FORCE_COMM : Cuint(0), err, length(err))
+        rc == 0 || error("libdfmhip: dfm_multi_create: status $rc: $(unsafe_string(pointer(err)))")
+    end
+    m = Multi(ref[], (0, 0, 0, 0), 0)
+    finalizer(x -> (x.ptr != C_NULL && ccall((:dfm_multi_destroy, LIB), Cint, (Ptr{Cvoid},), x.ptr); x.ptr = C_NULL), m)
+    return m
+end
+const MULTIS = Dict{Int,Multi}()
+function multi(ngpu::Integer = 1)
+    m = get(MULTIS, Int(ngpu), nothing)
+    (m === nothing || m.ptr == C_NULL) && (m = MULTIS[Int(ngpu)] = multi_create(ngpu))
+    return m
+end
+
+"Upload a job: panel (N, T, B), Lam (r, N, B), R (N, B), A / Q / P0 (r, r, B), mu0 (r, B) -- the C layouts."
+function multi_load(m::Multi, panel::Array{Float64,3}, Lam::Array{Float64,3}, R::Matrix{Float64}, A::Array{Float64,3},
+                    Q::Array{Float64,3}, mu0::Matrix{Float64}, P0::Array{Float64,3})
+    N, T, B = size(panel); r = size(Lam, 1)
+    GC.@preserve panel Lam R A Q mu0 P0 begin
+        mcheck(m, ccall((:dfm_multi_load, LIB), Cint,
+                        (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), m.ptr, B, T, N, r, panel, Lam, R, A, Q, mu0, P0))
+    end
+    m.shape = (B, T, N, r)
+    return m
+end
+
+"Generate a synthetic job where it lives (SURVEY 8(d) DGP): GPU g draws replicates first_replicate + [lo_g, hi_g); nothing
+crosses PCIe (BASELINE configs[2]: 65 536 replicates).  pca_start: the PCA + OLS start instead of the DGP parameters."
+function multi_synth(m::Multi, seed::Integer, first_replicate::Integer, B::Integer, T::Integer, N::Integer, r::Integer;
+                     missing_prob::Real = 0.0, pca_start::Bool = false)
+    mcheck(m, ccall((:dfm_multi_synth, LIB), Cint, (Ptr{Cvoid}, UInt64, Int64, Cint, Cint, Cint, Cint, Cdouble, Cint),
+                    m.ptr, seed, first_replicate, B, T, N, r, missing_prob, pca_start ? 1 : 0))
+    m.shape = (Int(B), Int(T), Int(N), Int(r))
+    return m
+end
+
+function multi_ks_pass(m::Multi; want_P::Bool = true, flags::Cuint = Cuint(0))
+    mcheck(m, ccall((:dfm_multi_ks_pass, LIB), Cint, (Ptr{Cvoid}, Cint, Cuint), m.ptr, want_P ? 1 : 0, flags))
+end
+
+"The EM loop on the resident job (one ncclAllGather of {loglik, active} per iteration); returns the iterations run."
+function multi_em(m::Multi; max_iter::Integer = 50, tol::Real = 1e-6, want_smooth::Bool = false, want_P::Bool = false,
+                  flags::Cuint = Cuint(0))
+    ran = Ref{Cint}(0)
+    m.max_iter = Int(max_iter)
+    mcheck(m, ccall((:dfm_multi_em, LIB), Cint, (Ptr{Cvoid}, Cint, Cdouble, Cint, Cint, Cuint, Ptr{Cint}),
+                    m.ptr, max_iter, tol, want_smooth ? 1 : 0, want_P ? 1 : 0, flags, ran))
+    return Int(ran[])
+end
+
+"One resident array of the whole job in global replicate order, in its C layout (replicate index last in Julia)."
+function multi_fetch(m::Multi, what::Cint)
+    B, T, N, r = m.shape; np = div(r * (r + 1), 2)
+    if what == MULTI_ITERS
+        out = Array{Cint}(undef, B)
+        GC.@preserve out mcheck(m, ccall((:dfm_multi_fetch, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), m.ptr, what, pointer(out)))
+        return out
+    end
+    dims = what == MULTI_LAM ? (r, N, B) : what == MULTI_R ? (N, B) : what == MULTI_MU0 ? (r, B) :
+           what == MULTI_F_SMOOTH ? (r, T, B) : what == MULTI_P_SMOOTH ? (np, T, B) : what == MULTI_LOGLIK ? (B,) :
+           what == MULTI_LOGLIK_PATH ? (m.max_iter, B) : what == MULTI_PANEL ? (N, T, B) : (r, r, B)
+    out = Array{Float64}(undef, dims...)
+    GC.@preserve out mcheck(m, ccall((:dfm_multi_fetch, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Cvoid}), m.ptr, what, pointer(out)))
+    return out
+end
+
+"EM for B replicates in ONE call on `ngpu` GPUs of this node: the cached multi-GPU object (one RCCL communicator per GPU
+count for the whole session) -- replicates split over the GPUs, one host thread per GPU inside the library, ONE RCCL
+all-gather of {loglik, active} after every EM iteration (SURVEY.md 8(e)).  panels[b]: T x N, starts[b] = (Lam, R, A, Q,
+mu0, P0).  Returns the per-replicate estimates, log-likelihood paths and iteration counts."
 function em_batch(panels::Vector{Matrix{Float64}}, starts::Vector; max_iter::Integer = 50, tol::Real = 1e-6,
-                  ngpu::Integer = 1, want_smooth::Bool = false)
+                  ngpu::Integer = 1, want_smooth::Bool = false, singular_q::Bool = false)
     B = length(panels); T, N = size(panels[1]); r = size(starts[1].Lam, 2)
     panel = cat([permutedims(z, (2, 1)) for z in panels]...; dims = 3)
     Lam = pack3([p.Lam for p in starts]); R = hcat([p.R for p in starts]...)
     A = pack3([p.A for p in starts]); Q = pack3([p.Q for p in starts]); P0 = pack3([p.P0 for p in starts])
     mu0 = hcat([p.mu0 for p in starts]...)
-    path = Array{Float64}(undef, max_iter, B); iters = Array{Cint}(undef, B); ran = Ref{Cint}(0)
-    np = div(r * (r + 1), 2)
-    f = want_smooth ? Array{Float64}(undef, r, T, B) : Array{Float64}(undef, 0, 0, 0)
-    P = want_smooth ? Array{Float64}(undef, np, T, B) : Array{Float64}(undef, 0, 0, 0)
-    flags = any(isnan, panel) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
-    err = zeros(UInt8, 700)
-    GC.@preserve panel Lam R A Q mu0 P0 path iters f P err begin
-        rc = ccall((:dfm_em_batch_multi, LIB), Cint,
-                   (Cint, Ptr{Cint}, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
-                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cdouble, Ptr{Float64}, Ptr{Cint}, Ptr{Float64},
-                    Ptr{Float64}, Cuint, Ptr{Cint}, Ptr{UInt8}, Cint),
-                   ngpu, C_NULL, B, T, N, r, panel, Lam, R, A, Q, mu0, P0, max_iter, tol, path, iters,
-                   want_smooth ? pointer(f) : Ptr{Float64}(C_NULL), want_smooth ? pointer(P) : Ptr{Float64}(C_NULL), flags,
-                   ran, err, length(err))
-        rc == 0 || error("libdfmhip: status $rc: $(unsafe_string(pointer(err)))")
-    end
-    return (Lam = unpack3(Lam), R = [R[:, b] for b in 1:B], A = unpack3(A), Q = unpack3(Q), mu0 = [mu0[:, b] for b in 1:B],
-            P0 = unpack3(P0), loglik = [path[1:iters[b], b] for b in 1:B], iters = Int.(iters), iterations = Int(ran[]),
-            factor = want_smooth ? unpack3(f) : nothing)
+    flags = (any(isnan, panel) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)) | (singular_q ? DFM_F_SINGULAR_Q : Cuint(0))
+    m = multi_load(multi(ngpu), panel, Lam, R, A, Q, mu0, P0)
+    ran = multi_em(m; max_iter = max_iter, tol = tol, want_smooth = want_smooth, want_P = want_smooth, flags = flags)
+    path = multi_fetch(m, MULTI_LOGLIK_PATH); iters = multi_fetch(m, MULTI_ITERS)
+    Rm = multi_fetch(m, MULTI_R); mu = multi_fetch(m, MULTI_MU0)
+    return (Lam = unpack3(multi_fetch(m, MULTI_LAM)), R = [Rm[:, b] for b in 1:B], A = unpack3(multi_fetch(m, MULTI_A)),
+            Q = unpack3(multi_fetch(m, MULTI_Q)), mu0 = [mu[:, b] for b in 1:B], P0 = unpack3(multi_fetch(m, MULTI_P0)),
+            loglik = [path[1:iters[b], b] for b in 1:B], iters = Int.(iters), iterations = ran,
+            factor = want_smooth ? unpack3(multi_fetch(m, MULTI_F_SMOOTH)) : nothing)
 end
 
 "EM for VAR(p) factor dynamics in companion form (dfm_em_varp_batch; include/dfm_hip.h): p.Avar is r x (r p) =
@@ -273,6 +354,34 @@ function als(h::Handle, z::Matrix{Float64}, F0::Matrix{Float64}; nt_min::Integer
     end
     return (factor = permutedims(F[:, :, 1]), Lam = permutedims(Lam[:, :, 1]), ssr = ssr[1], iters = Int(iters[1]),
             R2 = R2[:, 1])
+end
+
+"`estimate_factor!` sweeps for B runs in ONE call (dfm_als_batch): the runs of `estimate_factor_numbers` /
+`amengual_watson_test` (dfm_functions.ipynb:698-768).  zs: one T x N window shared by every run, or a vector of B windows;
+F0s[b]: T x r_b start (the first r_b columns of a `pca_score`); every run may have its own number of factors."
+function als_batch(h::Handle, zs, F0s::Vector{Matrix{Float64}}; nt_min::Integer = 20, max_iter::Integer = 100000000,
+                   tol::Real = 1e-8)
+    shared = zs isa AbstractMatrix
+    B = length(F0s); T = size(F0s[1], 1); r = maximum(size(f, 2) for f in F0s)
+    N = shared ? size(zs, 2) : size(zs[1], 2)
+    zc = shared ? permutedims(zs, (2, 1)) : cat([permutedims(z, (2, 1)) for z in zs]...; dims = 3)   # C [b][t][i]
+    F = zeros(r, T, B)
+    for b in 1:B
+        F[1:size(F0s[b], 2), :, b] = permutedims(F0s[b], (2, 1))
+    end
+    r_each = Cint[size(f, 2) for f in F0s]
+    Lam = Array{Float64}(undef, r, N, B); iters = Array{Cint}(undef, B); ssr = Array{Float64}(undef, B)
+    R2 = Array{Float64}(undef, N, B)
+    GC.@preserve zc r_each F Lam iters ssr R2 begin
+        rc = ccall((:dfm_als_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Ptr{Float64}, Clonglong, Ptr{Cint}, Ptr{Float64}, Ptr{Float64},
+                    Cint, Cint, Cdouble, Ptr{Float64}, Cint, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}),
+                   h.ptr, B, T, N, r, zc, shared ? 0 : T * N, r_each, F, Lam, nt_min, min(max_iter, typemax(Cint)), tol,
+                   C_NULL, 0, iters, ssr, R2)
+        check(h.ptr, rc)
+    end
+    return (factor = [permutedims(F[1:r_each[b], :, b]) for b in 1:B], Lam = [permutedims(Lam[1:r_each[b], :, b]) for b in 1:B],
+            ssr = ssr, iters = Int.(iters), R2 = [R2[:, b] for b in 1:B])
 end
 
 "P complete-case regressions (`ols_skipmissing(..., Balanced())`, dfm_functions.ipynb:242-252): column p of Y (T x P,
@@ -408,14 +517,19 @@ function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em:
     var.nlag > 1 && (var.M[r+1:end, 1:end-r] = Matrix(1.0I, r * (var.nlag - 1), r * (var.nlag - 1)))
     var.Q[1:r, 1:r] = Matrix(1.0I, r, r)
     var.seps[:, :] = fit.Q
-    var.G[1:r, 1:r] = cholesky(Symmetric(fit.Q)).L
+    # fill_matrices! takes the lower Cholesky factor (:489); a rank-deficient Q (covariance-form fit) has none: its
+    # symmetric square root then stands in (G G' = Q still holds)
+    var.G[1:r, 1:r] = isposdef(Symmetric(fit.Q)) ? cholesky(Symmetric(fit.Q)).L :
+                      (e = eigen(Symmetric(fit.Q)); e.vectors * Diagonal(sqrt.(max.(e.values, 0.0))) * e.vectors')
     nrep == 0 && return fit.loglik
     # ---- parametric-bootstrap replicates, re-estimated in one batched multi-GPU call (api.estimate: same steps) ----
     rng = Random.MersenneTwister(seed)
     T = size(z, 1)
-    LQ = cholesky(Symmetric(fit.Q)).L
-    Sf = copy(fit.P0)                                                     # start the factor path from the fitted f_0 moments
-    LS = cholesky(Symmetric((Sf + Sf') / 2)).L
+    # square roots by eigendecomposition: a fit that needed the covariance-form recursion (DFM_F_SINGULAR_Q) has a
+    # rank-deficient Q, and `cholesky` would throw AFTER the point estimate was written into the model
+    psd_sqrt(S) = (e = eigen(Symmetric((S + S') / 2)); e.vectors * Diagonal(sqrt.(max.(e.values, 0.0))))
+    LQ = psd_sqrt(fit.Q)
+    LS = psd_sqrt(fit.P0)                                                 # start the factor path from the fitted f_0 moments
     panels = Vector{Matrix{Float64}}(undef, nrep)
     for b in 1:nrep
         f = fit.mu0 + LS * randn(rng, r)
@@ -428,7 +542,8 @@ function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em:
         panels[b] = x
     end
     start = (Lam = fit.Lam, R = fit.R, A = fit.A, Q = fit.Q, mu0 = fit.mu0, P0 = fit.P0)
-    reps = DFMHip.em_batch(panels, [start for _ in 1:nrep]; max_iter = max_em_iter, tol = tol_em, ngpu = ngpu)
+    reps = DFMHip.em_batch(panels, [start for _ in 1:nrep]; max_iter = max_em_iter, tol = tol_em, ngpu = ngpu,
+                           singular_q = fit.singular_q)
     return (loglik = fit.loglik, replicates = reps)
 end
 
@@ -473,4 +588,71 @@ function bootstrap_irf_bands(varm::VARModel, H::Integer; ndraws::Integer = 10000
     resid = zeros(size(y)); resid[varm.nlag+1:end, :] = Float64.(varm.resid[rows, :])
     h = handle === nothing ? DFMHip.handle(device) : handle
     return DFMHip.bootstrap_irf(h, y, Float64.(varm.betahat), resid, varm.nlag, H, ndraws; seed = seed)
+end
+
+# ---------------------------------------------------------------------------------------------------------
+# `estimate_factor_numbers(m, nfacs)` (dfm_functions.ipynb:698-725) with its batch axis on the GPU.  The reference runs
+# `estimate_factor!` once per static factor count and, inside each, `amengual_watson_test` (:734-768) runs it once more per
+# dynamic factor count: 10 + 55 serial estimations for Table 2 (Stock_Watson.ipynb:516, 591, 643, 893).  Here:
+#   1 dfm_pca_init_batch + ONE dfm_als_batch        for the max_nfac static runs (shared window, r_each = 1..max_nfac;
+#                                                    `pca_score` columns are nested, so run r starts from the first r);
+#   per static count i: 1 dfm_ols_batch             (every series on [1, lags of the i factors], :741-750) and
+#                       1 dfm_pca_init_batch        (start of the residual panel's runs);
+#   ONE dfm_als_batch                                for ALL max_nfac (max_nfac + 1) / 2 dynamic runs, each on its own
+#                                                    residual window.
+# Same return type and fields as the reference (FactorNumberEstimateStats); mirrors api.estimate_factor_numbers(with_aw).
+function estimate_factor_numbers_hip(m::DFMModel, nfacs::Union{Real, AbstractVector}; device::Integer = 0, handle = nothing)
+    m.nfac_o == 0 || error("observed factors are not supported on the HIP path")
+    max_nfac = Int(maximum(nfacs))
+    h = handle === nothing ? DFMHip.handle(device) : handle
+    incl = m.inclcode .== 1
+    ns = count(incl)
+    xdata = m.data[m.initperiod:m.lastperiod, incl]                       # :335-336
+    xstd, _ = standardize_data(xdata)                                     # :339
+    tss = sum(skipmissing(xstd .^ 2)); nobs = count(.!ismissing.(xstd)); T = size(xstd, 1)
+    xbal, _ = drop_missing_col(xstd)                                      # :345
+    F0 = DFMHip.pca_init(h, Float64.(xbal), max_nfac).F                   # pca_score (:348), nested columns
+    z = reshape(DFMHip.nan_for_missing(xstd), size(xstd))
+    st = DFMHip.als_batch(h, z, [F0[:, 1:k] for k in 1:max_nfac]; nt_min = m.nt_min_factor_estimation, tol = m.tol)
+    bn(ssr, no, Tn, k) = (nbar = no / Tn; log(ssr / no) + k * log(min(nbar, Tn)) * (nbar + Tn) / no)   # bai_ng_criterion (:684-690)
+    bn_icp = Vector{Union{Missing, Float64}}(undef, max_nfac)
+    ssr_static = Vector{Float64}(undef, max_nfac)
+    R2_static = Matrix{Union{Missing, Float64}}(undef, ns, max_nfac)
+    aw_icp = Matrix{Union{Missing, Float64}}(missing, max_nfac, max_nfac)
+    ssr_dynamic = Matrix{Union{Missing, Float64}}(missing, max_nfac, max_nfac)
+    R2_dynamic = Array{Union{Missing, Float64}}(missing, ns, max_nfac, max_nfac)
+    nan2missing(v) = Union{Missing, Float64}[isnan(x) ? missing : x for x in v]
+    for i in 1:max_nfac
+        bn_icp[i] = bn(st.ssr[i], nobs, T, i); ssr_static[i] = st.ssr[i]; R2_static[:, i] = nan2missing(st.R2[i])
+    end
+    # ---- amengual_watson_test of every static run: residual panels, then ALL dynamic runs in one call ----
+    est = m.data[:, incl]
+    Tall = size(est, 1)
+    nlag = m.factor_var_model.nlag
+    estn = reshape(DFMHip.nan_for_missing(est), size(est))
+    zs = Matrix{Float64}[]; F0s = Matrix{Float64}[]; owner = Tuple{Int,Int}[]; nobs_i = Int[]; T_i = Int[]
+    for i in 1:max_nfac
+        fac = Matrix{Union{Missing, Float64}}(missing, Tall, i)
+        fac[m.initperiod:m.lastperiod, :] = st.factor[i]
+        x = [ones(Tall) lagmat(fac, 1:nlag)]                              # :741
+        xn = reshape(DFMHip.nan_for_missing(x), size(x))
+        # a series keeps its residuals when it has at least nt_min rows MORE than regressors (:744)
+        o = DFMHip.ols(h, xn, estn; nt_min = size(xn, 2) + m.nt_min_factor_estimation)
+        res = Union{Missing, Float64}[isnan(v) ? missing : v for v in o.resid]
+        rstd, _ = standardize_data(res[m.initperiod+4:m.lastperiod, :])  # :761 (the reference hard-codes the 4)
+        rbal, _ = drop_missing_col(rstd)
+        Fi = DFMHip.pca_init(h, Float64.(rbal), i).F
+        zi = reshape(DFMHip.nan_for_missing(rstd), size(rstd))
+        for k in 1:i
+            push!(zs, zi); push!(F0s, Fi[:, 1:k]); push!(owner, (k, i))
+        end
+        push!(nobs_i, count(.!ismissing.(rstd))); push!(T_i, size(rstd, 1))
+    end
+    dy = DFMHip.als_batch(h, zs, F0s; nt_min = m.nt_min_factor_estimation, tol = m.tol)
+    for (b, (k, i)) in enumerate(owner)
+        aw_icp[k, i] = bn(dy.ssr[b], nobs_i[i], T_i[i], k)
+        ssr_dynamic[k, i] = dy.ssr[b]
+        R2_dynamic[:, k, i] = nan2missing(dy.R2[b])
+    end
+    return FactorNumberEstimateStats(bn_icp, ssr_static, R2_static, aw_icp, ssr_dynamic, R2_dynamic, tss, nobs, T)
 end

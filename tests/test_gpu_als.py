@@ -259,6 +259,31 @@ def test_table2C_amengual_watson_on_the_gpu(ctx, sw):
             assert _shown(aw[k]) == g or abs(aw[k] - g) <= 5.0001e-4, (r, k, aw[k], g)
 
 
+def test_table2_all_runs_batched_in_two_als_calls(ctx, sw):
+    """`estimate_factor_numbers(m, 1:10)` as the notebook calls it (Stock_Watson.ipynb:516, 643): the 10 static runs in
+    ONE dfm_als_batch call and the 55 Amengual-Watson runs (k <= r, each on the residual window of its static run) in a
+    SECOND one -- what julia/dfm_hip.jl estimate_factor_numbers_hip does.  Every printed digit of Tables 2A (:572-576) and
+    2C (:673-682) must come out of the batched path."""
+    from dynamic_factor_models_amd import api
+    m = _model(api, sw["all"], sw["inc_all"], 1)
+    o = api.estimate_factor_numbers(m, range(1, 11), ctx=ctx, with_aw=True)
+    rows = GOLD["table2C_aw"]["rows"]
+    for r in range(1, 11):
+        for k in range(r):
+            g = rows[k][1 + (r - 1)]
+            assert g is not None
+            v = o["aw_icp"][k, r - 1]
+            assert _shown(v) == g or abs(v - g) <= 5.0001e-4, (r, k, v, g)
+        assert np.isnan(o["aw_icp"][r:, r - 1]).all()                         # the reference's `missing` above the diagonal
+    # the same runs one static count at a time (the unbatched route of test_table2C_...) give the same numbers
+    m4 = _model(api, sw["all"], sw["inc_all"], 4)
+    api.estimate_factor(m4, computeR2=False, ctx=ctx)
+    aw4, ssr4 = api.amengual_watson_test(m4, 4, ctx=ctx)
+    # (the ALS stopping rule is |dSSR| < tol T N: two routes to the same fixed point agree to that, not to rounding)
+    np.testing.assert_allclose(o["aw_icp"][:4, 3], aw4, rtol=1e-5)
+    np.testing.assert_allclose(o["ssr_dynamic"][:4, 3], ssr4, rtol=1e-5)
+
+
 def test_standardize_batch_matches_reference_semantics(ctx):
     """dfm_functions.ipynb:501-509: mean and POPULATION s.d. over the observed cells, NaN preserved."""
     import torch

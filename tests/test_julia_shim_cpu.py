@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C2J = {
     "dfm_handle*": {"Ptr{Cvoid}"},
     "dfm_handle**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
+    "dfm_multi*": {"Ptr{Cvoid}"},
+    "dfm_multi**": {"Ref{Ptr{Cvoid}}", "Ptr{Ptr{Cvoid}}"},
     "void*": {"Ptr{Cvoid}"},
     "int": {"Cint"},
     "unsigned": {"Cuint"},
@@ -101,9 +103,29 @@ def test_every_julia_ccall_matches_the_header():
 def test_the_shim_binds_the_batched_and_multi_gpu_entries():
     bound = {name for name, _, _ in julia_ccalls()}
     for need in ("dfm_create", "dfm_destroy", "dfm_last_error", "dfm_pca_init_batch", "dfm_em_batch", "dfm_em_varp_batch",
-                 "dfm_ks_pass_batch", "dfm_ks_pass_batch_multi", "dfm_em_batch_multi", "dfm_ks_pass_ar_batch", "dfm_als_batch",
-                 "dfm_ols_batch", "dfm_chow_batch", "dfm_var_bootstrap_irf", "dfm_quantile_bands"):
+                 "dfm_ks_pass_batch", "dfm_ks_pass_batch_multi", "dfm_ks_pass_ar_batch", "dfm_als_batch",
+                 "dfm_ols_batch", "dfm_chow_batch", "dfm_var_bootstrap_irf", "dfm_quantile_bands",
+                 # the library's multi-GPU object (one communicator for the session, resident jobs, device generation)
+                 "dfm_multi_create", "dfm_multi_destroy", "dfm_multi_last_error", "dfm_multi_load", "dfm_multi_synth",
+                 "dfm_multi_ks_pass", "dfm_multi_em", "dfm_multi_fetch"):
         assert need in bound, need
+
+
+def test_the_shim_batches_the_factor_number_tables():
+    """estimate_factor_numbers / amengual_watson_test (dfm_functions.ipynb:698-768) reach the GPU as batched calls: the
+    forwarding method packs every static run into one dfm_als_batch call and every dynamic run of every static count into
+    a second one (r_each per run), and returns the reference's own FactorNumberEstimateStats."""
+    src = open(os.path.join(ROOT, "julia", "dfm_hip.jl")).read()
+    body = src[src.index("function estimate_factor_numbers_hip"):]
+    body = body[:body.index("\nend\n")]
+    assert body.count("DFMHip.als_batch(") == 2                               # static runs; all dynamic runs
+    assert "FactorNumberEstimateStats(" in body and "lagmat(" in body and "initperiod+4" in body
+    als = src[src.index("function als_batch"):]
+    als = als[:als.index("\nend\n")]
+    assert "r_each" in als and ":dfm_als_batch" in als and "shared ? 0 : T * N" in als
+    em = src[src.index("function em_batch"):]
+    em = em[:em.index("\nend\n")]
+    assert "multi(ngpu)" in em and "multi_em(" in em                          # the cached object, not a communicator per call
 
 
 def test_the_shim_never_drops_loading_constraints():
