@@ -8,23 +8,32 @@ replicate batch is sharded with the same 1024 replicates per GPU (weak scaling),
 north_star prescribes -- one all_gather of the per-replicate log-likelihoods closes every step.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats 9] [--batch-per-gpu 1024] [--missing 0.0]
-                  [--mode pass|em|pca]
+                  [--mode pass|em|pca] [--driver torch|lib] [--no-secondary] [--no-cpu-baseline]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Timing: W untimed warm-up steps, then `--repeats` blocks of EXACTLY K steps, each block bracketed by barrier +
-torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` / `ms_per_step` are the MEDIAN block
-(boxes of this pool differ by +-8 % and a 5 ms region is noisy), min / max / every block are printed beside them.
-Panels come from the product's own device generator (dfm_synth_panels_dev: counter-based Philox keyed by (seed,
+`--gpus N` WITHOUT a torchrun environment launches the N ranks itself (re-exec under torch.distributed.run on
+127.0.0.1) and fails loudly when the box has fewer than N devices; n_gpus in the line is dist.get_world_size().
+
+Timing: an untimed pre-heat of >= 50 ms of the same steps (clocks ramp on a fresh box), W untimed warm-up steps, then
+`--repeats` blocks of EXACTLY K steps, each block bracketed by barrier + torch.cuda.synchronize() on both sides and
+reduced with MAX over ranks; `value` / `ms_per_step` are the MEDIAN block, min / max / every block are printed beside
+them.  Panels come from the product's own device generator (dfm_synth_panels_dev: counter-based Philox keyed by (seed,
 global replicate index); checked cell by cell against its host restatement in the GPU tests).
 
 --mode em : a step = ONE EM ITERATION (E-step pass + M-step, SURVEY §8(d) "EM iteration") of the replicate-sharded
             driver shard.em_batch_sharded -- dfm_em_iterate_batch_dev on the shard, then the all-gather of {loglik,
             active} every iteration (north_star's collective).  Reported as EM iterations/s (a different metric).
 --mode pca: a step = the PCA initialisation (pca_score + OLS start) of the batch (dfm_pca_init_batch_dev).
+--driver lib: the same steps through the LIBRARY's multi-GPU object (dfm_multi, csrc/multi.hip: what a Julia host binds):
+            ONE process drives --gpus N devices, the job is generated where it lives (dfm_multi_synth), `--mode em` times
+            dfm_multi_em (one ncclAllGather per iteration inside the library), `--mode pass` dfm_multi_ks_pass.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed on the
-launch stream inside this script) and "cpu_baseline" (oracle/dfm_oracle.c, the C restatement, timed
-on the host cores of this box on a bounded sample of the same workload; rank 0, N=1 only).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, HIP-event timed on the launch stream inside
+this script; `ceiling_measured` = this box's own streaming ceilings from dfm_hbm_probe), "cpu_baseline" (oracle/
+dfm_oracle.c, the C restatement, timed on the host cores of this box on a bounded sample of the same workload; rank 0,
+N=1 only), "device" (clocks / power sampled while the bench batch runs) and -- default invocation only -- "secondary":
+the other lines of the path (B = 8192 shard, 10 % missing, EM, config 4, config 4 with missing cells, PCA start), three
+blocks each, same method.
 """
 from __future__ import annotations
 
@@ -32,6 +41,8 @@ import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,9 +50,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the CPU baseline's OpenMP runtime reads these when it is loaded: one thread per core, no migration
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # AMD MI355X spec sheet, FP64 matrix (the guide's table has no fp64 row; measured
                                 # v_mfma_f64_4x4x4 issue rate here: 68 TF/s, scripts/microbench/mfma64.hip)
+PREHEAT_MS = 50.0
 
 
 def algorithmic_bytes(N, T, r):
@@ -49,18 +65,6 @@ def algorithmic_bytes(N, T, r):
     inputs = 8 * (N * T + N * r + N + 2 * r * r + r + r * r)
     outputs = 8 * (T * r + T * r * (r + 1) // 2 + 1)
     return inputs, outputs
-
-
-def synth_on_device(torch, dev, B, N, T, r, seed, missing=0.0):
-    """(scripts/): SURVEY §8(d) replicates from the product's device generator; returns (panel, params)."""
-    from dynamic_factor_models_amd import DfmContext
-    c = DfmContext(dev.index or 0)
-    try:
-        out = c.synth_panels(seed, 0, B, T, N, r, missing_prob=missing)
-        torch.cuda.synchronize()
-    finally:
-        c.close()
-    return out
 
 
 def source_hash():
@@ -75,69 +79,371 @@ def source_hash():
 
 
 def measured_traffic(kernel, workload_key):
-    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes (scripts/gpu_profile.sh -> profiles/r02/
-    pmc_traffic.json), ONLY when that file was produced by exactly this source tree on this workload; else None."""
-    for name in ("pmc_traffic.json", "pmc_traffic_c4.json"):      # headline workload; BASELINE config 4
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02", name)) as fh:
-                d = json.load(fh)
-            if d.get("_source_hash") == source_hash() and d.get("_workload") == workload_key:
-                for k in (kernel, kernel.replace("collapse_wide_kernel", "collapse_wide2_kernel")):   # (profile scope -> rocprof name)
-                    if k in d:
-                        return d[k].get("hbm_bytes_per_launch")
-        except Exception:  # noqa: BLE001
-            pass
+    """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes (scripts/gpu_profile.sh -> profiles/rNN/
+    pmc_traffic*.json), ONLY when that file was produced by exactly this source tree on this workload; else None."""
+    for rnd in ("r03", "r02"):
+        for name in ("pmc_traffic.json", "pmc_traffic_c4.json"):      # headline workload; BASELINE config 4
+            try:
+                with open(os.path.join(ROOT, "profiles", rnd, name)) as fh:
+                    d = json.load(fh)
+                if d.get("_source_hash") == source_hash() and d.get("_workload") == workload_key and kernel in d:
+                    return d[kernel].get("hbm_bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                pass
     return None
 
 
-def cpu_baseline(panel_host, params_host, target_seconds=12.0):
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher decision (pure: tested on CPU)
+def launch_plan(gpus: int, env: dict, n_devices: int, driver: str = "torch"):
+    """What `bench.py --gpus N` does given the environment: ("inline", why) = run in this process; ("spawn", why) =
+    re-exec N ranks under torch.distributed.run; ("error", why) = refuse."""
+    if gpus < 1:
+        return "error", f"--gpus {gpus}: need at least one GPU"
+    world = env.get("WORLD_SIZE")
+    if world is not None:
+        if int(world) != gpus:
+            return "error", f"--gpus {gpus} but WORLD_SIZE={world}: the launcher and the flag disagree"
+        if driver == "lib" and int(world) > 1:
+            return "error", "--driver lib is ONE process driving N GPUs: run it without torchrun"
+        return "inline", f"rank {env.get('RANK', '0')} of a torchrun job of {world}"
+    if n_devices < gpus:
+        return "error", f"--gpus {gpus} but this box exposes {n_devices} HIP device(s)"
+    if gpus == 1 or driver == "lib":
+        return "inline", "single process"
+    return "spawn", f"no torchrun environment: launching {gpus} ranks (torch.distributed.run, 127.0.0.1)"
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(gpus: int, argv):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def host_cpu_info():
+    """Cores this process may really use: affinity mask and the cgroup CPU quota (the box shows 256 cores, the container
+    may own fewer: an "all cores" figure measured on more threads than that is an oversubscription artefact)."""
+    info = dict(os_cpu_count=os.cpu_count())
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        info["affinity"] = None
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                 # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()
+            quota = None if q == "max" else float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+                quota = None if q <= 0 else q / per
+        except Exception:  # noqa: BLE001
+            pass
+    info["cgroup_cpu_quota"] = quota
+    usable = info["affinity"] or info["os_cpu_count"] or 1
+    if quota:
+        usable = max(1, min(usable, int(quota)))
+    info["usable"] = usable
+    return info
+
+
+def cpu_baseline(panel_host, params_host, target_seconds=20.0):
     """Time the C restatement (oracle/dfm_oracle.c, OpenMP over replicates) on this box's host cores on a bounded
-    sample of the same workload: all threads (>= 8 replicates per thread, persistent output buffers touched before the
-    clock starts) and one thread."""
+    sample of the same workload.  Thread counts up to what the container may use (affinity, cgroup quota) are probed for
+    >= 1 s each on >= 8 replicates per thread into persistent output buffers; the fastest is then timed for the rest of
+    the budget, and one thread beside it.  OMP_PROC_BIND=close / OMP_PLACES=cores (set at the top of this file)."""
     import numpy as np
     from oracle import c_oracle as co
-    cores = co.num_threads()
+    info = host_cpu_info()
+    cap = max(1, min(info["usable"], co.num_threads()))
     S, T, N = panel_host.shape
     r = params_host[0].shape[2]
     out = (np.zeros((S, T, r)), np.zeros((S, T, r * (r + 1) // 2)), np.zeros(S))
     co.ks_pass_batch(panel_host, *params_host, out=out)          # warm: thread pool up, every page touched
-    # the box may give this container fewer CPUs than it shows (cgroup quota): take the thread count that is fastest
-    # on a short probe, so that the "all cores" figure is not an oversubscription artefact
-    probe = {}
-    for n in sorted({cores, max(cores // 2, 1), max(cores // 4, 1), max(cores // 8, 1), min(cores, 32), min(cores, 16), min(cores, 8)}):
+
+    def rate(n, seconds):
         Sn = min(S, max(8 * n, 16))
-        tp = time.perf_counter()
-        co.ks_pass_batch(panel_host[:Sn], *[p[:Sn] for p in params_host], out=tuple(o[:Sn] for o in out), nthreads=n)
-        probe[n] = Sn / (time.perf_counter() - tp)
+        args = (panel_host[:Sn],) + tuple(p[:Sn] for p in params_host)
+        o = tuple(x[:Sn] for x in out)
+        co.ks_pass_batch(*args, out=o, nthreads=n)               # this thread count's pool, warm
+        done, t0 = 0, time.perf_counter()
+        while True:
+            co.ks_pass_batch(*args, out=o, nthreads=n)
+            done += Sn
+            el = time.perf_counter() - t0
+            if el >= seconds:
+                return done / el, done, el, Sn
+
+    counts = sorted({c for c in (cap, cap // 2, cap // 4, 64, 32, 16, 8) if 1 <= c <= cap})
+    probe = {n: rate(n, 1.0)[0] for n in counts}
     cores = max(probe, key=probe.get)
-    S = min(S, max(8 * cores, 16))
-    panel_host = panel_host[:S]; params_host = [p[:S] for p in params_host]; out = tuple(o[:S] for o in out)
-    co.ks_pass_batch(panel_host, *params_host, out=out, nthreads=cores)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        co.ks_pass_batch(panel_host, *params_host, out=out)
-        done += S
-        el = time.perf_counter() - t0
-        if el >= 0.75 * target_seconds:
-            break
-    S1 = min(S, 16)
-    sub = (panel_host[:S1],) + tuple(p[:S1] for p in params_host)
-    out1 = tuple(o[:S1] for o in out)
-    co.ks_pass_batch(*sub, out=out1, nthreads=1)
-    d1, t1 = 0, time.perf_counter()
-    while True:
-        co.ks_pass_batch(*sub, out=out1, nthreads=1)
-        d1 += S1
-        e1 = time.perf_counter() - t1
-        if e1 >= 0.25 * target_seconds:
-            break
-    co.ks_pass_batch(*sub, out=out1, nthreads=cores)             # leave the pool at its default size
-    return dict(value=done / el, unit="passes/s", cores=cores, kind="port", per_thread=done / el / cores,
-                thread_probe={str(k): round(v, 1) for k, v in sorted(probe.items())},
-                single_thread=dict(value=d1 / e1, cores=1, sample=f"{d1} passes in {e1:.1f} s"),
-                sample=f"{done} passes ({S} distinct replicates of the bench batch = {S / cores:.1f} per thread, repeated) "
-                       f"in {el:.1f} s; oracle/dfm_oracle.c, gcc -O2 -fopenmp, {cores} threads, outputs into "
-                       f"persistent buffers")
+    left = max(3.0, target_seconds - 1.0 * len(counts) - 3.0)
+    v, done, el, Sn = rate(cores, left)
+    v1, d1, e1, _ = rate(1, 3.0)
+    co.ks_pass_batch(panel_host[:16], *[p[:16] for p in params_host], out=tuple(x[:16] for x in out), nthreads=cap)
+    return dict(value=v, unit="passes/s", cores=cores, kind="port", per_thread=v / cores,
+                thread_probe={str(k): round(x, 1) for k, x in sorted(probe.items())}, host=info,
+                single_thread=dict(value=v1, cores=1, sample=f"{d1} passes in {e1:.1f} s"),
+                sample=f"{done} passes ({Sn} distinct replicates of the bench batch = {Sn / cores:.1f} per thread, repeated) "
+                       f"in {el:.1f} s; oracle/dfm_oracle.c, gcc -O2 -fopenmp, {cores} threads pinned (OMP_PROC_BIND=close), "
+                       f"outputs into persistent buffers; every probed thread count ran >= 1 s")
+
+
+def device_telemetry():
+    """sclk / mclk / power / temperature from rocm-smi, sampled by the caller WHILE the bench batch is running."""
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(out[out.index("{"):])
+        card = d.get("card0") or next(iter(d.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(s in kl for s in ("sclk", "mclk", "fclk", "socclk", "power", "temperature (sensor junction)", "temperature (sensor memory)",
+                                     "performance level")):
+                keep[k] = v
+        return keep
+    except Exception as e:  # noqa: BLE001
+        return dict(error=f"rocm-smi not readable: {e}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def kernel_bytes_table(B, N, T, r):
+    """Algorithmic bytes per launch of the kernels a roofline line may name (DESIGN.md "Kernels"): compulsory inputs read
+    once + outputs written once.  Keys are the names rocprofv3 prints."""
+    b_in, b_out = algorithmic_bytes(N, T, r)
+    panel_b = 8 * (N * T + N * r + N)                      # panel + loadings + idiosyncratic variances
+    npack = r * (r + 1) // 2
+    seq = B * (b_in - panel_b + b_out)
+    return {"collapse_mfma_kernel": B * panel_b, "collapse_dma_kernel": B * panel_b, "collapse_wide_kernel": B * panel_b,
+            "collapse_wide2_kernel": B * panel_b, "collapse_kernel": B * panel_b, "collapse_miss_kernel": B * panel_b,
+            "pass_fused_kernel": B * (b_in + b_out),
+            "recursion_kernel": seq, "recursion_wave_kernel": seq, "recursion_pair_kernel": seq,
+            "meanscan_kernel": B * (b_in - panel_b + 8 * (T * r + 1)), "meanscan_mfma_kernel": B * (b_in - panel_b + 8 * (T * r + 1)),
+            "pfill_kernel": B * 8 * T * npack,
+            "mstep_mfma_kernel": B * 8 * (N * T + T * r), "mstep_wide_kernel": B * 8 * (N * T + T * r),
+            "mstep_lam_kernel": B * 8 * (N * T + T * (r + npack)),
+            "gram_kernel": B * 8 * (N * r + N), "wide_prep_kernel": B * 8 * (N * r + N), "cov_kernel": B * 8 * (3 * r * r + r),
+            "cov_grid_kernel": B * 8 * (3 * r * r + r), "ct_miss_wide_kernel": B * 8 * T * npack}
+
+
+class Workload:
+    """One bench line: a batch resident in HBM, `step(k)` = k steps of the mode, timed as the contract prescribes."""
+
+    def __init__(self, torch, dist, ctx, shard, world, rank, dev, B, N, T, r, missing, mode, seed=20160415):
+        self.torch, self.dist, self.ctx, self.shard = torch, dist, ctx, shard
+        self.world, self.rank, self.dev = world, rank, dev
+        self.B, self.N, self.T, self.r, self.missing, self.mode = B, N, T, r, missing, mode
+        self.distributed = world > 1
+        self.may_missing = missing > 0.0
+        # this rank's replicates [rank B, (rank + 1) B) of the job's world * B (shard.replicate_range), generated where they live
+        self.panel, self.params = ctx.synth_panels(seed, rank * B, B, T, N, r, missing_prob=missing)
+        f64 = torch.float64
+        self.f = torch.empty((B, T, r), dtype=f64, device=dev)
+        self.P = torch.empty((B, T, r * (r + 1) // 2), dtype=f64, device=dev) if mode == "pass" else None
+        self.ll = torch.empty((B,), dtype=f64, device=dev)
+        self.ll_all = torch.empty((world * B,), dtype=f64, device=dev) if self.distributed else None
+        self.em_params = None
+        if mode == "em":
+            if self.may_missing:
+                self.em_params = [p.clone() for p in self.params]       # DGP parameters as the start (PCA needs a balanced panel)
+            else:
+                self.em_params = list(ctx.pca_init_batch(self.panel, r, want_factors=False)[:6])
+
+    def steps(self, k, profile=False):
+        ctx, dist = self.ctx, self.dist
+        if self.mode == "pass":
+            for _ in range(k):
+                ctx.ks_pass_batch(self.panel, *self.params, may_have_missing=self.may_missing, out=(self.f, self.P, self.ll))
+                if self.distributed and not profile:   # north_star: a single RCCL all-gather of the replicates' log-likelihoods
+                    dist.all_gather_into_tensor(self.ll_all, self.ll)
+        elif self.mode == "em":
+            # k EM iterations of the sharded driver: dfm_em_iterate_batch_dev + the all-gather of {loglik, active} EVERY
+            # iteration (tol = 0: no early stop, so exactly k iterations are timed)
+            self.shard.em_batch_sharded(ctx, self.panel, *self.em_params, B_global=self.world * self.B, max_iter=k, tol=0.0,
+                                        want_smooth=False, may_have_missing=self.may_missing)
+        else:
+            for _ in range(k):
+                ctx.pca_init_batch(self.panel, self.r, want_factors=False)
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, steps, warmup, repeats, preheat_ms=PREHEAT_MS):
+        torch, dist = self.torch, self.dist
+        # pre-heat: the same steps, untimed, until >= preheat_ms of device time have passed (DVFS ramp of a fresh box)
+        self.fence()
+        t0 = time.perf_counter()
+        heat = 0
+        while (time.perf_counter() - t0) * 1e3 < preheat_ms:
+            self.steps(max(2, steps // 4)); heat += max(2, steps // 4)
+            torch.cuda.synchronize()
+        self.steps(max(warmup, 1) if self.mode == "em" else warmup)
+        blocks = []
+        for _ in range(max(repeats, 1)):
+            self.fence()
+            t0 = time.perf_counter()
+            self.steps(steps)
+            self.fence()
+            el = time.perf_counter() - t0
+            if self.distributed:
+                tt = torch.tensor([el], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            blocks.append(el)
+        srt = sorted(blocks)
+        elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        if self.mode == "pass":
+            assert bool(torch.isfinite(self.ll).all()), "non-finite log-likelihood in the bench batch"
+            self.ctx.synchronize()              # + the status word of the last pass (an expired bounded wait would raise)
+        # roofline leg: K more steps with a HIP-event pair around every kernel launch (on the launch stream)
+        self.ctx.profile_enable(True)
+        self.steps(steps, profile=True)
+        prof = self.ctx.profile_read()
+        self.ctx.profile_enable(False)
+        return dict(ms_per_step=1e3 * elapsed / steps, value=self.world * self.B * steps / elapsed, blocks=blocks, sorted=srt,
+                    avg={k: v[0] / v[1] for k, v in prof.items()}, launches={k: v[1] for k, v in prof.items()}, steps=steps,
+                    preheat_steps=heat)
+
+    def roofline(self, res):
+        """The roofline object of one line (rank 0)."""
+        B, N, T, r = self.B, self.N, self.T, self.r
+        avg, ms_per_step = res["avg"], res["ms_per_step"]
+        b_in, b_out = algorithmic_bytes(N, T, r)
+        workload_key = f"{self.mode}:B{B}:N{N}:T{T}:r{r}:m{self.missing}"
+        kern_bytes = kernel_bytes_table(B, N, T, r)
+        kernels_ms = {k: round(v, 4) for k, v in avg.items()}
+        if self.mode == "pca":
+            dom = max(avg, key=avg.get)
+            flops = {"gram_xx_kernel": 2.0 * T * N * N * B, "gram_xx_mfma_kernel": 2.0 * T * N * N * B, "gram_xx_wide_kernel": 2.0 * T * N * N * B}
+            gx = next((k for k in flops if k in avg), None)
+            out = dict(bound="mfma", kernel=dom, achieved=None, peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
+                       avg_launch_ms=avg[dom], kernels_ms=kernels_ms,
+                       note="pca_kernel (subspace iteration, Rayleigh-Ritz, OLS start) is latency-bound small-matrix work on an "
+                            "L2-resident Gram matrix -- no roofline claim for it; `gram` = X'X of the batch on v_mfma_f64_16x16x4")
+            if gx:
+                ach = flops[gx] / (avg[gx] * 1e-3) / 1e12
+                out["gram"] = dict(kernel=gx, achieved=ach, peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_MATRIX_PEAK_TFLOPS,
+                                   avg_launch_ms=avg[gx], flops_per_launch=flops[gx])
+                if dom == gx:
+                    out.update(achieved=ach, frac=ach / FP64_MATRIX_PEAK_TFLOPS)
+            return out
+        cands = [k for k in avg if k in kern_bytes]
+        dom = max(cands, key=avg.get)
+        # a kernel cannot take longer than the step that contains it: the event pair adds its own latency (measured +3..8 %),
+        # so when the step IS one kernel the step's wall clock is the better estimate of the launch duration
+        one_kernel = sum(res["launches"].values()) == res["launches"][dom]
+        dur = min(avg[dom], ms_per_step) if one_kernel else avg[dom]
+        achieved = kern_bytes[dom] / (dur * 1e-3) / 1e9
+        unit_bytes = (b_in + b_out) if self.mode == "pass" else (b_in + b_out + 8 * N * T + 8 * (N * r + N + 2 * r * r))
+        whole = B * unit_bytes / (ms_per_step * 1e-3) / 1e9
+        out = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                   traffic=measured_traffic(dom, workload_key), avg_launch_ms=dur, avg_launch_ms_hip_events=avg[dom],
+                   duration_source=("min(HIP-event pair, wall clock of the step): the step is this one kernel" if one_kernel
+                                    else "HIP-event pairs on the launch stream"),
+                   bytes_per_launch=kern_bytes[dom], kernels_ms=kernels_ms,
+                   note=("pass_fused_kernel = the whole pass in one launch: every input read once, every output written once"
+                         if dom == "pass_fused_kernel" else
+                         "sequential path (panel with missing cells): the collapse streams the panel once, the recursion kernel is "
+                         "a chain of T dependent r x r inversions per replicate -- latency-bound, not HBM-bound"
+                         if dom.startswith("recursion") else "dominant kernel of this mode by HIP-event time"),
+                   whole_step=dict(bytes_per_unit=unit_bytes, achieved=whole, frac=whole / HBM_PEAK_GBS,
+                                   note="SURVEY §8(d) algorithmic bytes per " + ("pass" if self.mode == "pass" else "EM iteration")
+                                        + " x units/s of ONE GPU (median wall clock of the timed blocks) / HBM peak"))
+        out["whole_pass"] = out["whole_step"]      # round-1 key kept for the driver's readers
+        return out
+
+    def free(self):
+        for k in ("panel", "params", "f", "P", "ll", "ll_all", "em_params"):
+            setattr(self, k, None)
+        self.torch.cuda.empty_cache()
+
+
+METRIC = {"pass": ("Kalman-smoother passes/sec", "passes/s", "one full Kalman-smoother pass per step"),
+          "em": ("EM iterations/sec (E-step pass + M-step)", "EM iterations/s", "one EM iteration (pass + M-step) per step"),
+          "pca": ("PCA initialisations/sec (pca_score + OLS start)", "initialisations/s", "one PCA initialisation per step")}
+
+SECONDARY = [   # (key, dict(B, N, T, r, missing, mode), steps, warmup) -- three blocks each
+    ("b8192", dict(B=8192, N=200, T=500, r=8, missing=0.0, mode="pass"), 5, 2),
+    ("missing10", dict(B=1024, N=200, T=500, r=8, missing=0.1, mode="pass"), 10, 3),
+    ("em", dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="em"), 10, 3),
+    ("em_missing10", dict(B=1024, N=200, T=500, r=8, missing=0.1, mode="em"), 10, 3),
+    ("pca", dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="pca"), 3, 1),
+    ("c4", dict(B=256, N=1000, T=2000, r=20, missing=0.0, mode="pass"), 5, 2),
+    ("c4_em", dict(B=256, N=1000, T=2000, r=20, missing=0.0, mode="em"), 3, 1),
+    ("c4_missing10", dict(B=256, N=1000, T=2000, r=20, missing=0.1, mode="pass"), 2, 1),
+]
+
+
+def workload_name(N, T, r, B):
+    return ("BASELINE configs[1]" if (N, T, r, B) == (200, 500, 8, 1024) else
+            "BASELINE configs[2] per-GPU shard" if (N, T, r, B) == (200, 500, 8, 8192) else
+            "BASELINE configs[3]" if (N, T, r) == (1000, 2000, 20) else "custom")
+
+
+def run_lib_driver(args, torch):
+    """--driver lib: ONE process, the library's dfm_multi object over --gpus N devices (what the Julia host binds)."""
+    from dynamic_factor_models_amd import DfmMulti
+    G, B, N, T, r = args.gpus, args.batch_per_gpu, args.N, args.T, args.r
+    m = DfmMulti(G, force_comm=args.force_comm)
+    try:
+        m.synth(20160415, 0, G * B, T, N, r, missing_prob=args.missing, pca_start=(args.mode == "em" and args.missing == 0.0))
+        may = args.missing > 0.0
+
+        def steps(k):
+            if args.mode == "em":
+                assert m.em(max_iter=k, tol=0.0, want_smooth=False, want_P=False, may_have_missing=may) == k
+            else:
+                for _ in range(k):
+                    m.ks_pass(want_P=True, may_have_missing=may)
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < PREHEAT_MS:
+            steps(max(2, args.steps // 4))
+        steps(max(args.warmup, 1))
+        blocks = []
+        for _ in range(max(args.repeats, 1)):
+            t0 = time.perf_counter()
+            steps(args.steps)                    # (every call of the object synchronises all its GPUs before it returns)
+            blocks.append(time.perf_counter() - t0)
+        srt = sorted(blocks)
+        el = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+        name, unit, what = METRIC["em" if args.mode == "em" else "pass"]
+        b_in, b_out = algorithmic_bytes(N, T, r)
+        unit_bytes = (b_in + b_out) if args.mode != "em" else (b_in + b_out + 8 * N * T + 8 * (N * r + N + 2 * r * r))
+        ms = 1e3 * el / args.steps
+        whole = B * unit_bytes / (ms * 1e-3) / 1e9
+        out = dict(metric=f"{name}, N={N} T={T} r={r} panel", value=G * B * args.steps / el, unit=unit, n_gpus=G, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=ms, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
+                   data="synthetic (generated on the owning GPU by dfm_multi_synth, Philox4x32-10 keyed by (seed, global replicate))",
+                   config=dict(workload=workload_name(N, T, r, B) + f": synthetic panel N={N} T={T} r={r}, batch={B} replicates per GPU, {what}",
+                               N=N, T=T, r=r, batch_per_gpu=B, global_batch=G * B, missing=args.missing, mode=args.mode,
+                               driver="lib (dfm_multi: one process, one host thread per GPU, library-owned RCCL communicator"
+                                      + (", ncclAllGather of {loglik, active} per EM iteration)" if m.has_comm else ", no communicator)"),
+                               parallelism=f"replicate-sharded x{G} inside libdfmhip.so", has_comm=m.has_comm),
+                   timing=dict(repeats=len(blocks), ms_per_step_blocks=[round(1e3 * b / args.steps, 5) for b in blocks],
+                               note="wall clock of the synchronising library calls (host-side thread fork/join and the per-iteration "
+                                    "D2H of the gathered convergence state included)"),
+                   roofline=dict(bound="hbm", kernel=None, achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS, traffic=None,
+                                 whole_step=dict(bytes_per_unit=unit_bytes, achieved=whole, frac=whole / HBM_PEAK_GBS)),
+                   cpu_baseline=None, source_hash=source_hash())
+        print(json.dumps(out))
+    finally:
+        m.close()
 
 
 def main():
@@ -152,185 +458,117 @@ def main():
     ap.add_argument("--r", type=int, default=8)
     ap.add_argument("--missing", type=float, default=0.0)
     ap.add_argument("--mode", choices=("pass", "em", "pca"), default="pass")
+    ap.add_argument("--driver", choices=("torch", "lib"), default="torch")
+    ap.add_argument("--force-comm", action="store_true", help="--driver lib: build the RCCL communicator also for one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
+    what, why = launch_plan(args.gpus, os.environ, torch.cuda.device_count(), args.driver)
+    if what == "error":
+        raise SystemExit("bench.py: " + why)
+    if what == "spawn":
+        print("bench.py: " + why, file=sys.stderr)
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.driver == "lib":
+        if args.mode == "pca":
+            raise SystemExit("--driver lib times --mode pass or --mode em")
+        return run_lib_driver(args, torch)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device; the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
-    if distributed:
+    if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
+        world = dist.get_world_size()                             # n_gpus in the line is what the job really has
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {world} ranks")
 
     from dynamic_factor_models_amd import DfmContext, shard
     ctx = DfmContext(local_rank)
-
     B, N, T, r = args.batch_per_gpu, args.N, args.T, args.r
-    seed = 20160415
-    # this rank's replicates [rank B, (rank + 1) B) of the job's world * B (shard.replicate_range), generated where they live
-    panel, params = ctx.synth_panels(seed, rank * B, B, T, N, r, missing_prob=args.missing)
-    may_missing = args.missing > 0.0
-    f = torch.empty((B, T, r), dtype=torch.float64, device=dev)
-    P = torch.empty((B, T, r * (r + 1) // 2), dtype=torch.float64, device=dev)
-    ll = torch.empty((B,), dtype=torch.float64, device=dev)
-    ll_all = torch.empty((world * B,), dtype=torch.float64, device=dev) if distributed else None
-    em_params = None
-    if args.mode == "em":
-        if may_missing:
-            em_params = [p.clone() for p in params]                 # DGP parameters as the start (PCA needs a balanced panel)
-        else:
-            em_params = list(ctx.pca_init_batch(panel, r, want_factors=False)[:6])
+    default_line = (args.mode, B, N, T, r, args.missing) == ("pass", 1024, 200, 500, 8, 0.0)
 
-    def run_pass():
-        ctx.ks_pass_batch(panel, *params, may_have_missing=may_missing, out=(f, P, ll))
-
-    def steps(k, profile=False):
-        if args.mode == "pass":
-            for _ in range(k):
-                run_pass()
-                if distributed and not profile:   # north_star: a single RCCL all-gather of the replicates' log-likelihoods
-                    dist.all_gather_into_tensor(ll_all, ll)
-        elif args.mode == "em":
-            # k EM iterations of the sharded driver: dfm_em_iterate_batch_dev + the all-gather of {loglik, active} EVERY
-            # iteration (tol = 0: no early stop, so exactly k iterations are timed)
-            shard.em_batch_sharded(ctx, panel, *em_params, B_global=world * B, max_iter=k, tol=0.0, want_smooth=False,
-                                   may_have_missing=may_missing)
-        else:
-            for _ in range(k):
-                ctx.pca_init_batch(panel, r, want_factors=False)
-
-    def fence():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    steps(max(args.warmup, 1) if args.mode == "em" else args.warmup)
-    blocks = []
-    for _ in range(max(args.repeats, 1)):
-        fence()
-        t0 = time.perf_counter()
-        steps(args.steps)
-        fence()
-        el = time.perf_counter() - t0
-        if distributed:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        blocks.append(el)
-    srt = sorted(blocks)
-    elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
-    ms_per_step = 1e3 * elapsed / args.steps
-    per_s = world * B * args.steps / elapsed
-    if args.mode == "pass":
-        assert bool(torch.isfinite(ll).all()), "non-finite log-likelihood in the bench batch"
-
-    # ---- roofline leg: K more steps with a HIP-event pair around every kernel launch (on the launch stream)
-    ctx.profile_enable(True)
-    steps(args.steps, profile=True)
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
-
+    wl = Workload(torch, dist, ctx, shard, world, rank, dev, B, N, T, r, args.missing, args.mode)
+    res = wl.run(args.steps, args.warmup, args.repeats)
+    # clocks / power while the bench batch runs: enqueue ~0.5 s of steps, read rocm-smi meanwhile (rank 0)
+    telemetry = None
     if rank == 0:
-        b_in, b_out = algorithmic_bytes(N, T, r)
-        panel_b = 8 * (N * T + N * r + N)                      # panel + loadings + idiosyncratic variances
-        npack = r * (r + 1) // 2
-        # algorithmic bytes per launch (DESIGN.md "Kernels"): compulsory inputs read once + outputs written once
-        kern_bytes = {"collapse_mfma_kernel": B * panel_b, "collapse_dma_kernel": B * panel_b,
-                      "collapse_wide_kernel": B * panel_b, "collapse_kernel": B * panel_b,
-                      "pass_fused_kernel": B * (b_in + b_out),
-                      "recursion_kernel": B * (b_in - panel_b + b_out),
-                      "meanscan_kernel": B * (b_in - panel_b + 8 * (T * r + 1)),
-                      "pfill_kernel": B * 8 * T * npack,
-                      "mstep_mfma_kernel": B * 8 * (N * T + T * r), "mstep_lam_kernel": B * 8 * (N * T + T * (r + npack)),
-                      "gram_kernel": B * 8 * (N * r + N), "cov_kernel": B * 8 * (3 * r * r + r)}
-        avg = {k: v[0] / v[1] for k, v in prof.items()}
-        fused = "collapse_mfma_kernel" in avg and "cov_kernel" not in avg and "pfill_kernel" not in avg
-        if fused:   # the covariance workgroups + P_smooth fill ride in the collapse launch: it also writes P_smooth
-            kern_bytes["collapse_mfma_kernel"] += B * 8 * (T * npack + 3 * r * r + r)
-        workload_key = f"{args.mode}:B{B}:N{N}:T{T}:r{r}:m{args.missing}"
-        if args.mode == "pca" and "gram_xx_kernel" in avg:
-            dom = max(avg, key=avg.get)
-            flops = {"gram_xx_kernel": 2.0 * T * N * N * B}
-            if dom in flops:
-                ach = flops[dom] / (avg[dom] * 1e-3) / 1e12
-                roofline = dict(bound="mfma", kernel=dom, achieved=ach, peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                                frac=ach / FP64_MATRIX_PEAK_TFLOPS, traffic=measured_traffic(dom, workload_key),
-                                avg_launch_ms=avg[dom], flops_per_launch=flops[dom],
-                                kernels_ms={k: round(v, 4) for k, v in avg.items()},
-                                note="X'X of the batch (T x N by N x N per replicate) on v_mfma_f64_16x16x4; the subspace "
-                                     "iteration behind it (pca_kernel) is latency-bound small-matrix work")
-            else:
-                roofline = dict(bound="hbm", kernel=dom, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
-                                avg_launch_ms=avg[dom], kernels_ms={k: round(v, 4) for k, v in avg.items()},
-                                note="pca_kernel (subspace iteration, Rayleigh-Ritz, OLS start) dominates: latency-bound "
-                                     "small-matrix work on an L2-resident Gram matrix -- no roofline claim")
-        else:
-            cands = [k for k in avg if k in kern_bytes]
-            dom = max(cands, key=avg.get)
-            achieved = kern_bytes[dom] / (avg[dom] * 1e-3) / 1e9
-            unit_bytes = (b_in + b_out) if args.mode == "pass" else (b_in + b_out + 8 * N * T + 8 * (N * r + N + 2 * r * r))
-            roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=achieved / HBM_PEAK_GBS, traffic=measured_traffic(dom, workload_key),
-                            avg_launch_ms=avg[dom], bytes_per_launch=kern_bytes[dom],
-                            kernels_ms={k: round(v, 4) for k, v in avg.items()},
-                            note=("pass_fused_kernel = the whole pass in one launch: every input read once, every output written once"
-                                  if dom == "pass_fused_kernel" else
-                                  "collapse_mfma_kernel = streaming collapse + the covariance workgroups and the P_smooth fill at the "
-                                  "front of the same grid: algorithmic bytes = panel + Lam + R read, P_smooth written" if fused else
-                                  "sequential path (panel with missing cells): collapse_kernel streams the panel once, the recursion "
-                                  "kernel is a chain of T dependent r x r inversions per replicate -- latency-bound, not HBM-bound"
-                                  if "recursion_kernel" in avg else
-                                  "dominant kernel of this mode by HIP-event time"),
-                            whole_step=dict(bytes_per_unit=unit_bytes,
-                                            achieved=B * unit_bytes / (ms_per_step * 1e-3) / 1e9,
-                                            frac=B * unit_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            note="SURVEY §8(d) algorithmic bytes per " + ("pass" if args.mode == "pass" else "EM iteration")
-                                                 + " x units/s of ONE GPU (median wall clock of the timed blocks) / HBM peak"))
-            roofline["whole_pass"] = roofline["whole_step"]      # round-1 key kept for the driver's readers
+        n = int(min(4000, max(50, 500.0 / max(res["ms_per_step"], 1e-3)))) if args.mode != "em" else args.steps
+        wl.steps(n, profile=True)
+        telemetry = device_telemetry()
+        torch.cuda.synchronize()
+    ceiling = None
+    if rank == 0 and world == 1:
+        try:
+            pr = ctx.hbm_probe(1 << 30, 10)
+            ceiling = dict(read_dma_gbs=pr["read_dma"], copy_gbs=pr["copy"], write_gbs=pr["write"],
+                           note="dfm_hbm_probe on this device right after the timed blocks: 1 GiB, 10 launches each -- read-only LDS-DMA "
+                                "ring (the collapse's pattern), 16-byte copy (read + write counted), write-only")
+        except Exception as e:  # noqa: BLE001
+            ceiling = dict(error=str(e))
+
+    out = None
+    if rank == 0:
+        roofline = wl.roofline(res)
+        roofline["ceiling_measured"] = ceiling
+        if ceiling and "copy_gbs" in ceiling and roofline.get("whole_step"):
+            roofline["whole_step"]["frac_of_measured_copy_ceiling"] = roofline["whole_step"]["achieved"] / ceiling["copy_gbs"]
         cpu = None
         if world == 1 and not args.no_cpu_baseline and args.mode == "pass":
-            import numpy as np
             from oracle import c_oracle as co
             S = min(B, max(256, 8 * co.num_threads()))
-            ph = panel[:S].cpu().numpy()
-            pr = [p[:S].cpu().numpy() for p in params]
+            ph = wl.panel[:S].cpu().numpy()
+            pr = [p[:S].cpu().numpy() for p in wl.params]
             cpu = cpu_baseline(ph, pr, args.cpu_seconds)
-        metric = {"pass": f"Kalman-smoother passes/sec, N={N} T={T} r={r} panel",
-                  "em": f"EM iterations/sec (E-step pass + M-step), N={N} T={T} r={r} panel",
-                  "pca": f"PCA initialisations/sec (pca_score + OLS start), N={N} T={T} r={r} panel"}[args.mode]
-        unit = {"pass": "passes/s", "em": "EM iterations/s", "pca": "initialisations/s"}[args.mode]
-        what = {"pass": "one full Kalman-smoother pass per step", "em": "one EM iteration (pass + M-step) per step",
-                "pca": "one PCA initialisation per step"}[args.mode]
+        name, unit, what_step = METRIC[args.mode]
         coll = {"pass": " + all_gather(loglik) per step", "em": " + all_gather({loglik, active}) per EM iteration", "pca": ""}[args.mode]
-        out = dict(metric=metric, value=per_s, unit=unit, n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
+        srt = res["sorted"]
+        out = dict(metric=f"{name}, N={N} T={T} r={r} panel", value=res["value"], unit=unit, n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
                    data="synthetic (device-generated, Philox4x32-10 keyed by (seed, global replicate))",
-                   config=dict(workload=("BASELINE configs[1]" if (N, T, r, B) == (200, 500, 8, 1024) else
-                                         "BASELINE configs[2] per-GPU shard" if (N, T, r, B) == (200, 500, 8, 8192) else
-                                         "BASELINE configs[3]" if (N, T, r) == (1000, 2000, 20) else "custom")
-                                        + f": synthetic panel N={N} T={T} r={r}, "
-                                        f"batch={B} replicates per GPU, {what}"
-                                        + (f", {args.missing:.0%} cells missing" if may_missing else ", balanced"),
+                   config=dict(workload=workload_name(N, T, r, B) + f": synthetic panel N={N} T={T} r={r}, batch={B} replicates per GPU, {what_step}"
+                                        + (f", {args.missing:.0%} cells missing" if args.missing > 0 else ", balanced"),
                                N=N, T=T, r=r, batch_per_gpu=B, global_batch=world * B, missing=args.missing, mode=args.mode,
-                               parallelism=f"replicate-sharded x{world}" + (coll if distributed else "")),
-                   timing=dict(repeats=len(blocks), statistic="median of the timed blocks (each: K steps between fences, MAX over ranks)",
+                               parallelism=f"replicate-sharded x{world}" + (coll if world > 1 else "")),
+                   timing=dict(repeats=len(res["blocks"]), statistic="median of the timed blocks (each: K steps between fences, MAX over ranks)",
+                               preheat=f">= {PREHEAT_MS:.0f} ms of untimed steps before the W warm-up steps ({res['preheat_steps']} steps)",
                                ms_per_step_min=1e3 * srt[0] / args.steps, ms_per_step_max=1e3 * srt[-1] / args.steps,
                                value_min=world * B * args.steps / srt[-1], value_max=world * B * args.steps / srt[0],
-                               ms_per_step_blocks=[round(1e3 * b / args.steps, 5) for b in blocks]),
-                   roofline=roofline, cpu_baseline=cpu, host_cores=os.cpu_count(), source_hash=source_hash())
+                               ms_per_step_blocks=[round(1e3 * b / args.steps, 5) for b in res["blocks"]]),
+                   roofline=roofline, cpu_baseline=cpu, device=telemetry, host_cores=os.cpu_count(), source_hash=source_hash())
+    wl.free()
+
+    # ---- the other lines of the path, driver-visible (default invocation on one GPU only; < 60 s together) ----
+    if default_line and world == 1 and not args.no_secondary:
+        sec = {}
+        for key, cfg, k, w in SECONDARY:
+            t0 = time.perf_counter()
+            try:
+                s = Workload(torch, dist, ctx, shard, 1, 0, dev, cfg["B"], cfg["N"], cfg["T"], cfg["r"], cfg["missing"], cfg["mode"])
+                rs = s.run(k, w, 3, preheat_ms=20.0)
+                rf = s.roofline(rs)
+                sec[key] = dict(workload=workload_name(cfg["N"], cfg["T"], cfg["r"], cfg["B"]), **cfg, value=rs["value"], unit=METRIC[cfg["mode"]][1],
+                                ms_per_step=rs["ms_per_step"], ms_per_step_blocks=[round(1e3 * b / k, 5) for b in rs["blocks"]], steps=k,
+                                whole_step=(rf.get("whole_step") or {}).get("frac"), dominant=rf["kernel"],
+                                dominant_frac=rf.get("frac"), kernels_ms=rf["kernels_ms"], gram=rf.get("gram"),
+                                seconds=None)
+                s.free()
+            except Exception as e:  # noqa: BLE001  (a secondary line must never take the headline down)
+                sec[key] = dict(error=f"{type(e).__name__}: {e}")
+            sec[key]["seconds"] = round(time.perf_counter() - t0, 2)
+        out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out))
-    if distributed:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -50,6 +50,7 @@ SYMBOLS = {
     "dfm_version": (ctypes.c_char_p, []),
     "dfm_profile_enable": (c_int, [c_vp, c_int]),
     "dfm_profile_read": (c_int, [c_vp, c_int, ctypes.c_char_p, c_int, c_dp, c_ip]),
+    "dfm_hbm_probe": (c_int, [c_vp, ctypes.c_size_t, c_int, c_int, c_dp, c_dp]),
     "dfm_workspace_bytes": (ctypes.c_size_t, [c_int, c_int, c_int, c_int, c_uint]),
     "dfm_ks_pass_batch_dev": (c_int, _PASS_ARGS),
     "dfm_ks_pass_batch": (c_int, _PASS_ARGS),

@@ -14,6 +14,8 @@
 
 using namespace dfm;
 
+thread_local const char* dfm::t_launched_kernel = nullptr;
+
 struct dfm_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -53,8 +55,9 @@ struct dfm_handle {
     char err[512] = {0};
     // optional per-kernel timing (bench.py roofline leg): event pairs on the launch stream
     bool profiling = false;
-    struct Ev { int kid; hipEvent_t a, b; };
+    struct Ev { const char* name; hipEvent_t a, b; };   // name: the kernel the launcher dispatched to (static string)
     std::vector<Ev> events;
+    std::vector<const char*> prof_names;                // distinct names of `events`, in order of first launch
 };
 
 enum KernelId { K_COLLAPSE = 0, K_RECURSION, K_MSTEP_STATS, K_MSTEP_SOLVE, K_PCA, K_SYNTH, K_PAD,
@@ -84,13 +87,19 @@ struct ProfScope {  // records an event pair around one kernel launch when profi
     dfm_handle* h; int idx = -1; hipStream_t st;
     ProfScope(dfm_handle* h_, int kid, hipStream_t st_ = nullptr) : h(h_), st(st_ ? st_ : h_->stream) {
         if (!h->profiling) return;
-        dfm_handle::Ev ev; ev.kid = kid;
+        dfm_handle::Ev ev; ev.name = kKernelNames[kid];
         if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+        dfm::t_launched_kernel = nullptr;
         (void)hipEventRecord(ev.a, st);
         h->events.push_back(ev);
         idx = (int)h->events.size() - 1;
     }
-    ~ProfScope() { if (idx >= 0) (void)hipEventRecord(h->events[idx].b, st); }
+    ~ProfScope() {
+        if (idx < 0) return;
+        (void)hipEventRecord(h->events[idx].b, st);
+        // the launcher says which kernel it dispatched to (rocprofv3's name); the scope's id is only the default
+        if (dfm::t_launched_kernel) h->events[idx].name = dfm::t_launched_kernel;
+    }
 };
 
 int pad_r(int r) { return pow2_ge(r) < 2 ? 2 : pow2_ge(r); }
@@ -510,14 +519,13 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ca.ldfull = at<double>(h, p.ldfull); ca.status = at<int>(h, p.status);
     {
         const int Rcol = p.Rc ? p.Rc : p.Rp;
-        ProfScope ps(h, K_COLLAPSE);
-        if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream));
+        if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream)); }
         else if (p.Wwide != (size_t)-1 && N > collapse_max_n(Rcol)) {   // Rp = 32 beyond the register tiling (config 4 with missing cells)
             double* W = at<double>(h, p.Wwide);
-            HIP_TRY(h, launch_wide_prep(ca, W, 32, h->stream));
-            HIP_TRY(h, launch_collapse_wide2(ca, W, 32, p.r, h->num_cu, h->stream));
-            HIP_TRY(h, launch_ct_miss_wide(ca, W, h->stream));
-        } else HIP_TRY(h, launch_collapse(Rcol, ca, h->stream));
+            { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(ca, W, 32, h->stream)); }
+            { ProfScope ps(h, K_COLLAPSE_WIDE); HIP_TRY(h, launch_collapse_wide2(ca, W, 32, p.r, h->num_cu, h->stream)); }
+            { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_ct_miss_wide(ca, W, h->stream)); }
+        } else { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(Rcol, ca, h->stream)); }
     }
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
@@ -1036,15 +1044,23 @@ int dfm_profile_enable(dfm_handle* h, int on) {
 int dfm_profile_read(dfm_handle* h, int kernel_index, char* name_out, int name_cap, double* total_ms,
                      int* launches) {
     if (!h) return DFM_E_NULL;
-    if (kernel_index < 0 || kernel_index >= K_COUNT) return DFM_E_DIMS;
+    if (kernel_index < 0) return DFM_E_DIMS;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->prof_names.clear();                                  // distinct kernel names, in order of first launch
+    for (auto& ev : h->events) {
+        bool seen = false;
+        for (const char* n : h->prof_names) seen = seen || strcmp(n, ev.name) == 0;
+        if (!seen) h->prof_names.push_back(ev.name);
+    }
+    if (kernel_index >= (int)h->prof_names.size()) return DFM_E_DIMS;
+    const char* want = h->prof_names[kernel_index];
     double tot = 0.0; int n = 0;
     for (auto& ev : h->events)
-        if (ev.kid == kernel_index) {
+        if (strcmp(ev.name, want) == 0) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) { tot += ms; ++n; }
         }
-    if (name_out && name_cap > 0) { strncpy(name_out, kKernelNames[kernel_index], name_cap - 1); name_out[name_cap - 1] = 0; }
+    if (name_out && name_cap > 0) { strncpy(name_out, want, name_cap - 1); name_out[name_cap - 1] = 0; }
     if (total_ms) *total_ms = tot;
     if (launches) *launches = n;
     return 0;

@@ -264,6 +264,7 @@ static hipError_t launch_r(const CollapseArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s) {
+    note_kernel("collapse_kernel");
     switch (Rpad) {
         case 2: return launch_r<2>(a, s);
         case 4: return launch_r<4>(a, s);

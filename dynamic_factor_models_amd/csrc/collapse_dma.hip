@@ -345,6 +345,7 @@ bool collapse_dma_supported(int Rpad, int N) { return (N % 2 == 0) && N <= colla
 
 hipError_t launch_collapse_dma(int Rpad, const CollapseArgs& a, hipStream_t s, int variant) {
     if (variant >= 200 && variant < 300 && collapse_mfma_supported(Rpad, a.N)) return launch_collapse_mfma(Rpad, a, s, variant - 200);
+    note_kernel("collapse_dma_kernel");
     switch (Rpad) {
         case 2: return launch_dma_r<2>(a, s, variant);
         case 4: return launch_dma_r<4>(a, s, variant);

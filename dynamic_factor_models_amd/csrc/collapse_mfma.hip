@@ -599,6 +599,7 @@ static hipError_t launch_mfma_r(const CollapseArgs& a, hipStream_t s, int varian
 }
 
 hipError_t launch_collapse_mfma(int Rpad, const CollapseArgs& a, hipStream_t s, int variant) {
+    note_kernel("collapse_mfma_kernel");
     switch (Rpad) {
         case 2: return launch_mfma_r<2>(a, s, variant);
         case 4: return launch_mfma_r<4>(a, s, variant);

@@ -389,6 +389,7 @@ static hipError_t launch_cm_pick(const CollapseArgs& a, int num_cu, hipStream_t 
 }
 
 hipError_t launch_collapse_miss(const CollapseArgs& a, int num_cu, hipStream_t s) {
+    note_kernel("collapse_miss_kernel");
     return launch_cm_pick<1>(a, num_cu, s, (a.N + 7) / 8);
 }
 

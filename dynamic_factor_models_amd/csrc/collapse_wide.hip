@@ -133,6 +133,7 @@ int collapse_wide_tiles(int T) { return (T + kWideRows - 1) / kWideRows; }
 bool collapse_wide_supported(int Rpad, int N) { return Rpad >= 2 && Rpad <= 32 && N >= 1; }
 
 hipError_t launch_collapse_wide(int Rpad, const CollapseArgs& a, hipStream_t s) {
+    note_kernel("collapse_wide_kernel");
     const int ntile = collapse_wide_tiles(a.T);
     const long long units = (long long)a.B * ntile;
     const unsigned grid = (unsigned)((units + 3) / 4);
@@ -148,6 +149,7 @@ hipError_t launch_collapse_wide(int Rpad, const CollapseArgs& a, hipStream_t s) 
 }
 
 hipError_t launch_gram_wide(int Rpad, const CollapseArgs& a, hipStream_t s) {
+    note_kernel("gram_wide_kernel");
     switch (Rpad) {
         case 2: hipLaunchKernelGGL((gram_wide_kernel<2>), dim3(a.B), dim3(256), 0, s, a); break;
         case 4: hipLaunchKernelGGL((gram_wide_kernel<4>), dim3(a.B), dim3(256), 0, s, a); break;

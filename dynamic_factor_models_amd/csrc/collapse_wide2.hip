@@ -598,6 +598,7 @@ hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, in
 }  // namespace
 
 hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s) {
+    note_kernel("wide_prep_kernel");
     const W2Ws w = w2_ws(a, ws, Rpad);
     if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad);
     else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, 32);
@@ -606,6 +607,7 @@ hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStre
 
 // r = the caller's factor count (columns r .. Rpad - 1 of Lam are zero padding)
 hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
+    note_kernel("collapse_wide2_kernel");
     const W2Ws w = w2_ws(a, ws, Rpad);
     const int ntile = collapse_wide2_tiles(a.T);
     const size_t lds = (size_t)kW2NBuf * kW2StageB + 32 * sizeof(double) + 64 * 4 * sizeof(unsigned long long);   // stages | redS, itemq | DIAG stamps
@@ -634,6 +636,7 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, in
 // C_t of the periods with missing cells (a.Ct, packed; the other periods keep Cfull): after launch_wide_prep, beside or after
 // the collapse (it reads the panel itself)
 hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, hipStream_t s) {
+    note_kernel("ct_miss_wide_kernel");
     static const int skip = [] { const char* v = getenv("DFM_CT_SKIP"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
     if (skip) return hipSuccess;
     const W2Ws w = w2_ws(a, ws, kW2R);

@@ -8,6 +8,14 @@
 
 namespace dfm {
 
+// The kernel a launcher actually dispatched to, for the per-kernel timing of dfm_profile_* (capi.hip): several launch_*
+// functions choose among kernels (cov_kernel | cov_grid_kernel, recursion_kernel | recursion_wave_kernel |
+// recursion_pair_kernel, ...), and bench.py's JSON must carry the names rocprofv3 prints.  thread_local: the multi-GPU
+// object launches from one host thread per GPU.
+extern thread_local const char* t_launched_kernel;
+inline void note_kernel(const char* name) { t_launched_kernel = name; }
+
+
 // All device arrays below use the PADDED factor dimension Rp (2,4,8,16,32 >= r): parameters are
 // embedded by pad_params_kernel (extra states: A = 0, Q = I, P0 = I, mu0 = 0, Lam = 0 -- independent
 // unit-variance noise states that no series loads on; every determinant / quadratic form they add

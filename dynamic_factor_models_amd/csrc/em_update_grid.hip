@@ -159,6 +159,7 @@ hipError_t launch_eug(const EmUpdArgs& a, hipStream_t s) {
 
 bool em_update_grid_supported(int Rpad) { return Rpad == 16 || Rpad == 32; }
 hipError_t launch_em_update_grid(int Rpad, const EmUpdArgs& a, hipStream_t s) {
+    note_kernel("em_update_grid_kernel");
     return Rpad == 32 ? launch_eug<32>(a, s) : Rpad == 16 ? launch_eug<16>(a, s) : hipErrorInvalidValue;
 }
 

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(kGxThreads) void gram_xx_wide_kernel(PcaArgs a, int
 
 bool gram_xx_wide_supported(int N) { return (N & 1) == 0 && N > 256; }
 hipError_t launch_gram_xx_wide(const PcaArgs& a, hipStream_t s) {
+    note_kernel("gram_xx_wide_kernel");
     const int nb = (a.N + kGxSer - 1) / kGxSer, npair = nb * (nb + 1) / 2;
     const size_t lds = (size_t)kGxNBuf * kGxStageB;
     static LdsOptIn attr_done;

@@ -257,6 +257,7 @@ static hipError_t launch_ar_r(const ArMstepArgs& a, hipStream_t s) {
 }
 bool mstep_ar_supported(int r, int q) { return r >= 1 && r <= 8 && q >= 0 && q <= 4 && r * (q + 1) <= 32; }
 hipError_t launch_mstep_ar(const ArMstepArgs& a, hipStream_t s) {
+    note_kernel("mstep_ar_kernel");
     switch (a.r) {
         case 1: return launch_ar_r<1>(a, s);
         case 2: return launch_ar_r<2>(a, s);

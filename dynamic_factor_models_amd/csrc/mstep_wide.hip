@@ -339,6 +339,7 @@ hipError_t launch_mw(const MstepArgs& a, double* sxf, double* sxx, int* ctr, int
 
 // r = the caller's factor count (columns r .. Rpad - 1 of the smoothed factors are zero padding)
 hipError_t launch_mstep_wide(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
+    note_kernel("mstep_wide_kernel");
     double* sxf = ws;
     double* sxx = ws + (size_t)a.B * a.N * Rpad;
     int* ctr = reinterpret_cast<int*>(sxx + (size_t)a.B * a.N);

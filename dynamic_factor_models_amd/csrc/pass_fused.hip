@@ -886,12 +886,14 @@ static hipError_t launch_cov_grid_r(const FastArgs& a, hipStream_t s) {
 }
 bool cov_grid_supported(int Rpad) { return Rpad == 16 || Rpad == 32; }
 hipError_t launch_cov_grid(int Rpad, const FastArgs& a, hipStream_t s) {
+    note_kernel("cov_grid_kernel");
     if (Rpad == 16) return launch_cov_grid_r<16>(a, s);
     if (Rpad == 32) return launch_cov_grid_r<32>(a, s);
     return hipErrorInvalidValue;
 }
 
 hipError_t launch_cov_wave(const FastArgs& a, hipStream_t s) {
+    note_kernel("cov_wave_kernel");
     hipLaunchKernelGGL(cov_wave_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
 }

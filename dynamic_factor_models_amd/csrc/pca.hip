@@ -1059,6 +1059,7 @@ static hipError_t launch_gx_mfma(const PcaArgs& a, hipStream_t s) {
 hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant) {
     const int NT = (a.N + 15) / 16;
     const int per_wave = (NT * (NT + 1) / 2 + 7) / 8;
+    if (variant == 0 && a.N <= 256 && per_wave <= 17) note_kernel("gram_xx_mfma_kernel");
     if (variant == 0 && a.N <= 256) {
         if (per_wave <= 4) return launch_gx_mfma<4>(a, s);
         if (per_wave <= 8) return launch_gx_mfma<8>(a, s);

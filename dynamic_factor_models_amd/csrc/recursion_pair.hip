@@ -591,6 +591,7 @@ bool recursion_pair_supported(const RecursionArgs& a) {
 }
 
 hipError_t launch_recursion_pair(const RecursionArgs& a, hipStream_t s) {
+    note_kernel("recursion_pair_kernel");
     hipLaunchKernelGGL(recursion_pair_kernel, dim3(a.B), dim3(128), pair_lds_bytes(a.T), s, a);
     return hipGetLastError();
 }

@@ -530,6 +530,7 @@ static hipError_t launch_wave(const RecursionArgs& a, hipStream_t s) {
 
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad) {
     if (Rpad == 8 && recursion_pair_supported(a)) return launch_recursion_pair(a, s);
+    note_kernel("recursion_wave_kernel");
     return Rpad == 32 ? launch_wave<32>(a, s) : Rpad == 16 ? launch_wave<16>(a, s) : launch_wave<8>(a, s);
 }
 

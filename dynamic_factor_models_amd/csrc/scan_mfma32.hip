@@ -371,6 +371,7 @@ hipError_t launch_scan_mfma_r(const FastArgs& a, hipStream_t s) {
 }  // namespace
 
 hipError_t launch_meanscan_mfma(int Rpad, const FastArgs& a, hipStream_t s) {
+    note_kernel("meanscan_mfma_kernel");
     return Rpad == 32 ? launch_scan_mfma_r<32>(a, s) : Rpad == 16 ? launch_scan_mfma_r<16>(a, s) : hipErrorInvalidValue;
 }
 

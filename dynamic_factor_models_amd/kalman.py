@@ -163,6 +163,17 @@ class DfmContext:
 
     check_status = synchronize
 
+    def hbm_probe(self, nbytes: int = 1 << 30, iters: int = 10):
+        """dfm_hbm_probe: {"read_dma": GB/s, "copy": GB/s, "write": GB/s} of this device, measured now."""
+        self._torch.cuda.synchronize(self.device)
+        out = {}
+        for name, mode in (("read_dma", 0), ("copy", 1), ("write", 2)):
+            g = ctypes.c_double(); ms = ctypes.c_double()
+            with self._torch.cuda.device(self.device):
+                _check(self._h, self._lib.dfm_hbm_probe(self._h, int(nbytes), mode, int(iters), ctypes.byref(g), ctypes.byref(ms)))
+            out[name] = g.value
+        return out
+
     def profile_enable(self, on: bool = True):
         self._sync_stream()
         _check(self._h, self._lib.dfm_profile_enable(self._h, 1 if on else 0))

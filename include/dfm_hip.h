@@ -81,6 +81,13 @@ int dfm_profile_enable(dfm_handle* h, int on);
 int dfm_profile_read(dfm_handle* h, int kernel_index, char* name_out, int name_cap, double* total_ms,
                      int* launches);
 
+/* dfm_hbm_probe: the streaming ceilings of the handle's device measured on the spot with the pass's own access patterns
+ * (bench.py reports them beside the 8 TB/s spec peak; no reference counterpart).  mode 0: read-only LDS-DMA ring
+ * (global_load_lds_dwordx4 -- the collapse's pattern); 1: 16-byte copy (read + write bytes both counted); 2: write-only.
+ * `bytes` >= 16 MB of device memory are allocated for the call and freed; `iters` back-to-back launches are timed with HIP
+ * events.  *gbs = GB/s, *ms_per_launch may be NULL. */
+int dfm_hbm_probe(dfm_handle* h, size_t bytes, int mode, int iters, double* gbs, double* ms_per_launch);
+
 /* Bytes of device workspace the handle will hold for a pass / EM call on a (B,T,N,r) problem with these flags (for
  * capacity planning; the larger of the sequential and -- for balanced panels -- the time-parallel plan).  The VAR(p),
  * AR-idiosyncratic, PCA and synthetic-panel entry points add their own scratch on top (a quasi-differenced panel copy,

@@ -1,0 +1,72 @@
+"""CPU tests of bench.py's launcher decision (`bench.py --gpus N` without a torchrun environment used to
+run ONE GPU silently and print n_gpus: 1) and of its bookkeeping helpers."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def test_gpus_n_without_torchrun_spawns_n_ranks():
+    what, why = bench.launch_plan(8, {}, 8)
+    assert what == "spawn" and "8 ranks" in why
+    assert bench.launch_plan(2, {}, 8)[0] == "spawn"
+    assert bench.launch_plan(1, {}, 8)[0] == "inline"
+    assert bench.launch_plan(1, {}, 1)[0] == "inline"
+
+
+def test_fewer_devices_than_requested_is_an_error():
+    what, why = bench.launch_plan(8, {}, 1)
+    assert what == "error" and "8" in why and "1 HIP device" in why
+    assert bench.launch_plan(0, {}, 8)[0] == "error"
+
+
+def test_inside_torchrun_the_flag_must_match_the_world():
+    assert bench.launch_plan(4, {"WORLD_SIZE": "4", "RANK": "2"}, 8)[0] == "inline"
+    assert bench.launch_plan(8, {"WORLD_SIZE": "4"}, 8)[0] == "error"
+    assert bench.launch_plan(1, {"WORLD_SIZE": "4"}, 8)[0] == "error"       # (used to pass silently when --gpus was 1)
+    assert bench.launch_plan(1, {"WORLD_SIZE": "1"}, 1)[0] == "inline"
+
+
+def test_the_library_driver_is_one_process():
+    assert bench.launch_plan(8, {}, 8, driver="lib")[0] == "inline"
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8"}, 8, driver="lib")[0] == "error"
+    assert bench.launch_plan(8, {}, 4, driver="lib")[0] == "error"
+
+
+def test_spawn_command_is_a_local_torchrun(monkeypatch):
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"] = cmd; seen["env"] = env
+        return 0
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    assert bench.spawn_ranks(4, ["--gpus", "4", "--steps", "3"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "3"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_no_device_is_a_loud_exit():
+    """No HIP device in this container: bench.py must refuse (the product path has no CPU fallback), not print a line."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "HIP device" in (r.stderr + r.stdout) and not r.stdout.strip().startswith("{")
+
+
+def test_algorithmic_bytes_and_kernel_table():
+    b_in, b_out = bench.algorithmic_bytes(200, 500, 8)
+    assert b_in + b_out == 992008                                             # DESIGN.md section 2 / SURVEY 8(d)
+    tab = bench.kernel_bytes_table(1024, 200, 500, 8)
+    assert tab["pass_fused_kernel"] == 1024 * 992008
+    for k in ("recursion_pair_kernel", "collapse_miss_kernel", "collapse_wide2_kernel", "meanscan_mfma_kernel"):
+        assert k in tab                                                       # the names rocprofv3 prints
+    info = bench.host_cpu_info()
+    assert info["usable"] >= 1

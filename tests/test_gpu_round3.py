@@ -1,0 +1,210 @@
+"""GPU parity tests added in round 3 for paths that were benchmarked but never compared with the oracle at the size / launch
+geometry they are benchmarked at, and for the library's multi-GPU object (csrc/multi.hip):
+
+* the HEADLINE batch itself -- BASELINE configs[1]: 1024 device-generated replicates, N = 200, T = 500, r = 8, the one-launch
+  pass (4 replicates per persistent workgroup) -- 64 replicates (all four of 16 workgroups) vs the C oracle at 1e-9;
+* the same batch with 10 % of the cells missing: collapse_miss + recursion_pair at one replicate per SIMD;
+* BASELINE configs[3] WITH missing cells at full size (N = 1000, T = 2000, r = 20, 256 replicates), pass and 2 EM iterations;
+* dfm_multi: device-generated resident job == the single-handle entry points, and the RCCL exchange forced on one GPU.
+"""
+import numpy as np
+import pytest
+
+from oracle import kalman_oracle as ko
+from test_gpu_ks_pass import _compare, _oracle
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
+RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from dynamic_factor_models_amd import DfmContext
+    c = DfmContext()
+    yield c
+    c.close()
+
+
+def _workgroup_quads(B=1024, grid=256, n=16, seed=1):
+    """All replicates b, b + grid, b + 2 grid, ... of n persistent workgroups (first, last, a seeded rest)."""
+    rng = np.random.default_rng(seed)
+    wgs = sorted(set([0, 1, grid - 1, grid // 2] + rng.choice(grid, size=n, replace=False).tolist()))[:n]
+    return sorted(b + j * grid for b in wgs for j in range(B // grid))
+
+
+def _take(t, ix):
+    return t.index_select(0, ix).cpu().numpy()
+
+
+def test_headline_batch_1024_against_the_oracle(ctx):
+    """The bench batch of BASELINE configs[1] (bench.py: seed 20160415, replicates 0..1023), one-launch pass."""
+    import torch
+    B, N, T, r = 1024, 200, 500, 8
+    panel, par = ctx.synth_panels(20160415, 0, B, T, N, r)
+    f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=False)
+    ctx.synchronize()                                   # (+ the status word: an expired bounded wait would raise here)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ll).all())
+    idx = _workgroup_quads(B)
+    assert len(idx) >= 64
+    ix = torch.tensor(idx, device=panel.device)
+    st = dict(zip(KEYS, [_take(p, ix) for p in par]))
+    ref = _oracle(_take(panel, ix), st)
+    _compare((_take(f, ix), _take(P, ix), _take(ll, ix)), ref, "headline batch, one-launch pass")
+    # run-to-run: the pipeline's hand-overs (LDS counters) must not leak into the numbers
+    f2, P2, ll2 = ctx.ks_pass_batch(panel, *par, may_have_missing=False)
+    torch.cuda.synchronize()
+    assert torch.equal(f, f2) and torch.equal(P, P2) and torch.equal(ll, ll2)
+
+
+def test_headline_batch_1024_with_missing_cells_against_the_oracle(ctx):
+    """Same shape, 10 % of the cells missing: collapse_miss_kernel + recursion_pair_kernel at the occupancy they are
+    benchmarked at (one replicate per SIMD), 64 replicates vs the oracle."""
+    import torch
+    B, N, T, r = 1024, 200, 500, 8
+    panel, par = ctx.synth_panels(20160415, 0, B, T, N, r, missing_prob=0.1)
+    f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=True)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ll).all())
+    idx = _workgroup_quads(B, seed=2)
+    ix = torch.tensor(idx, device=panel.device)
+    st = dict(zip(KEYS, [_take(p, ix) for p in par]))
+    _compare((_take(f, ix), _take(P, ix), _take(ll, ix)), _oracle(_take(panel, ix), st), "headline batch, 10 % missing")
+
+
+def test_config4_full_size_with_missing_cells(ctx):
+    """BASELINE configs[3] (N = 1000, T = 2000, r = 20, 256 replicates) with 10 % of the cells missing -- the batch
+    `bench.py --N 1000 --T 2000 --r 20 --batch-per-gpu 256 --missing 0.1` times: 3 replicates of the pass vs the C oracle,
+    then 2 EM iterations of 2 replicates vs the oracle's EM (the whole batch runs; the oracle checks a few)."""
+    import torch
+    B, N, T, r = 256, 1000, 2000, 20
+    panel, par = ctx.synth_panels(11, 0, B, T, N, r, missing_prob=0.1)
+    f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=True)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ll).all())
+    idx = [0, 129, 255]
+    ix = torch.tensor(idx, device=panel.device)
+    st = dict(zip(KEYS, [_take(p, ix) for p in par]))
+    xs = _take(panel, ix)
+    _compare((_take(f, ix), _take(P, ix), _take(ll, ix)), _oracle(xs, st), "config 4, 10 % missing, full size")
+    del f, P
+    torch.cuda.empty_cache()
+    iters = 2
+    path, its, _, _ = ctx.em_batch(panel, *par, max_iter=iters, tol=0.0, want_smooth=False, may_have_missing=True)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(path).all()) and bool((its == iters).all())
+    got = dict(zip(KEYS, [_take(p, ix) for p in par]))
+    pth = _take(path, ix)
+    for j in (0, 2):
+        p, opath, _ = ko.em(xs[j], {k: st[k][j] for k in KEYS}, max_iter=iters, tol=0.0)
+        np.testing.assert_allclose(pth[j], opath, rtol=RTOL, err_msg=f"replicate {idx[j]}")
+        for k in KEYS:
+            assert np.abs(got[k][j] - p[k]).max() <= 1e-8 * max(1.0, np.abs(p[k]).max()), (k, idx[j], np.abs(got[k][j] - p[k]).max())
+    del panel
+    torch.cuda.empty_cache()
+
+
+# ---- the library's multi-GPU object on one GPU ----------------------------------------------------------------------
+@pytest.mark.parametrize("force_comm", [False, True])
+def test_multi_object_device_generated_job_equals_the_single_handle_path(ctx, force_comm):
+    """dfm_multi_synth + dfm_multi_em / dfm_multi_ks_pass (the job generated where it lives, resident between calls) ==
+    dfm_synth_panels_dev + dfm_em_batch_dev / dfm_ks_pass_batch_dev on a plain handle.  force_comm: the object builds a
+    1-rank RCCL communicator, so every EM iteration runs ncclAllGather -- the exchange branch of multi.hip on one GPU."""
+    import torch
+    from dynamic_factor_models_amd import DfmMulti
+    B, N, T, r, iters = 37, 200, 120, 8, 5
+    seed, first = 424242, 1000
+    m = DfmMulti(1, force_comm=force_comm)
+    try:
+        assert m.ngpu == 1 and m.has_comm == force_comm
+        m.synth(seed, first, B, T, N, r)
+        panel, par = ctx.synth_panels(seed, first, B, T, N, r)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(m.fetch("panel"), panel.cpu().numpy())
+        for k, p in zip(KEYS, par):
+            np.testing.assert_array_equal(m.fetch(k), p.cpu().numpy())
+        m.ks_pass(want_P=True)
+        f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=False)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(m.fetch("loglik"), ll.cpu().numpy())
+        np.testing.assert_array_equal(m.fetch("f_smooth"), f.cpu().numpy())
+        np.testing.assert_array_equal(m.fetch("P_smooth"), P.cpu().numpy())
+        for tol in (0.0, 1e-4):
+            m.synth(seed, first, B, T, N, r)                      # EM updates the resident parameters: start again
+            ran = m.em(max_iter=iters, tol=tol, want_smooth=True, want_P=True)
+            q = [p.clone() for p in par]
+            path, its, f2, P2 = ctx.em_batch(panel, *q, max_iter=iters, tol=tol, may_have_missing=False)
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(m.fetch("iters"), its.cpu().numpy())
+            np.testing.assert_array_equal(np.nan_to_num(m.fetch("loglik_path")), np.nan_to_num(path.cpu().numpy()))
+            for k, p in zip(KEYS, q):
+                np.testing.assert_array_equal(m.fetch(k), p.cpu().numpy())
+            np.testing.assert_array_equal(m.fetch("f_smooth"), f2.cpu().numpy())
+            assert ran == (iters if tol == 0.0 else int(its.max().item()))
+    finally:
+        m.close()
+
+
+def test_multi_object_load_pca_start_and_errors(ctx):
+    """Host-uploaded job (dfm_multi_load) with missing cells; the PCA start generated on the devices; argument errors."""
+    import torch
+    from dynamic_factor_models_amd import DfmError, DfmMulti
+    from test_gpu_em import _start
+    panel, st = _start(5, 30, 50, 3, 0.1)
+    m = DfmMulti(1, force_comm=True)
+    try:
+        with pytest.raises(DfmError):
+            m.em(max_iter=2)                                       # no resident job yet
+        m.load(panel, *[st[k] for k in KEYS])
+        ran = m.em(max_iter=6, tol=0.0, may_have_missing=True)
+        p0, path0, its0, f0, P0 = ctx.em_batch_host(panel, *[st[k] for k in KEYS], max_iter=6, tol=0.0)
+        assert ran == 6
+        np.testing.assert_allclose(m.fetch("loglik_path"), path0, rtol=1e-11)
+        for k in KEYS:
+            np.testing.assert_allclose(m.fetch(k), p0[k], rtol=1e-10, atol=1e-13)
+        np.testing.assert_allclose(m.fetch("f_smooth"), f0, rtol=1e-10, atol=1e-12)
+        # PCA start on the devices == dfm_pca_init_batch_dev on the same generated panels
+        B, N, T, r = 9, 64, 80, 4
+        m.synth(5, 0, B, T, N, r, pca_start=True)
+        pn, _ = ctx.synth_panels(5, 0, B, T, N, r)
+        start = ctx.pca_init_batch(pn, r, want_factors=False)[:6]
+        torch.cuda.synchronize()
+        for k, p in zip(KEYS, start):
+            np.testing.assert_allclose(m.fetch(k), p.cpu().numpy(), rtol=1e-11, atol=1e-14)
+        with pytest.raises(DfmError) as ei:
+            m.synth(5, 0, B, T, N, r, missing_prob=0.1, pca_start=True)
+        assert ei.value.code == -4
+        with pytest.raises(DfmError):
+            m.fetch("loglik")                                      # no pass has run on this job
+    finally:
+        m.close()
+    with pytest.raises(DfmError):
+        DfmMulti(2, device_ids=[0, 0])
+    with pytest.raises(DfmError):
+        DfmMulti(1, device_ids=[99])
+
+
+def test_status_word_reaches_device_pointer_callers(ctx):
+    """the *_dev entry points only enqueue; a NaN in a panel declared balanced must surface at synchronize()."""
+    import torch
+    from dynamic_factor_models_amd import DfmError
+    panel, par = ctx.synth_panels(3, 0, 8, 60, 40, 8)
+    ctx.ks_pass_batch(panel, *par, may_have_missing=False)
+    ctx.synchronize()                                              # clean batch: no error
+    panel[5, 17, 3] = float("nan")
+    ctx.ks_pass_batch(panel, *par, may_have_missing=False)
+    with pytest.raises(DfmError) as ei:
+        ctx.synchronize()
+    assert ei.value.code == -4
+    q = [p.clone() for p in par]
+    with pytest.raises(DfmError):                                  # (the EM loop may notice by itself; if not, the check does)
+        ctx.em_batch(panel, *q, max_iter=2, tol=0.0, may_have_missing=False)
+        ctx.check_status()
+    torch.cuda.synchronize()
