@@ -63,6 +63,7 @@ constexpr int kPfNst = stead_mats(kPfR);                    // steady Z, J, G + 
 constexpr int kPfNlev = scan_levels(kPfR);
 constexpr int kPfScanWaves = kScanThreads / 64;             // 4
 constexpr int kPfMaxCov = 2;
+constexpr int kPfDeferDefault = 1;                          // P_smooth fills left to the stream waves' tail (replicates per workgroup)
 constexpr int kPfMaxWaves = 12;                             // 3 waves per SIMD: 168 VGPRs each
 constexpr int kPfMaxThreads = 64 * kPfMaxWaves;
 constexpr unsigned kPfLdsLimit = 160u * 1024u;
@@ -74,11 +75,13 @@ constexpr int kFCovDone = 3;      // [kPfMaxCov] replicates finished by each cov
 constexpr int kFScanBar = 5;      // arrivals at the scan waves' barrier
 constexpr int kFAbort = 6;
 constexpr int kFTabReady = 7;     // replicates whose tables the mover has put into the LDS table set
+constexpr int kFScanArrive = 8;   // scan_reg: scan waves that have finished their part of a replicate (4 per replicate)
+constexpr int kFStreamWaits = 9;  // 1 while stream wave 0 waits for a b_t buffer, i.e. for the scan: the scan is then the critical path
 constexpr int kFCount = 64;
 
 // misc doubles (LDS)
 constexpr int kMiscXi0 = 0, kMiscLlc = 8, kMiscE = 9, kMiscVec = 16, kMiscRed = 32, kMiscSsum = 40 /* [2][8] */,
-              kMiscPs = 56 /* [36] */, kMiscDoubles = 92;
+              kMiscPs = 56 /* [36] */, kMiscWtr = 92 /* [kPfEcap][8] */, kMiscDoubles = 92 + kPfEcap * 8;
 
 // row-slot stride: as collapse_mfma.hip (4 consecutive slots start 64 bytes apart modulo 256)
 __host__ __device__ inline unsigned pf_slot_bytes(int N) {
@@ -140,6 +143,31 @@ __device__ __forceinline__ double ld_dev(const double* p) { return __hip_atomic_
 __device__ __forceinline__ int ld_dev(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 }  // namespace
+
+// Rows [lo, hi) of one replicate's P_smooth (npr packed values per row) := ps[0 .. npr): fire-and-forget 16-byte stores by
+// ONE wave; part `w` of `nw` equal row ranges (nw = 1: the whole range).  ps: LDS.
+__device__ __forceinline__ void pf_fill_rows(double* Prep, int lo, int hi, int npr, const double* ps, int lane, int w, int nw) {
+    const int per = (hi - lo + nw - 1) / nw;
+    const int a0 = lo + w * per;
+    const int a1 = a0 + per < hi ? a0 + per : hi;
+    if (a1 <= a0) return;
+    double* base = Prep + (size_t)a0 * npr;
+    const unsigned n = (unsigned)(a1 - a0) * (unsigned)npr;
+    const unsigned peel = ((reinterpret_cast<size_t>(base) & 15) != 0) ? 1u : 0u;
+    if (peel && lane == 0) base[0] = ps[0];
+    const unsigned npair = (n - peel) / 2;
+    const unsigned step = 128u % (unsigned)npr;
+    unsigned k = peel + 2u * lane;
+    unsigned v = k % (unsigned)npr;
+    for (unsigned p = lane; p < npair; p += 64) {
+        const unsigned v1 = (v + 1 == (unsigned)npr) ? 0u : v + 1;
+        *reinterpret_cast<double2*>(base + k) = make_double2(ps[v], ps[v1]);
+        k += 128u;
+        v += step;
+        if (v >= (unsigned)npr) v -= (unsigned)npr;
+    }
+    if (((n - peel) & 1u) != 0 && lane == 0) base[n - 1] = ps[(n - 1) % (unsigned)npr];
+}
 
 // byte offsets into the dynamic LDS of pass_fused_kernel (computed by the host)
 struct PfLds {
@@ -301,6 +329,234 @@ __device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, doub
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// scan_reg (round 3): the same scan with every lane group owning ONE time range in BOTH directions, so that its b_t -> w_t
+// never leave its registers, and with the cross-wave hand-overs cut from ~20 LDS-counter barriers per replicate to 2.
+//
+// At B = 1024 a CU has 4 replicates and the scans form a chain (the first one waits for the covariance chain, each next one
+// for the previous): cov + 4 scans ~ 200 us on a fast box and more than the 4 x 47 us the stream needs on a box whose
+// latency-bound code runs 20-30 % slower -- the pass then runs at the speed of this chain, not of HBM (0.44 of
+// peak on the driver's box, 0.51-0.55 on others).  In-kernel stamps say where a scan's 34 us go (20 us when it runs alone):
+// nine phases of 3-5 us, most of them a handful of dependent steps between two barriers on an LDS counter, each barrier
+// several LDS round trips behind the stream waves' DMA writes and operand reads.  Here:
+//   * group c owns steady steps ts + c L .. ts + c L + L - 1 forward AND backward: b_t is read from LDS once (phase 1),
+//     phase 3 overwrites the registers with w_t, the backward runs read those registers -- a quarter of the LDS traffic and
+//     no "every w_t is written" barrier between the directions; xi_T / f_T live in the group that produced them;
+//   * the forward transient (E - 1 <= kPfEcap steps) is computed by EVERY group redundantly: no broadcast barrier;
+//   * chunk carries: ONE barrier, then every group runs the affine maps of the chunks before it sequentially (<= 31
+//     dependent 8 x 8 mat-vecs of ~50 cycles, operands prefetched) instead of a 5-level Kogge-Stone with a barrier per level;
+//   * backward, the (partial) top chunk starts from its TRUE state f_T, so no power of J for a partial chunk is needed and
+//     its rows are emitted in that first run;
+//   * the backward transient runs in group 0 right behind its own phase 3 (it owns the lowest range);
+//   * epilogue: the waves meet at an arrival counter; the LAST one adds the four partial sums in a fixed order, writes the
+//     log-likelihood and releases the b_t buffer / the table set -- nobody waits at a barrier for it.
+// Conditions (else scan_lds): L <= kRegL, E - 1 <= kPfEcap (all transient tables in LDS).  Same outputs to rounding (the sum
+// xi_t' w_t is accumulated in another order).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kRegL = 16;
+
+template <class Sync, class Prio>
+__device__ __forceinline__ void scan_reg(const FastArgs& a, int b, int tid, const double* bt, const double* s_tab, const double* s_mat,
+                                         const double* xi0p, const double* llcp, int E, double* sE, double* sEb, double* s_red,
+                                         const double* ssum, int nseg, Sync& sync, unsigned* arrive, unsigned arrive_last,
+                                         unsigned* scan_done, unsigned done_value, double* wtr, Prio&& prio, double* pslot) {
+    auto mark = [&](int k) {
+        if (pslot && tid == 0) pslot[k] = (double)__builtin_amdgcn_s_memrealtime();
+    };
+    constexpr int R = kPfR, NLEV = kPfNlev, NST = kPfNst, LM = kRegL;
+    const int c = tid / R, i = tid % R, lane = tid & 63;
+    const int T = a.T, r = a.r, L = a.L;
+    const int ts = E - 1;                                     // <= kPfEcap
+    double* fout = a.f_smooth + (size_t)b * T * r;
+    const int clast = (T - ts - 1) / L;                       // group that owns step T - 1 (its chunk may be partial)
+    const int t0 = ts + c * L;
+    const int Lc = (T - t0) < L ? (T - t0) : L;               // valid steps of this group (<= 0: idle group)
+    const int wlo = __builtin_amdgcn_readfirstlane(c & ~7);  // first group of this wave (scalar: uniform loops below)
+    double dot = 0.0;
+
+    // ---- forward transient, every group redundantly: xi_ts; group 0 keeps w_t for the backward transient -----------
+    double xi = xi0p[i];
+#pragma unroll
+    for (int t = 0; t < kPfEcap; ++t) {
+        if (t < ts) {                                         // (uniform)
+            double Zp[R], Gp[R];
+            const double* ent = s_tab + (size_t)t * 3 * R * R;
+            load_xperm<R>(Zp, ent, i);
+            load_xperm<R>(Gp, ent + 2 * R * R, i);
+            const double btv = bt[t * R + i];
+            const double w = matvec_x<R>(Zp, xi);
+            if (c == 0) {
+                dot = fma(xi, w, dot);
+                wtr[t * R + i] = w;                           // (LDS; read back by the same lanes in the backward transient)
+            }
+            xi = matvec_x<R>(Gp, xi, btv);
+        }
+    }
+    mark(1);
+
+    // ---- phase 1: b_t of the group's range into registers; chunk run from a zero state ------------------------------
+    double u[LM];
+#pragma unroll
+    for (int j = 0; j < LM; ++j) {
+        u[j] = 0.0;
+        if (j < L) {                                          // (uniform)
+            const bool ok = j < Lc;
+            const int tc = ok ? t0 + j : T - 1;               // a row that exists; selected away below
+            const double x = bt[tc * R + i];
+            u[j] = ok ? x : 0.0;
+        }
+    }
+    double Gp[R];
+    load_xperm<R>(Gp, s_mat + 2 * R * R, i);
+    {
+        double e = 0.0;
+#pragma unroll
+        for (int j = 0; j < LM; ++j) {
+            if (j < L) {
+                const double vn = matvec_x<R>(Gp, e, u[j]);
+                e = (j < Lc) ? vn : e;
+            }
+        }
+        sE[c * R + i] = e;
+    }
+    mark(2);
+    sync();                                                   // (1 of 2) the chunk end states are in LDS
+    prio();                                                   // (is the stream waiting for this scan by now?)
+    // ---- state entering the group's chunk: the chunks before it, one after the other ---------------------------------
+    double v = xi;
+    {
+        double ML[R];
+        load_xperm<R>(ML, s_mat + 3 * R * R, i);              // G^L
+        for (int k0 = 0; k0 <= wlo; k0 += 8) {                // (uniform: blocks of 8 chunks up to this wave's own)
+            double ek[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ek[q] = sE[(k0 + q) * R + i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double vn = matvec_x<R>(ML, v, ek[q]);
+                v = (k0 + q < c) ? vn : v;
+            }
+        }
+    }
+    mark(3);
+    // ---- phase 3: re-run from the true state; w_t replaces b_t in the registers ---------------------------------------
+    {
+        double Zp[R];
+        load_xperm<R>(Zp, s_mat, i);
+#pragma unroll
+        for (int j = 0; j < LM; ++j) {
+            if (j < L) {
+                const bool ok = j < Lc;
+                const double w = matvec_x<R>(Zp, v);
+                const double vn = matvec_x<R>(Gp, v, u[j]);
+                dot = ok ? fma(v, w, dot) : dot;
+                u[j] = w;
+                v = ok ? vn : v;
+            }
+        }
+    }
+    mark(4);
+    // ---- terminal (group clast: v = xi_T) + backward run of the chunk -------------------------------------------------
+    double Jp[R];
+    load_xperm<R>(Jp, s_mat + R * R, i);
+    double eb;                                                // state leaving the chunk downwards
+    {
+        double PTp[R];
+        load_xperm<R>(PTp, s_mat + NST * R * R, i);
+        const double fT = matvec_x<R>(PTp, v);                // meaningful in group clast only
+        const bool top = (c == clast);
+        if (top) {
+            dot = fma(v, fT, dot);                            // the log-likelihood needs sum xi'w + xi_T' f_T
+            if (i < r) fout[(size_t)(T - 1) * r + i] = fT;
+        }
+        eb = top ? fT : 0.0;                                  // the top chunk starts from its true state, the others from zero
+#pragma unroll
+        for (int j = LM - 1; j >= 0; --j) {
+            if (j < L) {
+                const bool ok = j < Lc;
+                const double vn = matvec_x<R>(Jp, eb, u[j]);
+                eb = ok ? vn : eb;
+                const int t = t0 + j;
+                if (top && ok && t >= 1 && i < r) fout[(size_t)(t - 1) * r + i] = eb;   // f of period t -> row t - 1
+            }
+        }
+        sEb[c * R + i] = eb;
+    }
+    mark(5);
+    sync();                                                   // (2 of 2)
+    prio();
+    // ---- backward carries: the true state leaving the top chunk, then the zero-state runs of the chunks in between -----
+    double vb = 0.0;
+    if (wlo < clast) {                                        // (uniform) this wave has a group below the top chunk
+        double JL[R];
+        load_xperm<R>(JL, s_mat + (size_t)(3 + NLEV) * R * R, i);   // J^L
+        vb = sEb[clast * R + i];
+        for (int k0 = clast - 1; k0 > wlo; k0 -= 8) {         // chunks k0, k0 - 1, .. (those above c apply)
+            double ek[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int k = k0 - q; ek[q] = sEb[(k > 0 ? k : 0) * R + i]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double vn = matvec_x<R>(JL, vb, ek[q]);
+                vb = (k0 - q > c) ? vn : vb;
+            }
+        }
+    }
+    mark(6);
+    // ---- backward phase 3 (groups below the top chunk; all of them hold full chunks) -------------------------------
+    {
+        const bool below = c < clast;
+#pragma unroll
+        for (int j = LM - 1; j >= 0; --j) {
+            if (j < L) {
+                vb = matvec_x<R>(Jp, vb, u[j]);
+                const int t = t0 + j;
+                if (below && t >= 1 && i < r) fout[(size_t)(t - 1) * r + i] = vb;
+            }
+        }
+        vb = below ? vb : eb;                                 // group 0 == top chunk (short panels): its first run was the true one
+    }
+    mark(7);
+    // ---- backward transient: steps ts-1 .. 0, group 0 (it owns the lowest range; the other groups' values are unused) --
+    if (tid < 64) {                                           // (wave 0)
+        double vt = vb;
+#pragma unroll
+        for (int t = kPfEcap - 1; t >= 0; --t) {
+            if (t < ts) {
+                double Jt[R];
+                load_xperm<R>(Jt, s_tab + (size_t)t * 3 * R * R + R * R, i);
+                vt = matvec_x<R>(Jt, vt, wtr[t * R + (tid & 7)]);
+                if (c == 0 && t >= 1 && i < r) fout[(size_t)(t - 1) * r + i] = vt;
+            }
+        }
+        if (a.f0s && c == 0) {                                // E[f_0 | X] (EM)
+            int ii = tid & 7;
+            asm volatile("" : "+v"(ii));                      // address formed here: a pointer kept live across the scan is spilled
+            a.f0s[(size_t)b * R + ii] = vt;
+        }
+    }
+    mark(8);
+    // ---- log-likelihood + release: the last wave to arrive does both ----------------------------------------------
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, kWave);
+    if (lane == 0) s_red[tid >> 6] = dot;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    unsigned before = 0;
+    if (lane == 0) before = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    before = __builtin_amdgcn_readfirstlane(before);
+    if (before + 1u == arrive_last) {                         // every scan wave is done with bt / the table set / ssum
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) {
+            double d = 0.0, sq = 0.0;
+#pragma unroll
+            for (int w = 0; w < kPfScanWaves; ++w) d += s_red[w];
+            for (int w = 0; w < nseg; ++w) sq += ssum[w];
+            a.loglik[b] = -0.5 * (llcp[0] + sq - d);
+            __hip_atomic_store(scan_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Gram matrix C = Lam' R^-1 Lam of one replicate by ONE wave on the fp64 matrix pipe, in the collapse's own operand layout:
 // lane (K, g, h, q) holds W[c][4 h + q] = lam_c,4h+q / R_c for the series c = 8 s + 4 g + K (the B operands of the stream
 // waves).  Rows i = 4 p + (0..3) of Lam' play the part of the 4 periods of a row block: the A operand of block p is
@@ -380,6 +636,9 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
     double* bt0 = reinterpret_cast<double*>(smem + ly.bt);
     const int N = a.N, T = a.T, B = a.B;
     const int G = (int)gridDim.x;
+    const int nrep_wg = (B - (int)blockIdx.x + G - 1) / G;   // replicates of this workgroup
+    // P_smooth fills deferred to the tail (see the mover): DFM_SCAN_ABL bits 12-14 = count + 1 (diagnostics), default 1
+    const int ndefer = (fa.P_smooth == nullptr) ? 0 : (((fa.abl >> 12) & 7) ? ((fa.abl >> 12) & 7) - 1 : kPfDeferDefault);
 
     if (tid_wg < kFCount) flags[tid_wg] = 0u;
     __syncthreads();                                         // the only workgroup barrier of the kernel
@@ -499,7 +758,10 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
                 bt = bt0 + (size_t)buf * ly.bt_stride;
                 // the b_t buffer is free once the scan of the replicate that used it last is complete
                 if (j >= nbuf) {
+                    const bool must_wait = wave == 0 && (int)(ld_flag(flags + kFScanDone) - (unsigned)(j - nbuf + 1)) < 0;
+                    if (must_wait && lane == 0) __hip_atomic_store(flags + kFStreamWaits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (!pf_wait_ge(flags + kFScanDone, (unsigned)(j - nbuf + 1), flags + kFAbort)) { wait_vmf<0>(); return; }
+                    if (must_wait && lane == 0) __hip_atomic_store(flags + kFStreamWaits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 if (wave == 0) stamp(b, 1);
                 stamp(b, 32 + wave);                              // per-wave segment start / end (diagnostics)
@@ -572,6 +834,29 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
                 if (wave == nsw - 1) stamp(b, 3);
                 stamp(b, 24 + wave);
             }
+            // ---- the deferred P_smooth fills: the panel is through, HBM is idle but for the last scan's outputs ----------
+            if (ndefer > 0) {
+                wait_vmf<0>();
+                const int nact = (T + tq - 1) / tq;               // stream waves that own periods (they all get here)
+                const int npr = fa.r * (fa.r + 1) / 2;
+                double* ps = reinterpret_cast<double*>(const_cast<char*>(ring));   // this wave's ring is free now
+                for (int j = (nrep - ndefer > 0 ? nrep - ndefer : 0); j < nrep; ++j) {
+                    const int b = (int)blockIdx.x + j * G;
+                    // (the covariance wave of replicate j published these long ago; the mover has raised tab_ready past j)
+                    if (!pf_wait_ge(flags + kFTabReady, (unsigned)(j + 1), flags + kFAbort)) break;
+                    const int flo = __builtin_amdgcn_readfirstlane(ld_dev(fa.fill + 2 * b));
+                    const int fhi = __builtin_amdgcn_readfirstlane(ld_dev(fa.fill + 2 * b + 1));
+                    if (fhi <= flo) continue;
+                    int ri = 0;                                   // packed (caller's r) copy of P_s,inf
+                    const int lv = lane < npr ? lane : 0;
+                    while ((ri + 1) * (ri + 2) / 2 <= lv) ++ri;
+                    const double psv = ld_dev(fa.PsInf + (size_t)b * 64 + ri * R + (lv - ri * (ri + 1) / 2));
+                    wave_lds_sync();
+                    if (lane < npr) ps[lane] = psv;
+                    wave_lds_sync();
+                    pf_fill_rows(fa.P_smooth + (size_t)b * T * npr, flo, fhi, npr, ps, lane, wave, nact);
+                }
+            }
         } else {
             // a wave without periods (T shorter than the segments): it only keeps the arrival counts
             for (int j = 0; j < nrep; ++j) {
@@ -590,7 +875,10 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
         const int cw = wave - nsw;
         double* ws = reinterpret_cast<double*>(smem + ly.covws) + (size_t)cw * kCov8ScratchDoubles;
         double* Cs = ws + 5 * kCov8TileDoubles;                  // Gram matrix
-        __builtin_amdgcn_s_setprio(2);                            // a latency chain (ahead of the stream after the first replicates)
+        // a latency chain (ahead of the stream after the first replicates).  (Round 3: dropping to priority 0 after the
+        // workgroup's first replicate -- the only one whose chain somebody waits for -- measured neutral: the stream's first
+        // two rounds are slower because the covariance waves' work shares the CU, not because of their priority.)
+        __builtin_amdgcn_s_setprio(2);
         for (int b = (int)blockIdx.x + cw * G; b < B; b += ncov * G) {
             stamp(b, 6);
             const double ld = gram_mfma8<STEPS, NDR>(fa.Lam + (size_t)b * N * R, fa.Rv + (size_t)b * N, N, lane, Cs);
@@ -670,26 +958,13 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
             if (lane == 0) misc[kMiscE] = (double)E;
             pf_signal(flags + kFTabReady, lane);
             stamp(b, 5);
-            // rows [lo, hi) of P_smooth equal the backward fixed point: fire-and-forget 16-byte stores
-            if (fill_hi > fill_lo) {
+            // rows [lo, hi) of P_smooth equal the backward fixed point: fire-and-forget 16-byte stores.  The fills of the
+            // workgroup's LAST replicates are left to the stream waves, who write them once their last row has been issued:
+            // HBM is the bottleneck while the panel streams and idle during the scan-only tail of the kernel
+            if (fill_hi > fill_lo && j < nrep_wg - ndefer) {
                 if (lane < npr) s_ps[lane] = psv;
                 wave_lds_sync();
-                double* base = fa.P_smooth + ((size_t)b * T + fill_lo) * npr;
-                const unsigned n = (unsigned)(fill_hi - fill_lo) * (unsigned)npr;
-                const unsigned peel = ((reinterpret_cast<size_t>(base) & 15) != 0) ? 1u : 0u;
-                if (peel && lane == 0) base[0] = s_ps[0];
-                const unsigned npair = (n - peel) / 2;
-                const unsigned step = 128u % (unsigned)npr;
-                unsigned k = peel + 2u * lane;
-                unsigned v = k % (unsigned)npr;
-                for (unsigned p = lane; p < npair; p += 64) {
-                    const unsigned v1 = (v + 1 == (unsigned)npr) ? 0u : v + 1;
-                    *reinterpret_cast<double2*>(base + k) = make_double2(s_ps[v], s_ps[v1]);
-                    k += 128u;
-                    v += step;
-                    if (v >= (unsigned)npr) v -= (unsigned)npr;
-                }
-                if (((n - peel) & 1u) != 0 && lane == 0) base[n - 1] = s_ps[(n - 1) % (unsigned)npr];
+                pf_fill_rows(fa.P_smooth + (size_t)b * T * npr, fill_lo, fill_hi, npr, s_ps, lane, 0, 1);
                 wave_lds_sync();
             }
         }
@@ -701,7 +976,18 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
         double* s_a = reinterpret_cast<double*>(smem + ly.sa);
         double* s_b = reinterpret_cast<double*>(smem + ly.sb);
         PfScanSync sync{flags + kFScanBar, flags + kFAbort, 0u, lane};
-        __builtin_amdgcn_s_setprio(3);                            // THE latency chain of the pipeline: the stream waits for its buffers
+        const bool use_reg = fa.L <= kRegL && (fa.abl & 512) == 0;    // DFM_SCAN_ABL bit 9: the round-2 scan (A/B, diagnostics)
+        // Priority.  The scan is the pipeline's latency chain only while somebody waits for it: the first replicate of the
+        // workgroup (everything behind it waits), or a stream that has run out of b_t buffers.  Otherwise it runs BESIDE a
+        // stream that is the bottleneck, and at high priority its bursts delay the stream waves' DMA issue (measured at
+        // B = 8192: -4 % with the faster scan at priority 3 throughout).  DFM_SCAN_ABL bit 10: always 3; bit 11: always 0.
+        const int prio_mode = (fa.abl & 1024) ? 1 : (fa.abl & 2048) ? 2 : 0;
+        auto set_prio = [&](int j) {
+            const bool hot = prio_mode == 1 || (prio_mode == 0 && (j == 0 || ld_flag(flags + kFStreamWaits) != 0));
+            if (hot) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+        };
+        __builtin_amdgcn_s_setprio(3);
         int b = blockIdx.x;
         for (int j = 0; b < B; b += G, ++j) {
             const int buf = nbuf == 2 ? (j & 1) : 0;
@@ -711,14 +997,24 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
             if (tid == 0) stamp(b, 11);
             if (!pf_wait_ge(flags + kFBtReady + buf, (unsigned)(nsw * (j / nbuf + 1)), flags + kFAbort)) break;
             if (tid == 0) stamp(b, 12);
+            set_prio(j);
             const int E = __builtin_amdgcn_readfirstlane((int)misc[kMiscE]);
-            scan_lds(fa, b, tid, bt, s_tab, fa.tab + (size_t)b * T * 3 * 64, s_mat, misc + kMiscXi0, misc + kMiscLlc, E, s_a, s_b,
-                     misc + kMiscVec, misc + kMiscRed, misc + kMiscSsum + buf * 8, nsw, sync,
-                     (prof && tid == 0) ? a.scol + (size_t)b * T + 13 : nullptr);
-            sync();                       // the scan is done with bt / the table set / ssum
-            if (tid == 0) {
-                __hip_atomic_store(flags + kFScanDone, (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                stamp(b, 22);
+            if (use_reg && E - 1 <= kPfEcap) {
+                // (the arrival counter counts 4 per replicate on EITHER path, so the two can alternate between replicates)
+                scan_reg(fa, b, tid, bt, s_tab, s_mat, misc + kMiscXi0, misc + kMiscLlc, E, s_a, s_b, misc + kMiscRed,
+                         misc + kMiscSsum + buf * 8, nsw, sync, flags + kFScanArrive, (unsigned)(kPfScanWaves * (j + 1)),
+                         flags + kFScanDone, (unsigned)(j + 1), misc + kMiscWtr, [&]() { set_prio(j); }, (prof && tid == 0) ? a.scol + (size_t)b * T + 13 : nullptr);
+                if (tid == 0) stamp(b, 22);
+            } else {
+                scan_lds(fa, b, tid, bt, s_tab, fa.tab + (size_t)b * T * 3 * 64, s_mat, misc + kMiscXi0, misc + kMiscLlc, E, s_a, s_b,
+                         misc + kMiscVec, misc + kMiscRed, misc + kMiscSsum + buf * 8, nsw, sync,
+                         (prof && tid == 0) ? a.scol + (size_t)b * T + 13 : nullptr);
+                sync();                       // the scan is done with bt / the table set / ssum
+                if (lane == 0) __hip_atomic_fetch_add(flags + kFScanArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tid == 0) {
+                    __hip_atomic_store(flags + kFScanDone, (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    stamp(b, 22);
+                }
             }
         }
     }
@@ -799,6 +1095,9 @@ static hipError_t launch_pf_pick(const CollapseArgs& a, const FastArgs& fa, int 
     if constexpr (S > 32) {
         return hipErrorInvalidValue;
     } else {
+#ifdef DFM_PF_ONLY            // development builds: one instantiation (ISA inspection in seconds instead of minutes)
+        if constexpr (S == DFM_PF_ONLY)
+#endif
         if (steps == S) {
             const int ndr = (a.N * 8 + 1023) / 1024;
             constexpr int lo = (8 * (S - 1) * 8 + 8 + 1023) / 1024, hi = (8 * S * 8 + 1023) / 1024;
