@@ -33,6 +33,7 @@ _VPASS_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_int] + [c_vp] * 10 + [c_uint]
 _VEM_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_int] + [c_vp] * 7 + [c_int, ctypes.c_double] + [c_vp] * 4 + [c_uint]
 _ARPASS_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_int, c_int] + [c_vp] * 11 + [c_uint]
 _AREM_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_int, c_int] + [c_vp] * 8 + [c_int, ctypes.c_double] + [c_vp] * 4 + [c_uint]
+_OBSEM_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_int] + [c_vp] * 8 + [c_int, ctypes.c_double] + [c_vp] * 4 + [c_uint]
 _PCA_ARGS = [c_vp, c_int, c_int, c_int, c_int] + [c_vp] * 8
 c_ll = ctypes.c_longlong
 _ALS_ARGS = [c_vp, c_int, c_int, c_int, c_int, c_vp, c_ll, c_vp, c_vp, c_vp, c_int, c_int, ctypes.c_double,
@@ -81,6 +82,8 @@ SYMBOLS = {
     "dfm_ks_pass_ar_batch": (c_int, _ARPASS_ARGS),
     "dfm_em_ar_batch_dev": (c_int, _AREM_ARGS),
     "dfm_em_ar_batch": (c_int, _AREM_ARGS),
+    "dfm_em_obs_batch_dev": (c_int, _OBSEM_ARGS),
+    "dfm_em_obs_batch": (c_int, _OBSEM_ARGS),
     "dfm_pca_init_batch_dev": (c_int, _PCA_ARGS),
     "dfm_pca_init_batch": (c_int, _PCA_ARGS),
     "dfm_standardize_batch_dev": (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp]),

@@ -181,7 +181,9 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
     if lam_constr_f is not None or lam_constr_fl is not None:
         raise NotImplementedError("loading constraints are not supported on the parametric path")
     if m.nfac_o != 0:
-        raise NotImplementedError("observed factors (nfac_o > 0) are not supported (non-functional in the reference too)")
+        if nrep:
+            raise ValueError("bootstrap replicates (nrep > 0) are not available with observed factors")
+        return _estimate_parametric_observed(m, max_em_iter, tol_em, ctx)
     r = m.nfac_u
     nlag = m.n_factorlag if factor_lags is None else int(factor_lags)
     if nlag < 1 or r * nlag > 32:
@@ -221,6 +223,7 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
             from ._lib import DfmError
             args = (z[None], start["Lam"], start["R"], start["A"], start["Q"], start["mu0"], start["P0"])
             kw = dict(max_iter=max_em_iter, tol=tol_em, may_have_missing=bool((~obs).any()))
+            used_singular_q = False
             try:
                 params, path, iters, f, P = ctx.em_batch_host(*args, **kw)
             except DfmError as err:
@@ -229,6 +232,7 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
                 if err.code != -5:
                     raise
                 params, path, iters, f, P = ctx.em_batch_host(*args, singular_q=True, **kw)
+                used_singular_q = True
         else:
             # VAR(p) start (oracle/varp_oracle.py varp_init): OLS of the PCA factors on their p lags without constant
             # (dfm_ols_batch), Q = residual covariance / (T - p), z_0 ~ N(0, second moment of the stacked lags)
@@ -276,16 +280,93 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
         var.M[r:, :-r] = np.eye(r * (var.nlag - 1))
     var.Q[:, :r] = np.eye(r)
     var.seps[:] = Q
-    var.G[:r, :r] = np.linalg.cholesky(Q)
+    var.G[:r, :r] = _psd_sqrt(Q)            # lower Cholesky factor (:489); a rank-deficient Q has only a symmetric root
     var.betahat[:] = 0.0
     c0 = 1 if var.withconst else 0
     var.betahat[c0:c0 + ka, :] = A[:, :ka].T
     if nrep:
-        m.replicates = _bootstrap_replicates(z, params, int(nrep), int(seed), int(ngpu), max_em_iter, tol_em)
+        m.replicates = _bootstrap_replicates(z, params, int(nrep), int(seed), int(ngpu), max_em_iter, tol_em,
+                                             singular_q=(nlag == 1 and used_singular_q))
     return m.loglik_path
 
 
-def _bootstrap_replicates(z, params, nrep, seed, ngpu, max_em_iter, tol_em):
+def _estimate_parametric_observed(m: DFMModel, max_em_iter, tol_em, ctx):
+    """`estimate(m, Parametric())` with OBSERVED factors (nfac_o > 0).  The reference's estimator is
+    non-functional there (dfm_functions.ipynb:358-359, :371; App. D 7), so the semantics are those its data layout implies
+    (include/dfm_hip.h, oracle/obs_oracle.py): the caller has put the observed factors g_t into the FIRST nfac_o columns of
+    `m.factor` (rows initperiod..lastperiod, no gaps); they enter the measurement equation as known regressors,
+        x_it = lam_o,i' g_t + lam_u,i' f_t + e_it,
+    and only f_t (nfac_u columns, VAR(1)) is latent.  Start: per-series OLS on g (dfm_ols_batch), PCA + OLS start of the
+    residual panel (dfm_pca_init_batch); EM: dfm_em_obs_batch.  Afterwards `m.factor[:, nfac_o:]` holds E[f_t | X],
+    `m.lambda_` the nfac_t loadings in data units, and the factor VAR of ALL nfac_t factors -- the reference's own second
+    stage -- is `estimate_var(m.factor_var_model)` (dfm_functions.ipynb:444-492), run here on the GPU as well."""
+    ro, ru = m.nfac_o, m.nfac_u
+    incl = m.inclcode == 1
+    w0, w1 = m.initperiod - 1, m.lastperiod
+    G = np.array(m.factor[w0:w1, :ro], float)
+    if np.isnan(G).any():
+        raise ValueError("observed factors: fill m.factor[initperiod:lastperiod, :nfac_o] (no gaps) before estimate()")
+    z, sd = standardize_data(m.data[w0:w1, :][:, incl])                 # :335-339
+    obs = ~np.isnan(z)
+    m.fes.tss = float(np.nansum(z * z)); m.fes.nobs = int(obs.sum())    # :342-343
+    enough = obs.sum(axis=0) >= m.nt_min_factor_estimation              # :357
+    if not enough.all():
+        z = z[:, enough]
+    T, N = z.shape
+    ctx, own = _own(ctx)
+    try:
+        og = ctx.ols_batch_host(G, z, want_resid=True)                  # series on the observed factors, complete cases
+        Lam_o = og["beta"]
+        res = og["resid"]                                               # [T, N], NaN where the cell is missing
+        rbal, balmask = drop_missing_col(res)
+        if rbal.shape[1] < ru:
+            raise ValueError("fewer fully observed series than unobserved factors: cannot initialise by PCA")
+        p0, F0 = ctx.pca_init_batch_host(rbal[None, :, :], ru)
+        F0 = F0[0]
+        Lam_u = np.empty((N, ru)); R = np.empty(N)
+        Lam_u[balmask] = p0["Lam"][0]; R[balmask] = p0["R"][0]
+        gap = np.nonzero(~balmask)[0]
+        if gap.size:
+            o = ctx.ols_batch_host(F0, res[:, gap], want_resid=False)
+            Lam_u[gap] = o["beta"]; R[gap] = o["ssr"] / np.maximum(o["nobs"], 1)
+        Lam = np.hstack([Lam_o, Lam_u])
+        params, path, iters, f, P = ctx.em_obs_batch_host(z[None], G[None], Lam[None], R[None], p0["A"], p0["Q"], p0["mu0"], p0["P0"],
+                                                          max_iter=max_em_iter, tol=tol_em, may_have_missing=bool((~obs).any()))
+        k = int(iters[0]); f = f[0]
+        Lam, R = params["Lam"][0], params["R"][0]
+        m.loglik_path = path[0, :k].copy(); m.em_iters = k
+        m.em_params = {kk: v[0].copy() for kk, v in params.items()}
+        m.factor[w0:w1, ro:] = f                                        # in place (aliases factor_var_model.y, :80)
+        cols = np.nonzero(incl)[0][enough] if not enough.all() else np.nonzero(incl)[0]
+        sdv = sd[0][enough] if not enough.all() else sd[0]
+        m.lambda_[cols, :] = Lam * sdv[:, None]
+        m.uar_ser[cols] = np.sqrt(R) * sdv
+        m.uar_coef[cols, :] = 0.0
+        e = np.where(np.isnan(z), 0.0, z - np.hstack([G, f]) @ Lam.T)
+        m.fes.ssr = float((e * e).sum())
+        zc = z - np.nanmean(z, axis=0)
+        R2 = 1.0 - (e * e).sum(axis=0) / np.nansum(zc * zc, axis=0)
+        m.fes.R2 = np.full(m.fes.ns, np.nan); m.fes.R2[np.nonzero(enough)[0]] = R2
+        m.r2[cols] = R2
+        estimate_var(m.factor_var_model, ctx=ctx)                       # VAR of (g, f) jointly: the reference's second stage
+    finally:
+        if own:
+            ctx.close()
+    return m.loglik_path
+
+
+def _psd_sqrt(S):
+    """A square root L (L L' = S) of a symmetric positive SEMI-definite matrix: Cholesky when it exists, else the symmetric
+    eigen square root (a fit that needed the covariance-form recursion has a rank-deficient Q)."""
+    S = 0.5 * (S + S.T)
+    try:
+        return np.linalg.cholesky(S)
+    except np.linalg.LinAlgError:
+        w, V = np.linalg.eigh(S)
+        return (V * np.sqrt(np.maximum(w, 0.0))) @ V.T
+
+
+def _bootstrap_replicates(z, params, nrep, seed, ngpu, max_em_iter, tol_em, singular_q=False):
     """`nrep` parametric-bootstrap panels from the fitted model on the standardised window z (NaN where z is NaN),
     re-estimated from the point estimate in one dfm_em_batch_multi call (julia/dfm_hip.jl estimate!: same steps)."""
     from .kalman import DfmContext
@@ -293,8 +374,8 @@ def _bootstrap_replicates(z, params, nrep, seed, ngpu, max_em_iter, tol_em):
     T, N = z.shape
     r = Lam.shape[1]
     rng = np.random.default_rng(seed)
-    LQ = np.linalg.cholesky(0.5 * (Q + Q.T))
-    LS = np.linalg.cholesky(0.5 * (P0 + P0.T))
+    LQ = _psd_sqrt(Q)                      # (never raises after the point estimate has been written into the model)
+    LS = _psd_sqrt(P0)
     sq = np.sqrt(R)
     panels = np.empty((nrep, T, N))
     for b in range(nrep):
@@ -305,7 +386,8 @@ def _bootstrap_replicates(z, params, nrep, seed, ngpu, max_em_iter, tol_em):
     panels[:, np.isnan(z)] = np.nan
     rep = lambda a: np.repeat(a[None], nrep, axis=0)
     new, path, iters, _, _, ran = DfmContext.em_batch_multi_host(ngpu, panels, rep(Lam), rep(R), rep(A), rep(Q), rep(mu0),
-                                                                 rep(P0), max_iter=max_em_iter, tol=tol_em)
+                                                                 rep(P0), max_iter=max_em_iter, tol=tol_em,
+                                                                 singular_q=singular_q)
     return dict(params=new, loglik_path=path, iters=iters, iterations=ran, panels=panels)
 
 
@@ -346,7 +428,7 @@ def estimate_factor(m: DFMModel, max_iter: int = 100000000, computeR2: bool = Tr
     if lam_constr is not None:
         raise NotImplementedError("loading constraints are not supported on the HIP path")
     if m.nfac_o != 0:
-        raise NotImplementedError("observed factors (nfac_o > 0) are not supported (non-functional in the reference too)")
+        return _estimate_factor_observed(m, max_iter, computeR2, ctx)
     r = m.nfac_u
     xdata = m.data[m.initperiod - 1:m.lastperiod, :][:, m.inclcode == 1]   # :335-336
     z, _ = standardize_data(xdata)                                         # :339
@@ -365,6 +447,47 @@ def estimate_factor(m: DFMModel, max_iter: int = 100000000, computeR2: bool = Tr
     if computeR2:
         m.fes.R2 = o["R2"][0].copy()
     m.als_iters = int(o["iters"][0])
+    return None
+
+
+def _estimate_factor_observed(m: DFMModel, max_iter, computeR2, ctx):
+    """`estimate_factor!` with OBSERVED factors, as the reference's loop is evidently meant (dfm_functions.ipynb:352-371: the
+    factor step already regresses on `lambda[:, nfac_o+1:end]` only, :364; what is broken is that the loading step regresses
+    on the nfac_u estimated columns alone, :358-359, and :371 writes nfac_u columns into nfac_t -- App. D 7).  g_t = the first
+    nfac_o columns of `m.factor` (filled by the caller).  Per sweep TWO batched complete-case regressions on the GPU
+    (dfm_ols_batch): every series on [g, f] (N problems), then every period's x_t - Lam_o g_t on Lam_u (T problems sharing
+    the regressors) -- `ols_skipmissing(.., Unbalanced())` of :364; the stopping rule is the reference's (:366-368)."""
+    ro, ru = m.nfac_o, m.nfac_u
+    w0, w1 = m.initperiod - 1, m.lastperiod
+    G = np.array(m.factor[w0:w1, :ro], float)
+    if np.isnan(G).any():
+        raise ValueError("observed factors: fill m.factor[initperiod:lastperiod, :nfac_o] (no gaps) before estimate_factor()")
+    z, _ = standardize_data(m.data[w0:w1, :][:, m.inclcode == 1])          # :335-339
+    T, N = z.shape
+    m.fes.tss = float(np.nansum(z * z)); m.fes.nobs = int((~np.isnan(z)).sum())
+    ctx, own = _own(ctx)
+    try:
+        res = ctx.ols_batch_host(G, z, want_resid=True)["resid"]           # start: PCA of what g does not explain
+        F = pca_start(ctx, res, ru)
+        ssr, it = 0.0, 0
+        for it in range(1, int(min(max_iter, 10 ** 8)) + 1):
+            ssr_old = ssr
+            lam = ctx.ols_batch_host(np.hstack([G, F]), z, nt_min=m.nt_min_factor_estimation, want_resid=False)["beta"]   # :355-361
+            y = z - G @ lam[:, :ro].T                                      # NaN rows of lam (short series) drop out below
+            o = ctx.ols_batch_host(lam[:, ro:], y.T, want_resid=False)     # :364, one problem per period
+            F = o["beta"]
+            ssr = float(o["ssr"].sum())                                    # :366
+            if not abs(ssr_old - ssr) >= m.tol * m.fes.T * m.fes.ns:       # :367-368
+                break
+        m.factor[w0:w1, ro:] = F                                           # :371 (the observed columns stay the caller's)
+        m.fes.ssr = ssr
+        m.als_iters = it
+        if computeR2:                                                      # :372-380
+            o = ctx.ols_batch_host(np.hstack([G, F]), z, nt_min=m.nt_min_factor_estimation, want_resid=False)
+            m.fes.R2 = np.where(np.isnan(o["beta"][:, 0]), np.nan, 1.0 - o["ssr"] / o["tss"])
+    finally:
+        if own:
+            ctx.close()
     return None
 
 

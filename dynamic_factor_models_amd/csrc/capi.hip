@@ -919,6 +919,75 @@ int ar_em_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, const 
     return 0;
 }
 
+// ---- observed factors (mstep_obs.hip, oracle/obs_oracle.py em_obs) ------------------------------------
+// Per iteration: y = x - Lam_o g and the padded Lam_u -> the ordinary smoother pass on y with the transition M-step (the
+// pass's own EM epilogue: A, Q, mu0, P0 of the unobserved block) -> the joint loadings regression on z = (g, f).
+int obs_em_run(dfm_handle* h, int B, int T, int N, int ru, int ro, const double* panel, const double* G, double* Lam, double* R,
+               double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path, int* iters,
+               double* f_smooth, double* P_smooth, unsigned flags) {
+    if (!h) return DFM_E_NULL;
+    if (int rc = check_dims(h, B, T, N, ru)) return rc;
+    if (!mstep_obs_supported(ro, ru)) return fail(h, DFM_E_R_UNSUPPORTED, "observed factors: need r_o >= 1, r_u >= 1 and r_o + r_u <= 8%s");
+    if (int rc = check_em_n(h, N, ru, flags)) return rc;
+    if (!panel || !G || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const Plan p = make_plan(B, T, N, ru, flags, true, fast_eligible(h, N, ru, flags) && !h->em_general);
+    const size_t yoff = (p.total + 255) & ~(size_t)255;
+    if (int rc = ensure_ws(h, yoff + (size_t)B * T * N * sizeof(double))) return rc;
+    h->status_off = p.status;
+    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
+    const int Rp = p.Rp, Rl = p.Rc ? p.Rc : p.Rp;            // state width, loadings width
+    const bool padded = (ru != Rp);
+    double *LamP = at<double>(h, p.LamP), *y = at<double>(h, yoff);
+    double *AP = A, *QP = Q, *mu0P = mu0, *P0P = P0;
+    if (padded) {
+        AP = at<double>(h, p.AP); QP = at<double>(h, p.QP); mu0P = at<double>(h, p.mu0P); P0P = at<double>(h, p.P0P);
+        const size_t n = (size_t)B * Rp * Rp;                 // (N = 0: the loadings are embedded by launch_obs_residual)
+        hipLaunchKernelGGL(pad_params_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B, 0, ru, Rp, Rl,
+                           (const double*)nullptr, A, Q, mu0, P0, (double*)nullptr, AP, QP, mu0P, P0P);
+        HIP_TRY(h, hipGetLastError());
+    }
+    double* fsm = at<double>(h, p.fsm);
+    double* Psm = at<double>(h, p.Psm);
+    double* llbuf = at<double>(h, p.llbuf);
+    int* active = at<int>(h, p.active);
+    HIP_TRY(h, hipMemsetAsync(loglik_path, 0xFF, (size_t)B * max_iter * sizeof(double), h->stream));  // NaN
+    HIP_TRY(h, hipMemsetAsync(iters, 0, (size_t)B * sizeof(int), h->stream));
+    ObsArgs oa;
+    oa.B = B; oa.T = T; oa.N = N; oa.ro = ro; oa.ru = ru; oa.Rl = Rl;
+    oa.panel = panel; oa.G = G; oa.fsm = fsm; oa.Psm = Psm; oa.active = active; oa.Lam = Lam; oa.R = R;
+    PaddedParams pp{LamP, AP, QP, mu0P, P0P};
+    std::vector<int> act_host;
+    for (int it = 0; it < max_iter; ++it) {
+        { ProfScope ps(h, K_PAD); HIP_TRY(h, launch_obs_residual(oa, y, LamP, h->stream)); }
+        EmOpts eo;
+        eo.A_out = AP; eo.Q_out = QP; eo.mu0_out = mu0P; eo.P0_out = P0P;
+        eo.active = active; eo.iters = iters; eo.ll_path = loglik_path; eo.k = it; eo.max_iter = max_iter; eo.tol = tol;
+        if (int rc = enqueue_pass(h, p, B, T, N, Rl, y, pp, R, fsm, Psm, llbuf, &eo)) return rc;
+        { ProfScope ps(h, K_MSTEP_STATS); HIP_TRY(h, launch_mstep_obs(oa, h->stream)); }
+        if (tol > 0.0 && it + 1 < max_iter) {
+            act_host.resize(B);
+            HIP_TRY(h, hipMemcpyAsync(act_host.data(), active, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            bool any = false;
+            for (int b = 0; b < B; ++b) any = any || act_host[b] != 0;
+            if (!any) break;
+        }
+    }
+    const size_t np = (size_t)ru * (ru + 1) / 2, npl = (size_t)Rl * (Rl + 1) / 2;
+    if (padded) {
+        if (int rc = copy_block(h, B, Rp, Rp, ru, ru, AP, A)) return rc;
+        if (int rc = copy_block(h, B, Rp, Rp, ru, ru, QP, Q)) return rc;
+        if (int rc = copy_block(h, B, Rp, Rp, ru, ru, P0P, P0)) return rc;
+        if (int rc = copy_block(h, B, 1, Rp, 1, ru, mu0P, mu0)) return rc;
+    }
+    if (f_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, Rl, 1, ru, fsm, f_smooth)) return rc;
+    if (P_smooth) if (int rc = copy_block(h, (size_t)B * T, 1, (int)npl, 1, (int)np, Psm, P_smooth)) return rc;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1409,6 +1478,60 @@ int dfm_em_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, con
         auto down = [&](void* dst, const void* src, size_t bytes) { if (bytes) (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream); };
         down(Lam, lam_d, n_lam * d); down(sig2, R_d, n_R * d); down(rho, rho_d, n_rho * d); down(Avar, A_d, n_a * d);
         down(Q, Q_d, n_q * d); down(mu0, mu_d, n_v * d); down(P0, P0_d, n_p0 * d); down(loglik_path, ll_d, n_ll * d);
+        down(iters, it_d, (size_t)B * sizeof(int));
+        if (f_smooth) down(f_smooth, f_d, n_f * d);
+        if (P_smooth) down(P_smooth, P_d, n_P * d);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = hip_fail(h, e, "hipStreamSynchronize");
+    }
+    if (rc == 0) rc = post_check(h, loglik_path, B, (size_t)max_iter);
+    (void)hipFree(buf);
+    return rc;
+}
+
+// ---- observed factors ------------------------------------------------------------------------------------------------
+int dfm_em_obs_batch_dev(dfm_handle* h, int B, int T, int N, int r_u, int r_o, const double* panel, const double* G, double* Lam,
+                         double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                         int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
+    return obs_em_run(h, B, T, N, r_u, r_o, panel, G, Lam, R, A, Q, mu0, P0, max_iter, tol, loglik_path, iters, f_smooth, P_smooth,
+                      flags);
+}
+
+int dfm_em_obs_batch(dfm_handle* h, int B, int T, int N, int r_u, int r_o, const double* panel, const double* G, double* Lam,
+                     double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                     int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
+    if (int rc = check_dims(h, B, T, N, r_u)) return rc;
+    if (r_o < 1 || r_o + r_u > 8) return fail(h, DFM_E_R_UNSUPPORTED, "observed factors: need r_o >= 1 and r_o + r_u <= 8%s");
+    if (!panel || !G || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
+        return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    for (size_t k = 0; k < (size_t)B * T * r_o; ++k)
+        if (G[k] != G[k]) return fail(h, DFM_E_MISSING, "observed factors must not contain NaN%s");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t d = sizeof(double), re = (size_t)r_o + r_u, np = (size_t)r_u * (r_u + 1) / 2;
+    const size_t n_panel = (size_t)B * T * N, n_g = (size_t)B * T * r_o, n_lam = (size_t)B * N * re, n_R = (size_t)B * N,
+                 n_m = (size_t)B * r_u * r_u, n_v = (size_t)B * r_u, n_f = (size_t)B * T * r_u, n_P = (size_t)B * T * np,
+                 n_ll = (size_t)B * max_iter;
+    double* buf = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&buf), (n_panel + n_g + n_lam + n_R + 3 * n_m + n_v + n_f + n_P + n_ll) * d + (size_t)B * sizeof(int)));
+    double* dp = buf;
+    auto up = [&](const double* src, size_t n) -> double* {
+        double* dst = dp; dp += n;
+        (void)hipMemcpyAsync(dst, src, n * d, hipMemcpyHostToDevice, h->stream);
+        return dst;
+    };
+    double *x_d = up(panel, n_panel), *g_d = up(G, n_g), *lam_d = up(Lam, n_lam), *R_d = up(R, n_R), *A_d = up(A, n_m),
+           *Q_d = up(Q, n_m), *mu_d = up(mu0, n_v), *P0_d = up(P0, n_m);
+    double* f_d = dp; dp += n_f;
+    double* P_d = dp; dp += n_P;
+    double* ll_d = dp; dp += n_ll;
+    int* it_d = reinterpret_cast<int*>(dp);
+    int rc = obs_em_run(h, B, T, N, r_u, r_o, x_d, g_d, lam_d, R_d, A_d, Q_d, mu_d, P0_d, max_iter, tol, ll_d, it_d,
+                        f_smooth ? f_d : nullptr, P_smooth ? P_d : nullptr, flags);
+    if (rc == 0) {
+        auto down = [&](void* dst, const void* src, size_t bytes) { (void)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream); };
+        down(Lam, lam_d, n_lam * d); down(R, R_d, n_R * d); down(A, A_d, n_m * d); down(Q, Q_d, n_m * d);
+        down(mu0, mu_d, n_v * d); down(P0, P0_d, n_m * d); down(loglik_path, ll_d, n_ll * d);
         down(iters, it_d, (size_t)B * sizeof(int));
         if (f_smooth) down(f_smooth, f_d, n_f * d);
         if (P_smooth) down(P_smooth, P_d, n_P * d);

@@ -159,6 +159,23 @@ struct ArMstepArgs {
 bool mstep_ar_supported(int r, int q);
 hipError_t launch_mstep_ar(const ArMstepArgs& a, hipStream_t s);
 
+// Parametric model with OBSERVED factors (mstep_obs.hip): x_it = lam_o,i' g_t + lam_u,i' f_t + e_it with g_t
+// known regressors.  E-step on the residual panel y = x - Lam_o g; loadings by one joint regression per series on z = (g, f).
+struct ObsArgs {
+    int B, T, N, ro, ru, Rl;    // Rl: width of the rows of fsm (padded loadings width); Psm rows: Rl (Rl + 1) / 2 packed
+    const double* panel;        // [B][T][N], NaN = missing
+    const double* G;            // [B][T][ro]  observed factors (no NaN)
+    const double* fsm;          // [B][T][Rl]
+    const double* Psm;          // [B][T][Rl(Rl+1)/2]
+    const int* active;          // [B] or null
+    double* Lam;                // [B][N][ro + ru]  observed-factor loadings first   in / out
+    double* R;                  // [B][N]                                             in / out
+};
+bool mstep_obs_supported(int ro, int ru);
+hipError_t launch_mstep_obs(const ObsArgs& a, hipStream_t s);
+// y = x - Lam_o g (NaN stays NaN) and LamP [B][N][Rl] = unobserved-factor loadings, zero padded
+hipError_t launch_obs_residual(const ObsArgs& a, double* y, double* LamP, hipStream_t s);
+
 // Balanced-panel fast path (fastpath.hip): data-independent covariance steps (cov_kernel) and the
 // time-parallel mean recursion (meanscan_kernel).  All matrices in the padded dimension Rp.
 struct FastArgs {

@@ -323,10 +323,35 @@ class DfmContext:
         _check(self._h, rc)
         return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
 
+    def em_obs_batch_host(self, panel, G, Lam, R, A, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
+                          may_have_missing: Optional[bool] = None):
+        """dfm_em_obs_batch: EM of the model with OBSERVED factors g_t as known regressors (include/dfm_hip.h).
+        panel [B,T,N], G [B,T,r_o] (no NaN), Lam [B,N,r_o+r_u] (observed-factor loadings first), A / Q / P0 [B,r_u,r_u],
+        mu0 [B,r_u].  Returns (params dict, loglik_path, iters, f_smooth [B,T,r_u], P_smooth); inputs are not modified."""
+        c = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
+        panel = np.ascontiguousarray(panel, dtype=np.float64)
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        Lam, R, A, Q, mu0, P0 = map(c, (Lam, R, A, Q, mu0, P0))
+        B, T, N = panel.shape
+        ro = G.shape[2]
+        ru = Lam.shape[2] - ro
+        if G.shape[:2] != (B, T) or A.shape != (B, ru, ru):
+            raise ValueError("em_obs_batch_host: G must be [B,T,r_o] and A [B,r_u,r_u] with Lam [B,N,r_o+r_u]")
+        if may_have_missing is None:
+            may_have_missing = bool(np.isnan(panel).any())
+        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
+        f = np.empty((B, T, ru)); P = np.empty((B, T, ru * (ru + 1) // 2))
+        p = lambda a: ctypes.c_void_p(a.ctypes.data)
+        rc = self._lib.dfm_em_obs_batch(self._h, B, T, N, ru, ro, p(panel), p(G), p(Lam), p(R), p(A), p(Q), p(mu0), p(P0),
+                                        int(max_iter), float(tol), p(path), p(iters), p(f), p(P), flags)
+        _check(self._h, rc)
+        return dict(Lam=Lam, R=R, A=A, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
+
     # ------------------------------------------------------------------ several GPUs from one process (multi.hip)
     @staticmethod
     def em_batch_multi_host(ngpu, panel, Lam, R, A, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
-                            may_have_missing: Optional[bool] = None, device_ids=None):
+                            may_have_missing: Optional[bool] = None, device_ids=None, singular_q: bool = False):
         """dfm_em_batch_multi: the EM loop on `ngpu` GPUs from THIS process (one host thread per GPU, library-owned
         RCCL communicator, one all-gather of {loglik, active} per iteration) -- what the Julia host binds.  NumPy in /
         out as em_batch_host; also returns the number of iterations every GPU ran."""
@@ -338,7 +363,7 @@ class DfmContext:
         r = Lam.shape[2]
         if may_have_missing is None:
             may_have_missing = bool(np.isnan(panel).any())
-        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
         path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
         f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2))
         ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)

@@ -262,6 +262,24 @@ int dfm_em_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, con
                     double* sig2, double* rho, double* Avar, double* Q, double* mu0, double* P0, int max_iter, double tol,
                     double* loglik_path, int* iters, double* f_smooth, double* P_smooth, unsigned flags);
 
+/* --- OBSERVED factors ------------------------------------------------------------------------------
+ *   x_it = lam_o,i' g_t + lam_u,i' f_t + e_it,   e_it ~ N(0, R_i),     f_t = A f_{t-1} + eta_t,  eta_t ~ N(0, Q)
+ * The reference's DFMModel has `nfac_o` observed factors in front of the `nfac_u` estimated ones (`factor` is T x nfac_t,
+ * dfm_functions.ipynb:89-146; `lambda[:, nfac_o+1:end]` are the unobserved loadings, :364) but its estimator does not work for
+ * nfac_o > 0 (:358-359, :371) -- the semantics here are those its data layout implies: g_t = the observed columns of `factor`
+ * are KNOWN REGRESSORS of the measurement equation (FAVAR); their joint dynamics with f_t are the reference's own second
+ * stage (`estimate_var!` on the whole `factor` matrix, :444-468).  EM: E-step = the ordinary pass on x - Lam_o g; loadings =
+ * one joint regression per series on (g_t, f_t) over its observed periods; A, Q, mu0, P0 as dfm_em_batch (oracle/obs_oracle.py).
+ * G [B][T][r_o] (no NaN), Lam [B][N][r_o + r_u] with the OBSERVED-factor loadings first, A / Q / P0 [B][r_u][r_u], mu0 [B][r_u];
+ * f_smooth [B][T][r_u], P_smooth [B][T][r_u(r_u+1)/2] (may be NULL); bookkeeping (loglik_path, iters, tol) as dfm_em_batch.
+ * r_o >= 1, r_u >= 1, r_o + r_u <= 8.  A series with fewer than r_o + r_u + 1 observed cells keeps its loadings and variance. */
+int dfm_em_obs_batch_dev(dfm_handle* h, int B, int T, int N, int r_u, int r_o, const double* panel, const double* G, double* Lam,
+                         double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                         int* iters, double* f_smooth, double* P_smooth, unsigned flags);
+int dfm_em_obs_batch(dfm_handle* h, int B, int T, int N, int r_u, int r_o, const double* panel, const double* G, double* Lam,
+                     double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
+                     int* iters, double* f_smooth, double* P_smooth, unsigned flags);
+
 /* --- PCA initialisation (reference: pca_score, dfm_functions.ipynb:179-183, on the standardised
  * balanced panel, :339-348) followed by the OLS start of EM: Lam = OLS(x on F), R = residual
  * variance, A/Q = VAR(1) OLS of F, mu0 = 0, P0 = F'F/T.  Balanced panels only (no NaN). */

@@ -113,6 +113,30 @@ function em(h::Handle, z::Matrix{Float64}, p; max_iter::Integer = 50, tol::Real 
             factor = permutedims(f[:, :, 1]), singular_q = fallback)
 end
 
+"EM with OBSERVED factors as known regressors (dfm_em_obs_batch; include/dfm_hip.h): z is T x N (NaN = missing), G the
+T x r_o observed factors (no gaps), p.Lam N x (r_o + r_u) with the observed-factor loadings FIRST (the reference's column
+order, dfm_functions.ipynb:364), p.A / p.Q / p.P0 r_u x r_u, p.mu0 r_u."
+function em_obs(h::Handle, z::Matrix{Float64}, G::Matrix{Float64}, p; max_iter::Integer = 50, tol::Real = 1e-6)
+    T, N = size(z); ro = size(G, 2); re = size(p.Lam, 2); ru = re - ro
+    panel = to_c_panel(z); Gc = reshape(permutedims(G, (2, 1)), ro, T, 1)
+    Lam = reshape(permutedims(p.Lam), re, N, 1); R = reshape(copy(p.R), N, 1)
+    A = reshape(permutedims(p.A), ru, ru, 1); Q = reshape(permutedims(p.Q), ru, ru, 1)
+    mu0 = reshape(copy(p.mu0), ru, 1); P0 = reshape(permutedims(p.P0), ru, ru, 1)
+    path = Array{Float64}(undef, max_iter, 1); iters = Array{Cint}(undef, 1)
+    f = Array{Float64}(undef, ru, T, 1); np = div(ru * (ru + 1), 2); P = Array{Float64}(undef, np, T, 1)
+    flags = any(isnan, z) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    GC.@preserve panel Gc Lam R A Q mu0 P0 path iters f P begin
+        rc = ccall((:dfm_em_obs_batch, LIB), Cint,
+                   (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+                    Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cdouble, Ptr{Float64}, Ptr{Cint}, Ptr{Float64}, Ptr{Float64}, Cuint),
+                   h.ptr, 1, T, N, ru, ro, panel, Gc, Lam, R, A, Q, mu0, P0, max_iter, tol, path, iters, f, P, flags)
+        check(h.ptr, rc)
+    end
+    k = Int(iters[1])
+    return (Lam = permutedims(Lam[:, :, 1]), R = R[:, 1], A = permutedims(A[:, :, 1]), Q = permutedims(Q[:, :, 1]),
+            mu0 = mu0[:, 1], P0 = permutedims(P0[:, :, 1]), loglik = path[1:k, 1], iters = k, factor = permutedims(f[:, :, 1]))
+end
+
 # C [b][i][k] <-> Julia: a vector of B matrices (rows x cols) -> Array (cols, rows, B), and back
 pack3(ms::Vector{Matrix{Float64}}) = cat([permutedims(m) for m in ms]...; dims = 3)
 unpack3(a::Array{Float64,3}) = [permutedims(a[:, :, b]) for b in 1:size(a, 3)]
@@ -462,7 +486,7 @@ function estimate!(m::DFMModel, ::Parametric; max_em_iter::Integer = 50, tol_em:
                    device::Integer = 0, handle = nothing, lam_constr_f = nothing, lam_constr_fl = nothing)
     (lam_constr_f === nothing && lam_constr_fl === nothing) ||
         error("loading constraints are not supported on the parametric path")   # never drop them silently
-    m.nfac_o == 0 || error("observed factors are not supported on the parametric path")
+    m.nfac_o == 0 || return estimate_observed!(m; max_em_iter = max_em_iter, tol_em = tol_em, device = device, handle = handle)
     r = m.nfac_u
     nlag = Int(factor_lags)
     (nlag >= 1 && r * nlag <= 32) || error("need 1 <= factor_lags and nfac_u * factor_lags <= 32")
@@ -655,4 +679,51 @@ function estimate_factor_numbers_hip(m::DFMModel, nfacs::Union{Real, AbstractVec
         R2_dynamic[:, k, i] = nan2missing(dy.R2[b])
     end
     return FactorNumberEstimateStats(bn_icp, ssr_static, R2_static, aw_icp, ssr_dynamic, R2_dynamic, tss, nobs, T)
+end
+
+
+# ---------------------------------------------------------------------------------------------------------
+# `estimate!(m, Parametric())` with OBSERVED factors (nfac_o > 0).  The reference's estimator is non-functional there
+# (dfm_functions.ipynb:358-359, :371), so the semantics are those its data layout implies (include/dfm_hip.h,
+# oracle/obs_oracle.py; api._estimate_parametric_observed is the same sequence): the caller has filled
+# m.factor[initperiod:lastperiod, 1:nfac_o] with the observed factors; they are known regressors of the measurement
+# equation, only the nfac_u remaining factors are latent.  Afterwards m.factor[:, nfac_o+1:end] = E[f_t | X], m.lambda the
+# nfac_t loadings, and the factor VAR of ALL factors is the reference's own `estimate_var!(m.factor_var_model)`.
+function estimate_observed!(m::DFMModel; max_em_iter::Integer = 50, tol_em::Real = 1e-6, device::Integer = 0, handle = nothing)
+    ro, ru = m.nfac_o, m.nfac_u
+    incl = m.inclcode .== 1
+    Gm = m.factor[m.initperiod:m.lastperiod, 1:ro]
+    any(ismissing, Gm) && error("observed factors: fill m.factor[initperiod:lastperiod, 1:nfac_o] (no gaps) before estimate!")
+    G = Float64.(Gm)
+    xstd, xsd = standardize_data(m.data[m.initperiod:m.lastperiod, incl])      # :335-339
+    m.fes.tss = sum(skipmissing(xstd .^ 2)); m.fes.nobs = count(.!ismissing.(xstd))
+    enough = vec(sum(.!ismissing.(xstd), dims = 1)) .>= m.nt_min_factor_estimation
+    xstd = xstd[:, enough]; xsd = vec(xsd)[enough]
+    z = reshape(DFMHip.nan_for_missing(xstd), size(xstd))
+    h = handle === nothing ? DFMHip.handle(device) : handle
+    og = DFMHip.ols(h, G, z)                                                   # every series on the observed factors
+    res = Union{Missing, Float64}[isnan(v) ? missing : v for v in og.resid]
+    rbal, balmask = drop_missing_col(res)
+    balmask = vec(balmask)
+    size(rbal, 2) >= ru || error("fewer fully observed series than unobserved factors: cannot initialise by PCA")
+    p0 = DFMHip.pca_init(h, Float64.(rbal), ru)
+    N = size(z, 2)
+    Lam_u = Matrix{Float64}(undef, N, ru); R = Vector{Float64}(undef, N)
+    Lam_u[balmask, :] = p0.Lam; R[balmask] = p0.R
+    gap = findall(.!balmask)
+    if !isempty(gap)
+        o = DFMHip.ols(h, p0.F, og.resid[:, gap])
+        Lam_u[gap, :] = permutedims(o.beta); R[gap] = o.ssr ./ max.(o.nobs, 1)
+    end
+    fit = DFMHip.em_obs(h, z, G, (Lam = hcat(permutedims(og.beta), Lam_u), R = R, A = p0.A, Q = p0.Q, mu0 = p0.mu0, P0 = p0.P0);
+                        max_iter = max_em_iter, tol = tol_em)
+    m.factor[m.initperiod:m.lastperiod, ro+1:end] = fit.factor               # in place (aliases factor_var_model.y, :80)
+    cols = findall(incl)[enough]
+    m.lambda[cols, :] = fit.Lam .* xsd
+    m.uar_ser[cols] = sqrt.(fit.R) .* xsd
+    m.uar_coef[cols, :] .= 0.0
+    common = hcat(G, fit.factor) * fit.Lam'
+    m.fes.ssr = sum(abs2, [isnan(z[t, i]) ? 0.0 : z[t, i] - common[t, i] for t in 1:size(z, 1), i in 1:N])
+    estimate_var!(m.factor_var_model)                                          # VAR of (g, f): the reference's second stage (:444-492)
+    return fit.loglik
 end

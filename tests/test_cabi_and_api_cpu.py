@@ -113,9 +113,16 @@ def test_estimate_rejects_what_the_path_does_not_cover():
         api.estimate(m, api.NonParametric())                             # no CPU fallback
     with pytest.raises(TypeError):
         api.estimate(m, object())
+    # observed factors (round 3: supported on the parametric path): the caller must have filled the observed columns of
+    # `factor` -- a host-side check that runs before any device work
     m2 = api.DFMModel(_data(), np.ones(7), 5, 5, 1, 40, 1, 2, 1e-8, 4, 4)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="observed factors"):
         api.estimate(m2, api.Parametric())
+    m2.factor[:, :1] = 0.5
+    with pytest.raises(RuntimeError, match="HIP device"):
+        api.estimate(m2, api.Parametric())                               # ... and then there is no CPU fallback
+    with pytest.raises(RuntimeError, match="HIP device"):
+        api.estimate_factor(m2)                                          # the ALS estimator takes them too (two dfm_ols_batch calls per sweep)
 
 
 def test_parametric_argument_checks_run_before_any_device_work():
