@@ -236,7 +236,7 @@ def kernel_bytes_table(B, N, T, r):
             "mstep_mfma_kernel": B * 8 * (N * T + T * r), "mstep_wide_kernel": B * 8 * (N * T + T * r),
             "mstep_lam_kernel": B * 8 * (N * T + T * (r + npack)),
             "gram_kernel": B * 8 * (N * r + N), "wide_prep_kernel": B * 8 * (N * r + N), "cov_kernel": B * 8 * (3 * r * r + r),
-            "cov_grid_kernel": B * 8 * (3 * r * r + r), "ct_miss_wide_kernel": B * 8 * T * npack}
+            "cov_grid_kernel": B * 8 * (3 * r * r + r), "ct_miss_wide_kernel": B * 8 * T * npack, "ct_miss_wide2_kernel": B * 8 * T * npack}
 
 
 class Workload:
@@ -441,7 +441,7 @@ def run_lib_driver(args, torch):
                    roofline=dict(bound="hbm", kernel=None, achieved=whole, peak=HBM_PEAK_GBS, unit="GB/s", frac=whole / HBM_PEAK_GBS, traffic=None,
                                  whole_step=dict(bytes_per_unit=unit_bytes, achieved=whole, frac=whole / HBM_PEAK_GBS)),
                    cpu_baseline=None, source_hash=source_hash())
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)       # (before the object's teardown: RCCL's exit path must not eat the line)
     finally:
         m.close()
 
@@ -567,7 +567,7 @@ def main():
             sec[key]["seconds"] = round(time.perf_counter() - t0, 2)
         out["secondary"] = sec
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -524,7 +524,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
             double* W = at<double>(h, p.Wwide);
             { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(ca, W, 32, h->stream)); }
             { ProfScope ps(h, K_COLLAPSE_WIDE); HIP_TRY(h, launch_collapse_wide2(ca, W, 32, p.r, h->num_cu, h->stream)); }
-            { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_ct_miss_wide(ca, W, h->stream)); }
+            { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_ct_miss_wide(ca, W, p.r, h->stream)); }
         } else { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(Rcol, ca, h->stream)); }
     }
     RecursionArgs ra;

@@ -554,6 +554,155 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide_kernel(CollapseArgs a
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// ct_miss_wide2_kernel (round 3): the same C_t with (i) the stage loads of W / lam double-buffered through registers -- the
+// first version waited a full L2 round trip per stage of 32 series, 32 times per tile -- and (ii) a 2-D register blocking of
+// the rank-1 updates: the lower-triangular 4 x 4 blocks of the r x r matrix (r = the caller's factor count, 15 blocks at
+// r = 20) are dealt to the lanes of a SLOT of 16 | 32 | 64 lanes, and the 4 | 2 | 1 slots of a wave take different missing
+// series of the stage at the same time: per series and lane 4 LDS reads of 16 bytes and 16 FMAs instead of 18 reads of 8
+// bytes and 9 FMAs on every lane (the packed-entry-per-lane form was LDS-bound: two operand reads per FMA).  The slots'
+// partial sums meet in two butterfly steps per accumulator at the end of the tile.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall, int ntile16, int r) {
+    constexpr int R = kW2R, NP = R * (R + 1) / 2, SE = kW2Chunk * R;        // SE: elements of a stage (32 series x 32)
+    constexpr unsigned kStagesB = 3u * 2u * 8u * 1088u;       // three stage buffers (see the stage loop)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, T = a.T;
+    const int npad = ((N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
+    unsigned short* mask = reinterpret_cast<unsigned short*>(smem + kStagesB);   // [npad]
+    unsigned* anyS = reinterpret_cast<unsigned*>(mask + npad);
+    const size_t cs_off = ((size_t)kStagesB + (size_t)npad * sizeof(unsigned short) + 16 + 15) & ~(size_t)15;   // [16][NP] output tiles
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.x / ntile16, t0 = ((int)blockIdx.x % ntile16) * kCtP;
+    const double* __restrict__ X = a.panel + (size_t)b * T * N;
+    if (tid == 0) *anyS = 0u;
+    __syncthreads();
+    unsigned many = 0u;
+    for (int i = tid; i < npad; i += kCtThreads) {
+        unsigned m = 0u;
+        if (i < N) {
+#pragma unroll
+            for (int t = 0; t < kCtP; ++t) {
+                const int tt = t0 + t < T ? t0 + t : T - 1;
+                const double x = X[(size_t)tt * N + i];
+                m |= (x != x && t0 + t < T) ? (1u << t) : 0u;
+            }
+        }
+        mask[i] = (unsigned short)m;
+        many |= m;
+    }
+    if (many) atomicOr(anyS, many);
+    __syncthreads();
+    const unsigned tilemask = *anyS;                          // periods of the tile with a missing cell
+    if (tilemask == 0u) return;
+    const bool mine = (tilemask >> wave) & 1u;                // (wave-uniform) this wave's period has a missing cell
+    // blocks: nb x nb of 4 x 4 over the r x r matrix, lower triangle; LS lanes per slot
+    const int nb = (r + 3) / 4, nlt = nb * (nb + 1) / 2;
+    const int LS = nlt <= 16 ? 16 : (nlt <= 32 ? 32 : 64), NS = 64 / LS;
+    const int slot = lane / LS, bl = lane % LS;
+    const bool act = bl < nlt;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= (act ? bl : 0)) ++bi;
+    const int bj = (act ? bl : 0) - bi * (bi + 1) / 2;
+    double E[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) E[x][y] = 0.0;
+    const double* __restrict__ Wb = Wall + (size_t)b * N * R;
+    const double* __restrict__ Lb = a.Lam + (size_t)b * N * R;
+    const int nch = npad / kW2Chunk;
+    // Stage ch = W and lam of series 32 ch .. 32 ch + 31 (8 KB each, contiguous in global memory): 16 pieces of 1 KB, ONE
+    // global_load_lds_dwordx4 per wave and stage, three stage buffers, counted waits (the compiler's own scoreboard put a
+    // vmcnt(0) in front of every register-staged LDS write, i.e. one L2 round trip per stage -- ~1.2 us x 32 stages per tile).
+    // A piece = 4 series rows of 256 bytes; pieces sit 1024 + 64 bytes apart so that rows of different pieces start on
+    // different banks (the slots read different series at the same column block).
+    constexpr unsigned kPieceB = 1088, kHalfB = 8 * kPieceB, kStageB = 2 * kHalfB;       // W half | lam half
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_w)(smem));
+    const unsigned wbytes = (unsigned)N * R * 8u;
+    const char* srcb = reinterpret_cast<const char*>(wave < 8 ? Wb : Lb);
+    auto issue = [&](int ch, int buf) {
+        unsigned o = (unsigned)ch * 8192u + (unsigned)(wave & 7) * 1024u + 16u * lane;
+        o = o < wbytes ? o : wbytes - 16u;                    // the last stage may be partial: its rows past N are never selected
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * kStageB + (wave < 8 ? 0u : kHalfB) + (unsigned)(wave & 7) * kPieceB);
+        dma16w(srcb + o, dst);
+    };
+    issue(0, 0);
+    if (nch > 1) issue(1, 1);
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // this wave's piece of stage ch has landed
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // ... and everybody's; every wave is done with stage ch - 1
+        if (ch + 2 < nch) issue(ch + 2, (ch + 2) % 3);        // into the buffer stage ch - 1 used
+        if (!mine) continue;
+        const char* st = smem + (size_t)(ch % 3) * kStageB;
+        unsigned long long bits = __ballot(lane < kW2Chunk && ((mask[ch * kW2Chunk + (lane & (kW2Chunk - 1))] >> wave) & 1u) != 0u);
+#pragma unroll 1
+        while (bits != 0ull) {
+            int my = -1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                     // the next NS missing series of the stage, one per slot
+                if (q < NS && bits != 0ull) {
+                    const int ii = __builtin_ctzll(bits);
+                    bits &= bits - 1ull;
+                    my = (slot == q) ? ii : my;
+                }
+            }
+            if (act && my >= 0) {
+                const int sw = 16 * (my & 1);                 // (stage start is a multiple of 32: parity of ii = parity of the series)
+                const char* row = st + (unsigned)(my >> 2) * kPieceB + (unsigned)(my & 3) * 256u;
+                const double2* wp = reinterpret_cast<const double2*>(row + 8 * ((4 * bi) ^ sw));
+                const double2* lp = reinterpret_cast<const double2*>(row + kHalfB + 8 * (4 * bj));
+                const double2 w01 = wp[0], w23 = wp[1], l01 = lp[0], l23 = lp[1];
+                const double wv[4] = {w01.x, w01.y, w23.x, w23.y}, lv[4] = {l01.x, l01.y, l23.x, l23.y};
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) E[x][y] = fma(wv[x], lv[y], E[x][y]);
+            }
+        }
+    }
+    if (!mine) return;
+    // fold the slots (lanes bl, bl + LS, ...)
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            double e = E[x][y];
+            if (NS >= 2) e += __shfl_xor(e, 32, 64);
+            if (NS >= 4) e += __shfl_xor(e, 16, 64);
+            E[x][y] = e;
+        }
+    // The period's packed C_t is assembled in LDS and leaves as whole 16-byte pieces, 1 KB per store instruction: written
+    // straight from the blocks it was 16 scattered 8-byte stores per lane -- 270 M partial-sector writes per config-4 batch,
+    // which (not the arithmetic) then bounded the kernel.
+    const int t = t0 + wave;
+    double* Co = a.Ct + ((size_t)b * T + t) * NP;
+    const double* Cf = a.Cfull + (size_t)b * R * R;
+    double* Cs = reinterpret_cast<double*>(smem + cs_off) + (size_t)wave * NP;   // (its own LDS: slower waves still read the stage buffers)
+    if (act && slot == 0) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                const int jj = 4 * bi + x, kk = 4 * bj + y;
+                if (kk <= jj && jj < R) Cs[jj * (jj + 1) / 2 + kk] = Cf[jj * R + kk] - E[x][y];
+            }
+    }
+    // rows past the blocks (padding of the state): no series loads on them, C_t = C
+    const int j0 = 4 * nb < R ? 4 * nb : R;
+    for (int v = j0 * (j0 + 1) / 2 + lane; v < NP; v += 64) {
+        int jj = j0;
+        while ((jj + 1) * (jj + 2) / 2 <= v) ++jj;
+        Cs[v] = Cf[jj * R + (v - jj * (jj + 1) / 2)];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    static_assert(NP % 2 == 0, "packed rows leave in 16-byte pieces");
+    for (int v = 2 * lane; v < NP; v += 128) *reinterpret_cast<double2*>(Co + v) = *reinterpret_cast<const double2*>(Cs + v);
+}
+
 int collapse_wide2_tiles(int T) { return (T + kW2Rows - 1) / kW2Rows; }
 // Rp = 16 | 32 with an even N; narrower states (computed 16 wide) only where the row ring of the MFMA collapse ends (8 N > 4 KB)
 bool collapse_wide2_supported(int Rpad, int N) {
@@ -635,12 +784,27 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, in
 
 // C_t of the periods with missing cells (a.Ct, packed; the other periods keep Cfull): after launch_wide_prep, beside or after
 // the collapse (it reads the panel itself)
-hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, hipStream_t s) {
-    note_kernel("ct_miss_wide_kernel");
+hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s) {
     static const int skip = [] { const char* v = getenv("DFM_CT_SKIP"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
     if (skip) return hipSuccess;
     const W2Ws w = w2_ws(a, ws, kW2R);
     const int ntile16 = (a.T + kCtP - 1) / kCtP;
+    static const int old = [] { const char* v = getenv("DFM_CT_OLD"); return v ? atoi(v) : 0; }();     // A/B: the round-2 kernel
+    if (!old) {
+        note_kernel("ct_miss_wide2_kernel");
+        const size_t lds2 = (((size_t)3 * 2 * 8 * 1088 + (size_t)w.npad * sizeof(unsigned short) + 16 + 15) & ~(size_t)15)
+                            + (size_t)kCtP * (kW2R * (kW2R + 1) / 2) * sizeof(double);      // stage buffers | masks | [16][528] output tiles
+        static LdsOptIn attr_ct;
+        if (!attr_ct) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_ct = true;
+        }
+        hipLaunchKernelGGL(ct_miss_wide2_kernel, dim3((unsigned)((long long)a.B * ntile16)), dim3(kCtThreads), lds2, s, a, w.W, ntile16,
+                           r > 0 && r <= kW2R ? r : kW2R);
+        return hipGetLastError();
+    }
+    note_kernel("ct_miss_wide_kernel");
     const size_t lds = (size_t)2 * kW2Chunk * kW2R * sizeof(double) + (size_t)w.npad * sizeof(unsigned short) + 16;
     hipLaunchKernelGGL(ct_miss_wide_kernel, dim3((unsigned)((long long)a.B * ntile16)), dim3(kCtThreads), lds, s, a, w.W, ntile16);
     return hipGetLastError();

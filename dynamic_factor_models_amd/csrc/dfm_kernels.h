@@ -133,7 +133,7 @@ size_t collapse_wide2_ws_bytes(int B, int N, int Rpad);    // W [B][N][Rp] | 1 /
 hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s);
 hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s);
 // a.nobs != nullptr selects the variant for panels with missing cells (per-period scol / nobs / ldrow); their C_t:
-hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, hipStream_t s);
+hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s);   // r: the caller's factor count
 bool gram_supported(int Rpad, int N);       // launch_gram's register tilings
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
 hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
