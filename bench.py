@@ -287,12 +287,18 @@ class Workload:
     def run(self, steps, warmup, repeats, preheat_ms=PREHEAT_MS):
         torch, dist = self.torch, self.dist
         # pre-heat: the same steps, untimed, until >= preheat_ms of device time have passed (DVFS ramp of a fresh box)
+        # (every rank decides by its OWN clock how long it pre-heats, so the pre-heat steps must not contain a collective:
+        # the pass and the PCA start run without their all-gather here; the EM driver's iterations end in one, so a
+        # multi-rank EM job pre-heats a fixed number of iterations instead)
         self.fence()
         t0 = time.perf_counter()
         heat = 0
-        while (time.perf_counter() - t0) * 1e3 < preheat_ms:
-            self.steps(max(2, steps // 4)); heat += max(2, steps // 4)
-            torch.cuda.synchronize()
+        if self.distributed and self.mode == "em":
+            self.steps(2 * steps); heat = 2 * steps
+        else:
+            while (time.perf_counter() - t0) * 1e3 < preheat_ms:
+                self.steps(max(2, steps // 4), profile=True); heat += max(2, steps // 4)
+                torch.cuda.synchronize()
         self.steps(max(warmup, 1) if self.mode == "em" else warmup)
         blocks = []
         for _ in range(max(repeats, 1)):
@@ -502,9 +508,9 @@ def main():
     # clocks / power while the bench batch runs: enqueue ~0.5 s of steps, read rocm-smi meanwhile (rank 0)
     telemetry = None
     if rank == 0:
-        n = int(min(4000, max(50, 500.0 / max(res["ms_per_step"], 1e-3)))) if args.mode != "em" else args.steps
-        wl.steps(n, profile=True)
-        telemetry = device_telemetry()
+        if args.mode != "em":                                     # (no collective in these steps: rank 0 may run them alone)
+            wl.steps(int(min(4000, max(50, 500.0 / max(res["ms_per_step"], 1e-3)))), profile=True)
+        telemetry = device_telemetry()                            # (EM mode: read right behind the timed blocks)
         torch.cuda.synchronize()
     ceiling = None
     if rank == 0 and world == 1:
