@@ -131,6 +131,30 @@ def spawn_ranks(gpus: int, argv):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner with C stdio on STDOUT when its first communicator is created -- buffered, so it lands
+    BEHIND the JSON line at exit and the driver (one JSON line on stdout) would read the banner.  While a communicator is
+    being created, file descriptor 1 points at stderr; C stdio is flushed before it is pointed back."""
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 def host_cpu_info():
     """Cores this process may really use: affinity mask and the cgroup CPU quota (the box shows 256 cores, the container
     may own fewer: an "all cores" figure measured on more threads than that is an oversubscription artefact)."""
@@ -417,7 +441,8 @@ def run_lib_driver(args, torch):
     """--driver lib: ONE process, the library's dfm_multi object over --gpus N devices (what the Julia host binds)."""
     from dynamic_factor_models_amd import DfmMulti
     G, B, N, T, r = args.gpus, args.batch_per_gpu, args.N, args.T, args.r
-    m = DfmMulti(G, force_comm=args.force_comm)
+    with stdout_to_stderr():                                      # (ncclCommInitAll prints RCCL's banner on stdout)
+        m = DfmMulti(G, force_comm=args.force_comm)
     try:
         m.synth(20160415, 0, G * B, T, N, r, missing_prob=args.missing, pca_start=(args.mode == "em" and args.missing == 0.0))
         may = args.missing > 0.0
@@ -504,7 +529,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        with stdout_to_stderr():                                  # (RCCL's banner goes to stderr, not in front of / behind the JSON line)
+            dist.init_process_group(backend="nccl", device_id=dev)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                                # creates the communicator now
+            torch.cuda.synchronize()
         world = dist.get_world_size()                             # n_gpus in the line is what the job really has
         if world != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {world} ranks")

@@ -49,7 +49,7 @@ for f in bench bench_lib_em bench_lib_em_comm bench_lib_em_b8192 bench_em_b8192 
   [ -f $OUT/$f.json ] && python - $OUT/$f.json <<'PY'
 import json, sys
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    d = json.loads([l for l in open(sys.argv[1]).read().strip().splitlines() if l.startswith("{")][-1])
     r = d["roofline"]
     print(sys.argv[1].split("/")[-1], "value=%.4g %s ms=%.4f" % (d["value"], d["unit"], d["ms_per_step"]), d["timing"].get("ms_per_step_blocks"),
           "dom=%s frac=%s whole=%s" % (r.get("kernel"), r.get("frac"), (r.get("whole_step") or {}).get("frac")), r.get("kernels_ms"), "ceiling=", r.get("ceiling_measured"),

@@ -70,3 +70,18 @@ def test_algorithmic_bytes_and_kernel_table():
         assert k in tab                                                       # the names rocprofv3 prints
     info = bench.host_cpu_info()
     assert info["usable"] >= 1
+
+
+def test_the_json_line_is_alone_on_stdout_when_a_library_prints_with_c_stdio():
+    """RCCL prints a version banner on stdout (C stdio, buffered: it would land BEHIND the JSON line at exit).  While a
+    communicator is created bench.py points fd 1 at stderr and flushes C stdio before pointing it back."""
+    code = (
+        "import sys, ctypes\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "libc = ctypes.CDLL(None)\n"
+        "with bench.stdout_to_stderr():\n"
+        "    libc.printf(b'RCCL version : banner\\n')\n"
+        "print('{\"metric\": 1}', flush=True)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.stdout == '{"metric": 1}\n' and "banner" in r.stderr
