@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""A/B of two DFM_SCAN_ABL settings of the one-launch pass INSIDE one process on the same buffers (processes of this pool
+differ by +-3 % on identical code -- physical placement of the 819 MB panel -- so cross-process A/B needs many repeats).
+Usage: python scripts/dbg/inproc_ab.py <ablA> <ablB> [B]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from dynamic_factor_models_amd import DfmContext
+A, Bv = sys.argv[1], sys.argv[2]
+Brep = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+ctxs = []
+for v in (A, Bv):
+    os.environ["DFM_SCAN_ABL"] = v
+    ctxs.append(DfmContext(0))
+panel, par = ctxs[0].synth_panels(20160415, 0, Brep, 500, 200, 8)
+dev = panel.device
+f = torch.empty((Brep, 500, 8), dtype=torch.float64, device=dev); P = torch.empty((Brep, 500, 36), dtype=torch.float64, device=dev)
+ll = torch.empty((Brep,), dtype=torch.float64, device=dev)
+K = 200 if Brep <= 1024 else 30
+def run(c, k):
+    for _ in range(k):
+        c.ks_pass_batch(panel, *par, may_have_missing=False, out=(f, P, ll))
+for c in ctxs:
+    run(c, K); torch.cuda.synchronize()
+res = {0: [], 1: []}
+for rnd in range(8):
+    for i, c in enumerate(ctxs):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(c, K); torch.cuda.synchronize()
+        res[i].append((time.perf_counter() - t0) / K * 1e3)
+for i, v in enumerate((A, Bv)):
+    r = sorted(res[i])
+    print(f"DFM_SCAN_ABL={v:>6}: median {r[len(r)//2]:.5f} ms  min {r[0]:.5f}  max {r[-1]:.5f}  -> {Brep / r[len(r)//2] * 1e3 / 1e6:.3f} M passes/s   all {[round(x, 4) for x in res[i]]}")
