@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """A/B of two DFM_SCAN_ABL settings of the one-launch pass INSIDE one process on the same buffers (processes of this pool
 differ by +-3 % on identical code -- physical placement of the 819 MB panel -- so cross-process A/B needs many repeats).
-Usage: python scripts/dbg/inproc_ab.py <ablA> <ablB> [B]"""
+Usage: python scripts/dbg/inproc_ab.py <A> <B> [batch]   with A, B = a DFM_SCAN_ABL value or "ENV=VAL,ENV=VAL" """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -10,8 +10,15 @@ from dynamic_factor_models_amd import DfmContext
 A, Bv = sys.argv[1], sys.argv[2]
 Brep = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 ctxs = []
+KNOBS = ("DFM_SCAN_ABL", "DFM_PASS_NSW", "DFM_PASS_NCOV", "DFM_PASS_FUSED", "DFM_NUM_CU")
 for v in (A, Bv):
-    os.environ["DFM_SCAN_ABL"] = v
+    for k in KNOBS:
+        os.environ.pop(k, None)
+    if "=" in v:
+        for kv in v.split(","):
+            k, x = kv.split("="); os.environ[k] = x
+    else:
+        os.environ["DFM_SCAN_ABL"] = v
     ctxs.append(DfmContext(0))
 panel, par = ctxs[0].synth_panels(20160415, 0, Brep, 500, 200, 8)
 dev = panel.device
@@ -31,4 +38,4 @@ for rnd in range(8):
         res[i].append((time.perf_counter() - t0) / K * 1e3)
 for i, v in enumerate((A, Bv)):
     r = sorted(res[i])
-    print(f"DFM_SCAN_ABL={v:>6}: median {r[len(r)//2]:.5f} ms  min {r[0]:.5f}  max {r[-1]:.5f}  -> {Brep / r[len(r)//2] * 1e3 / 1e6:.3f} M passes/s   all {[round(x, 4) for x in res[i]]}")
+    print(f"{v:>22}: median {r[len(r)//2]:.5f} ms  min {r[0]:.5f}  max {r[-1]:.5f}  -> {Brep / r[len(r)//2] * 1e3 / 1e6:.3f} M passes/s   all {[round(x, 4) for x in res[i]]}")

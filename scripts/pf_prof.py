@@ -44,6 +44,19 @@ print("per stream wave: segment duration (us) / end relative to wave 0's end")
 for w in range(nsw):
     dur = s[:, 24 + w] - s[:, 32 + w]; rel = s[:, 24 + w] - s[:, 24]
     print(f"  wave {w}: duration mean {dur.mean():6.2f} p10 {np.percentile(dur, 10):6.2f} p90 {np.percentile(dur, 90):6.2f}   end - end(w0) mean {rel.mean():6.2f}   start - start(w0) {(s[:, 32 + w] - s[:, 32]).mean():6.2f}")
+# per workgroup (replicates b % ncu): when its last scan ended, when its first covariance chain ended, its stream's total
+wg = b % ncu
+fin = np.array([s[wg == g, 22].max() - t0 for g in range(ncu)])
+cov0 = np.array([s[(wg == g) & (b // ncu == 0), 8].max() - t0 for g in range(ncu)])
+str_end = np.array([s[wg == g, 3].max() - t0 for g in range(ncu)])
+pc = lambda v: " ".join(f"{np.percentile(v, q):7.1f}" for q in (0, 10, 50, 90, 99, 100))
+print("per workgroup (us; min p10 p50 p90 p99 max):")
+print("  last scan end      ", pc(fin))
+print("  last stream end    ", pc(str_end))
+print("  first cov chain end", pc(cov0))
+slow = np.argsort(fin)[-8:]
+print("  slowest workgroups :", [(int(g), round(float(fin[g]), 1), round(float(cov0[g]), 1)) for g in slow], "(id, last scan end, first cov end)")
+print("  XCD (id % 8) of the 32 slowest:", sorted(int(g) % 8 for g in np.argsort(fin)[-32:]))
 for rnd in range(min(8, (B + ncu - 1) // ncu)):
     sel = (b // ncu) == rnd
     print(f"round {rnd}: stream start {s[sel, 0].mean() - t0:7.1f}  buffer free {s[sel, 1].mean() - t0:7.1f}  stream end {s[sel, 3].mean() - t0:7.1f}"
