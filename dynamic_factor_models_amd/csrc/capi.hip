@@ -418,7 +418,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
             if (FILE* fp = fopen(h->prof_file.c_str(), "w")) {
                 for (int bb = 0; bb < B; ++bb) {
                     fprintf(fp, "%d", bb);
-                    for (int k = 0; k < 40; ++k) fprintf(fp, " %.0f", st[(size_t)bb * T + k]);
+                    for (int k = 0; k < 56; ++k) fprintf(fp, " %.0f", st[(size_t)bb * T + k]);
                     fprintf(fp, "\n");
                 }
                 fclose(fp);

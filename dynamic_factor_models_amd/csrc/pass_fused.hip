@@ -565,7 +565,7 @@ __device__ __forceinline__ void scan_reg(const FastArgs& a, int b, int tid, cons
 // ------------------------------------------------------------------------------------------------------------------
 template <int STEPS, int NQ>
 __device__ __forceinline__ double gram_mfma8(const double* __restrict__ Lg, const double* __restrict__ Rg, int N, int lane,
-                                             double* Cs) {
+                                             double* Cs, double* tstamp = nullptr) {
     constexpr int R = 8, CS = 8;
     const int K = lane >> 4, blk = (lane >> 2) & 3, q = lane & 3;
     const int g = blk >> 1, h = blk & 1;
@@ -592,6 +592,10 @@ __device__ __forceinline__ double gram_mfma8(const double* __restrict__ Lg, cons
     // every load is in flight before anything is consumed: under register pressure the scheduler otherwise pairs each load
     // with its use (a full round trip per step -- 5 to 8 us each beside the streaming waves)
     __builtin_amdgcn_sched_barrier(0);
+    if (tstamp) {                                                // diagnostics: when the batch of loads has landed
+        wait_vmf<0>();
+        if (lane == 0) *tstamp = (double)__builtin_amdgcn_s_memrealtime();
+    }
     double ld = 0.0;
 #pragma unroll
     for (int jq = 0; jq < NQ; ++jq)
@@ -648,6 +652,14 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
     auto stamp = [&](int bb, int slot) {
         if (prof && lane == 0) a.scol[(size_t)bb * T + slot] = (double)__builtin_amdgcn_s_memrealtime();
     };
+
+    // (diagnostics) where the hardware put this wave: HW_REG_HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SE [15:13])
+    if (prof) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        for (int bb = (int)blockIdx.x; bb < B; bb += G) {
+            if (lane == 0) a.scol[(size_t)bb * T + 40 + wave] = (double)hw;
+        }
+    }
 
     if (wave < nsw) {
         // ================= STREAM: segment [ta, tb) of every replicate -> bt[buf][t][0..7], ssum[buf][wave] ==========
@@ -881,7 +893,8 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
         __builtin_amdgcn_s_setprio(2);
         for (int b = (int)blockIdx.x + cw * G; b < B; b += ncov * G) {
             stamp(b, 6);
-            const double ld = gram_mfma8<STEPS, NDR>(fa.Lam + (size_t)b * N * R, fa.Rv + (size_t)b * N, N, lane, Cs);
+            const double ld = gram_mfma8<STEPS, NDR>(fa.Lam + (size_t)b * N * R, fa.Rv + (size_t)b * N, N, lane, Cs,
+                                                     prof ? a.scol + (size_t)b * T + 36 : nullptr);
             wave_lds_sync();
             const double Cel = 0.5 * (Cs[lane] + Cs[(lane & 7) * 8 + (lane >> 3)]);   // exactly symmetric
             wave_lds_sync();

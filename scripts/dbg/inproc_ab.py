@@ -1,17 +1,17 @@
 #!/usr/bin/env python
 """A/B of two DFM_SCAN_ABL settings of the one-launch pass INSIDE one process on the same buffers (processes of this pool
 differ by +-3 % on identical code -- physical placement of the 819 MB panel -- so cross-process A/B needs many repeats).
-Usage: python scripts/dbg/inproc_ab.py <A> <B> [batch]   with A, B = a DFM_SCAN_ABL value or "ENV=VAL,ENV=VAL" """
+Usage: python scripts/dbg/inproc_ab.py <A> <B> [<C> ...] [batch=N]   with A, B, ... = a DFM_SCAN_ABL value or "ENV=VAL,ENV=VAL" """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from dynamic_factor_models_amd import DfmContext
-A, Bv = sys.argv[1], sys.argv[2]
-Brep = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+VARS = [a for a in sys.argv[1:] if not a.startswith("batch=")]
+Brep = ([int(a[6:]) for a in sys.argv[1:] if a.startswith("batch=")] or [1024])[0]
 ctxs = []
 KNOBS = ("DFM_SCAN_ABL", "DFM_PASS_NSW", "DFM_PASS_NCOV", "DFM_PASS_FUSED", "DFM_NUM_CU")
-for v in (A, Bv):
+for v in VARS:
     for k in KNOBS:
         os.environ.pop(k, None)
     if "=" in v:
@@ -30,12 +30,12 @@ def run(c, k):
         c.ks_pass_batch(panel, *par, may_have_missing=False, out=(f, P, ll))
 for c in ctxs:
     run(c, K); torch.cuda.synchronize()
-res = {0: [], 1: []}
+res = {i: [] for i in range(len(VARS))}
 for rnd in range(8):
     for i, c in enumerate(ctxs):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         run(c, K); torch.cuda.synchronize()
         res[i].append((time.perf_counter() - t0) / K * 1e3)
-for i, v in enumerate((A, Bv)):
+for i, v in enumerate(VARS):
     r = sorted(res[i])
     print(f"{v:>22}: median {r[len(r)//2]:.5f} ms  min {r[0]:.5f}  max {r[-1]:.5f}  -> {Brep / r[len(r)//2] * 1e3 / 1e6:.3f} M passes/s   all {[round(x, 4) for x in res[i]]}")

@@ -17,7 +17,14 @@ from dynamic_factor_models_amd import DfmContext
 B = int(os.environ.get("B", 1024))
 c = DfmContext(0)
 panel, par = c.synth_panels(1, 0, B, 500, 200, 8)
+# PF_POLLUTE=1: a pass of another shape (another 105 KB instantiation of the kernel) before every profiled pass -- the
+# instruction cache starts cold, as it does at EVERY launch on the boxes with host kernel 6.18.50 (scripts/microbench/icache.hip)
+pollute = os.environ.get("PF_POLLUTE", "0") == "1"
+if pollute:
+    panel2, par2 = c.synth_panels(2, 0, B, 500, 208, 8)
 for _ in range(3):
+    if pollute:
+        c.ks_pass_batch(panel2, *par2, may_have_missing=False)
     c.ks_pass_batch(panel, *par, may_have_missing=False)
 torch.cuda.synchronize()
 d = np.loadtxt("/tmp/pf_prof.txt")
@@ -30,6 +37,12 @@ for name, a, z in [("stream: wait buffer", 0, 1), ("stream: wave 0 segment", 1, 
                    ("scan: compute", 12, 22), ("replicate: start -> scan end", 0, 22)]:
     v = s[:, z] - s[:, a]
     print(f"{name:30s} mean {v.mean():7.2f}  p10 {np.percentile(v, 10):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f}")
+# the covariance wave's Gram step: one batch of 54 global loads, then 4 log() and 50 MFMAs -- per round of the workgroup's
+# covariance waves (round 0 = the chain everything behind it waits for; code cold at launch on some boxes)
+for rnd in range(2):
+    sel = (b // (2 * ncu)) == rnd
+    if sel.any():
+        print(f"cov round {rnd}: gram loads {(s[sel, 36] - s[sel, 6]).mean():6.2f}  gram compute {(s[sel, 7] - s[sel, 36]).mean():6.2f}  recursion {(s[sel, 8] - s[sel, 7]).mean():6.2f}")
 names = ["sync + fwd transient", "fwd phase 1", "fwd carry scan", "fwd phase 3", "terminal + bwd phase 1", "bwd carry scan", "bwd phase 3",
          "bwd transient", "loglik + release"]
 prev = 12
@@ -57,6 +70,15 @@ print("  first cov chain end", pc(cov0))
 slow = np.argsort(fin)[-8:]
 print("  slowest workgroups :", [(int(g), round(float(fin[g]), 1), round(float(cov0[g]), 1)) for g in slow], "(id, last scan end, first cov end)")
 print("  XCD (id % 8) of the 32 slowest:", sorted(int(g) % 8 for g in np.argsort(fin)[-32:]))
+# where the hardware put the 11 waves of a workgroup: SIMD of each role (stream x4, cov x2, mover, scan x4)
+hw = np.rint(d[:ncu, 41:52]).astype(np.int64)
+simd = (hw >> 4) & 3
+from collections import Counter
+pat = Counter("".join(str(int(v)) for v in row) for row in simd)
+print("wave -> SIMD patterns (waves 0..10 = 4 stream, 2 cov, mover, 4 scan):", pat.most_common(6))
+cu = (hw[:, 0] >> 8) & 15; se = (hw[:, 0] >> 13) & 7
+print("distinct (SE, CU) of the workgroups:", len(set(zip(se.tolist(), cu.tolist()))), " same-CU for all waves of a WG:",
+      bool(np.all(((hw >> 8) & 15) == cu[:, None])))
 for rnd in range(min(8, (B + ncu - 1) // ncu)):
     sel = (b // ncu) == rnd
     print(f"round {rnd}: stream start {s[sel, 0].mean() - t0:7.1f}  buffer free {s[sel, 1].mean() - t0:7.1f}  stream end {s[sel, 3].mean() - t0:7.1f}"
