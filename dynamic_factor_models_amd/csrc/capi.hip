@@ -115,6 +115,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t f_tab, f_E, f_stead, f_xi0, f_PT, f_llc, f_fill, f_PsInf, f_ssum;
     size_t ms_ws = (size_t)-1; int ms_wpr = 0;   // mstep_mfma partial sums (EM on the fast path)
     size_t mw_ws = (size_t)-1;                     // mstep_wide: Sxf, Sxx of the Rp = 32 loadings step (EM on the fast path)
+    size_t mm_ws = (size_t)-1;                     // mstep_miss: V, [D | Sxf], Sxx, counts of the loadings step with missing cells
     size_t Wwide = (size_t)-1;                     // W = lam / R of the Rp = 32 collapse (collapse_wide2.hip)
     bool fast;
     // covariance-form recursion (DFM_F_SINGULAR_Q) and companion states (dfm_*_varp_*): see RecursionArgs
@@ -131,6 +132,9 @@ size_t take(size_t& off, size_t bytes) {
 // Sequential path with r <= 4: the state is padded to 8 so that the one-wave-per-replicate recursion (recursion_wave.hip)
 // applies; collapse, loadings and the loadings M-step stay pad_r(r) wide (Plan::Rc).  DFM_NO_RECURSION_WAVE=1 turns it off.
 bool g_widen_small_r = true;
+// Loadings step with missing cells on the matrix pipe (mstep_miss.hip).  DFM_MSTEP_MISS: 0 = never (mstep_lam_kernel),
+// 1 = where mstep_lam_kernel keeps its per-series accumulators in global memory (Rp > 8 or N > 256; default), 2 = wherever supported.
+int g_mstep_miss_mode = 1;
 
 Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = false) {
     Plan p;
@@ -200,6 +204,10 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
             p.ms_ws = take(off, mstep_mfma_workspace(B, N, Rp, w));
         }
         if (fast && mstep_wide_supported(Rp, N)) p.mw_ws = take(off, mstep_wide_workspace(B, N, Rp));
+        // (sized for loadings as wide as the state: companion models narrow them after the plan is made)
+        if (!fast && g_mstep_miss_mode && mstep_miss_supported(Rp, r < Rp ? r : Rp, N) &&
+            (g_mstep_miss_mode == 2 || mstep_needs_dmiss(Rp, N)))
+            p.mm_ws = take(off, mstep_miss_workspace(B, T, N, Rp, r < Rp ? r : Rp));
     }
     p.total = off;
     return p;
@@ -590,6 +598,15 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
         ProfScope ps(h, K_MSTEP_MFMA);
         HIP_TRY(h, launch_mstep_wide(ma, at<double>(h, p.mw_ws), Rp, p.r, h->num_cu, h->stream));
         return 0;
+    }
+    {
+        // panels with missing cells: both contractions of the loadings step as one product per replicate on the matrix pipe
+        const int rl = p.Rc ? (p.rl ? p.rl : Rp) : (p.r < Rp ? p.r : Rp);     // the loadings' factor count
+        if (p.mm_ws != (size_t)-1 && mstep_miss_supported(Rp, rl, N) && (g_mstep_miss_mode == 2 || mstep_needs_dmiss(Rp, N))) {
+            ProfScope ps(h, K_MSTEP_STATS);
+            HIP_TRY(h, launch_mstep_miss(ma, at<double>(h, p.mm_ws), Rp, rl, h->num_cu, h->stream));
+            return 0;
+        }
     }
     if (ma.Dmiss)
         HIP_TRY(h, hipMemsetAsync(ma.Dmiss, 0, (size_t)B * N * (Rp * (Rp + 1) / 2) * sizeof(double), h->stream));
@@ -1043,6 +1060,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = getenv("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
     if (const char* v = getenv("DFM_SUBBATCH")) h->subbatch = atoi(v);
     if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
+    if (const char* v = getenv("DFM_MSTEP_MISS")) g_mstep_miss_mode = atoi(v);
     if (const char* v = getenv("DFM_PASS_FUSED")) h->pass_fused = atoi(v);
     if (const char* v = getenv("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
     if (const char* v = getenv("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);

@@ -101,6 +101,11 @@ struct MstepArgs {
 bool mstep_wide_supported(int Rpad, int N);
 size_t mstep_wide_workspace(int B, int N, int Rpad);
 hipError_t launch_mstep_wide(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s);
+// panels with missing cells, Rp = 8 | 16 | 32 (even N): D_i = sum over the series' missing periods of vec(E[f f']) and Sxf_i as one
+// product per replicate on the matrix pipe, then a per-series Cholesky solve (mstep_miss.hip); r = the loadings' factor count
+bool mstep_miss_supported(int Rpad, int r, int N);
+size_t mstep_miss_workspace(int B, int T, int N, int Rpad, int r);
+hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s);
 hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
 // the same contract on the LDS-DMA ring + matrix pipe (collapse_miss.hip): Rp = 8, the shapes of the MFMA collapse
 bool collapse_miss_supported(int Rpad, int N);

@@ -1,0 +1,361 @@
+// mstep_miss.hip -- the loadings half of the M-step for panels WITH missing cells on the f64 matrix pipe
+// (Banbura & Modugno 2014; reference counterpart: the per-series OLS over each series' complete cases,
+// dfm_functions.ipynb:355-362 and :391-404).
+//
+//   per series i, with m_it = 1 where x_it is missing and xz_it = x_it with NaN -> 0:
+//     D_i   = sum_t m_it vec(E_t)        E_t = f_t|T f_t|T' + P_t|T (packed lower, r (r + 1) / 2 values)
+//     Sxf_i = sum_t xz_it f_t|T          Sxx_i = sum_t xz_it^2        n_i = sum_t (1 - m_it)
+//     Sff_i = S11 - D_i,  lam_i = Sff_i^-1 Sxf_i,  R_i = (Sxx_i - lam_i' Sxf_i) / n_i
+//
+// mstep_lam_kernel (mstep.hip: lane = series) adds vec(E_t) into a per-series accumulator for every missing cell -- 528
+// uncoalesced read-modify-writes of global memory per cell at Rp = 32: 337 ms per EM iteration at BASELINE config 4 with 10 %
+// of the cells missing.  Here both contractions are ONE product per replicate,
+//     [D | Sxf] (N x (np + r))  =  [M | XZ]' (N x T, two A operands from the same panel element)  x  V (T x (np + r)),
+// V_t = [vec(E_t) | f_t] written once per iteration by mmw_vec_kernel (it is read back from L2 by the 8 series blocks of a
+// replicate, which run on the same XCD at the same pace), on `v_mfma_f64_16x16x4`:
+//   * an item = (replicate, block of 16 SG series); workgroups of 8 waves, wave = (series group sg, column group cg), holding
+//     its 16 x 16 accumulator tiles in registers for the whole item (r = 20: 14 tiles of D + 2 of Sxf = 64 doubles per lane);
+//   * the item streams through LDS in stages of 8 periods, three stage buffers, all by `global_load_lds_dwordx4` with a
+//     counted `s_waitcnt vmcnt` (every wave issues the same number of DMAs per stage); rows 128 bytes (mod 256) apart;
+//   * the mask costs nothing extra: it is the A operand (1.0 | 0.0) of the D tiles, as xz is the A operand of the Sxf tiles.
+// mmw_finish_kernel (thread = series, its packed Sff in a conflict-free LDS column) then solves by Cholesky.
+// Flops at config 4: 2 x 256 x 1000 x 2000 x 256 = 2.6e11 = 3.3 ms at the fp64 matrix peak.
+#include <stdlib.h>
+
+#include "dfm_device.h"
+#include "dfm_kernels.h"
+
+namespace dfm {
+
+namespace {
+
+using lds_char_ptr_mm = __attribute__((address_space(3))) char*;
+using lds_cvd_ptr_mm = const volatile __attribute__((address_space(3))) double*;
+__device__ __forceinline__ double lds_read64mm(unsigned a) { return *(lds_cvd_ptr_mm)(size_t)a; }
+typedef double mm_v4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void dma16mm(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+constexpr int kMmKP = 8;                                 // periods per stage
+constexpr int kMmNBuf = 3;
+constexpr int kMmWaves = 8;
+
+struct MmGeo {
+    int r, Rp, npr;                                      // caller's factor count, padded width, r (r + 1) / 2
+    int ntm, ntf, tt;                                    // tiles of D, of Sxf, total (16 columns each)
+    int cg, sg, ser;                                     // column groups, series groups, series per item
+    int tpw;                                             // tiles per wave (upper bound; the last column group may hold fewer)
+    int nv;                                              // 1-KB DMAs per row of V
+    unsigned vrowB, vstride, pstride, panelB, stageB;    // bytes: a row of V, its LDS stride, panel row stride, panel block, stage
+    int U;                                               // DMAs per wave and stage
+};
+
+MmGeo mm_geo(int Rp, int r) {
+    MmGeo g;
+    g.r = r; g.Rp = Rp; g.npr = r * (r + 1) / 2;
+    g.ntm = (g.npr + 15) / 16;
+    g.ntf = (Rp + 15) / 16;
+    g.tt = g.ntm + g.ntf;
+    g.cg = g.tt > 21 ? 2 : 1;
+    g.sg = kMmWaves / g.cg;
+    g.ser = 16 * g.sg;
+    g.tpw = (g.tt + g.cg - 1) / g.cg;
+    g.vrowB = (unsigned)g.tt * 128u;
+    g.nv = (int)((g.vrowB + 1023u) / 1024u);
+    g.vstride = g.vrowB + ((g.tt & 1) ? 0u : 128u);      // = 128 (mod 256): the four periods of a step on distinct banks
+    g.pstride = (unsigned)g.ser * 8u + 128u;
+    g.panelB = kMmKP * g.pstride;
+    g.stageB = g.panelB + kMmKP * g.vstride;
+    g.U = (kMmKP * (1 + g.nv) + kMmWaves - 1) / kMmWaves;
+    return g;
+}
+
+}  // namespace
+
+// V[b][t][0 .. 16 ntm) = vec(E_t) (npr values, then zeros), V[b][t][16 ntm .. 16 tt) = f_t (Rp values, then zeros)
+__global__ __launch_bounds__(256) void mmw_vec_kernel(MstepArgs a, double* __restrict__ V, int r, int Rp, int ntm16, int tt16) {
+    const int b = blockIdx.x;
+    if (a.active && !a.active[b]) return;
+    const int T = a.T, npr = r * (r + 1) / 2, npp = Rp * (Rp + 1) / 2;
+    const int t0 = (int)blockIdx.y * 16;
+    __shared__ double fs[16][32];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 16 * Rp; e += 256) {
+        const int u = e / Rp, k = e % Rp, t = t0 + u;
+        fs[u][k] = t < T ? a.fsm[((size_t)b * T + t) * Rp + k] : 0.0;
+    }
+    __syncthreads();
+    for (int c = tid; c < tt16; c += 256) {
+        int i = 0, j = 0, kind = 0;                      // 0: zero, 1: E_ij, 2: f_i
+        if (c < npr) {
+            while ((i + 1) * (i + 2) / 2 <= c) ++i;
+            j = c - i * (i + 1) / 2;
+            kind = 1;
+        } else if (c >= ntm16 && c - ntm16 < Rp) {
+            i = c - ntm16;
+            kind = 2;
+        }
+        for (int u = 0; u < 16; ++u) {
+            const int t = t0 + u;
+            if (t >= T) break;
+            double v = 0.0;
+            if (kind == 1) v = fma(fs[u][i], fs[u][j], a.Psm[((size_t)b * T + t) * npp + c]);
+            else if (kind == 2) v = fs[u][i];
+            V[((size_t)b * T + t) * tt16 + c] = v;
+        }
+    }
+}
+
+// OUT[b][series][16 tt]: D (16 ntm columns) then Sxf (16 ntf columns); sxx, cnt [b][series]
+template <int TPW, int U>
+__global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, const double* __restrict__ V, double* __restrict__ OUT,
+                                                                  double* __restrict__ sxx, double* __restrict__ cnt, MmGeo g, int nsb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, T = a.T, B = a.B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sgi = wave % g.sg, cgi = wave / g.sg;
+    const int tile0 = cgi * g.tpw;
+    const int ntile = (g.tt - tile0 < g.tpw) ? g.tt - tile0 : g.tpw;   // tiles of this wave
+    const int k4 = lane >> 4, c16 = lane & 15;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_mm)(smem));
+    const int nst = (T + kMmKP - 1) / kMmKP;
+    const int tt16 = g.tt * 16;
+    const int ND = kMmKP * (1 + g.nv);
+    // items: XCD x (= blockIdx.x & 7 under the round-robin dispatch) owns the replicates b = x (mod 8); its workgroups take
+    // (replicate, series block) pairs in order, so the blocks of a replicate run side by side on one L2
+    // (small batches: plain round robin over all workgroups)
+    const bool xmap = B >= 16;
+    const int xcd = xmap ? (int)blockIdx.x & 7 : 0, slot = xmap ? (int)blockIdx.x >> 3 : (int)blockIdx.x;
+    const int nslot = xmap ? (int)gridDim.x >> 3 : (int)gridDim.x, xstep = xmap ? 8 : 1;
+    const int nrep_x = xmap ? (B - xcd + 7) / 8 : B;
+
+    // no NaN bit patterns in LDS bytes no DMA writes (columns of a partial series block)
+    for (int e = tid; e < (int)(kMmNBuf * g.stageB / 8); e += 64 * kMmWaves) reinterpret_cast<double*>(smem)[e] = 0.0;
+    __syncthreads();
+
+    for (int q = slot; q < nrep_x * nsb; q += nslot) {
+        const int b = xcd + xstep * (q / nsb), sb = q % nsb;
+        if (a.active && !a.active[b]) continue;
+        const int s0 = sb * g.ser;
+        const char* Xb = reinterpret_cast<const char*>(a.panel + (size_t)b * T * N);
+        const char* Vb = reinterpret_cast<const char*>(V + (size_t)b * T * tt16);
+        auto issue_stage = [&](int st, int bsel) {
+            const unsigned sbase = lds0 + (unsigned)bsel * g.stageB;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int d = wave + kMmWaves * u;
+                d = d < ND ? d : ND - 1;                          // (a duplicate of the last DMA keeps the count equal)
+                const int per = d / (1 + g.nv), piece = d % (1 + g.nv);
+                int t = st * kMmKP + per;
+                t = t < T ? t : T - 1;
+                if (piece == 0) {
+                    const int ser = s0 + 2 * lane;
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + (unsigned)per * g.pstride);
+                    if (2 * lane < g.ser && ser < N) dma16mm(Xb + ((size_t)t * N + ser) * 8, dst);
+                } else {
+                    const unsigned o = 1024u * (unsigned)(piece - 1) + 16u * (unsigned)lane;
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + g.panelB + (unsigned)per * g.vstride + 1024u * (unsigned)(piece - 1));
+                    if (o < g.vrowB) dma16mm(Vb + (size_t)t * g.vrowB + o, dst);
+                }
+            }
+        };
+        mm_v4 acc[TPW];
+#pragma unroll
+        for (int x = 0; x < TPW; ++x) acc[x] = mm_v4{0.0, 0.0, 0.0, 0.0};
+        double qs = 0.0, nc = 0.0;
+        const bool ser_ok = s0 + 16 * sgi + c16 < N;
+        const unsigned a_off = (unsigned)k4 * g.pstride + (unsigned)(16 * sgi + c16) * 8u;
+        const unsigned b_off = g.panelB + (unsigned)k4 * g.vstride + (unsigned)(16 * tile0 + c16) * 8u;
+
+        issue_stage(0, 0);
+        if (nst > 1) issue_stage(1, 1);
+        int bsel = 0;
+        for (int st = 0; st < nst; ++st) {
+            if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (st + 2 < nst) issue_stage(st + 2, bsel == 0 ? 2 : bsel - 1);
+            const unsigned stg = lds0 + (unsigned)bsel * g.stageB;
+#pragma unroll
+            for (int s = 0; s < kMmKP / 4; ++s) {
+                const double xr = lds_read64mm(stg + a_off + (unsigned)s * 4u * g.pstride);
+                const bool valid = ser_ok && (st * kMmKP + 4 * s + k4 < T);
+                const bool ok = xr == xr;
+                const double m = (valid && !ok) ? 1.0 : 0.0;
+                const double xz = (valid && ok) ? xr : 0.0;
+#pragma unroll
+                for (int x = 0; x < TPW; ++x) {
+                    if (x < ntile) {
+                        const double bv = lds_read64mm(stg + b_off + (unsigned)s * 4u * g.vstride + 128u * (unsigned)x);
+                        const double av = (tile0 + x < g.ntm) ? m : xz;
+                        acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[x], 0, 0, 0);
+                    }
+                }
+                qs = fma(xz, xz, qs);
+                nc += (valid && ok) ? 1.0 : 0.0;
+            }
+            bsel = bsel == 2 ? 0 : bsel + 1;
+        }
+        // the item is complete: 16x16x4 D[(l / 16) + 4 v][l % 16] -> series k4 + 4 v of the group, column c16 of the tile
+        double* out = OUT + ((size_t)b * N + s0 + 16 * sgi) * tt16 + 16 * tile0 + c16;
+#pragma unroll
+        for (int x = 0; x < TPW; ++x) {
+            if (x < ntile) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = k4 + 4 * v;
+                    if (s0 + 16 * sgi + row < N) out[(size_t)row * tt16 + 16 * x] = acc[x][v];
+                }
+            }
+        }
+        if (cgi == 0) {
+            qs += __shfl_xor(qs, 16, 64); qs += __shfl_xor(qs, 32, 64);
+            nc += __shfl_xor(nc, 16, 64); nc += __shfl_xor(nc, 32, 64);
+            if (k4 == 0 && ser_ok) {
+                sxx[(size_t)b * N + s0 + 16 * sgi + c16] = qs;
+                cnt[(size_t)b * N + s0 + 16 * sgi + c16] = nc;
+            }
+        }
+        __builtin_amdgcn_s_barrier();                         // every wave is done with the stage buffers before the next item's DMAs
+        asm volatile("" ::: "memory");
+    }
+}
+
+// thread = series: packed Sff_i = S11 - D_i in the thread's own LDS column, Cholesky in place, lam_i, R_i
+__global__ void mmw_finish_kernel(MstepArgs a, const double* __restrict__ OUT, const double* __restrict__ sxx,
+                                  const double* __restrict__ cnt, int r, int Rp, int ntm16, int tt16) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (a.active && !a.active[b]) return;
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int N = a.N, npr = r * (r + 1) / 2;
+    double* S = reinterpret_cast<double*>(smem);              // [npr + r][nthr]: packed Sff, then the right-hand side
+    double* s11 = S + (size_t)(npr + r) * nthr;               // [npr] packed, symmetrised
+    for (int v = tid; v < npr; v += nthr) {
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= v) ++i;
+        const int j = v - i * (i + 1) / 2;
+        s11[v] = 0.5 * (a.S11[(size_t)b * Rp * Rp + i * Rp + j] + a.S11[(size_t)b * Rp * Rp + j * Rp + i]);
+    }
+    __syncthreads();
+    const int s0 = (int)blockIdx.y * nthr;
+    const int nrow = (N - s0 < nthr) ? N - s0 : nthr;
+    // the block's rows of OUT are one contiguous piece: coalesced reads, transposed into the threads' columns
+    const double* src = OUT + ((size_t)b * N + s0) * tt16;
+    for (int e = tid; e < nrow * tt16; e += nthr) {
+        const int row = e / tt16, c = e % tt16;
+        if (c < npr) S[(size_t)c * nthr + row] = s11[c] - src[e];
+        else if (c >= ntm16 && c - ntm16 < r) S[(size_t)(npr + c - ntm16) * nthr + row] = src[e];
+    }
+    __syncthreads();
+    if (tid >= nrow) return;
+    double* L = S + tid;
+    double* y = S + (size_t)npr * nthr + tid;
+#define LL(i, j) L[(size_t)((i) * ((i) + 1) / 2 + (j)) * nthr]
+    for (int i = 0; i < r; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double s = LL(i, j);
+            for (int k = 0; k < j; ++k) s = fma(-LL(i, k), LL(j, k), s);
+            LL(i, j) = (j == i) ? sqrt(s) : s / LL(j, j);
+        }
+    }
+    double yy = 0.0;
+    for (int i = 0; i < r; ++i) {                             // L y = Sxf
+        double s = y[(size_t)i * nthr];
+        for (int k = 0; k < i; ++k) s = fma(-LL(i, k), y[(size_t)k * nthr], s);
+        s /= LL(i, i);
+        y[(size_t)i * nthr] = s;
+        yy = fma(s, s, yy);                                   // lam' Sff lam = lam' Sxf = y'y
+    }
+    for (int i = r - 1; i >= 0; --i) {                        // L' lam = y
+        double s = y[(size_t)i * nthr];
+        for (int k = i + 1; k < r; ++k) s = fma(-LL(k, i), y[(size_t)k * nthr], s);
+        y[(size_t)i * nthr] = s / LL(i, i);
+    }
+#undef LL
+    const int col = s0 + tid;
+    a.R_out[(size_t)b * N + col] = (sxx[(size_t)b * N + col] - yy) / cnt[(size_t)b * N + col];
+    double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
+    for (int k = 0; k < Rp; ++k) lo[k] = k < r ? y[(size_t)k * nthr] : 0.0;
+}
+
+// Rp = 8 | 16 | 32 (r <= Rp the caller's factor count), even N (16-byte aligned series pairs)
+bool mstep_miss_supported(int Rpad, int r, int N) {
+    if (Rpad != 8 && Rpad != 16 && Rpad != 32) return false;
+    if (r < 1 || r > Rpad) return false;
+    return (N & 1) == 0 && N >= 2;
+}
+// V [B][T][16 tt] | OUT [B][N][16 tt] | sxx [B][N] | cnt [B][N]
+size_t mstep_miss_workspace(int B, int T, int N, int Rpad, int r) {
+    const MmGeo g = mm_geo(Rpad, r);
+    return ((size_t)B * T * g.tt * 16 + (size_t)B * N * g.tt * 16 + 2 * (size_t)B * N) * sizeof(double) + 256;
+}
+
+namespace {
+template <int TPW, int U>
+hipError_t launch_mm(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MmGeo& g, int G, hipStream_t s) {
+    static LdsOptIn attr_done;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_miss_kernel<TPW, U>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int nsb = (a.N + g.ser - 1) / g.ser;
+    hipLaunchKernelGGL((mstep_miss_kernel<TPW, U>), dim3((unsigned)G), dim3(64 * kMmWaves), (size_t)kMmNBuf * g.stageB, s, a, V, OUT,
+                       sxx, cnt, g, nsb);
+    return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
+    note_kernel("mstep_miss_kernel");
+    const MmGeo g = mm_geo(Rpad, r);
+    const int tt16 = g.tt * 16, ntm16 = g.ntm * 16;
+    double* V = ws;
+    double* OUT = V + (size_t)a.B * a.T * tt16;
+    double* sxx = OUT + (size_t)a.B * a.N * tt16;
+    double* cnt = sxx + (size_t)a.B * a.N;
+    hipLaunchKernelGGL(mmw_vec_kernel, dim3(a.B, (a.T + 15) / 16), dim3(256), 0, s, a, V, r, Rpad, ntm16, tt16);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    int G = num_cu > 0 ? num_cu : 256;
+    G = (G / 8) * 8;
+    if (G < 8) G = 8;
+    // the instantiation's U is what every wave issues per stage (DMAs past the stage's list repeat its last one)
+    if (g.tpw <= 4 && g.U <= 2) e = launch_mm<4, 2>(a, V, OUT, sxx, cnt, g, G, s);            // Rp = 8
+    else if (g.tpw <= 10 && g.U <= 2) e = launch_mm<10, 2>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 13 at Rp = 16
+    else if (g.tpw <= 10 && g.U <= 3) e = launch_mm<10, 3>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 16
+    else if (g.tpw <= 16 && g.U <= 3) e = launch_mm<16, 3>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 20 (config 4)
+    else if (g.tpw <= 21 && g.U <= 4) e = launch_mm<21, 4>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 24; two column groups up to r = 29
+    else if (g.tpw <= 18 && g.U <= 6) e = launch_mm<18, 6>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 32
+    else return hipErrorInvalidValue;
+    if (e != hipSuccess) return e;
+    const int npr = r * (r + 1) / 2;
+    const int nthr = npr <= 300 ? 64 : 32;
+    const size_t lds = ((size_t)(npr + r) * nthr + npr) * sizeof(double);
+    static LdsOptIn fin_done;
+    if (!fin_done) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmw_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        fin_done = true;
+    }
+    hipLaunchKernelGGL(mmw_finish_kernel, dim3(a.B, (a.N + nthr - 1) / nthr), dim3(nthr), lds, s, a, (const double*)OUT, (const double*)sxx,
+                       (const double*)cnt, r, Rpad, ntm16, tt16);
+    return hipGetLastError();
+}
+
+}  // namespace dfm
