@@ -30,7 +30,7 @@ namespace dfm {
 namespace {
 
 using lds_char_ptr_mm = __attribute__((address_space(3))) char*;
-using lds_cvd_ptr_mm = const volatile __attribute__((address_space(3))) double*;
+using lds_cvd_ptr_mm = const __attribute__((address_space(3))) double*;   // (not volatile: a "memory" clobber follows every barrier)
 __device__ __forceinline__ double lds_read64mm(unsigned a) { return *(lds_cvd_ptr_mm)(size_t)a; }
 typedef double mm_v4 __attribute__((ext_vector_type(4)));
 
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void mmw_vec_kernel(MstepArgs a, double* __res
 }
 
 // OUT[b][series][16 tt]: D (16 ntm columns) then Sxf (16 ntf columns); sxx, cnt [b][series]
-template <int TPW, int U>
+template <int TPW>
 __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, const double* __restrict__ V, double* __restrict__ OUT,
                                                                   double* __restrict__ sxx, double* __restrict__ cnt, MmGeo g, int nsb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
     const int nst = (T + kMmKP - 1) / kMmKP;
     const int tt16 = g.tt * 16;
     const int ND = kMmKP * (1 + g.nv);
+    const int U = g.U;                                        // DMAs per wave and stage (the same for every wave: counted waits)
     // items: XCD x (= blockIdx.x & 7 under the round-robin dispatch) owns the replicates b = x (mod 8); its workgroups take
     // (replicate, series block) pairs in order, so the blocks of a replicate run side by side on one L2
     // (small batches: plain round robin over all workgroups)
@@ -153,7 +154,6 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
         const char* Vb = reinterpret_cast<const char*>(V + (size_t)b * T * tt16);
         auto issue_stage = [&](int st, int bsel) {
             const unsigned sbase = lds0 + (unsigned)bsel * g.stageB;
-#pragma unroll
             for (int u = 0; u < U; ++u) {
                 int d = wave + kMmWaves * u;
                 d = d < ND ? d : ND - 1;                          // (a duplicate of the last DMA keeps the count equal)
@@ -179,33 +179,46 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
         const unsigned a_off = (unsigned)k4 * g.pstride + (unsigned)(16 * sgi + c16) * 8u;
         const unsigned b_off = g.panelB + (unsigned)k4 * g.vstride + (unsigned)(16 * tile0 + c16) * 8u;
 
+        unsigned xoff[TPW];                                   // byte offset of tile slot x in a row of V
+#pragma unroll
+        for (int x = 0; x < TPW; ++x) xoff[x] = 128u * (unsigned)(x < ntile ? x : ntile - 1);
+
         issue_stage(0, 0);
         if (nst > 1) issue_stage(1, 1);
         int bsel = 0;
         for (int st = 0; st < nst; ++st) {
-            if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(U) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (st + 1 >= nst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (U == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (U == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (U == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (U == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (st + 2 < nst) issue_stage(st + 2, bsel == 0 ? 2 : bsel - 1);
             const unsigned stg = lds0 + (unsigned)bsel * g.stageB;
+            const int nm = g.ntm - tile0;                     // tiles x < nm of this wave belong to D (A = the mask), the others to Sxf (A = xz)
+            double mk[kMmKP / 4], xk[kMmKP / 4];
 #pragma unroll
             for (int s = 0; s < kMmKP / 4; ++s) {
                 const double xr = lds_read64mm(stg + a_off + (unsigned)s * 4u * g.pstride);
                 const bool valid = ser_ok && (st * kMmKP + 4 * s + k4 < T);
                 const bool ok = xr == xr;
-                const double m = (valid && !ok) ? 1.0 : 0.0;
-                const double xz = (valid && ok) ? xr : 0.0;
-#pragma unroll
-                for (int x = 0; x < TPW; ++x) {
-                    if (x < ntile) {
-                        const double bv = lds_read64mm(stg + b_off + (unsigned)s * 4u * g.vstride + 128u * (unsigned)x);
-                        const double av = (tile0 + x < g.ntm) ? m : xz;
-                        acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[x], 0, 0, 0);
-                    }
-                }
-                qs = fma(xz, xz, qs);
+                mk[s] = (valid && !ok) ? 1.0 : 0.0;
+                xk[s] = (valid && ok) ? xr : 0.0;
+                qs = fma(xk[s], xk[s], qs);
                 nc += (valid && ok) ? 1.0 : 0.0;
+            }
+            // every tile slot of the instantiation runs (slots past the wave's last tile repeat it and are not stored): no
+            // branches, the B operands of a step in flight before its first MFMA
+#pragma unroll
+            for (int s = 0; s < kMmKP / 4; ++s) {
+                double bv[TPW];
+#pragma unroll
+                for (int x = 0; x < TPW; ++x) bv[x] = lds_read64mm(stg + b_off + (unsigned)s * 4u * g.vstride + xoff[x]);
+#pragma unroll
+                for (int x = 0; x < TPW; ++x)
+                    acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(x < nm ? mk[s] : xk[s], bv[x], acc[x], 0, 0, 0);
             }
             bsel = bsel == 2 ? 0 : bsel + 1;
         }
@@ -234,62 +247,73 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
     }
 }
 
-// thread = series: packed Sff_i = S11 - D_i in the thread's own LDS column, Cholesky in place, lam_i, R_i
-__global__ void mmw_finish_kernel(MstepArgs a, const double* __restrict__ OUT, const double* __restrict__ sxx,
-                                  const double* __restrict__ cnt, int r, int Rp, int ntm16, int tt16) {
+// thread = series: packed Sff_i = S11 - D_i in the thread's own LDS column, Cholesky in place, lam_i, R_i.  256 threads load
+// the block's rows (one contiguous piece of OUT); the first ns of them solve (ns = series per block = the LDS column count)
+__global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const double* __restrict__ OUT, const double* __restrict__ sxx,
+                                                         const double* __restrict__ cnt, int r, int Rp, int ntm16, int tt16, int ns) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
     if (a.active && !a.active[b]) return;
-    const int nthr = blockDim.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int N = a.N, npr = r * (r + 1) / 2;
-    double* S = reinterpret_cast<double*>(smem);              // [npr + r][nthr]: packed Sff, then the right-hand side
-    double* s11 = S + (size_t)(npr + r) * nthr;               // [npr] packed, symmetrised
-    for (int v = tid; v < npr; v += nthr) {
+    double* S = reinterpret_cast<double*>(smem);              // [npr + r][ns]: packed Sff, then the right-hand side
+    double* s11 = S + (size_t)(npr + r) * ns;                 // [npr] packed, symmetrised
+    for (int v = tid; v < npr; v += 256) {
         int i = 0;
         while ((i + 1) * (i + 2) / 2 <= v) ++i;
         const int j = v - i * (i + 1) / 2;
         s11[v] = 0.5 * (a.S11[(size_t)b * Rp * Rp + i * Rp + j] + a.S11[(size_t)b * Rp * Rp + j * Rp + i]);
     }
     __syncthreads();
-    const int s0 = (int)blockIdx.y * nthr;
-    const int nrow = (N - s0 < nthr) ? N - s0 : nthr;
-    // the block's rows of OUT are one contiguous piece: coalesced reads, transposed into the threads' columns
+    const int s0 = (int)blockIdx.y * ns;
+    const int nrow = (N - s0 < ns) ? N - s0 : ns;
     const double* src = OUT + ((size_t)b * N + s0) * tt16;
-    for (int e = tid; e < nrow * tt16; e += nthr) {
+    const int ne = nrow * tt16;
+#pragma unroll 8
+    for (int e = tid; e < ne; e += 256) {
         const int row = e / tt16, c = e % tt16;
-        if (c < npr) S[(size_t)c * nthr + row] = s11[c] - src[e];
-        else if (c >= ntm16 && c - ntm16 < r) S[(size_t)(npr + c - ntm16) * nthr + row] = src[e];
+        const double v = src[e];
+        if (c < npr) S[(size_t)c * ns + row] = s11[c] - v;
+        else if (c >= ntm16 && c - ntm16 < r) S[(size_t)(npr + c - ntm16) * ns + row] = v;
     }
     __syncthreads();
     if (tid >= nrow) return;
     double* L = S + tid;
-    double* y = S + (size_t)npr * nthr + tid;
-#define LL(i, j) L[(size_t)((i) * ((i) + 1) / 2 + (j)) * nthr]
+    double* y = S + (size_t)npr * ns + tid;
+#define LL(i, j) L[(size_t)((i) * ((i) + 1) / 2 + (j)) * ns]
     for (int i = 0; i < r; ++i) {
         for (int j = 0; j <= i; ++j) {
-            double s = LL(i, j);
-            for (int k = 0; k < j; ++k) s = fma(-LL(i, k), LL(j, k), s);
+            double s0_ = LL(i, j), s1_ = 0.0, s2_ = 0.0, s3_ = 0.0;   // four partial sums: the LDS reads of a row pair overlap
+            int k = 0;
+            for (; k + 3 < j; k += 4) {
+                s0_ = fma(-LL(i, k), LL(j, k), s0_);
+                s1_ = fma(-LL(i, k + 1), LL(j, k + 1), s1_);
+                s2_ = fma(-LL(i, k + 2), LL(j, k + 2), s2_);
+                s3_ = fma(-LL(i, k + 3), LL(j, k + 3), s3_);
+            }
+            for (; k < j; ++k) s0_ = fma(-LL(i, k), LL(j, k), s0_);
+            const double s = (s0_ + s1_) + (s2_ + s3_);
             LL(i, j) = (j == i) ? sqrt(s) : s / LL(j, j);
         }
     }
     double yy = 0.0;
     for (int i = 0; i < r; ++i) {                             // L y = Sxf
-        double s = y[(size_t)i * nthr];
-        for (int k = 0; k < i; ++k) s = fma(-LL(i, k), y[(size_t)k * nthr], s);
+        double s = y[(size_t)i * ns];
+        for (int k = 0; k < i; ++k) s = fma(-LL(i, k), y[(size_t)k * ns], s);
         s /= LL(i, i);
-        y[(size_t)i * nthr] = s;
+        y[(size_t)i * ns] = s;
         yy = fma(s, s, yy);                                   // lam' Sff lam = lam' Sxf = y'y
     }
     for (int i = r - 1; i >= 0; --i) {                        // L' lam = y
-        double s = y[(size_t)i * nthr];
-        for (int k = i + 1; k < r; ++k) s = fma(-LL(k, i), y[(size_t)k * nthr], s);
-        y[(size_t)i * nthr] = s / LL(i, i);
+        double s = y[(size_t)i * ns];
+        for (int k = i + 1; k < r; ++k) s = fma(-LL(k, i), y[(size_t)k * ns], s);
+        y[(size_t)i * ns] = s / LL(i, i);
     }
 #undef LL
     const int col = s0 + tid;
     a.R_out[(size_t)b * N + col] = (sxx[(size_t)b * N + col] - yy) / cnt[(size_t)b * N + col];
     double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
-    for (int k = 0; k < Rp; ++k) lo[k] = k < r ? y[(size_t)k * nthr] : 0.0;
+    for (int k = 0; k < Rp; ++k) lo[k] = k < r ? y[(size_t)k * ns] : 0.0;
 }
 
 // Rp = 8 | 16 | 32 (r <= Rp the caller's factor count), even N (16-byte aligned series pairs)
@@ -305,17 +329,17 @@ size_t mstep_miss_workspace(int B, int T, int N, int Rpad, int r) {
 }
 
 namespace {
-template <int TPW, int U>
+template <int TPW>
 hipError_t launch_mm(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MmGeo& g, int G, hipStream_t s) {
     static LdsOptIn attr_done;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_miss_kernel<TPW, U>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_miss_kernel<TPW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int nsb = (a.N + g.ser - 1) / g.ser;
-    hipLaunchKernelGGL((mstep_miss_kernel<TPW, U>), dim3((unsigned)G), dim3(64 * kMmWaves), (size_t)kMmNBuf * g.stageB, s, a, V, OUT,
+    hipLaunchKernelGGL((mstep_miss_kernel<TPW>), dim3((unsigned)G), dim3(64 * kMmWaves), (size_t)kMmNBuf * g.stageB, s, a, V, OUT,
                        sxx, cnt, g, nsb);
     return hipGetLastError();
 }
@@ -335,13 +359,15 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     int G = num_cu > 0 ? num_cu : 256;
     G = (G / 8) * 8;
     if (G < 8) G = 8;
-    // the instantiation's U is what every wave issues per stage (DMAs past the stage's list repeat its last one)
-    if (g.tpw <= 4 && g.U <= 2) e = launch_mm<4, 2>(a, V, OUT, sxx, cnt, g, G, s);            // Rp = 8
-    else if (g.tpw <= 10 && g.U <= 2) e = launch_mm<10, 2>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 13 at Rp = 16
-    else if (g.tpw <= 10 && g.U <= 3) e = launch_mm<10, 3>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 16
-    else if (g.tpw <= 16 && g.U <= 3) e = launch_mm<16, 3>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 20 (config 4)
-    else if (g.tpw <= 21 && g.U <= 4) e = launch_mm<21, 4>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 24; two column groups up to r = 29
-    else if (g.tpw <= 18 && g.U <= 6) e = launch_mm<18, 6>(a, V, OUT, sxx, cnt, g, G, s);     // r <= 32
+    // tile slots per wave: the next instantiation at or above the geometry's (at most 3 idle slots)
+    if (g.U > 6) return hipErrorInvalidValue;
+    if (g.tpw <= 4) e = launch_mm<4>(a, V, OUT, sxx, cnt, g, G, s);              // Rp = 8
+    else if (g.tpw <= 7) e = launch_mm<7>(a, V, OUT, sxx, cnt, g, G, s);
+    else if (g.tpw <= 10) e = launch_mm<10>(a, V, OUT, sxx, cnt, g, G, s);       // r = 16
+    else if (g.tpw <= 13) e = launch_mm<13>(a, V, OUT, sxx, cnt, g, G, s);
+    else if (g.tpw <= 16) e = launch_mm<16>(a, V, OUT, sxx, cnt, g, G, s);       // r = 20 (config 4)
+    else if (g.tpw <= 18) e = launch_mm<18>(a, V, OUT, sxx, cnt, g, G, s);       // r = 32: two column groups
+    else if (g.tpw <= 21) e = launch_mm<21>(a, V, OUT, sxx, cnt, g, G, s);       // r = 24
     else return hipErrorInvalidValue;
     if (e != hipSuccess) return e;
     const int npr = r * (r + 1) / 2;
@@ -353,8 +379,8 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
         if (e != hipSuccess) return e;
         fin_done = true;
     }
-    hipLaunchKernelGGL(mmw_finish_kernel, dim3(a.B, (a.N + nthr - 1) / nthr), dim3(nthr), lds, s, a, (const double*)OUT, (const double*)sxx,
-                       (const double*)cnt, r, Rpad, ntm16, tt16);
+    hipLaunchKernelGGL(mmw_finish_kernel, dim3(a.B, (a.N + nthr - 1) / nthr), dim3(256), lds, s, a, (const double*)OUT, (const double*)sxx,
+                       (const double*)cnt, r, Rpad, ntm16, tt16, nthr);
     return hipGetLastError();
 }
 
