@@ -428,6 +428,7 @@ SECONDARY = [   # (key, dict(B, N, T, r, missing, mode), steps, warmup) -- three
     ("c4", dict(B=256, N=1000, T=2000, r=20, missing=0.0, mode="pass"), 5, 2),
     ("c4_em", dict(B=256, N=1000, T=2000, r=20, missing=0.0, mode="em"), 3, 1),
     ("c4_missing10", dict(B=256, N=1000, T=2000, r=20, missing=0.1, mode="pass"), 2, 1),
+    ("c4_em_missing10", dict(B=256, N=1000, T=2000, r=20, missing=0.1, mode="em"), 2, 1),
 ]
 
 
