@@ -31,7 +31,11 @@ struct dfm_handle {
     int num_cu = 256;
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
-    size_t status_off = (size_t)-1;        // status word of the plan used by the last call ((size_t)-1: none yet)
+    // The handle's status word: its own 256-byte allocation, zeroed at creation and again by whoever READS a non-zero value
+    // (status_check).  It is sticky between checks -- no memset per call: that was a 5 us fill kernel in front of every pass,
+    // 2 % of the headline's step.  Device-pointer callers that never check see nothing; dfm_synchronize / dfm_check_status and
+    // every host-pointer entry report (and clear) whatever was raised since the last check.
+    int* status_dev = nullptr;
     bool no_rec_wave = false;              // DFM_NO_RECURSION_WAVE=1: lane-group recursion_kernel also at Rp = 8 (A/B)
     int pair_bmax = -1;                    // Rp = 8: batch limit of the covariance-wave + mean-wave pair (recursion_pair.hip); -1 = one replicate per SIMD,
                                            // DFM_PAIR_BMAX=n; DFM_NO_PAIR=1 = 0 (never)
@@ -214,7 +218,6 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
 }
 
 int ensure_ws(dfm_handle* h, size_t bytes) {
-    h->status_off = (size_t)-1;     // a new layout of the workspace: the caller names its status word (if it has one)
     if (bytes <= h->ws_bytes) return 0;
     if (h->ws) {
         // every stream this handle has launched on (the caller may have swapped streams with dfm_set_stream, and the
@@ -336,7 +339,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     ca.B = B; ca.T = T; ca.N = N;
     ca.panel = panel; ca.Lam = pp.Lam; ca.Rv = Rv;
     ca.bcol = at<double>(h, p.bcol); ca.scol = at<double>(h, p.scol); ca.ssum = at<double>(h, p.f_ssum);
-    ca.Cfull = at<double>(h, p.Cfull); ca.ldfull = at<double>(h, p.ldfull); ca.status = at<int>(h, p.status);
+    ca.Cfull = at<double>(h, p.Cfull); ca.ldfull = at<double>(h, p.ldfull); ca.status = h->status_dev;
     FastArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.B = B; fa.T = T; fa.N = N; fa.r = out_r; fa.L = fast_chunk_len(p.Rp, T);
@@ -524,7 +527,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ca.panel = panel; ca.Lam = pp.Lam; ca.Rv = Rv;
     ca.bcol = at<double>(h, p.bcol); ca.scol = at<double>(h, p.scol); ca.nobs = at<int>(h, p.nobs);
     ca.ldrow = at<double>(h, p.ldrow); ca.Ct = at<double>(h, p.Ct); ca.Cfull = at<double>(h, p.Cfull);
-    ca.ldfull = at<double>(h, p.ldfull); ca.status = at<int>(h, p.status);
+    ca.ldfull = at<double>(h, p.ldfull); ca.status = h->status_dev;
     {
         const int Rcol = p.Rc ? p.Rc : p.Rp;
         if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream)); }
@@ -630,8 +633,6 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
     // M-step by em_update_kernel; panels with missing cells: recursion_kernel does both
     const Plan p = make_plan(B, T, N, r, flags, true, fast_eligible(h, N, r, flags) && !h->em_general);
     if (int rc = ensure_ws(h, p.total)) return rc;
-    h->status_off = p.status;
-    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     const int Rp = p.Rp, Rl = p.Rc ? p.Rc : p.Rp;            // state width, loadings width
     const size_t np = (size_t)r * (r + 1) / 2, npp = (size_t)Rl * (Rl + 1) / 2;
     const bool padded = (r != Rp);
@@ -735,8 +736,6 @@ int varp_run(dfm_handle* h, int B, int T, int N, int r, int nlag, const double* 
     Plan p = make_plan(B, T, N, k, flags | DFM_F_SINGULAR_Q, em, false);
     p.Rc = pad_r(r); p.rl = r; p.kdim = k;
     if (int rc = ensure_ws(h, p.total)) return rc;
-    h->status_off = p.status;
-    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     const int Rk = p.Rp, Rc = p.Rc;
     double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
            *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P);
@@ -825,8 +824,6 @@ int ar_pass_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, cons
     Plan p = make_plan(B, Tq, N, k, flags | DFM_F_SINGULAR_Q, false, false);
     const size_t xoff = (p.total + 255) & ~(size_t)255;
     if (int rc = ensure_ws(h, xoff + (size_t)B * Tq * N * sizeof(double))) return rc;
-    h->status_off = p.status;
-    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     const int Rk = p.Rp;
     double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
            *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P), *xq = at<double>(h, xoff);
@@ -875,8 +872,6 @@ int ar_em_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, const 
     p.kdim = k; p.kb = r; p.ka = r * nlag;                   // companion constraints; the observation loads on q + 1 blocks (rl = 0)
     const size_t xoff = (p.total + 255) & ~(size_t)255;
     if (int rc = ensure_ws(h, xoff + (size_t)B * Tq * N * sizeof(double))) return rc;
-    h->status_off = p.status;
-    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     const int Rk = p.Rp;
     double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
            *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P), *xq = at<double>(h, xoff);
@@ -953,8 +948,6 @@ int obs_em_run(dfm_handle* h, int B, int T, int N, int ru, int ro, const double*
     const Plan p = make_plan(B, T, N, ru, flags, true, fast_eligible(h, N, ru, flags) && !h->em_general);
     const size_t yoff = (p.total + 255) & ~(size_t)255;
     if (int rc = ensure_ws(h, yoff + (size_t)B * T * N * sizeof(double))) return rc;
-    h->status_off = p.status;
-    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     const int Rp = p.Rp, Rl = p.Rc ? p.Rc : p.Rp;            // state width, loadings width
     const bool padded = (ru != Rp);
     double *LamP = at<double>(h, p.LamP), *y = at<double>(h, yoff);
@@ -1038,6 +1031,8 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_post, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&h->status_dev), 256);
+    if (e == hipSuccess) e = hipMemset(h->status_dev, 0, 256);
     if (e != hipSuccess) {
         delete h;
         return (int)e;
@@ -1083,6 +1078,7 @@ int dfm_destroy(dfm_handle* h) {
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ws) hipFree(h->ws);
+    if (h->status_dev) hipFree(h->status_dev);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -1180,8 +1176,6 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     HIP_TRY(h, hipSetDevice(h->device));
     const Plan p = make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags));
     if (int rc = ensure_ws(h, p.total)) return rc;
-    h->status_off = p.status;
-    HIP_TRY(h, hipMemsetAsync(at<int>(h, p.status), 0, sizeof(int), h->stream));
     PaddedParams pp;
     if (int rc = pad_params(h, p, B, N, r, Lam, A, Q, mu0, P0, &pp)) return rc;
     return enqueue_pass(h, p, B, T, N, r, panel, pp, R, f_smooth, P_smooth, loglik, nullptr);
@@ -1192,9 +1186,10 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
 // one-launch pass ran out (its outputs are invalid even where the log-likelihood happens to be finite).  Every synchronising
 // entry point goes through here; device-pointer callers get the same check from dfm_synchronize / dfm_check_status.
 static int status_check(dfm_handle* h) {
-    if (!h->ws || h->status_off == (size_t)-1) return 0;
+    if (!h->status_dev) return 0;
     int st = 0;
-    HIP_TRY(h, hipMemcpy(&st, at<int>(h, h->status_off), sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(&st, h->status_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) HIP_TRY(h, hipMemset(h->status_dev, 0, sizeof(int)));      // reported once
     if (st & 4) return fail(h, DFM_E_NUMERIC, "one-launch pass: a bounded wait between its waves ran out (results invalid)%s");
     if (st & 1) return fail(h, DFM_E_MISSING, "panel contains NaN but DFM_F_MAY_HAVE_MISSING was not set%s");
     if (st & 2) return fail(h, DFM_E_NUMERIC, "PCA subspace iteration did not converge (near-degenerate spectrum at the cut)%s");
@@ -1575,8 +1570,6 @@ int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doub
     const size_t oS = take(off, (size_t)B * N * N * d), oV = take(off, (size_t)B * N * Rp * d),
                  oY = take(off, (size_t)B * N * Rp * d), oF = take(off, (size_t)B * T * Rp * d), oSt = take(off, 256);
     if (int rc = ensure_ws(h, off)) return rc;
-    h->status_off = oSt;
-    HIP_TRY(h, hipMemsetAsync(at<int>(h, oSt), 0, sizeof(int), h->stream));
     PcaArgs pa;
     pa.B = B; pa.T = T; pa.N = N; pa.r = r; pa.max_iter = 4000;
     { static const int mi = [] { const char* v = getenv("DFM_PCA_MAXIT"); return v ? atoi(v) : 0; }(); if (mi > 0) pa.max_iter = mi; }   // diagnostics
@@ -1584,7 +1577,7 @@ int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doub
     pa.panel = panel;
     pa.S = at<double>(h, oS); pa.V = at<double>(h, oV); pa.Y = at<double>(h, oY); pa.F = at<double>(h, oF);
     pa.Lam = Lam; pa.Rv = R; pa.A = A; pa.Q = Q; pa.mu0 = mu0; pa.P0 = P0; pa.factors = factors;
-    pa.status = at<int>(h, oSt);
+    pa.status = h->status_dev;
     { ProfScope ps(h, K_GRAM_XX); HIP_TRY(h, launch_gram_xx(pa, h->stream, h->gram_xx_valu ? 1 : 0)); }
     { ProfScope ps(h, K_PCA); HIP_TRY(h, launch_pca(Rp, pa, h->stream)); }
     return 0;

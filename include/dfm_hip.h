@@ -63,11 +63,13 @@ typedef struct dfm_handle dfm_handle;
 int dfm_create(dfm_handle** h, int device_id, void* stream);
 int dfm_destroy(dfm_handle* h);
 int dfm_set_stream(dfm_handle* h, void* stream);
-/* dfm_synchronize: wait for the handle's stream, THEN read the status word the kernels of the last call left behind --
- * DFM_E_MISSING (NaN in a panel that was declared balanced), DFM_E_NUMERIC (a bounded wait inside the one-launch pass
- * ran out: outputs invalid; PCA start not converged).  The "_dev" entry points only enqueue, so this is where a
- * device-pointer caller learns that a call went wrong; the host-pointer entry points make the same check themselves.
- * dfm_check_status is the same call under the name a reader looks for. */
+/* dfm_synchronize: wait for the handle's stream, THEN read the handle's status word -- DFM_E_MISSING (NaN in a panel that
+ * was declared balanced), DFM_E_NUMERIC (a bounded wait inside the one-launch pass ran out: outputs invalid; PCA start not
+ * converged).  The word is STICKY: kernels only ever set bits, and the call that reads a non-zero value reports it once and
+ * clears it -- so it covers every call enqueued since the previous check (no per-call reset: that was a fill kernel in front
+ * of every pass).  The "_dev" entry points only enqueue, so this is where a device-pointer caller learns that a call went
+ * wrong; the host-pointer entry points make the same check themselves.  dfm_check_status is the same call under the name a
+ * reader looks for. */
 int dfm_synchronize(dfm_handle* h);
 int dfm_check_status(dfm_handle* h);
 const char* dfm_last_error(const dfm_handle* h);
