@@ -47,9 +47,8 @@ __device__ __forceinline__ void dma16mm(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-constexpr int kMmKP = 8;                                 // periods per stage
-constexpr int kMmNBuf = 3;
 constexpr int kMmWaves = 8;
+constexpr unsigned kMmLdsMax = 156 * 1024;               // stage buffers of a workgroup
 
 struct MmGeo {
     int r, Rp, npr;                                      // caller's factor count, padded width, r (r + 1) / 2
@@ -59,9 +58,11 @@ struct MmGeo {
     int nv;                                              // 1-KB DMAs per row of V
     unsigned vrowB, vstride, pstride, panelB, stageB;    // bytes: a row of V, its LDS stride, panel row stride, panel block, stage
     int U;                                               // DMAs per wave and stage
+    int kp, nbuf;                                        // periods per stage, stage buffers (2: one stage ahead, 3: two)
 };
 
-MmGeo mm_geo(int Rp, int r) {
+// kp_want: 0 = the deepest stage that fits twice (32, then 16 periods), else 8 periods in three buffers
+MmGeo mm_geo(int Rp, int r, int kp_want = 0) {
     MmGeo g;
     g.r = r; g.Rp = Rp; g.npr = r * (r + 1) / 2;
     g.ntm = (g.npr + 15) / 16;
@@ -75,9 +76,14 @@ MmGeo mm_geo(int Rp, int r) {
     g.nv = (int)((g.vrowB + 1023u) / 1024u);
     g.vstride = g.vrowB + ((g.tt & 1) ? 0u : 128u);      // = 128 (mod 256): the four periods of a step on distinct banks
     g.pstride = (unsigned)g.ser * 8u + 128u;
-    g.panelB = kMmKP * g.pstride;
-    g.stageB = g.panelB + kMmKP * g.vstride;
-    g.U = (kMmKP * (1 + g.nv) + kMmWaves - 1) / kMmWaves;
+    g.kp = 8; g.nbuf = 3;
+    for (int kp : {32, 16}) {
+        if ((kp_want != 0 && kp_want != kp) || g.tpw > 18) continue;      // (21 tile slots + a deep stage spill)
+        if (2u * (unsigned)kp * (g.pstride + g.vstride) <= kMmLdsMax) { g.kp = kp; g.nbuf = 2; break; }
+    }
+    g.panelB = (unsigned)g.kp * g.pstride;
+    g.stageB = g.panelB + (unsigned)g.kp * g.vstride;
+    g.U = (g.kp * (1 + g.nv) + kMmWaves - 1) / kMmWaves;
     return g;
 }
 
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256) void mmw_vec_kernel(MstepArgs a, double* __res
 }
 
 // OUT[b][series][16 tt]: D (16 ntm columns) then Sxf (16 ntf columns); sxx, cnt [b][series]
-template <int TPW>
+template <int TPW, int KP, int NBUF>
 __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, const double* __restrict__ V, double* __restrict__ OUT,
                                                                   double* __restrict__ sxx, double* __restrict__ cnt, MmGeo g, int nsb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,9 +136,9 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
     const int ntile = (g.tt - tile0 < g.tpw) ? g.tt - tile0 : g.tpw;   // tiles of this wave
     const int k4 = lane >> 4, c16 = lane & 15;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_mm)(smem));
-    const int nst = (T + kMmKP - 1) / kMmKP;
+    const int nst = (T + KP - 1) / KP;
     const int tt16 = g.tt * 16;
-    const int ND = kMmKP * (1 + g.nv);
+    const int ND = KP * (1 + g.nv);
     const int U = g.U;                                        // DMAs per wave and stage (the same for every wave: counted waits)
     // items: XCD x (= blockIdx.x & 7 under the round-robin dispatch) owns the replicates b = x (mod 8); its workgroups take
     // (replicate, series block) pairs in order, so the blocks of a replicate run side by side on one L2
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
     const int nrep_x = xmap ? (B - xcd + 7) / 8 : B;
 
     // no NaN bit patterns in LDS bytes no DMA writes (columns of a partial series block)
-    for (int e = tid; e < (int)(kMmNBuf * g.stageB / 8); e += 64 * kMmWaves) reinterpret_cast<double*>(smem)[e] = 0.0;
+    for (int e = tid; e < (int)(NBUF * g.stageB / 8); e += 64 * kMmWaves) reinterpret_cast<double*>(smem)[e] = 0.0;
     __syncthreads();
 
     for (int q = slot; q < nrep_x * nsb; q += nslot) {
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
                 int d = wave + kMmWaves * u;
                 d = d < ND ? d : ND - 1;                          // (a duplicate of the last DMA keeps the count equal)
                 const int per = d / (1 + g.nv), piece = d % (1 + g.nv);
-                int t = st * kMmKP + per;
+                int t = st * KP + per;
                 t = t < T ? t : T - 1;
                 if (piece == 0) {
                     const int ser = s0 + 2 * lane;
@@ -184,25 +190,27 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
         for (int x = 0; x < TPW; ++x) xoff[x] = 128u * (unsigned)(x < ntile ? x : ntile - 1);
 
         issue_stage(0, 0);
-        if (nst > 1) issue_stage(1, 1);
+        if (NBUF == 3 && nst > 1) issue_stage(1, 1);
         int bsel = 0;
         for (int st = 0; st < nst; ++st) {
-            if (st + 1 >= nst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // this wave's DMAs of stage st have landed (three buffers: those of stage st + 1 may still be in flight)
+            if (NBUF == 2 || st + 1 >= nst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (U == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (U == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else if (U == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (U == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();                     // ... everybody's have, and the buffer read one (two) stages ago is free
             asm volatile("" ::: "memory");
-            if (st + 2 < nst) issue_stage(st + 2, bsel == 0 ? 2 : bsel - 1);
+            if (NBUF == 2) { if (st + 1 < nst) issue_stage(st + 1, bsel ^ 1); }
+            else if (st + 2 < nst) issue_stage(st + 2, bsel == 0 ? 2 : bsel - 1);
             const unsigned stg = lds0 + (unsigned)bsel * g.stageB;
             const int nm = g.ntm - tile0;                     // tiles x < nm of this wave belong to D (A = the mask), the others to Sxf (A = xz)
-            double mk[kMmKP / 4], xk[kMmKP / 4];
+            double mk[KP / 4], xk[KP / 4];
 #pragma unroll
-            for (int s = 0; s < kMmKP / 4; ++s) {
+            for (int s = 0; s < KP / 4; ++s) {
                 const double xr = lds_read64mm(stg + a_off + (unsigned)s * 4u * g.pstride);
-                const bool valid = ser_ok && (st * kMmKP + 4 * s + k4 < T);
+                const bool valid = ser_ok && (st * KP + 4 * s + k4 < T);
                 const bool ok = xr == xr;
                 mk[s] = (valid && !ok) ? 1.0 : 0.0;
                 xk[s] = (valid && ok) ? xr : 0.0;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
             // every tile slot of the instantiation runs (slots past the wave's last tile repeat it and are not stored): no
             // branches, the B operands of a step in flight before its first MFMA
 #pragma unroll
-            for (int s = 0; s < kMmKP / 4; ++s) {
+            for (int s = 0; s < KP / 4; ++s) {
                 double bv[TPW];
 #pragma unroll
                 for (int x = 0; x < TPW; ++x) bv[x] = lds_read64mm(stg + b_off + (unsigned)s * 4u * g.vstride + xoff[x]);
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
                 for (int x = 0; x < TPW; ++x)
                     acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(x < nm ? mk[s] : xk[s], bv[x], acc[x], 0, 0, 0);
             }
-            bsel = bsel == 2 ? 0 : bsel + 1;
+            bsel = NBUF == 2 ? (bsel ^ 1) : (bsel == 2 ? 0 : bsel + 1);
         }
         // the item is complete: 16x16x4 D[(l / 16) + 4 v][l % 16] -> series k4 + 4 v of the group, column c16 of the tile
         double* out = OUT + ((size_t)b * N + s0 + 16 * sgi) * tt16 + 16 * tile0 + c16;
@@ -329,25 +337,38 @@ size_t mstep_miss_workspace(int B, int T, int N, int Rpad, int r) {
 }
 
 namespace {
-template <int TPW>
+template <int TPW, int KP, int NBUF>
 hipError_t launch_mm(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MmGeo& g, int G, hipStream_t s) {
     static LdsOptIn attr_done;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_miss_kernel<TPW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_miss_kernel<TPW, KP, NBUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     const int nsb = (a.N + g.ser - 1) / g.ser;
-    hipLaunchKernelGGL((mstep_miss_kernel<TPW>), dim3((unsigned)G), dim3(64 * kMmWaves), (size_t)kMmNBuf * g.stageB, s, a, V, OUT,
+    hipLaunchKernelGGL((mstep_miss_kernel<TPW, KP, NBUF>), dim3((unsigned)G), dim3(64 * kMmWaves), (size_t)NBUF * g.stageB, s, a, V, OUT,
                        sxx, cnt, g, nsb);
     return hipGetLastError();
+}
+// tile slots per wave: the next instantiation at or above the geometry's (at most 3 idle slots)
+template <int KP, int NBUF>
+hipError_t launch_mm_slots(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MmGeo& g, int G, hipStream_t s) {
+    if (g.tpw <= 4) return launch_mm<4, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);              // Rp = 8
+    if (g.tpw <= 7) return launch_mm<7, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);
+    if (g.tpw <= 10) return launch_mm<10, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);            // r = 16
+    if (g.tpw <= 13) return launch_mm<13, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);
+    if (g.tpw <= 16) return launch_mm<16, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);            // r = 20 (config 4)
+    if (g.tpw <= 18) return launch_mm<18, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);            // r = 32: two column groups
+    if (g.tpw <= 21) return launch_mm<21, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);            // r = 24
+    return hipErrorInvalidValue;
 }
 }  // namespace
 
 hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
     note_kernel("mstep_miss_kernel");
-    const MmGeo g = mm_geo(Rpad, r);
+    static const int kp_want = [] { const char* v = getenv("DFM_MM_KP"); return v ? atoi(v) : 0; }();   // diagnostics: 8 | 16 | 32
+    const MmGeo g = mm_geo(Rpad, r, kp_want);
     const int tt16 = g.tt * 16, ntm16 = g.ntm * 16;
     double* V = ws;
     double* OUT = V + (size_t)a.B * a.T * tt16;
@@ -359,16 +380,10 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     int G = num_cu > 0 ? num_cu : 256;
     G = (G / 8) * 8;
     if (G < 8) G = 8;
-    // tile slots per wave: the next instantiation at or above the geometry's (at most 3 idle slots)
-    if (g.U > 6) return hipErrorInvalidValue;
-    if (g.tpw <= 4) e = launch_mm<4>(a, V, OUT, sxx, cnt, g, G, s);              // Rp = 8
-    else if (g.tpw <= 7) e = launch_mm<7>(a, V, OUT, sxx, cnt, g, G, s);
-    else if (g.tpw <= 10) e = launch_mm<10>(a, V, OUT, sxx, cnt, g, G, s);       // r = 16
-    else if (g.tpw <= 13) e = launch_mm<13>(a, V, OUT, sxx, cnt, g, G, s);
-    else if (g.tpw <= 16) e = launch_mm<16>(a, V, OUT, sxx, cnt, g, G, s);       // r = 20 (config 4)
-    else if (g.tpw <= 18) e = launch_mm<18>(a, V, OUT, sxx, cnt, g, G, s);       // r = 32: two column groups
-    else if (g.tpw <= 21) e = launch_mm<21>(a, V, OUT, sxx, cnt, g, G, s);       // r = 24
-    else return hipErrorInvalidValue;
+    if (g.nbuf == 3 && g.U > 6) return hipErrorInvalidValue;
+    if (g.kp == 32) e = launch_mm_slots<32, 2>(a, V, OUT, sxx, cnt, g, G, s);
+    else if (g.kp == 16) e = launch_mm_slots<16, 2>(a, V, OUT, sxx, cnt, g, G, s);
+    else e = launch_mm_slots<8, 3>(a, V, OUT, sxx, cnt, g, G, s);
     if (e != hipSuccess) return e;
     const int npr = r * (r + 1) / 2;
     const int nthr = npr <= 300 ? 64 : 32;
