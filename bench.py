@@ -238,9 +238,24 @@ def device_telemetry():
             if any(s in kl for s in ("sclk", "mclk", "fclk", "socclk", "power", "temperature (sensor junction)", "temperature (sensor memory)",
                                      "performance level")):
                 keep[k] = v
+        keep.update(host_box())
         return keep
     except Exception as e:  # noqa: BLE001
-        return dict(error=f"rocm-smi not readable: {e}")
+        return dict(error=f"rocm-smi not readable: {e}", **host_box())
+
+
+def host_box():
+    """Host kernel of the box.  About one box in ten of this pool runs 6.18.50 (the others 6.18.51); on those the kernel's code
+    is cold at EVERY launch and the headline measures 0.40-0.44 instead of 0.54-0.58 of the HBM peak with the same binary
+    (clocks, HBM ceilings and idle latencies identical): profiles/r03/slow_boxes/README.md, scripts/microbench/icache.hip."""
+    import platform
+    rel = platform.release()
+    out = dict(host_kernel=rel)
+    if rel.startswith("6.18.50"):
+        out["box_kind"] = ("slow kind: kernel code not cached across launches on this host kernel (first execution of every "
+                           "role of the one-launch pass is 1.5-4x slower); same binary gives 0.54-0.58 on the 6.18.51 boxes "
+                           "-- profiles/r03/slow_boxes/README.md")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------
