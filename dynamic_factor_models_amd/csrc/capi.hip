@@ -179,7 +179,8 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.f_fill = take(off, (size_t)B * 2 * sizeof(int));
         p.f_PsInf = take(off, B * rr * d);
         p.f_ssum = take(off, (size_t)B * kSsumSlots * d);
-        if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, Rp));
+        // (+ room for up to 8 sub-batches laid out as batches of their own: enqueue_pass_fast)
+        if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, Rp) + 8 * collapse_wide2_ws_bytes(1, N, Rp));
     } else {
         p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
         if (p.Rc == 0 && Rp == 32 && N > collapse_max_n(32) && collapse_wide2_supported(32, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, 32));
@@ -447,6 +448,57 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         ca.fuse_cov = nullptr;
         if (P_smooth) fa.abl |= 1;
         { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fa, h->stream)); }
+        return em_update();
+    }
+    // Wide states (collapse_wide2), DFM_WIDE_SUB = n > 1 (diagnostics; default off): the batch in n sub-batches, each a complete
+    // small batch of its own (own W workspace slice, own tile queues), the mean scan of sub-batch s beside the collapse of sub-batch
+    // s + 1.  MEASURED SLOWER at config 4 (B = 256): 1.39 ms -> 1.56 (n = 2) -> 1.81 (n = 4).  The scan is a latency chain per
+    // replicate -- 0.41 ms for 256 replicates, 0.46 ms for 128 -- so a sub-batch's scan hides nothing and the last one still runs alone.
+    static const int wide_sub = [] { const char* v = getenv("DFM_WIDE_SUB"); return v ? atoi(v) : 1; }();
+    const int Sw = (use_wide2 && wide_sub > 1 && wide_sub <= 8 && B >= 32 * wide_sub) ? wide_sub : 1;
+    if (S == 1 && Sw > 1) {
+        while ((int)h->ev_sub.size() < Sw + 1) {
+            hipEvent_t e;
+            HIP_TRY(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->ev_sub.push_back(e);
+        }
+        const int bmax = (B + Sw - 1) / Sw;
+        const size_t slice = collapse_wide2_ws_bytes(bmax, N, p.Rp);
+        auto sub_lo = [&](int s_) { return (int)((long long)B * s_ / Sw); };
+        auto sub_args = [&](int s_) {
+            const int b0 = sub_lo(s_), b1 = sub_lo(s_ + 1);
+            CollapseArgs c = ca;
+            c.B = b1 - b0;
+            c.panel = ca.panel + (size_t)b0 * T * N; c.Lam = ca.Lam + (size_t)b0 * N * p.Rp; c.Rv = ca.Rv + (size_t)b0 * N;
+            c.bcol = ca.bcol + (size_t)b0 * T * p.Rp; c.scol = ca.scol + (size_t)b0 * T; c.ssum = ca.ssum + (size_t)b0 * kSsumSlots;
+            c.Cfull = ca.Cfull + (size_t)b0 * p.Rp * p.Rp; c.ldfull = ca.ldfull + b0;
+            return c;
+        };
+        auto sub_ws = [&](int s_) { return reinterpret_cast<double*>(reinterpret_cast<char*>(Wwide) + (size_t)s_ * slice); };
+        for (int s_ = 0; s_ < Sw; ++s_) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(sub_args(s_), sub_ws(s_), p.Rp, h->stream)); }
+        HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }      // resident before the collapse fills the CUs
+        HIP_TRY(h, hipEventRecord(h->ev_sub[Sw], h->stream));                         // covariance tables done
+        for (int s_ = 0; s_ < Sw; ++s_) {
+            { ProfScope ps(h, K_COLLAPSE_WIDE, h->side); HIP_TRY(h, launch_collapse_wide2(sub_args(s_), sub_ws(s_), p.Rp, p.r, h->num_cu, h->side)); }
+            HIP_TRY(h, hipEventRecord(h->ev_sub[s_], h->side));
+        }
+        const bool fill = !h->no_pfill && P_smooth;
+        if (fill) {                       // 0.86 GB of stores at config 4: beside the scan of the last sub-batch, not beside the collapse
+            HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_sub[Sw], 0));
+            HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_sub[Sw - 1], 0));
+            { ProfScope ps(h, K_PFILL, h->post); HIP_TRY(h, launch_pfill(p.Rp, fa, h->post)); }
+            HIP_TRY(h, hipEventRecord(h->ev_post, h->post));
+            fa.abl |= 1;
+        }
+        for (int s_ = 0; s_ < Sw; ++s_) {
+            HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_sub[s_], 0));
+            FastArgs fs = fa;
+            fs.b0 = sub_lo(s_); fs.B = sub_lo(s_ + 1) - sub_lo(s_);
+            { ProfScope ps(h, K_MEANSCAN); HIP_TRY(h, launch_meanscan(p.Rp, fs, h->stream)); }
+        }
+        if (fill) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_post, 0));
         return em_update();
     }
     if (S == 1) {
