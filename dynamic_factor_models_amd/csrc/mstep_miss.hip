@@ -386,7 +386,7 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     else e = launch_mm_slots<8, 3>(a, V, OUT, sxx, cnt, g, G, s);
     if (e != hipSuccess) return e;
     const int npr = r * (r + 1) / 2;
-    const int nthr = npr <= 300 ? 64 : 32;
+    const int nthr = ((size_t)(npr + r) * 64 + npr) * sizeof(double) <= 150 * 1024 ? 64 : 32;   // series per block: their packed matrices fit LDS
     const size_t lds = ((size_t)(npr + r) * nthr + npr) * sizeof(double);
     static LdsOptIn fin_done;
     if (!fin_done) {

@@ -1,0 +1,120 @@
+"""GPU parity of the loadings M-step with missing cells on the matrix pipe (mstep_miss.hip) against the CPU oracle's EM, one
+case per class of its geometry: tile slots per wave (4 / 7 / 10 / 13 / 16 / 18 / 21), one and two column groups, stages of
+32 / 16 / 8 periods, partial series blocks, partial last stage, XCD-ordered and flat item order, a replicate that has stopped
+iterating.  DFM_MSTEP_MISS=2 sends EVERY shape the kernel supports through it (the default keeps mstep_lam_kernel at Rp = 8,
+N <= 256); the switch is read when a handle is created, so each mode gets its own handle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import kalman_oracle as ko
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-8
+KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
+
+
+def _ctx(mode, kp=None):
+    import torch
+    assert torch.cuda.is_available()
+    from dynamic_factor_models_amd import DfmContext
+    old = {k: os.environ.get(k) for k in ("DFM_MSTEP_MISS", "DFM_MM_KP")}
+    os.environ["DFM_MSTEP_MISS"] = str(mode)
+    if kp:
+        os.environ["DFM_MM_KP"] = str(kp)
+    try:
+        return DfmContext()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _start(B, N, T, r, missing):
+    panels, starts = [], []
+    for b in range(B):
+        x, _ = ko.synth_replicate(100 + b, N, T, r, missing=missing)
+        p0, _ = ko.pca_init(np.nan_to_num(x), r)
+        panels.append(x); starts.append(p0)
+    return np.stack(panels), {k: np.stack([s[k] for s in starts]) for k in starts[0]}
+
+
+def _dev(ctx, a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.device("cuda", ctx.device))
+
+
+@pytest.mark.parametrize("B,N,T,r,missing", [
+    (3, 18, 37, 1, 0.2),        # Rp = 2 is outside the kernel: falls back to mstep_lam_kernel (must still be right)
+    (2, 30, 50, 5, 0.15),       # Rp = 8, 2 + 1 tiles, one partial series block, stages of 32 periods (the last of 18)
+    (17, 130, 65, 8, 0.1),      # Rp = 8, 4 tile slots, two series blocks, XCD-ordered items with B not a multiple of 8
+    (2, 40, 40, 12, 0.1),       # Rp = 16: 5 + 1 tiles in 7 slots
+    (2, 48, 57, 16, 0.1),       # Rp = 16: 9 + 1 tiles = 10 slots
+    (2, 34, 61, 17, 0.1),       # Rp = 32: 10 + 2 tiles in 13 slots, stages of 16 periods (T > 3 r: the start's Q must be regular)
+    (2, 300, 60, 20, 0.1),      # config 4's class: 14 + 2 tiles = 16 slots, three series blocks (the last of 44)
+    (2, 50, 83, 24, 0.1),       # 19 + 2 = 21 slots: stages of 8 periods in three buffers
+    (2, 70, 92, 27, 0.1),       # two column groups (24 + 2 tiles, 13 per wave), 64 series per item
+    (2, 66, 107, 32, 0.05),     # 33 + 2 tiles, 18 slots per wave, every factor column in use
+])
+def test_loadings_step_with_missing_cells_matches_the_oracle(B, N, T, r, missing):
+    import torch
+    ctx = _ctx(2)
+    try:
+        panel, st = _start(B, N, T, r, missing)
+        dev = {k: _dev(ctx, st[k]) for k in KEYS}
+        iters = 2
+        path, its, f, P = ctx.em_batch(_dev(ctx, panel), *[dev[k] for k in KEYS], max_iter=iters, tol=0.0)
+        torch.cuda.synchronize()
+        path = path.cpu().numpy()
+        for b in range(B):
+            p, opath, _ = ko.em(panel[b], {k: st[k][b] for k in KEYS}, max_iter=iters, tol=0.0)
+            np.testing.assert_allclose(path[b], opath, rtol=RTOL, err_msg=f"loglik path b={b}")
+            for k in KEYS:
+                got = dev[k][b].cpu().numpy()
+                assert np.abs(got - p[k]).max() <= RTOL * max(1.0, np.abs(p[k]).max()), (k, b, np.abs(got - p[k]).max())
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("kp", [8, 16, 32])
+def test_stage_depths_agree(kp):
+    """The same EM step through every stage depth that fits (8 periods x 3 buffers, 16 x 2, 32 x 2): identical to rounding."""
+    import torch
+    B, N, T, r = 3, 140, 75, 8
+    panel, st = _start(B, N, T, r, 0.12)
+    outs = []
+    for k in (None, kp):
+        ctx = _ctx(2, k)
+        try:
+            dev = {kk: _dev(ctx, st[kk]) for kk in KEYS}
+            ctx.em_batch(_dev(ctx, panel), *[dev[kk] for kk in KEYS], max_iter=1, tol=0.0)
+            torch.cuda.synchronize()
+            outs.append({kk: dev[kk].cpu().numpy() for kk in ("Lam", "R")})
+        finally:
+            ctx.close()
+    for kk in ("Lam", "R"):
+        assert np.abs(outs[0][kk] - outs[1][kk]).max() <= 1e-12 * max(1.0, np.abs(outs[0][kk]).max()), kk
+
+
+def test_a_stopped_replicate_keeps_its_loadings():
+    """tol > 0: a replicate that has converged is inactive in later iterations -- its items are skipped, its parameters stay."""
+    import torch
+    ctx = _ctx(2)
+    try:
+        B, N, T, r = 4, 60, 50, 12
+        panel, st = _start(B, N, T, r, 0.1)
+        dev = {k: _dev(ctx, st[k]) for k in KEYS}
+        path, its, _, _ = ctx.em_batch(_dev(ctx, panel), *[dev[k] for k in KEYS], max_iter=12, tol=1e-4)
+        torch.cuda.synchronize()
+        its = its.cpu().numpy()
+        for b in range(B):
+            p, opath, _ = ko.em(panel[b], {k: st[k][b] for k in KEYS}, max_iter=12, tol=1e-4)
+            assert its[b] == len(opath), (b, its[b], len(opath))
+            for k in ("Lam", "R"):
+                got = dev[k][b].cpu().numpy()
+                assert np.abs(got - p[k]).max() <= 1e-7 * max(1.0, np.abs(p[k]).max()), (k, b)
+    finally:
+        ctx.close()
