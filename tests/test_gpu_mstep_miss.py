@@ -118,3 +118,26 @@ def test_a_stopped_replicate_keeps_its_loadings():
                 assert np.abs(got - p[k]).max() <= 1e-7 * max(1.0, np.abs(p[k]).max()), (k, b)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("B,N,T,r,missing", [
+    (2, 260, 67, 17, 0.1),      # Rp = 32 beyond the register tiling of collapse_kernel: collapse_wide2 (missing-cell mode) + ct_miss_wide2
+    (3, 300, 110, 32, 0.3),     # every factor column in use, heavy missingness, T not a multiple of 16
+    (17, 270, 70, 20, 0.05),    # XCD-ordered queues with B not a multiple of 8
+])
+def test_wide_pass_with_missing_cells_matches_the_oracle(B, N, T, r, missing):
+    """The pass (not the EM) of the wide sequential path: C_t of the periods with missing cells from ct_miss_wide2_kernel."""
+    import torch
+    ctx = _ctx(1)
+    try:
+        panel, st = _start(B, N, T, r, missing)
+        f, P, ll = ctx.ks_pass_batch(_dev(ctx, panel), *[_dev(ctx, st[k]) for k in KEYS], may_have_missing=True)
+        torch.cuda.synchronize()
+        f = f.cpu().numpy(); P = P.cpu().numpy(); ll = ll.cpu().numpy()
+        for b in range(min(B, 4)):
+            out = ko.kfs_pass(panel[b], *[st[k][b] for k in KEYS], lag_one=False)
+            assert abs(ll[b] - out["loglik"]) <= 1e-9 * abs(out["loglik"]), (b, ll[b], out["loglik"])
+            assert np.abs(f[b] - out["f_smooth"]).max() <= 1e-9 * np.abs(out["f_smooth"]).max()
+            assert np.abs(P[b] - ko.pack_sym(out["P_smooth"])).max() <= 1e-9 * np.abs(out["P_smooth"]).max()
+    finally:
+        ctx.close()
