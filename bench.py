@@ -386,7 +386,7 @@ class Workload:
         kernels_ms = {k: round(v, 4) for k, v in avg.items()}
         if self.mode == "pca":
             dom = max(avg, key=avg.get)
-            flops = {"gram_xx_kernel": 2.0 * T * N * N * B, "gram_xx_mfma_kernel": 2.0 * T * N * N * B, "gram_xx_wide_kernel": 2.0 * T * N * N * B}
+            flops = {"gram_xx_kernel": 2.0 * T * N * N * B, "gram_xx_mfma_kernel": 2.0 * T * N * N * B, "gram_xx_dma_kernel": 2.0 * T * N * N * B, "gram_xx_wide_kernel": 2.0 * T * N * N * B}
             gx = next((k for k in flops if k in avg), None)
             out = dict(bound="mfma", kernel=dom, achieved=None, peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
                        avg_launch_ms=avg[dom], kernels_ms=kernels_ms,

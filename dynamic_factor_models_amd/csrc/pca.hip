@@ -177,6 +177,113 @@ __global__ __launch_bounds__(kGxThreads) void gram_xx_mfma_kernel(PcaArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same kernel with the panel rows brought in by LDS-DMA (even N: rows start on 16-byte boundaries).  The register-staged
+// version above pays an integer division per staged element for its (row, column) -- 8 of them in front of every tile, more VALU
+// time than the tile's 8 MFMAs take -- and holds the staged values across the tile.  Here wave w issues rows w, w + 8, ... of the
+// NEXT block as `global_load_lds_dwordx4` (1 KB per instruction) before it starts on its tiles and waits for them at the block's
+// barrier; nothing else moves the panel.  Row stride = 128 bytes (mod 256): the four k-rows of an MFMA step on distinct banks.
+// Columns >= N of the buffers stay zero (zeroed once: the DMAs never write them); the rows of a partial last block are zeroed.
+namespace {
+using lds_char_ptr_gx = __attribute__((address_space(3))) char*;
+__device__ __forceinline__ void dma16gx(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+__host__ __device__ inline int gx_dma_ld(int N) { const int NT = (N + 15) / 16; return NT * 16 + ((NT & 1) ? 0 : 16); }
+}  // namespace
+
+template <int MAXP>
+__global__ __launch_bounds__(kGxThreads) void gram_xx_dma_kernel(PcaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double gx_lds[];
+    const int b = blockIdx.x;
+    const int N = a.N, T = a.T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char* __restrict__ X = reinterpret_cast<const char*>(a.panel + (size_t)b * T * N);
+    double* S = a.S + (size_t)b * N * N;
+    const int NT = (N + 15) / 16;
+    const int P = NT * (NT + 1) / 2;
+    const int ld = gx_dma_ld(N);
+    const unsigned rowB = (unsigned)N * 8u, ldB = (unsigned)ld * 8u;
+    const int npiece = (int)((rowB + 1023u) / 1024u);
+    const int k4 = lane >> 4, c16 = lane & 15;
+    int tbi[MAXP], tbj[MAXP];
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) {
+        const int p = wave + 8 * m;
+        int bi = 0, rem = p < P ? p : 0;
+        while (rem >= NT - bi) { rem -= NT - bi; ++bi; }
+        tbi[m] = bi; tbj[m] = bi + rem;
+    }
+    gx_v4 acc[MAXP];
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) acc[m] = gx_v4{0.0, 0.0, 0.0, 0.0};
+    const int nblk = (T + kGxPB - 1) / kGxPB;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_gx)(gx_lds));
+    const unsigned bufB = (unsigned)kGxPB * ldB;
+    for (int e = tid; e < 2 * kGxPB * ld; e += kGxThreads) gx_lds[e] = 0.0;
+    __syncthreads();
+    auto issue = [&](int blk, int sel) {                         // rows wave, wave + 8, ... of block blk into buffer sel
+        const int t0 = blk * kGxPB;
+        for (int rr = wave; rr < kGxPB; rr += 8) {
+            const int t = t0 + rr;
+            if (t < T) {                                         // (wave-uniform)
+                const char* src = X + (size_t)t * rowB + 16u * (unsigned)lane;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)sel * bufB + (unsigned)rr * ldB);
+                for (int pc = 0; pc < npiece; ++pc)
+                    if (16u * (unsigned)lane + 1024u * (unsigned)pc < rowB) dma16gx(src + 1024 * pc, dst + 1024u * (unsigned)pc);
+            } else {                                             // past the sample: a zero row
+                double* row = gx_lds + (size_t)sel * kGxPB * ld + (size_t)rr * ld;
+                for (int c = lane; c < N; c += 64) row[c] = 0.0;
+            }
+        }
+    };
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int blk = 0; blk < nblk; ++blk) {
+        const double* cur = gx_lds + (size_t)(blk & 1) * kGxPB * ld;
+        if (blk + 1 < nblk) issue(blk + 1, (blk + 1) & 1);       // (that buffer was last read in block blk - 1: everybody is past its barrier)
+#pragma unroll
+        for (int m = 0; m < MAXP; ++m) {
+            if (wave + 8 * m < P) {                              // (wave-uniform)
+                const double* pa = cur + (size_t)k4 * ld + tbi[m] * 16 + c16;
+                const double* pb = cur + (size_t)k4 * ld + tbj[m] * 16 + c16;
+                double av[kGxPB / 4], bv[kGxPB / 4];
+#pragma unroll
+                for (int kk = 0; kk < kGxPB / 4; ++kk) { av[kk] = pa[(size_t)kk * 4 * ld]; bv[kk] = pb[(size_t)kk * 4 * ld]; }
+#pragma unroll
+                for (int kk = 0; kk < kGxPB / 4; ++kk) acc[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], acc[m], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's rows of the next block have landed
+        __syncthreads();
+    }
+#pragma unroll
+    for (int m = 0; m < MAXP; ++m) {
+        if (wave + 8 * m < P) {
+            const int j = tbj[m] * 16 + c16;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = tbi[m] * 16 + k4 + 4 * v;
+                if (i < N && j < N) {
+                    S[(size_t)i * N + j] = acc[m][v];
+                    S[(size_t)j * N + i] = acc[m][v];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // block-wide sum of NV values per thread -> every thread gets the totals (through LDS)
 template <int NV, int NT = kPcaThreads>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double* red /* [NT / 64][NV] */) {
@@ -1041,7 +1148,23 @@ __global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 template <int MAXP>
+static hipError_t launch_gx_dma(const PcaArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * kGxPB * gx_dma_ld(a.N) * sizeof(double);
+    static LdsOptIn attr_done;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_xx_dma_kernel<MAXP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gram_xx_dma_kernel<MAXP>), dim3(a.B), dim3(kGxThreads), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int MAXP>
 static hipError_t launch_gx_mfma(const PcaArgs& a, hipStream_t s) {
+    static const int no_dma = [] { const char* v = getenv("DFM_GRAM_XX_NO_DMA"); return v ? atoi(v) : 0; }();   // A/B: the register-staged kernel
+    if ((a.N & 1) == 0 && !no_dma) return launch_gx_dma<MAXP>(a, s);
     const int NT = (a.N + 15) / 16;
     const size_t lds = (size_t)2 * kGxPB * (NT * 16 + 2) * sizeof(double);
     static LdsOptIn attr_done;
@@ -1059,7 +1182,7 @@ static hipError_t launch_gx_mfma(const PcaArgs& a, hipStream_t s) {
 hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant) {
     const int NT = (a.N + 15) / 16;
     const int per_wave = (NT * (NT + 1) / 2 + 7) / 8;
-    if (variant == 0 && a.N <= 256 && per_wave <= 17) note_kernel("gram_xx_mfma_kernel");
+    if (variant == 0 && a.N <= 256 && per_wave <= 17) note_kernel((a.N & 1) == 0 ? "gram_xx_dma_kernel" : "gram_xx_mfma_kernel");
     if (variant == 0 && a.N <= 256) {
         if (per_wave <= 4) return launch_gx_mfma<4>(a, s);
         if (per_wave <= 8) return launch_gx_mfma<8>(a, s);
