@@ -651,7 +651,7 @@ __device__ __forceinline__ bool pca_iterate_lds(const PcaArgs& a, const double* 
     extern __shared__ __attribute__((aligned(16))) double pl[];
     double* Vs = pl;                                           // [N][R]
     double* Ys = Vs + (size_t)N * R;                           // [N][R]
-    double* part = Ys + (size_t)N * R;                         // [NPART][N][R]; later [4 waves][2][RR] partial Gram matrices
+    double* part = Ys + (size_t)N * R;                         // [4 waves][2][RR] partial Gram matrices
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = tid >> 8, i = tid & 255;
     const int H4 = (N + NPART - 1) / NPART;
@@ -758,16 +758,19 @@ __device__ __forceinline__ bool pca_iterate_lds(const PcaArgs& a, const double* 
 #pragma unroll
                     for (int k = 0; k < R; ++k) acc[k] = fma(sv, vr[k], acc[k]);
                 }
-#pragma unroll
-                for (int k = 0; k < R; ++k) part[((size_t)p * N + i) * R + k] = acc[k];
             }
-        }
-        __syncthreads();
-        for (int e = tid; e < N * R; e += NT) {
-            double t = part[e];
+            // the two halves of a row meet in Ys itself (its old content is dead here): the second half's thread stores, the first
+            // half's adds -- no [2][N][R] buffer of partial rows, which kept a workgroup at 51 KB of LDS (three per CU at most)
+            static_assert(NPART == 2, "two half-row threads per row");
+            if (row && p == 1) {
 #pragma unroll
-            for (int q = 1; q < NPART; ++q) t += part[(size_t)q * N * R + e];
-            Ys[e] = t;
+                for (int k = 0; k < R; ++k) Ys[(size_t)i * R + k] = acc[k];
+            }
+            __syncthreads();
+            if (row && p == 0) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) Ys[(size_t)i * R + k] = acc[k] + Ys[(size_t)i * R + k];
+            }
         }
         __syncthreads();
     };
@@ -809,8 +812,10 @@ __device__ __forceinline__ bool pca_iterate_lds(const PcaArgs& a, const double* 
     return converged;
 }
 
+// (the 512-thread instantiations: 4 waves per SIMD = two workgroups per CU.  At 169 VGPRs a CU held ONE workgroup, so the 1024
+// replicates of config 2 ran as four rounds of a kernel whose every stage is a latency chain)
 template <int R, int NT>
-__global__ __launch_bounds__(NT) void pca_kernel(PcaArgs a) {
+__global__ __launch_bounds__(NT, (NT == kPcaFastThreads ? 4 : 1)) void pca_kernel(PcaArgs a) {
     __shared__ double sH[R * R], sW[R * R], sG[R * R], sM[R * R], sev[R], sred[(NT / 64) * (R > 2 ? R : 2)], sflag[2];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -1196,9 +1201,7 @@ hipError_t launch_gram_xx(const PcaArgs& a, hipStream_t s, int variant) {
 
 template <int R>
 static hipError_t launch_pca_fast(const PcaArgs& a, hipStream_t s) {
-    const size_t need = (size_t)(2 + kPcaFastThreads / 256) * a.N * R;   // Vs, Ys, the partial products
-    const size_t gr = (size_t)2 * a.N * R + 8 * R * R;                   // ... reused for 4 x 2 partial Gram matrices
-    const size_t lds = (need > gr ? need : gr) * sizeof(double);
+    const size_t lds = ((size_t)2 * a.N * R + 8 * R * R) * sizeof(double);   // Vs, Ys, 4 x 2 partial Gram matrices
     static LdsOptIn attr_done;
     if (!attr_done && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pca_kernel<R, kPcaFastThreads>),
