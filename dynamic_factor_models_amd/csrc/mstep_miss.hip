@@ -79,6 +79,9 @@ MmGeo mm_geo(int Rp, int r, int kp_want = 0) {
     g.kp = 8; g.nbuf = 3;
     for (int kp : {32, 16}) {
         if ((kp_want != 0 && kp_want != kp) || g.tpw > 18) continue;      // (21 tile slots + a deep stage spill)
+        // narrow states (4 tile slots, 95 VGPRs): 16 periods, so that TWO workgroups share a CU -- the stages are too short to
+        // hide the DMA latency one stage ahead (C2 shape: 0.68 ms against 0.77 with 32 periods and one workgroup)
+        if (kp_want == 0 && kp == 32 && g.tpw <= 4) continue;
         if (2u * (unsigned)kp * (g.pstride + g.vstride) <= kMmLdsMax) { g.kp = kp; g.nbuf = 2; break; }
     }
     g.panelB = (unsigned)g.kp * g.pstride;
@@ -377,7 +380,18 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     hipLaunchKernelGGL(mmw_vec_kernel, dim3(a.B, (a.T + 15) / 16), dim3(256), 0, s, a, V, r, Rpad, ntm16, tt16);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    int G = num_cu > 0 ? num_cu : 256;
+    // persistent workgroups: as many per CU as their stage buffers allow (the per-wave VGPR budget at 8 waves per workgroup:
+    // 256 / 128 / 85 for 1 / 2 / 3 workgroups -- the narrow shapes need 95 or fewer).  DFM_MM_WGS overrides (diagnostics).
+    static const int wgs_env = [] { const char* v = getenv("DFM_MM_WGS"); return v ? atoi(v) : 0; }();
+    int wgs = 1;
+    if (g.tpw <= 4) {
+        const size_t lds_wg = (size_t)g.nbuf * g.stageB + 1024;
+        wgs = (int)((160 * 1024) / lds_wg);
+        if (wgs > 2) wgs = 2;
+        if (wgs < 1) wgs = 1;
+    }
+    if (wgs_env > 0) wgs = wgs_env;
+    int G = (num_cu > 0 ? num_cu : 256) * wgs;
     G = (G / 8) * 8;
     if (G < 8) G = 8;
     if (g.nbuf == 3 && g.U > 6) return hipErrorInvalidValue;
