@@ -48,6 +48,21 @@ __device__ __forceinline__ void dma16mm(const void* gsrc, unsigned lds_dst) {
 }
 
 constexpr int kMmWaves = 8;
+// s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the immediate must be a constant): n in 0 .. 12
+__device__ __forceinline__ void wait_vm_upto(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (never less patient than needed)
+    }
+}
 constexpr unsigned kMmLdsMax = 156 * 1024;               // stage buffers of a workgroup
 
 struct MmGeo {
@@ -62,7 +77,7 @@ struct MmGeo {
 };
 
 // kp_want: 0 = the deepest stage that fits twice (32, then 16 periods), else 8 periods in three buffers
-MmGeo mm_geo(int Rp, int r, int kp_want = 0) {
+MmGeo mm_geo(int Rp, int r, int kp_want = 0, int nbuf_want = 0) {
     MmGeo g;
     g.r = r; g.Rp = Rp; g.npr = r * (r + 1) / 2;
     g.ntm = (g.npr + 15) / 16;
@@ -84,6 +99,7 @@ MmGeo mm_geo(int Rp, int r, int kp_want = 0) {
         if (kp_want == 0 && kp == 32 && g.tpw <= 4) continue;
         if (2u * (unsigned)kp * (g.pstride + g.vstride) <= kMmLdsMax) { g.kp = kp; g.nbuf = 2; break; }
     }
+    if (g.nbuf == 3 && nbuf_want == 4 && 4u * 8u * (g.pstride + g.vstride) <= kMmLdsMax) g.nbuf = 4;   // (diagnostics: DFM_MM_NBUF)
     g.panelB = (unsigned)g.kp * g.pstride;
     g.stageB = g.panelB + (unsigned)g.kp * g.vstride;
     g.U = (g.kp * (1 + g.nv) + kMmWaves - 1) / kMmWaves;
@@ -192,21 +208,19 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
 #pragma unroll
         for (int x = 0; x < TPW; ++x) xoff[x] = 128u * (unsigned)(x < ntile ? x : ntile - 1);
 
-        issue_stage(0, 0);
-        if (NBUF == 3 && nst > 1) issue_stage(1, 1);
+#pragma unroll
+        for (int q0 = 0; q0 < NBUF - 1; ++q0)
+            if (q0 < nst) issue_stage(q0, q0);                // NBUF - 1 stages ahead
         int bsel = 0;
         for (int st = 0; st < nst; ++st) {
-            // this wave's DMAs of stage st have landed (three buffers: those of stage st + 1 may still be in flight)
-            if (NBUF == 2 || st + 1 >= nst) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (U == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (U == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (U == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (U == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                     // ... everybody's have, and the buffer read one (two) stages ago is free
+            // this wave's DMAs of stage st have landed: at most those of the NBUF - 2 younger stages are still in flight
+            {
+                const int younger = (nst - 1 - st < NBUF - 2) ? nst - 1 - st : NBUF - 2;
+                wait_vm_upto(younger * U);
+            }
+            __builtin_amdgcn_s_barrier();                     // ... everybody's have, and the buffer read one stage ago is free
             asm volatile("" ::: "memory");
-            if (NBUF == 2) { if (st + 1 < nst) issue_stage(st + 1, bsel ^ 1); }
-            else if (st + 2 < nst) issue_stage(st + 2, bsel == 0 ? 2 : bsel - 1);
+            if (st + NBUF - 1 < nst) issue_stage(st + NBUF - 1, bsel == 0 ? NBUF - 1 : bsel - 1);
             const unsigned stg = lds0 + (unsigned)bsel * g.stageB;
             const int nm = g.ntm - tile0;                     // tiles x < nm of this wave belong to D (A = the mask), the others to Sxf (A = xz)
             double mk[KP / 4], xk[KP / 4];
@@ -231,7 +245,7 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
                 for (int x = 0; x < TPW; ++x)
                     acc[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(x < nm ? mk[s] : xk[s], bv[x], acc[x], 0, 0, 0);
             }
-            bsel = NBUF == 2 ? (bsel ^ 1) : (bsel == 2 ? 0 : bsel + 1);
+            bsel = bsel == NBUF - 1 ? 0 : bsel + 1;
         }
         // the item is complete: 16x16x4 D[(l / 16) + 4 v][l % 16] -> series k4 + 4 v of the group, column c16 of the tile
         double* out = OUT + ((size_t)b * N + s0 + 16 * sgi) * tt16 + 16 * tile0 + c16;
@@ -371,7 +385,8 @@ hipError_t launch_mm_slots(const MstepArgs& a, const double* V, double* OUT, dou
 hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
     note_kernel("mstep_miss_kernel");
     static const int kp_want = [] { const char* v = getenv("DFM_MM_KP"); return v ? atoi(v) : 0; }();   // diagnostics: 8 | 16 | 32
-    const MmGeo g = mm_geo(Rpad, r, kp_want);
+    static const int nbuf_want = [] { const char* v = getenv("DFM_MM_NBUF"); return v ? atoi(v) : 0; }();  // diagnostics: 4 (with DFM_MM_KP=8)
+    const MmGeo g = mm_geo(Rpad, r, kp_want, nbuf_want);
     const int tt16 = g.tt * 16, ntm16 = g.ntm * 16;
     double* V = ws;
     double* OUT = V + (size_t)a.B * a.T * tt16;
@@ -394,9 +409,10 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     int G = (num_cu > 0 ? num_cu : 256) * wgs;
     G = (G / 8) * 8;
     if (G < 8) G = 8;
-    if (g.nbuf == 3 && g.U > 6) return hipErrorInvalidValue;
+    if (g.nbuf >= 3 && g.U > 6) return hipErrorInvalidValue;
     if (g.kp == 32) e = launch_mm_slots<32, 2>(a, V, OUT, sxx, cnt, g, G, s);
     else if (g.kp == 16) e = launch_mm_slots<16, 2>(a, V, OUT, sxx, cnt, g, G, s);
+    else if (g.nbuf == 4) e = launch_mm_slots<8, 4>(a, V, OUT, sxx, cnt, g, G, s);
     else e = launch_mm_slots<8, 3>(a, V, OUT, sxx, cnt, g, G, s);
     if (e != hipSuccess) return e;
     const int npr = r * (r + 1) / 2;
