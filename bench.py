@@ -285,7 +285,9 @@ class Workload:
         self.torch, self.dist, self.ctx, self.shard = torch, dist, ctx, shard
         self.world, self.rank, self.dev = world, rank, dev
         self.B, self.N, self.T, self.r, self.missing, self.mode = B, N, T, r, missing, mode
-        self.distributed = world > 1
+        # (DFM_BENCH_FORCE_DIST=1 under a 1-rank torchrun: the multi-rank step -- async all-gather on RCCL's stream, barrier fences --
+        # on a one-GPU box; diagnostics)
+        self.distributed = world > 1 or (dist is not None and dist.is_initialized() and os.environ.get("DFM_BENCH_FORCE_DIST") == "1")
         self.may_missing = missing > 0.0
         # this rank's replicates [rank B, (rank + 1) B) of the job's world * B (shard.replicate_range), generated where they live
         self.panel, self.params = ctx.synth_panels(seed, rank * B, B, T, N, r, missing_prob=missing)
@@ -544,7 +546,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("DFM_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
+        # The step's collective moves 8 KB per rank.  RCCL's default channel count puts its kernel on several CUs at the moment
+        # the next pass (one persistent workgroup per CU, 146 KB of LDS: nothing fits beside it) wants all of them, and every
+        # workgroup that has to wait delays the whole pass.  One channel = one contended CU: measured with a forced 1-rank group
+        # 3.89 -> 4.14 M passes/s (4.59 M without the collective).  The user's own setting wins.
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "1")
         with stdout_to_stderr():                                  # (RCCL's banner goes to stderr, not in front of / behind the JSON line)
             dist.init_process_group(backend="nccl", device_id=dev)
             probe = torch.ones(1, device=dev)
