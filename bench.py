@@ -299,6 +299,10 @@ class Workload:
         # buffers in turn; a buffer is reused only after the gather that read it has completed)
         self.ll_pair = [self.ll, torch.empty((B,), dtype=f64, device=dev)] if self.distributed else [self.ll]
         self.ll_all = [torch.empty((world * B,), dtype=f64, device=dev) for _ in range(2)] if self.distributed else None
+        self.stream = None
+        if self.distributed and os.environ.get("DFM_BENCH_NO_PRIO") != "1":
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            self.stream = torch.cuda.Stream(device=dev, priority=hi)
         self.em_params = None
         if mode == "em":
             if self.may_missing:
@@ -307,6 +311,16 @@ class Workload:
                 self.em_params = list(ctx.pca_init_batch(self.panel, r, want_factors=False)[:6])
 
     def steps(self, k, profile=False):
+        # multi-rank: the passes go on a HIGH-priority stream.  The step's collective and the next pass become eligible at the same
+        # moment; at equal priority RCCL's workgroup sometimes takes a CU first and that CU's pass workgroup (one per CU, nothing
+        # fits beside it) starts ~20 us late.  With the pass preferred, the collective runs in the TAIL of the next pass, where
+        # CUs go idle one by one anyway.
+        if self.distributed and self.stream is not None and not profile:
+            with self.torch.cuda.stream(self.stream):
+                return self._steps(k, profile)
+        return self._steps(k, profile)
+
+    def _steps(self, k, profile=False):
         ctx, dist = self.ctx, self.dist
         if self.mode == "pass":
             pending = [None, None]
