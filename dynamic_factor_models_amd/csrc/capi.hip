@@ -55,6 +55,8 @@ struct dfm_handle {
     bool cov_wave = false;                 // DFM_COV_WAVE=1: one-wave-per-replicate covariance recursion on the separate-launch path
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    void* odd = nullptr;                   // panel / loadings / R with one all-missing series appended (odd N beyond the tilings, odd_pad)
+    size_t odd_bytes = 0;
     std::string prof_file;                 // DFM_PF_PROF_FILE with DFM_SCAN_ABL=256: phase stamps of the fused pass
     char err[512] = {0};
     // optional per-kernel timing (bench.py roofline leg): event pairs on the launch stream
@@ -70,6 +72,8 @@ static const char* const kKernelNames[K_COUNT] = {"collapse_kernel", "recursion_
                                                   "mstep_solve_kernel", "pca_kernel", "synth_kernel",
                                                   "pad_params_kernel", "collapse_dma_kernel", "gram_kernel",
                                                   "cov_kernel", "meanscan_kernel", "pfill_kernel", "collapse_mfma_kernel", "als_kernel", "ols_kernel", "var_boot_kernel", "quantile_kernel", "collapse_wide_kernel", "em_update_kernel", "chow_kernel", "mstep_mfma_kernel", "gram_xx_kernel", "pass_fused_kernel"};
+
+namespace dfm { int handle_device(const dfm_handle* h) { return h->device; } }   // (probe.hip)
 
 namespace {
 
@@ -248,7 +252,7 @@ int check_dims(dfm_handle* h, int B, int T, int N, int r) {
 // plain = the factor model itself (loadings as wide as the state): at Rp = 32 cross-sections beyond the register tiling take
 // the streaming collapse of config 4 in its variant for missing cells (collapse_wide2.hip)
 int check_general_n(dfm_handle* h, int N, int r, bool plain = false) {
-    if (plain && pad_r(r) == 32 && collapse_wide2_supported(32, N)) return 0;
+    if (plain && pad_r(r) == 32 && (collapse_wide2_supported(32, N) || collapse_wide2_supported(32, N + 1))) return 0;   // odd N: odd_pad
     if (N > collapse_max_n(pad_r(r)))
         return fail(h, DFM_E_DIMS, "N too large for this r on the path with missing cells / EM (collapse kernel register "
                                    "tiling: N <= 1024 for r <= 8, 512 for r <= 16; r > 16: 256, or any even N for the plain model)%s");
@@ -308,6 +312,50 @@ int pad_params(dfm_handle* h, const Plan& p, int B, int N, int r, const double* 
     return 0;
 }
 
+
+// ---- odd N beyond the register tiling, panel with missing cells, r > 16 ------------------------------------------------
+// The streaming collapse for missing cells (collapse_wide2.hip) and the matrix-pipe loadings step (mstep_miss.hip) move
+// 16-byte series pairs.  The reference's estimator takes any cross-section (dfm_functions.ipynb:352-366 exists because panels
+// are unbalanced), so an odd N gets ONE series appended: every cell missing, loadings 0, R = 1.  Its contribution to b_t, C_t,
+// n_t, s_t and sum log R over the observed cells is exactly 0, so the pass equals the N-series pass; the loadings step skips
+// a series without observed cells (mmw_finish_kernel), and its parameters are dropped on the way out.
+__global__ void pad_last_col_kernel(size_t rows, int N, const double* src, double* dst) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= rows * (size_t)(N + 1)) return;
+    const size_t row = tid / (size_t)(N + 1);
+    const int i = (int)(tid % (size_t)(N + 1));
+    dst[tid] = i < N ? src[row * N + i] : __builtin_nan("");
+}
+// dst[b][n][k] (n <= N) from src[b][n][k] (n < N), `fill` for the appended row; N1 = rows of dst per b (N + 1), or N to un-pad
+__global__ void copy_series_rows_kernel(size_t nb, int Ns, int Nd, int w, double fill, const double* src, double* dst) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nb * (size_t)Nd * w) return;
+    const int k = (int)(tid % w);
+    const int n = (int)((tid / w) % Nd);
+    const size_t b = tid / ((size_t)w * Nd);
+    dst[tid] = n < Ns ? src[(b * Ns + n) * w + k] : fill;
+}
+struct OddPad { double *panel, *Lam, *R; };
+int odd_pad(dfm_handle* h, int B, int T, int N, int r, const double* panel, const double* Lam, const double* R, OddPad* out) {
+    const size_t n_panel = (size_t)B * T * (N + 1), n_lam = (size_t)B * (N + 1) * r, n_R = (size_t)B * (N + 1);
+    const size_t bytes = (n_panel + n_lam + n_R) * sizeof(double) + 768;
+    if (bytes > h->odd_bytes) {
+        if (h->odd) { HIP_TRY(h, hipDeviceSynchronize()); HIP_TRY(h, hipFree(h->odd)); h->odd = nullptr; h->odd_bytes = 0; }
+        HIP_TRY(h, hipMalloc(&h->odd, bytes));
+        h->odd_bytes = bytes;
+    }
+    auto al = [](size_t n) { return (n + 31) & ~(size_t)31; };
+    out->panel = static_cast<double*>(h->odd);
+    out->Lam = out->panel + al(n_panel);
+    out->R = out->Lam + al(n_lam);
+    auto grid = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
+    hipLaunchKernelGGL(pad_last_col_kernel, grid(n_panel), dim3(256), 0, h->stream, (size_t)B * T, N, panel, out->panel);
+    hipLaunchKernelGGL(copy_series_rows_kernel, grid(n_lam), dim3(256), 0, h->stream, (size_t)B, N, N + 1, r, 0.0, Lam, out->Lam);
+    hipLaunchKernelGGL(copy_series_rows_kernel, grid(n_R), dim3(256), 0, h->stream, (size_t)B, N, N + 1, 1, 1.0, R, out->R);
+    HIP_TRY(h, hipGetLastError());
+    return 0;
+}
+
 struct EmOpts {          // all-null for a plain pass
     double *A_out = nullptr, *Q_out = nullptr, *mu0_out = nullptr, *P0_out = nullptr;
     int* active = nullptr; int* iters = nullptr; double* ll_path = nullptr;
@@ -318,6 +366,11 @@ struct EmOpts {          // all-null for a plain pass
 bool fast_eligible(const dfm_handle* h, int N, int r, unsigned flags) {
     if (h->force_general || (flags & (DFM_F_MAY_HAVE_MISSING | DFM_F_SINGULAR_Q))) return false;
     return collapse_dma_supported(pad_r(r), N) || collapse_wide_supported(pad_r(r), N);
+}
+
+bool needs_odd_pad(bool fast, int N, int r) {
+    if (fast) return false;
+    return pad_r(r) == 32 && (N & 1) && N > collapse_max_n(32) && collapse_wide2_supported(32, N + 1);
 }
 
 int check_em_n(dfm_handle* h, int N, int r, unsigned flags) {
@@ -681,6 +734,17 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
     HIP_TRY(h, hipSetDevice(h->device));
+    if (needs_odd_pad(fast_eligible(h, N, r, flags) && !h->em_general, N, r)) {   // odd N beyond the tilings: one all-missing series appended
+        OddPad o;
+        if (int rc = odd_pad(h, B, T, N, r, panel, Lam, R, &o)) return rc;
+        if (int rc = em_run(h, B, T, N + 1, r, o.panel, o.Lam, o.R, A, Q, mu0, P0, max_iter, tol, loglik_path, iters, loglik_single,
+                            f_smooth, P_smooth, flags, k_first, k_count, active_ext)) return rc;
+        const size_t n_lam = (size_t)B * N * r, n_R = (size_t)B * N;
+        hipLaunchKernelGGL(copy_series_rows_kernel, dim3((unsigned)((n_lam + 255) / 256)), dim3(256), 0, h->stream, (size_t)B, N + 1, N, r, 0.0, o.Lam, Lam);
+        hipLaunchKernelGGL(copy_series_rows_kernel, dim3((unsigned)((n_R + 255) / 256)), dim3(256), 0, h->stream, (size_t)B, N + 1, N, 1, 0.0, o.R, R);
+        HIP_TRY(h, hipGetLastError());
+        return 0;
+    }
     // balanced panels: E-step on the fast path (collapse on the matrix pipe, time-parallel scan), transition
     // M-step by em_update_kernel; panels with missing cells: recursion_kernel does both
     const Plan p = make_plan(B, T, N, r, flags, true, fast_eligible(h, N, r, flags) && !h->em_general);
@@ -1130,6 +1194,7 @@ int dfm_destroy(dfm_handle* h) {
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     if (h->ws) hipFree(h->ws);
+    if (h->odd) hipFree(h->odd);
     if (h->status_dev) hipFree(h->status_dev);
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1157,6 +1222,23 @@ int dfm_set_stream(dfm_handle* h, void* stream) {
 
 // (forward: defined with the entry points that use it)
 static int status_check(dfm_handle* h);
+// A host-pointer entry point opens a new status epoch: whatever earlier, unchecked *_dev calls left in the sticky word is
+// read and cleared here, so that the check at the END of the call reports this call's own kernels only (a stale NaN / PCA /
+// time-out bit used to fail the next unrelated host call, and silently triggered api.estimate's singular-Q retry).  The
+// discarded bits stay visible in dfm_last_error until the next error; device-pointer callers that care call dfm_check_status
+// after their own calls.  These entries copy whole panels across PCIe -- one 4-byte read more is free.
+static int status_epoch(dfm_handle* h) {
+    if (!h->status_dev) return 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int st = 0;
+    HIP_TRY(h, hipMemcpy(&st, h->status_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        HIP_TRY(h, hipMemset(h->status_dev, 0, sizeof(int)));
+        snprintf(h->err, sizeof(h->err), "note: status bits 0x%x of an earlier unchecked device-pointer call were discarded", st);
+    }
+    return 0;
+}
 
 int dfm_synchronize(dfm_handle* h) {
     if (!h) return DFM_E_NULL;
@@ -1226,6 +1308,11 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     if (!fast_eligible(h, N, r, flags))
         if (int rc = check_general_n(h, N, r, true)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
+    if (needs_odd_pad(fast_eligible(h, N, r, flags), N, r)) {  // odd N beyond the tilings: one all-missing series appended
+        OddPad o;
+        if (int rc = odd_pad(h, B, T, N, r, panel, Lam, R, &o)) return rc;
+        return dfm_ks_pass_batch_dev(h, B, T, N + 1, r, o.panel, o.Lam, o.R, A, Q, mu0, P0, f_smooth, P_smooth, loglik, flags);
+    }
     const Plan p = make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags));
     if (int rc = ensure_ws(h, p.total)) return rc;
     PaddedParams pp;
@@ -1261,6 +1348,7 @@ int dfm_ks_pass_batch(dfm_handle* h, int B, int T, int N, int r, const double* p
     if (int rc = check_dims(h, B, T, N, r)) return rc;
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0 || !f_smooth || !loglik)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (int rc = status_epoch(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t d = sizeof(double), np = (size_t)r * (r + 1) / 2;
     const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N,
@@ -1330,6 +1418,7 @@ int dfm_em_batch(dfm_handle* h, int B, int T, int N, int r, const double* panel,
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    if (int rc = status_epoch(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t d = sizeof(double), np = (size_t)r * (r + 1) / 2;
     const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_m = (size_t)B * r * r,
@@ -1394,6 +1483,7 @@ static int varp_host(dfm_handle* h, int B, int T, int N, int r, int p, const dou
     if (!panel || !Lam || !R || !Avar || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (em ? (!loglik_path || !iters) : (!f_smooth || !loglik)) return fail(h, DFM_E_NULL, "required output pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    if (int rc = status_epoch(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t d = sizeof(double), k = (size_t)r * p, np = (size_t)r * (r + 1) / 2;
     const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_a = (size_t)B * r * k,
@@ -1468,6 +1558,7 @@ int dfm_ks_pass_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q
     if (r * m > DFM_MAX_R) return fail(h, DFM_E_R_UNSUPPORTED, "r * max(p, q + 1) > DFM_MAX_R (32)%s");
     if (!panel || !Lam || !sig2 || (q > 0 && !rho) || !Avar || !Q || !mu0 || !P0 || !f_smooth || !loglik)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (int rc = status_epoch(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t d = sizeof(double), k = (size_t)r * m, np = (size_t)r * (r + 1) / 2, Tq = (size_t)(T - q);
     const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_rho = (size_t)B * N * q,
@@ -1517,6 +1608,7 @@ int dfm_em_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, con
     if (!panel || !Lam || !sig2 || (q > 0 && !rho) || !Avar || !Q || !mu0 || !P0 || !loglik_path || !iters)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
+    if (int rc = status_epoch(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t d = sizeof(double), k = (size_t)r * m, np = (size_t)r * (r + 1) / 2, Tq = (size_t)(T - q);
     const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_rho = (size_t)B * N * q,
@@ -1572,6 +1664,7 @@ int dfm_em_obs_batch(dfm_handle* h, int B, int T, int N, int r_u, int r_o, const
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
     for (size_t k = 0; k < (size_t)B * T * r_o; ++k)
         if (G[k] != G[k]) return fail(h, DFM_E_MISSING, "observed factors must not contain NaN%s");
+    if (int rc = status_epoch(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t d = sizeof(double), re = (size_t)r_o + r_u, np = (size_t)r_u * (r_u + 1) / 2;
     const size_t n_panel = (size_t)B * T * N, n_g = (size_t)B * T * r_o, n_lam = (size_t)B * N * re, n_R = (size_t)B * N,
@@ -1640,6 +1733,7 @@ int dfm_pca_init_batch(dfm_handle* h, int B, int T, int N, int r, const double* 
     if (!h) return DFM_E_NULL;
     if (B < 1 || T < 2 || N < 1 || r < 1 || r > DFM_MAX_R) return fail(h, DFM_E_DIMS, "bad dimensions%s");
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    if (int rc = status_epoch(h)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t d = sizeof(double);
     const size_t n_panel = (size_t)B * T * N, n_lam = (size_t)B * N * r, n_R = (size_t)B * N, n_m = (size_t)B * r * r,

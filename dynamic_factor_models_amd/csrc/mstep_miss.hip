@@ -306,6 +306,9 @@ __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const doub
     double* L = S + tid;
     double* y = S + (size_t)npr * ns + tid;
 #define LL(i, j) L[(size_t)((i) * ((i) + 1) / 2 + (j)) * ns]
+    // a series with fewer than r + 1 observed cells, or whose normal matrix is not positive definite, keeps its parameters
+    // (mstep_obs_kernel's rule; an all-missing series -- e.g. the one capi.hip appends to an odd N -- has S = 0, cnt = 0)
+    bool ok = true;
     for (int i = 0; i < r; ++i) {
         for (int j = 0; j <= i; ++j) {
             double s0_ = LL(i, j), s1_ = 0.0, s2_ = 0.0, s3_ = 0.0;   // four partial sums: the LDS reads of a row pair overlap
@@ -318,7 +321,8 @@ __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const doub
             }
             for (; k < j; ++k) s0_ = fma(-LL(i, k), LL(j, k), s0_);
             const double s = (s0_ + s1_) + (s2_ + s3_);
-            LL(i, j) = (j == i) ? sqrt(s) : s / LL(j, j);
+            if (j == i) ok = ok && (s > 0.0);
+            LL(i, j) = (j == i) ? sqrt(s > 0.0 ? s : 1.0) : s / LL(j, j);
         }
     }
     double yy = 0.0;
@@ -336,7 +340,9 @@ __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const doub
     }
 #undef LL
     const int col = s0 + tid;
-    a.R_out[(size_t)b * N + col] = (sxx[(size_t)b * N + col] - yy) / cnt[(size_t)b * N + col];
+    const double nobs_i = cnt[(size_t)b * N + col];
+    if (!ok || nobs_i < (double)(r + 1)) return;
+    a.R_out[(size_t)b * N + col] = (sxx[(size_t)b * N + col] - yy) / nobs_i;
     double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
     for (int k = 0; k < Rp; ++k) lo[k] = k < r ? y[(size_t)k * ns] : 0.0;
 }

@@ -125,6 +125,7 @@ struct Gpu {      // one GPU's part of the object
     int rc = 0;
     std::string msg;
     int ran = 0;
+    int path_cap = 0;           // row length (iterations) the resident loglik_path buffer was sized for by the last em_loop that got that far
 };
 
 }  // namespace
@@ -138,6 +139,7 @@ struct dfm_multi {
     int B = 0, T = 0, N = 0, r = 0, mx = 0;
     int path_iters = 0;          // max_iter of the last dfm_multi_em (row length of the resident loglik_path)
     bool have_f = false, have_P = false, have_ll = false, have_path = false;
+    std::atomic<int> poisoned{0};  // a rank aborted its communicator (em_loop): the collective object is gone, every further call is refused
     std::atomic<int> failed{0};
     char err[640] = {0};
 };
@@ -236,6 +238,7 @@ void em_loop(dfm_multi* m, int gi, int max_iter, double tol, bool want_smooth, b
         hipError_t e = g.path.need((size_t)(g.Bl > 0 ? g.Bl : 1) * max_iter * d);
         if (e == hipSuccess && want_smooth && want_P) e = g.P.need((size_t)g.Bl * m->T * np * d);
         if (e != hipSuccess) bail(m, g, DFM_E_DIMS, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+        else g.path_cap = max_iter;
     }
     std::vector<double> gathered((size_t)2 * m->mx * m->G);
     const bool exchange = m->has_comm || tol > 0.0;          // one GPU, no communicator, no stopping rule: nothing to agree on
@@ -263,7 +266,9 @@ void em_loop(dfm_multi* m, int gi, int max_iter, double tol, bool want_smooth, b
         (void)hipMemcpyAsync(gathered.data(), src, (size_t)2 * m->mx * m->G * d, hipMemcpyDeviceToHost, g.st);
         if (hipStreamSynchronize(g.st) != hipSuccess) {
             bail(m, g, DFM_E_COMM, "stream failed during the exchange");
-            if (m->has_comm && Rc.comm_abort && g.comm) { (void)Rc.comm_abort(g.comm); g.comm = nullptr; }
+            // the peers' collectives return once this rank's communicator is aborted; the object is unusable afterwards
+            // (dfm_multi_create refuses to build a communicator without ncclCommAbort, so the pointer is there)
+            if (m->has_comm && g.comm) { (void)Rc.comm_abort(g.comm); g.comm = nullptr; m->poisoned.store(1); }
             break;
         }
         bool any = false;
@@ -332,6 +337,7 @@ int dfm_multi_create(dfm_multi** out, int ngpu, const int* device_ids, unsigned 
     if (rc == 0 && want_comm) {
         Rccl& R = rccl();
         if (!R.so) rc = fail(m, DFM_E_COMM, R.why);
+        else if (!R.comm_abort) rc = fail(m, DFM_E_COMM, "librccl has no ncclCommAbort: a failed rank could not release its peers");
         else {
             std::vector<comm_t> comms(ngpu, nullptr);
             const int e = R.comm_init_all(comms.data(), ngpu, dev.data());
@@ -349,12 +355,14 @@ int dfm_multi_create(dfm_multi** out, int ngpu, const int* device_ids, unsigned 
 
 int dfm_multi_destroy(dfm_multi* m) {
     if (!m) return 0;
-    Rccl& R = rccl();
+    bool any_comm = m->has_comm;
+    for (auto& g : m->gpu) any_comm = any_comm || g.comm != nullptr;
+    Rccl* R = any_comm ? &rccl() : nullptr;                    // single-GPU objects never load RCCL, not even here
     on_all(m, [&](int gi) {
         Gpu& g = m->gpu[gi];
         (void)hipSetDevice(g.dev);
         if (g.st) (void)hipStreamSynchronize(g.st);
-        if (g.comm && R.so) { (void)R.comm_destroy(g.comm); g.comm = nullptr; }
+        if (g.comm && R && R->so) { (void)R->comm_destroy(g.comm); g.comm = nullptr; }
         for (Buf* b : {&g.x, &g.lam, &g.R, &g.A, &g.Q, &g.mu, &g.P0, &g.f, &g.P, &g.ll, &g.path, &g.it, &g.act, &g.send, &g.recv}) b->release();
         if (g.h) { (void)dfm_destroy(g.h); g.h = nullptr; }
         if (g.st) { (void)hipStreamDestroy(g.st); g.st = nullptr; }
@@ -412,6 +420,7 @@ int dfm_multi_synth(dfm_multi* m, uint64_t seed, int64_t first_replicate, int B,
 int dfm_multi_ks_pass(dfm_multi* m, int want_P, unsigned flags) {
     if (!m) return DFM_E_NULL;
     if (!m->loaded) return fail(m, DFM_E_NULL, "no resident job: call dfm_multi_load or dfm_multi_synth first");
+    if (m->poisoned.load()) return fail(m, DFM_E_COMM, "this object's communicator was aborted by an earlier failure: destroy it and create a new one");
     clear_status(m);
     on_all(m, [&](int g) { pass_one(m, g, want_P != 0, flags); });
     if (int rc = join_status(m)) return rc;
@@ -423,12 +432,17 @@ int dfm_multi_em(dfm_multi* m, int max_iter, double tol, int want_smooth, int wa
     if (!m) return DFM_E_NULL;
     if (!m->loaded) return fail(m, DFM_E_NULL, "no resident job: call dfm_multi_load or dfm_multi_synth first");
     if (max_iter < 1) return fail(m, DFM_E_DIMS, "max_iter must be >= 1");
+    if (m->poisoned.load()) return fail(m, DFM_E_COMM, "this object's communicator was aborted by an earlier failure: destroy it and create a new one");
     clear_status(m);
     m->have_path = false;
+    for (auto& g : m->gpu) g.path_cap = 0;
     on_all(m, [&](int g) { em_loop(m, g, max_iter, tol, want_smooth != 0, want_P != 0, flags); });
     if (iterations_run) *iterations_run = m->gpu[0].ran;
     m->path_iters = max_iter;
-    m->have_path = true;                       // (also after a failure: the path says which replicate went wrong)
+    // (also after a failure: the path says which replicate went wrong) -- but only if EVERY GPU's buffer holds rows of max_iter:
+    // a GPU that bailed before its allocation may still carry the shorter buffer of an earlier call
+    m->have_path = true;
+    for (auto& g : m->gpu) if (g.Bl > 0 && g.path_cap < max_iter) m->have_path = false;
     if (int rc = join_status(m)) return rc;
     if (want_smooth) { m->have_f = true; m->have_P = want_P != 0; }
     return 0;

@@ -9,6 +9,9 @@
 
 #include <hip/hip_runtime.h>
 
+struct dfm_handle;
+namespace dfm { int handle_device(const dfm_handle* h); }   // capi.hip
+
 namespace {
 
 using lds_ptr = __attribute__((address_space(3))) char*;
@@ -74,8 +77,12 @@ __global__ __launch_bounds__(256) void probe_write_kernel(double2* __restrict__ 
 extern "C" int dfm_hbm_probe(dfm_handle* h, size_t bytes, int mode, int iters, double* gbs_out, double* ms_out) {
     if (!gbs_out || mode < 0 || mode > 2 || iters < 1) return DFM_E_DIMS;
     if (bytes < (size_t)1 << 24) return DFM_E_DIMS;                     // below 16 MB the number says nothing about HBM
-    (void)h;                                                              // (measured on the current device's null stream:
-    hipStream_t st = nullptr;                                             //  the probe runs alone, between timed regions)
+    if (!h) return DFM_E_NULL;
+    {   // the HANDLE's device (a Julia / C caller with several handles, or the dfm_multi threads, may have another one current)
+        const hipError_t ed = hipSetDevice(dfm::handle_device(h));
+        if (ed != hipSuccess) return (int)ed;
+    }
+    hipStream_t st = nullptr;                                             // (its null stream: the probe runs alone, between timed regions)
     const int blocks = 1024;
     const size_t seg = (bytes / ((size_t)blocks * 4)) / 1024 * 1024;      // per wave, a multiple of 1 KiB
     const size_t used = mode == 0 ? seg * blocks * 4 : bytes / 16 * 16;

@@ -1,0 +1,191 @@
+"""GPU parity tests added in round 4 ("Next round" item 1): the last kernels that were benchmarked at one launch
+geometry and compared with the oracle at another.
+
+* PCA start (`gram_xx_dma_kernel` + `pca_kernel<8, 512>` with two workgroups per CU) at the batch `bench.py --mode pca` times:
+  B = 1024, N = 200, T = 500, r = 8 -- 32 scattered replicates (b, b + 256, b + 512, b + 768: both workgroups of a CU and all
+  four rounds of the grid) vs `ko.pca_init` at 1e-8; and at config 4's occupancy (B = 256, N = 1000, T = 2000, r = 20);
+* EM at the headline batch (B = 1024: `pass_fused` + `em_update` + `mstep_mfma`), three iterations from the GPU's PCA start vs
+  `ko.em` from the SAME start (1e-8) and, chained, vs the oracle's own PCA start + EM (north_star's 1e-6);
+* EM at B = 1024 with 10 % of the cells missing (`collapse_miss` + `recursion_pair` + `mstep_lam` at one replicate per SIMD);
+* odd N beyond the register tiling with missing cells at r > 16 (refused until round 4: the library appends one all-missing
+  series with zero loadings), pass and EM;
+* a series without a single observed cell keeps its parameters in every loadings step.
+"""
+import numpy as np
+import pytest
+
+from oracle import kalman_oracle as ko
+from test_gpu_ks_pass import _compare, _oracle
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from dynamic_factor_models_amd import DfmContext
+    c = DfmContext()
+    yield c
+    c.close()
+
+
+def _take(t, ix):
+    return t.index_select(0, ix).cpu().numpy()
+
+
+def _scattered(B, stride, n, seed):
+    """n residues b < stride (first, last, seeded rest), each with b + stride, b + 2 stride, ... below B."""
+    rng = np.random.default_rng(seed)
+    base = sorted(set([0, stride - 1] + rng.choice(stride, size=n, replace=False).tolist()))[:n]
+    return sorted(b + j * stride for b in base for j in range(B // stride))
+
+
+def _check_start(got, panel, r, idx, label):
+    for j, b in enumerate(idx):
+        ref, Fo = ko.pca_init(panel[j], r)
+        np.testing.assert_allclose(got["F"][j], Fo, rtol=0, atol=1e-8 * np.abs(Fo).max(), err_msg=f"{label}: scores, replicate {b}")
+        for k in KEYS:
+            np.testing.assert_allclose(got[k][j], ref[k], rtol=0, atol=1e-8 * max(np.abs(ref[k]).max(), 1e-300),
+                                       err_msg=f"{label}: {k}, replicate {b}")
+
+
+def test_pca_start_at_the_benchmarked_batch(ctx):
+    import torch
+    B, N, T, r = 1024, 200, 500, 8
+    panel, _ = ctx.synth_panels(20160415, 0, B, T, N, r)
+    out = ctx.pca_init_batch(panel, r)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    idx = _scattered(B, 256, 8, seed=4)
+    assert len(idx) == 32
+    ix = torch.tensor(idx, device=panel.device)
+    got = dict(zip(KEYS + ("F",), [_take(t, ix) for t in out]))
+    _check_start(got, _take(panel, ix), r, idx, "PCA start, B = 1024")
+
+
+def test_pca_start_at_config4_occupancy(ctx):
+    import torch
+    B, N, T, r = 256, 1000, 2000, 20
+    panel, _ = ctx.synth_panels(5, 0, B, T, N, r)
+    out = ctx.pca_init_batch(panel, r)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    idx = [3, 254]
+    ix = torch.tensor(idx, device=panel.device)
+    got = dict(zip(KEYS + ("F",), [_take(t, ix) for t in out]))
+    _check_start(got, _take(panel, ix), r, idx, "PCA start, config 4")
+    del panel, out
+    torch.cuda.empty_cache()
+
+
+def _em_vs_oracle(ctx, panel, par, idx, iters, missing, label, chain_r=None):
+    import torch
+    ix = torch.tensor(idx, device=panel.device)
+    start = dict(zip(KEYS, [_take(p, ix) for p in par]))          # the parameters entering the GPU's EM
+    xs = _take(panel, ix)
+    path, its, _, _ = ctx.em_batch(panel, *par, max_iter=iters, tol=0.0, want_smooth=False, may_have_missing=missing)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(path).all()) and bool((its == iters).all())
+    got = dict(zip(KEYS, [_take(p, ix) for p in par]))
+    pth = _take(path, ix)
+    for j, b in enumerate(idx):
+        p, opath, _ = ko.em(xs[j], {k: start[k][j] for k in KEYS}, max_iter=iters, tol=0.0)
+        np.testing.assert_allclose(pth[j], opath, rtol=1e-9, err_msg=f"{label}: log-likelihood path, replicate {b}")
+        for k in KEYS:
+            err = np.abs(got[k][j] - p[k]).max()
+            assert err <= 1e-8 * max(1.0, np.abs(p[k]).max()), (label, k, b, err)
+        if chain_r is not None:                                  # the oracle's OWN start, then its EM: the whole chain at north_star's 1e-6
+            ref, _ = ko.pca_init(xs[j], chain_r)
+            p2, opath2, _ = ko.em(xs[j], ref, max_iter=iters, tol=0.0)
+            np.testing.assert_allclose(pth[j], opath2, rtol=1e-6, err_msg=f"{label}: chained path, replicate {b}")
+            for k in KEYS:
+                err = np.abs(got[k][j] - p2[k]).max()
+                assert err <= 1e-6 * max(1.0, np.abs(p2[k]).max()), (label, "chained", k, b, err)
+
+
+def test_em_at_the_headline_batch_from_the_pca_start(ctx):
+    B, N, T, r = 1024, 200, 500, 8
+    panel, _ = ctx.synth_panels(20160415, 0, B, T, N, r)
+    out = ctx.pca_init_batch(panel, r)
+    par = [t.clone() for t in out[:6]]
+    _em_vs_oracle(ctx, panel, par, _scattered(B, 256, 4, seed=6), 3, False, "EM, B = 1024, balanced", chain_r=r)
+
+
+def test_em_at_the_headline_batch_with_missing_cells(ctx):
+    B, N, T, r = 1024, 200, 500, 8
+    panel, par = ctx.synth_panels(20160415, 0, B, T, N, r, missing_prob=0.1)
+    _em_vs_oracle(ctx, panel, list(par), _scattered(B, 256, 4, seed=7), 3, True, "EM, B = 1024, 10 % missing")
+
+
+@pytest.mark.parametrize("B,N,T,r,miss", [(3, 301, 40, 20, 0.1), (2, 257, 25, 17, 0.3), (2, 699, 60, 32, 0.05)])
+def test_odd_n_beyond_the_tiling_with_missing_cells(ctx, B, N, T, r, miss):
+    """dfm_functions.ipynb:352-366 takes any cross-section; until round 4 the library refused odd N > 256 at r > 16."""
+    import torch
+    reps = [ko.synth_replicate(b, N, T, r, seed=ko.SEED0 + N, missing=miss) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    st = {k: np.stack([p[k] for _, p in reps]) for k in KEYS}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_batch(t(panel), *[t(st[k]) for k in KEYS], may_have_missing=True)
+    torch.cuda.synchronize()
+    _compare((f.cpu().numpy(), P.cpu().numpy(), ll.cpu().numpy()), _oracle(panel, st), f"odd N = {N}, r = {r}")
+    if T >= 2 * r:
+        par = [t(st[k]) for k in KEYS]
+        iters = 2
+        path, its, _, _ = ctx.em_batch(t(panel), *par, max_iter=iters, tol=0.0, want_smooth=False, may_have_missing=True)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        for b in range(B):
+            p, opath, _ = ko.em(panel[b], {k: st[k][b] for k in KEYS}, max_iter=iters, tol=0.0)
+            np.testing.assert_allclose(path[b].cpu().numpy(), opath, rtol=1e-9)
+            for k, g in zip(KEYS, par):
+                err = np.abs(g[b].cpu().numpy() - p[k]).max()
+                assert err <= 1e-8 * max(1.0, np.abs(p[k]).max()), (k, b, err)
+
+
+@pytest.mark.parametrize("N,T,r", [(40, 60, 3), (300, 50, 6), (300, 40, 20)])
+def test_a_series_without_observed_cells_keeps_its_parameters(ctx, N, T, r):
+    """All three loadings steps (mstep_lam_kernel with register / global accumulators, mmw_finish_kernel) on a panel whose
+    series 5 has no observed cell: its loadings and R stay, every other series matches the oracle run without that series."""
+    import torch
+    B = 2
+    reps = [ko.synth_replicate(b, N, T, r, seed=77, missing=0.05) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    panel[:, :, 5] = np.nan
+    st = {k: np.stack([p[k] for _, p in reps]) for k in KEYS}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    par = [t(st[k]) for k in KEYS]
+    path, its, _, _ = ctx.em_batch(t(panel), *par, max_iter=1, tol=0.0, want_smooth=False, may_have_missing=True)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    keep = [i for i in range(N) if i != 5]
+    for b in range(B):
+        sub = {k: (st[k][b][keep] if k in ("Lam", "R") else st[k][b]) for k in KEYS}
+        p, opath, _ = ko.em(panel[b][:, keep], sub, max_iter=1, tol=0.0)
+        np.testing.assert_allclose(path[b].cpu().numpy(), opath, rtol=1e-9)
+        Lam = par[0][b].cpu().numpy(); R = par[1][b].cpu().numpy()
+        assert np.array_equal(Lam[5], st["Lam"][b][5]) and R[5] == st["R"][b][5]
+        assert np.abs(Lam[keep] - p["Lam"]).max() <= 1e-8 * max(1.0, np.abs(p["Lam"]).max())
+        assert np.abs(R[keep] - p["R"]).max() <= 1e-8
+
+
+def test_a_stale_status_bit_does_not_fail_the_next_host_call(ctx):
+    """the status word is sticky; an unchecked *_dev call that raised a bit (NaN in a panel declared balanced)
+    must not make the NEXT, unrelated host-pointer call fail -- host entries open a new status epoch."""
+    import torch
+    panel, par = ctx.synth_panels(3, 0, 4, 60, 40, 4)
+    bad = panel.clone()
+    bad[1, 7, 3] = float("nan")
+    ctx.ks_pass_batch(bad, *par, may_have_missing=False)          # raises bit 1 on the device, nobody checks
+    torch.cuda.synchronize()
+    x = panel.cpu().numpy()
+    st = [p.cpu().numpy() for p in par]
+    f, P, ll = ctx.ks_pass_batch_host(x, *st)                      # used to raise DFM_E_MISSING for a clean panel
+    fo, Po, llo = _oracle(x, dict(zip(KEYS, st)))
+    np.testing.assert_allclose(ll, llo, rtol=1e-9)
+    ctx.check_status()                                             # and nothing is left behind
