@@ -473,7 +473,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         fa.Lam = pp.Lam; fa.Rv = Rv;
         if (h->scan_abl & 256) {                                  // phase stamps of every replicate -> scol; readable through the
             ca.scol = at<double>(h, p.scol);                      // workspace dump below (diagnostics)
-            if (const char* f = getenv("DFM_PF_PROF_FILE")) h->prof_file = f;
+            if (const char* f = diag_env("DFM_PF_PROF_FILE")) h->prof_file = f;
         }
         { ProfScope ps(h, K_PASS_FUSED); HIP_TRY(h, launch_pass_fused(ca, fa, h->pass_nsw, h->pass_ncov, h->num_cu, h->stream)); }
         if ((h->scan_abl & 256) && !h->prof_file.empty()) {       // diagnostics: dump the stamps of this pass (synchronises)
@@ -507,7 +507,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     // small batch of its own (own W workspace slice, own tile queues), the mean scan of sub-batch s beside the collapse of sub-batch
     // s + 1.  MEASURED SLOWER at config 4 (B = 256): 1.39 ms -> 1.56 (n = 2) -> 1.81 (n = 4).  The scan is a latency chain per
     // replicate -- 0.41 ms for 256 replicates, 0.46 ms for 128 -- so a sub-batch's scan hides nothing and the last one still runs alone.
-    static const int wide_sub = [] { const char* v = getenv("DFM_WIDE_SUB"); return v ? atoi(v) : 1; }();
+    static const int wide_sub = [] { const char* v = diag_env("DFM_WIDE_SUB"); return v ? atoi(v) : 1; }();
     const int Sw = (use_wide2 && wide_sub > 1 && wide_sub <= 8 && B >= 32 * wide_sub) ? wide_sub : 1;
     if (S == 1 && Sw > 1) {
         while ((int)h->ev_sub.size() < Sw + 1) {
@@ -646,7 +646,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
-    ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim; ra.kb = p.kb; ra.ka = p.ka; ra.wave = h->no_rec_wave ? 0 : 1;
+    ra.rstate = p.r; ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim; ra.kb = p.kb; ra.ka = p.ka; ra.wave = h->no_rec_wave ? 0 : 1;
     ra.pair_bmax = h->pair_bmax >= 0 ? h->pair_bmax : 4 * h->num_cu;
     ra.A = pp.A; ra.Q = pp.Q; ra.mu0 = pp.mu0; ra.P0 = pp.P0;
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
@@ -1153,32 +1153,32 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
         delete h;
         return (int)e;
     }
-    if (const char* v = getenv("DFM_FORCE_GENERAL")) h->force_general = atoi(v) != 0;
-    if (const char* v = getenv("DFM_COLLAPSE_VARIANT")) h->collapse_variant = atoi(v);
-    if (const char* v = getenv("DFM_COLLAPSE_WPR")) { h->collapse_wpr = atoi(v); if (h->collapse_wpr < 0 || h->collapse_wpr > kSsumSlots) h->collapse_wpr = 0; }
+    if (const char* v = route_env("DFM_FORCE_GENERAL")) h->force_general = atoi(v) != 0;
+    if (const char* v = route_env("DFM_COLLAPSE_VARIANT")) h->collapse_variant = atoi(v);
+    if (const char* v = route_env("DFM_COLLAPSE_WPR")) { h->collapse_wpr = atoi(v); if (h->collapse_wpr < 0 || h->collapse_wpr > kSsumSlots) h->collapse_wpr = 0; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
-    if (const char* v = getenv("DFM_NUM_CU")) { if (atoi(v) > 0) h->num_cu = atoi(v); }   // diagnostics: persistent grids sized for fewer CUs
-    if (const char* v = getenv("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
-    if (const char* v = getenv("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
-    if (const char* v = getenv("DFM_PAIR_BMAX")) h->pair_bmax = atoi(v) > 0 ? atoi(v) : 0;
-    if (const char* v = getenv("DFM_NO_PAIR")) { if (atoi(v) != 0) h->pair_bmax = 0; }
+    if (const char* v = route_env("DFM_NUM_CU")) { if (atoi(v) > 0) h->num_cu = atoi(v); }   // diagnostics: persistent grids sized for fewer CUs
+    if (const char* v = diag_env("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
+    if (const char* v = route_env("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
+    if (const char* v = route_env("DFM_PAIR_BMAX")) h->pair_bmax = atoi(v) > 0 ? atoi(v) : 0;
+    if (const char* v = route_env("DFM_NO_PAIR")) { if (atoi(v) != 0) h->pair_bmax = 0; }
     g_widen_small_r = !h->no_rec_wave;      // process-wide: follows the most recently created handle
-    if (const char* v = getenv("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
-    if (const char* v = getenv("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
-    if (const char* v = getenv("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;
-    if (const char* v = getenv("DFM_NO_MSTEP_MFMA")) h->no_mstep_mfma = atoi(v) != 0;
-    if (const char* v = getenv("DFM_EM_GENERAL")) h->em_general = atoi(v) != 0;
-    if (const char* v = getenv("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
-    if (const char* v = getenv("DFM_SUBBATCH")) h->subbatch = atoi(v);
-    if (const char* v = getenv("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
-    if (const char* v = getenv("DFM_MSTEP_MISS")) g_mstep_miss_mode = atoi(v);
-    if (const char* v = getenv("DFM_PASS_FUSED")) h->pass_fused = atoi(v);
-    if (const char* v = getenv("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
-    if (const char* v = getenv("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
-    if (const char* v = getenv("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
-    if (const char* v = getenv("DFM_COLLAPSE_MISS_OLD")) h->collapse_miss_old = atoi(v) != 0;
-    if (const char* v = getenv("DFM_WIDE_OLD")) h->wide_old = atoi(v) != 0;
-    if (const char* v = getenv("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
+    if (const char* v = route_env("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_NO_MSTEP_MFMA")) h->no_mstep_mfma = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_EM_GENERAL")) h->em_general = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_SUBBATCH")) h->subbatch = atoi(v);
+    if (const char* v = diag_env("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
+    if (const char* v = route_env("DFM_MSTEP_MISS")) g_mstep_miss_mode = atoi(v);
+    if (const char* v = route_env("DFM_PASS_FUSED")) h->pass_fused = atoi(v);
+    if (const char* v = route_env("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
+    if (const char* v = diag_env("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
+    if (const char* v = diag_env("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_COLLAPSE_MISS_OLD")) h->collapse_miss_old = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_WIDE_OLD")) h->wide_old = atoi(v) != 0;
+    if (const char* v = route_env("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;
     return 0;
 }
@@ -1717,8 +1717,8 @@ int dfm_pca_init_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doub
     if (int rc = ensure_ws(h, off)) return rc;
     PcaArgs pa;
     pa.B = B; pa.T = T; pa.N = N; pa.r = r; pa.max_iter = 4000;
-    { static const int mi = [] { const char* v = getenv("DFM_PCA_MAXIT"); return v ? atoi(v) : 0; }(); if (mi > 0) pa.max_iter = mi; }   // diagnostics
-    { static const int stop = [] { const char* v = getenv("DFM_PCA_STOP"); return v ? atoi(v) : 0; }(); pa.stop_after = stop; }
+    { static const int mi = [] { const char* v = diag_env("DFM_PCA_MAXIT"); return v ? atoi(v) : 0; }(); if (mi > 0) pa.max_iter = mi; }   // diagnostics
+    { static const int stop = [] { const char* v = diag_env("DFM_PCA_STOP"); return v ? atoi(v) : 0; }(); pa.stop_after = stop; }
     pa.panel = panel;
     pa.S = at<double>(h, oS); pa.V = at<double>(h, oV); pa.Y = at<double>(h, oY); pa.F = at<double>(h, oF);
     pa.Lam = Lam; pa.Rv = R; pa.A = A; pa.Q = Q; pa.mu0 = mu0; pa.P0 = P0; pa.factors = factors;

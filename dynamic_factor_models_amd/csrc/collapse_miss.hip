@@ -365,7 +365,7 @@ static hipError_t launch_cm_one(const CollapseArgs& a, int num_cu, hipStream_t s
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    static const int abl = [] { const char* v = getenv("DFM_CM_ABL"); return v ? atoi(v) : 0; }();   // diagnostics: bit 0 skips C_t
+    static const int abl = [] { const char* v = diag_env("DFM_CM_ABL"); return v ? atoi(v) : 0; }();   // diagnostics: bit 0 skips C_t
     hipLaunchKernelGGL((collapse_miss_kernel<STEPS, NDR>), dim3(a.B), dim3(256), lds, s, a, SB, abl);
     return hipGetLastError();
 }

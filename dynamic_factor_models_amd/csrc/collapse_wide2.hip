@@ -760,9 +760,9 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, in
     const W2Ws w = w2_ws(a, ws, Rpad);
     const int ntile = collapse_wide2_tiles(a.T);
     const size_t lds = (size_t)kW2NBuf * kW2StageB + 32 * sizeof(double) + 64 * 4 * sizeof(unsigned long long);   // stages | redS, itemq | DIAG stamps
-    static const int xcd_env = [] { const char* v = getenv("DFM_WIDE_XCD"); return v ? atoi(v) : -1; }();
+    static const int xcd_env = [] { const char* v = diag_env("DFM_WIDE_XCD"); return v ? atoi(v) : -1; }();
     const int xcd_map = xcd_env >= 0 ? (xcd_env != 0) : (a.B >= 16);
-    static const int abl = [] { const char* v = getenv("DFM_W2_ABL"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
+    static const int abl = [] { const char* v = diag_env("DFM_W2_ABL"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
     // one persistent workgroup per CU (130 KB of LDS each), a multiple of 8 so that every XCD has the same number
     const long long NT = (long long)a.B * ntile;
     int G = (num_cu > 0 ? num_cu : 256) * (kW2Rows <= 64 ? 2 : 1);   // as many as fit the LDS of every CU
@@ -785,11 +785,11 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, in
 // C_t of the periods with missing cells (a.Ct, packed; the other periods keep Cfull): after launch_wide_prep, beside or after
 // the collapse (it reads the panel itself)
 hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s) {
-    static const int skip = [] { const char* v = getenv("DFM_CT_SKIP"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
+    static const int skip = [] { const char* v = diag_env("DFM_CT_SKIP"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
     if (skip) return hipSuccess;
     const W2Ws w = w2_ws(a, ws, kW2R);
     const int ntile16 = (a.T + kCtP - 1) / kCtP;
-    static const int old = [] { const char* v = getenv("DFM_CT_OLD"); return v ? atoi(v) : 0; }();     // A/B: the round-2 kernel
+    static const int old = [] { const char* v = diag_env("DFM_CT_OLD"); return v ? atoi(v) : 0; }();     // A/B: the round-2 kernel
     if (!old) {
         note_kernel("ct_miss_wide2_kernel");
         const size_t lds2 = (((size_t)3 * 2 * 8 * 1088 + (size_t)w.npad * sizeof(unsigned short) + 16 + 15) & ~(size_t)15)

@@ -1,5 +1,6 @@
 // dfm_kernels.h -- host-visible launch interface of the gfx950 kernels (internal to libdfmhip.so).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -13,6 +14,20 @@ namespace dfm {
 // recursion_pair_kernel, ...), and bench.py's JSON must carry the names rocprofv3 prints.  thread_local: the multi-GPU
 // object launches from one host thread per GPU.
 extern thread_local const char* t_launched_kernel;
+// Environment switches of the library, in two classes.
+//   route_env: selects among PRODUCTION kernels that compute the same result to rounding (the one-launch pass or the two-launch
+//              pass, one wave or a lane group per replicate, ...): what the test-suite uses to cover every fallback, and tuning
+//              knobs that cannot change a result (DFM_NUM_CU).  Listed in DESIGN.md section 11.
+//   diag_env:  ablations (some produce WRONG results on purpose: stream-only, compute-only, skipped stages), phase stamps, the
+//              *_OLD kernels kept for A/B.  Read only by a library built with -DDFM_DIAG (`python -m
+//              dynamic_factor_models_amd.build --diag`); the default libdfmhip.so ignores them.
+inline const char* route_env(const char* name) { return getenv(name); }
+#ifdef DFM_DIAG
+inline const char* diag_env(const char* name) { return getenv(name); }
+#else
+inline const char* diag_env(const char*) { return nullptr; }
+#endif
+
 inline void note_kernel(const char* name) { t_launched_kernel = name; }
 
 
@@ -80,7 +95,14 @@ struct RecursionArgs {
                           // (recursion_pair.hip); 0: never
     int ka;               // > 0 with kdim: only the first ka = r p columns of the transition rows are free (a VAR(p) inside a
                           // state that carries m > p lags); 0: all kdim columns
+    int rstate;           // the model's state width before padding (0: unknown) -- recursion_tile.hip executes ceil(rstate / 4) of
+                          // the 8 block pivots / k-steps of a 32-wide state and keeps the mean vectors in (padding) column 31
 };
+
+// Rp = 32, 17 <= rstate <= 31, information form, plain factor model: four waves per replicate, matrices as MFMA accumulator
+// tiles, 4 x 4 block-pivot sweep inverse (recursion_tile.hip)
+bool recursion_tile_supported(int Rpad, const RecursionArgs& a);
+hipError_t launch_recursion_tile(const RecursionArgs& a, hipStream_t s);
 
 struct MstepArgs {
     int B, T, N, r;

@@ -429,7 +429,7 @@ static hipError_t launch_em_update_r(const EmUpdArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_em_update(int Rpad, const EmUpdArgs& a, hipStream_t s) {
-    static const bool old_wide = [] { const char* v = getenv("DFM_EM_UPDATE_OLD"); return v && atoi(v) != 0; }();
+    static const bool old_wide = [] { const char* v = diag_env("DFM_EM_UPDATE_OLD"); return v && atoi(v) != 0; }();
     if (!old_wide && em_update_grid_supported(Rpad)) return launch_em_update_grid(Rpad, a, s);   // em_update_grid.hip
     switch (Rpad) {
         case 2: return launch_em_update_r<2>(a, s);
@@ -496,7 +496,7 @@ int fast_chunk_len(int Rpad, int T) {
 }
 
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s) {
-    static const bool rows_only = [] { const char* v = getenv("DFM_COV_ROWS"); return v && atoi(v) != 0; }();
+    static const bool rows_only = [] { const char* v = diag_env("DFM_COV_ROWS"); return v && atoi(v) != 0; }();
     if (!rows_only && a.Lam == nullptr && cov_grid_supported(Rpad)) return launch_cov_grid(Rpad, a, s);
     switch (Rpad) {
         case 2: return launch_cov_r<2>(a, s);

@@ -390,8 +390,8 @@ hipError_t launch_mm_slots(const MstepArgs& a, const double* V, double* OUT, dou
 
 hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
     note_kernel("mstep_miss_kernel");
-    static const int kp_want = [] { const char* v = getenv("DFM_MM_KP"); return v ? atoi(v) : 0; }();   // diagnostics: 8 | 16 | 32
-    static const int nbuf_want = [] { const char* v = getenv("DFM_MM_NBUF"); return v ? atoi(v) : 0; }();  // diagnostics: 4 (with DFM_MM_KP=8)
+    static const int kp_want = [] { const char* v = route_env("DFM_MM_KP"); return v ? atoi(v) : 0; }();   // diagnostics: 8 | 16 | 32
+    static const int nbuf_want = [] { const char* v = diag_env("DFM_MM_NBUF"); return v ? atoi(v) : 0; }();  // diagnostics: 4 (with DFM_MM_KP=8)
     const MmGeo g = mm_geo(Rpad, r, kp_want, nbuf_want);
     const int tt16 = g.tt * 16, ntm16 = g.ntm * 16;
     double* V = ws;
@@ -403,7 +403,7 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     if (e != hipSuccess) return e;
     // persistent workgroups: as many per CU as their stage buffers allow (the per-wave VGPR budget at 8 waves per workgroup:
     // 256 / 128 / 85 for 1 / 2 / 3 workgroups -- the narrow shapes need 95 or fewer).  DFM_MM_WGS overrides (diagnostics).
-    static const int wgs_env = [] { const char* v = getenv("DFM_MM_WGS"); return v ? atoi(v) : 0; }();
+    static const int wgs_env = [] { const char* v = diag_env("DFM_MM_WGS"); return v ? atoi(v) : 0; }();
     int wgs = 1;
     if (g.tpw <= 4) {
         const size_t lds_wg = (size_t)g.nbuf * g.stageB + 1024;

@@ -1168,7 +1168,7 @@ static hipError_t launch_gx_dma(const PcaArgs& a, hipStream_t s) {
 
 template <int MAXP>
 static hipError_t launch_gx_mfma(const PcaArgs& a, hipStream_t s) {
-    static const int no_dma = [] { const char* v = getenv("DFM_GRAM_XX_NO_DMA"); return v ? atoi(v) : 0; }();   // A/B: the register-staged kernel
+    static const int no_dma = [] { const char* v = diag_env("DFM_GRAM_XX_NO_DMA"); return v ? atoi(v) : 0; }();   // A/B: the register-staged kernel
     if ((a.N & 1) == 0 && !no_dma) return launch_gx_dma<MAXP>(a, s);
     const int NT = (a.N + 15) / 16;
     const size_t lds = (size_t)2 * kGxPB * (NT * 16 + 2) * sizeof(double);
@@ -1214,7 +1214,7 @@ static hipError_t launch_pca_fast(const PcaArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_pca(int Rpad, const PcaArgs& a, hipStream_t s) {
-    static const bool slow = [] { const char* v = getenv("DFM_PCA_GENERIC"); return v && atoi(v) != 0; }();
+    static const bool slow = [] { const char* v = diag_env("DFM_PCA_GENERIC"); return v && atoi(v) != 0; }();
     if (!slow && a.N <= 256 && a.N * Rpad >= 64 && Rpad <= 8) {   // the LDS-resident iteration (1024 threads per replicate)
         switch (Rpad) {
             case 2: return launch_pca_fast<2>(a, s);

@@ -632,6 +632,7 @@ static hipError_t launch_rec(const RecursionArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s) {
+    if (a.wave && recursion_tile_supported(Rpad, a)) return launch_recursion_tile(a, s);
     if (a.wave && recursion_wave_supported(Rpad, a)) return launch_recursion_wave(a, s, Rpad);
     if (a.cov) {
         switch (Rpad) {

@@ -1,0 +1,560 @@
+// recursion_tile.hip -- the sequential Kalman recursion for wide states (17 <= r <= 31, padded to 32: BASELINE config 4 with
+// missing cells) on the f64 matrix pipe: ONE workgroup of FOUR waves per replicate, every 32 x 32 matrix held as the four
+// 16 x 16 accumulator tiles of v_mfma_f64_16x16x4 -- wave w = 2 I + J owns tile (I, J); lane (q = l / 16, c = l % 16) holds
+// element (16 I + q + 4 v, 16 J + c) in register v: the "tile layout" (TL).
+//
+// recursion_wave_kernel<32> gives the same replicate 1024 threads with an ELEMENT per thread: 17.8 us per period, 61 % of the
+// forward sweep in the sweep inverse (16 block pivots x (a 16-wave barrier + the pivot wave's chain + 112 wave-level LDS reads)),
+// 0.003 of the HBM roofline.  What the tile layout buys:
+//   * products: with both operands in TL the instruction computes Y'X -- the A operand of k-step s is register s of Y's tile
+//     (kb, I) AS IT STANDS, the B operand register s of X's tile (kb, J).  The recursion is arranged so that every product has
+//     that form:  J = Z'K',  J' = (K')'Z,  K J = (K')'J  forward;  U = P'J',  J U = (J')'U  backward  (Z, P symmetric; K' constant).
+//     A product is <= 8 MFMAs per wave; tiles of other waves come through an 8-KB LDS buffer (ds_*_b128, lane-contiguous);
+//   * inverse: symmetric sweep operator with 4 x 4 BLOCK pivots.  The pivot rows k0 .. k0 + 3 over column block J are register
+//     (k0 % 16) / 4 of tile (k0 / 16, J), lane (q, c) = row k0 + q -- exactly the B-operand layout, and (by symmetry) the
+//     A-operand layout of the pivot COLUMNS.  With the pivot block replaced by -I in the published rows R~, one rank-4 update
+//     tile -= R~' (D^-1 R~) -- ONE MFMA per wave -- yields D^-1 A_Kj, its transpose and -D^-1 in place (the trick of
+//     Grid::sweep_inverse, dfm_grid.h).  One barrier of 4 waves per pivot; only ceil(r / 4) pivots and k-steps are executed:
+//     the identity padding beyond r is never touched (r = 20: 5 of 8, what an Rp = 24 instantiation would have bought);
+//   * matrix-vector products ride in column 31 (padding for r <= 31) of the products:  Z'[K' | xi] = [J | w],
+//     (K')'[J | w] = [K J | K w],  (J')'[U | f+] = [J U | J f+] -- no separate mean recursion, no lane reductions.
+// The algebra is recursion_wave_kernel's (information form, Z-smoother); scripts/dbg/tile_emul.py is a
+// lane-level NumPy model of this file that reproduces oracle/kalman_oracle.py.  Every period is a new covariance step (no
+// memoisation: at these widths a row without a missing cell is the exception).  EM: sums of P_t and U_t are accumulated in TL;
+// sum f f' terms are three more products over time (MFMA k = 4 periods) in the epilogue; the transition M-step is
+// tile_mstep_kernel (Grid<32>, the epilogue of recursion_wave_kernel on the sums this kernel leaves in the workspace).
+// The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
+#include <stdlib.h>
+
+#include "dfm_grid.h"
+#include "dfm_kernels.h"
+#include "dfm_smallmat.h"
+
+namespace dfm {
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int kRt = 32;
+constexpr int kRtTile = 256;                       // doubles of one tile: [2 register pairs][64 lanes] double2
+constexpr int kRtBufA = 0;                         // exchange 1: Z | P_s | prologue operands        (4 tiles)
+constexpr int kRtBufB = kRtBufA + 4 * kRtTile;     // exchange 2: [J | w] | [U | f+]                  (4 tiles)
+constexpr int kRtXk = kRtBufB + 4 * kRtTile;       // K' with column 31 := xi_t  (B operand of J = Z'[K' | xi])
+constexpr int kRtPraw = kRtXk + 4 * kRtTile;       // [2][4][32] published pivot rows (pivot block := -I)
+constexpr int kRtPD = kRtPraw + 2 * 128;           // [2][16]    raw pivot block
+constexpr int kRtRed = kRtPD + 32;                 // [64]
+constexpr int kRtLds = kRtRed + 64;
+constexpr double kLog2PiT = 1.8378770664093454835606594728112;
+constexpr int kRtCh = 2;                           // periods per prefetch chunk
+
+struct RtCtx {
+    double* sm;
+    int lane, w, I, J, q, c;
+    int pp;                                        // pivot exchanges so far (buffer parity)
+};
+
+__device__ __forceinline__ void st_tile(double* buf, int tile, int lane, const v4d& m) {
+    double2* p = reinterpret_cast<double2*>(buf + tile * kRtTile);
+    p[lane] = make_double2(m[0], m[1]);
+    p[64 + lane] = make_double2(m[2], m[3]);
+}
+__device__ __forceinline__ v4d ld_tile(const double* buf, int tile, int lane) {
+    const double2* p = reinterpret_cast<const double2*>(buf + tile * kRtTile);
+    const double2 a = p[lane], b = p[64 + lane];
+    v4d m;
+    m[0] = a.x; m[1] = a.y; m[2] = b.x; m[3] = b.y;
+    return m;
+}
+// the same register-pair layout in global memory (the (Z, J') table): 1-KB coalesced accesses
+__device__ __forceinline__ void st_tile_g(double* tab, int tile, int lane, const v4d& m) {
+    double2* p = reinterpret_cast<double2*>(tab + (size_t)tile * kRtTile);
+    p[lane] = make_double2(m[0], m[1]);
+    p[64 + lane] = make_double2(m[2], m[3]);
+}
+__device__ __forceinline__ v4d ld_tile_g(const double* tab, int tile, int lane) {
+    const double2* p = reinterpret_cast<const double2*>(tab + (size_t)tile * kRtTile);
+    const double2 a = p[lane], b = p[64 + lane];
+    v4d m;
+    m[0] = a.x; m[1] = a.y; m[2] = b.x; m[3] = b.y;
+    return m;
+}
+
+// acc + Y'X restricted to the first nks k-steps (rows 4 nks .. 31 of Y and X are padding that contributes nothing):
+// Y0 / Y1 = Y's tiles (0, I) / (1, I), X0 / X1 = X's tiles (0, J) / (1, J)
+__device__ __forceinline__ v4d mm_tn(const v4d& Y0, const v4d& Y1, const v4d& X0, const v4d& X1, int nks, v4d acc) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Y0[s], X0[s], acc, 0, 0, 0);   // (r > 16: the first tile row is full)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (4 + s < nks) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Y1[s], X1[s], acc, 0, 0, 0);           // (wave-uniform)
+    return acc;
+}
+
+// In-place inverse of the leading 4 npiv x 4 npiv block of a symmetric positive definite matrix in TL (the rest -- identity
+// padding, zero cross terms -- is left alone).  Returns the determinant.  One barrier per pivot block.
+__device__ __forceinline__ double rt_sweep_inverse(RtCtx& x, v4d& m, int npiv) {
+    double det = 1.0;
+    const int lane = x.lane, I = x.I, J = x.J, q = x.q, c = x.c;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p < npiv) {                                          // (wave-uniform)
+            const int Ik = p >> 2, vk = p & 3, ck = 4 * (p & 3);
+            double* praw = x.sm + kRtPraw + (x.pp & 1) * 128;
+            double* pD = x.sm + kRtPD + (x.pp & 1) * 16;
+            ++x.pp;
+            const bool inblk = (J == Ik) && (c >= ck) && (c < ck + 4);
+            if (I == Ik) {                                       // this wave holds pivot rows k0 .. k0 + 3 over its column block
+                double val = m[vk];
+                if (inblk) {
+                    pD[q * 4 + (c - ck)] = val;
+                    val = (c - ck == q) ? -1.0 : 0.0;
+                }
+                praw[q * 32 + 16 * J + c] = val;
+            }
+            __syncthreads();
+            // D^-1 by 2 x 2 blocks -- every lane, redundantly (the values are wave-uniform)
+            const double2* d2 = reinterpret_cast<const double2*>(pD);
+            const double2 r0a = d2[0], r0b = d2[1], r1a = d2[2], r1b = d2[3], r2b = d2[5], r3b = d2[7];
+            const double a00 = r0a.x, a01 = r0a.y, a11 = r1a.y;
+            const double b00 = r0b.x, b01 = r0b.y, b10 = r1b.x, b11 = r1b.y;
+            const double c00 = r2b.x, c01 = r2b.y, c11 = r3b.y;
+            const double detA = fma(a00, a11, -a01 * a01);
+            const double rA = fast_rcp(detA);
+            const double i00 = a11 * rA, i01 = -a01 * rA, i11 = a00 * rA;
+            const double w00 = fma(i00, b00, i01 * b10), w01 = fma(i00, b01, i01 * b11);
+            const double w10 = fma(i01, b00, i11 * b10), w11 = fma(i01, b01, i11 * b11);
+            const double s00 = c00 - fma(b00, w00, b10 * w10);
+            const double s01 = c01 - fma(b00, w01, b10 * w11);
+            const double s11 = c11 - fma(b01, w01, b11 * w11);
+            const double detS = fma(s00, s11, -s01 * s01);
+            const double rS = fast_rcp(detS);
+            const double t00 = s11 * rS, t01 = -s01 * rS, t11 = s00 * rS;
+            const double x00 = fma(w00, t00, w01 * t01), x01 = fma(w00, t01, w01 * t11);
+            const double x10 = fma(w10, t00, w11 * t01), x11 = fma(w10, t01, w11 * t11);
+            const double e00 = i00 + fma(x00, w00, x01 * w01);
+            const double e01 = i01 + fma(x00, w10, x01 * w11);
+            const double e11 = i11 + fma(x10, w10, x11 * w11);
+            det *= detA * detS;
+            // T~ = D^-1 R~ for the lane's column (all four rows; the lane keeps row q), A operand R~[q][16 I + c]
+            const int col = 16 * J + c;
+            const double p0 = praw[col], p1 = praw[32 + col], p2 = praw[64 + col], p3 = praw[96 + col];
+            const double aop = praw[q * 32 + 16 * I + c];
+            const double tq0 = fma(e00, p0, fma(e01, p1, fma(-x00, p2, -x01 * p3)));
+            const double tq1 = fma(e01, p0, fma(e11, p1, fma(-x10, p2, -x11 * p3)));
+            const double tq2 = fma(-x00, p0, fma(-x10, p1, fma(t00, p2, t01 * p3)));
+            const double tq3 = fma(-x01, p0, fma(-x11, p1, fma(t01, p2, t11 * p3)));
+            const double tq = (q & 2) ? ((q & 1) ? tq3 : tq2) : ((q & 1) ? tq1 : tq0);
+            v4d acc = m;
+            if (I == Ik) acc[vk] = 0.0;                           // pivot rows (a whole register of this wave) ...
+            if (inblk) { acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0; }   // ... and pivot columns start from zero
+            m = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, -tq, acc, 0, 0, 0);
+        }
+    }
+    const int lim = 4 * npiv;
+    const bool cin = 16 * J + c < lim;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) m[v] = (cin && 16 * I + q + 4 * v < lim) ? -m[v] : m[v];
+    return det;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a) {
+    constexpr int R = kRt, RR = R * R;
+    __shared__ __attribute__((aligned(16))) double sm[kRtLds];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RtCtx x;
+    x.sm = sm; x.lane = lane; x.w = w; x.I = w >> 1; x.J = w & 1; x.q = lane >> 4; x.c = lane & 15; x.pp = 0;
+    const int I = x.I, J = x.J, q = x.q, c = x.c;
+    const int b = blockIdx.x;
+    const int T = a.T, N = a.N, r = a.r;                      // r: width of the OUTPUT layout (the caller's r, or 32 inside EM)
+    const int rs = a.rstate;                                   // the model's state width, 17 .. 31
+    const int npiv = (rs + 3) >> 2, nks = npiv;
+    const int col = 16 * J + c;
+    const bool c31 = (J == 1) && (c == 15);                    // this lane holds column 31: the mean vectors
+    int rowv[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) rowv[v] = 16 * I + q + 4 * v;
+    double* bufA = sm + kRtBufA;
+    double* bufB = sm + kRtBufB;
+    double* Xk = sm + kRtXk;
+    const int tY0 = I, tY1 = 2 + I, tX0 = J, tX1 = 2 + J;      // tiles (0, I), (1, I), (0, J), (1, J)
+    // column 31 of an LDS tile buffer, rows of this wave's row block: element v of lane (q, 15) of tile (I, 1)
+    auto put_c31 = [&](double* buf, const double (&vec)[4]) {
+        if (c31) {
+            double2* p = reinterpret_cast<double2*>(buf + (2 * I + 1) * kRtTile);
+            p[lane] = make_double2(vec[0], vec[1]);
+            p[64 + lane] = make_double2(vec[2], vec[3]);
+        }
+    };
+
+    const double* bcol = a.bcol + (size_t)b * T * R;
+    const double* scol = a.scol + (size_t)b * T;
+    const int* nobs = a.nobs + (size_t)b * T;
+    const double* ldrow = a.ldrow + (size_t)b * T;
+    const double ldfull = a.ldfull[b];
+    double* ZJ = a.ZJtab + (size_t)b * (T + 1) * 2 * RR;       // per period: Z (4 tiles), J' (4 tiles), register-pair layout
+    double* wtab = a.wtab + (size_t)b * T * R;
+    constexpr int NPc = R * (R + 1) / 2;
+    int pk[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int i = rowv[v], j = col;
+        pk[v] = (i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i;
+    }
+
+    // ---------------- prologue: Qi = Q^-1, Om_f,0 = P0^-1, K' = A'Qi, Phi = A'Qi A, xi_0 = P0^-1 mu0 -----------------------
+    v4d Qi, Omf, Ael, Cf, zero4;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const size_t o = (size_t)b * RR + rowv[v] * R + col;
+        Qi[v] = a.Q[o]; Omf[v] = a.P0[o]; Ael[v] = a.A[o]; Cf[v] = a.Cfull[o];
+        zero4[v] = 0.0;
+    }
+    double mu0v[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) mu0v[v] = a.mu0[(size_t)b * R + rowv[v]];
+    const double detQ = rt_sweep_inverse(x, Qi, npiv);
+    const double detP0 = rt_sweep_inverse(x, Omf, npiv);
+    st_tile(bufA, w, lane, Ael);
+    st_tile(bufB, w, lane, Qi);
+    __syncthreads();
+    v4d KtY0, KtY1, Phi;
+    {
+        const v4d A0i = ld_tile(bufA, tY0, lane), A1i = ld_tile(bufA, tY1, lane);   // A as Y: tiles (kb, I)
+        const v4d A0j = ld_tile(bufA, tX0, lane), A1j = ld_tile(bufA, tX1, lane);   // A as X: tiles (kb, J)
+        const v4d Q0i = ld_tile(bufB, tY0, lane), Q1i = ld_tile(bufB, tY1, lane);
+        const v4d Q0j = ld_tile(bufB, tX0, lane), Q1j = ld_tile(bufB, tX1, lane);
+        const v4d Kt = mm_tn(A0i, A1i, Q0j, Q1j, nks, zero4);                       // K' = A'Qi
+        const v4d Km = mm_tn(Q0i, Q1i, A0j, A1j, nks, zero4);                       // K  = Qi A
+        st_tile(Xk, w, lane, Kt);
+        __syncthreads();                                                             // (bufA / bufB are read; Xk is complete)
+        st_tile(bufB, w, lane, Km);
+        __syncthreads();
+        const v4d K0i = ld_tile(bufB, tY0, lane), K1i = ld_tile(bufB, tY1, lane);
+        Phi = mm_tn(K0i, K1i, A0j, A1j, nks, zero4);                                // Phi = K'A
+        KtY0 = ld_tile(Xk, tY0, lane); KtY1 = ld_tile(Xk, tY1, lane);               // K' as Y: constant for the whole kernel
+        st_tile(bufA, w, lane, Omf);
+        __syncthreads();                                                             // (K' tiles are read before column 31 is patched)
+    }
+    put_c31(Xk, mu0v);
+    __syncthreads();
+    double xi[4];                                              // (column-31 lanes) xi_t, rows of this wave's row block
+    double qacc = 0.0;                                         // (column-31 lanes) mu0'xi_0 - xi_T'f_T - sum_t xi_t'w_t
+    {
+        const v4d Y0 = ld_tile(bufA, tY0, lane), Y1 = ld_tile(bufA, tY1, lane);
+        const v4d X0 = ld_tile(Xk, tX0, lane), X1 = ld_tile(Xk, tX1, lane);
+        const v4d x0 = mm_tn(Y0, Y1, X0, X1, 8, zero4);       // column 31: Om_f,0 mu0
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { xi[v] = x0[v]; qacc = fma(mu0v[v], x0[v], qacc); }
+    }
+    __syncthreads();                                           // (every wave has read Xk before the next patch)
+    put_c31(Xk, xi);
+
+    // ---------------- forward sweep (t = T: the terminal inverse P_T = Om_f,T^-1 and f_T = P_T xi_T) ----------------------
+    double cbn[kRtCh][4], ccn[kRtCh][4], csn[kRtCh], cln[kRtCh];
+    int cnn[kRtCh];
+    auto issue_fwd = [&](int ch) {
+#pragma unroll
+        for (int s = 0; s < kRtCh; ++s) {
+            int t = ch * kRtCh + s;
+            t = t < T ? t : T - 1;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                cbn[s][v] = bcol[(size_t)t * R + rowv[v]];
+                ccn[s][v] = a.Ct ? a.Ct[((size_t)b * T + t) * NPc + pk[v]] : 0.0;
+            }
+            csn[s] = scol[t]; cnn[s] = nobs[t]; cln[s] = ldrow[t];
+        }
+    };
+    double ssum = 0.0, nsum = 0.0, ldsum = 0.0;
+    LogProd detprod;
+    v4d Ps = zero4;
+    double fs[4] = {0.0, 0.0, 0.0, 0.0};
+    double detOmT = 1.0;
+    const int nchf = (T + 1 + kRtCh - 1) / kRtCh;              // T + 1 steps
+    issue_fwd(0);
+    for (int ch = 0; ch < nchf; ++ch) {
+        double cb[kRtCh][4], cc[kRtCh][4], cs[kRtCh], cl[kRtCh];
+        int cn[kRtCh];
+#pragma unroll
+        for (int s = 0; s < kRtCh; ++s) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { cb[s][v] = cbn[s][v]; cc[s][v] = ccn[s][v]; }
+            cs[s] = csn[s]; cl[s] = cln[s]; cn[s] = cnn[s];
+        }
+        if (ch + 1 < nchf) issue_fwd(ch + 1);
+#pragma unroll
+        for (int s = 0; s < kRtCh; ++s) {
+            const int t = ch * kRtCh + s;
+            if (t <= T) {                                        // (uniform)
+                const bool last = (t == T);
+                v4d Z;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Z[v] = last ? Omf[v] : Omf[v] + Phi[v];
+                const double dM = rt_sweep_inverse(x, Z, npiv);
+                st_tile(bufA, w, lane, Z);
+                __syncthreads();                                 // E1: Z in LDS; column 31 of Xk holds xi_t
+                const v4d ZY0 = ld_tile(bufA, tY0, lane), ZY1 = ld_tile(bufA, tY1, lane);
+                const v4d X0 = ld_tile(Xk, tX0, lane), X1 = ld_tile(Xk, tX1, lane);
+                const v4d Jaug = mm_tn(ZY0, ZY1, X0, X1, nks, zero4);          // [J | w] = Z'[K' | xi]
+                if (last) {
+                    detOmT = dM;
+                    Ps = Z;
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { fs[v] = Jaug[v]; qacc = fma(-xi[v], Jaug[v], qacc); }   // f_T = P_T xi_T (column 31)
+                } else {
+                    detprod.mul(dM);
+                    const v4d ZX0 = ld_tile(bufA, tX0, lane), ZX1 = ld_tile(bufA, tX1, lane);
+                    const v4d Jt = mm_tn(KtY0, KtY1, ZX0, ZX1, nks, zero4);    // J' = K Z
+                    st_tile(bufB, w, lane, Jaug);
+                    double* ent = ZJ + (size_t)t * 2 * RR;
+                    st_tile_g(ent, w, lane, Z);
+                    st_tile_g(ent + RR, w, lane, Jt);
+                    if (c31) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) wtab[(size_t)t * R + rowv[v]] = Jaug[v];
+                    }
+                    __syncthreads();                             // E2: [J | w] in LDS
+                    const v4d JX0 = ld_tile(bufB, tX0, lane), JX1 = ld_tile(bufB, tX1, lane);
+                    const v4d prod = mm_tn(KtY0, KtY1, JX0, JX1, nks, zero4);  // K [J | w]
+                    const bool full = (cn[s] == N);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const double omp = c31 ? Qi[v] : Qi[v] - prod[v];     // column 31 is padding: Qi's own entries
+                        Omf[v] = omp + (full ? Cf[v] : cc[s][v]);
+                    }
+                    if (c31) {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            qacc = fma(-xi[v], Jaug[v], qacc);   // xi_t'w_t
+                            xi[v] = prod[v] + cb[s][v];          // xi_t+1 = K w_t + b_t
+                        }
+                    }
+                    put_c31(Xk, xi);                             // (read again after the next barrier at the earliest)
+                    ssum += cs[s];
+                    nsum += (double)cn[s];
+                    ldsum += full ? ldfull : cl[s];
+                }
+            }
+        }
+    }
+
+    // ---------------- log-likelihood, EM bookkeeping ------------------------------------------------------------------
+    {
+        if (c31) sm[kRtRed + 4 * I + q] = qacc;
+        __syncthreads();
+        if (tid == 0) {
+            double qd = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) qd += sm[kRtRed + k];
+            const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) + detprod.log_value();
+            const double ll = -0.5 * (nsum * kLog2PiT + ldsum + LD + ssum + qd);
+            a.loglik[b] = ll;
+            if (a.ncov) a.ncov[b] = T;
+            if (a.active) {                                      // EM bookkeeping, as recursion_kernel
+                const bool was = a.k == 0 ? true : (a.active[b] != 0);
+                bool go = was;
+                if (was && a.k >= 1 && a.tol > 0.0) {
+                    const double llp = a.ll_path[(size_t)b * a.max_iter + a.k - 1];
+                    go = !((ll - llp) / (0.5 * (fabs(ll) + fabs(llp))) < a.tol);
+                }
+                if (was) { a.ll_path[(size_t)b * a.max_iter + a.k] = ll; a.iters[b] = a.k + 1; }
+                a.active[b] = go ? 1 : 0;
+            }
+        }
+    }
+
+    // ---------------- backward sweep -------------------------------------------------------------------------------------
+    const int npr = r * (r + 1) / 2;
+    auto emit = [&](int trow, const v4d& P, const double (&f)[4]) {   // smoothed moments of period trow + 1
+        if (c31) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (rowv[v] < r) a.f_smooth[((size_t)b * T + trow) * r + rowv[v]] = f[v];
+        }
+        if (a.P_smooth) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = rowv[v];
+                if (i < r && col <= i) a.P_smooth[((size_t)b * T + trow) * npr + i * (i + 1) / 2 + col] = P[v];
+            }
+        }
+    };
+    emit(T - 1, Ps, fs);
+    const bool em = a.S11 != nullptr;
+    const v4d PT = Ps;
+    v4d SP = Ps, SU = zero4;                                   // sum_t P_t (periods 1 .. T), sum of the lag-one covariances
+    v4d zn[kRtCh], jxn0[kRtCh], jxn1[kRtCh], jyn0[kRtCh], jyn1[kRtCh];
+    double wn[kRtCh][4];
+    auto issue_bwd = [&](int ch) {
+#pragma unroll
+        for (int s = 0; s < kRtCh; ++s) {
+            int t = ch * kRtCh + s;
+            t = t < T ? t : T - 1;
+            const double* ent = ZJ + (size_t)t * 2 * RR;
+            zn[s] = ld_tile_g(ent, w, lane);
+            jxn0[s] = ld_tile_g(ent + RR, tX0, lane); jxn1[s] = ld_tile_g(ent + RR, tX1, lane);
+            jyn0[s] = ld_tile_g(ent + RR, tY0, lane); jyn1[s] = ld_tile_g(ent + RR, tY1, lane);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) wn[s][v] = wtab[(size_t)t * R + rowv[v]];
+        }
+    };
+    const int nchb = (T + kRtCh - 1) / kRtCh;
+    __threadfence();
+    __syncthreads();                                           // (table and w_t stores of the forward sweep are visible: one CU, one L1)
+    issue_bwd(nchb - 1);
+    for (int ch = nchb - 1; ch >= 0; --ch) {
+        v4d zc[kRtCh], jx0[kRtCh], jx1[kRtCh], jy0[kRtCh], jy1[kRtCh];
+        double wc[kRtCh][4];
+#pragma unroll
+        for (int s = 0; s < kRtCh; ++s) {
+            zc[s] = zn[s]; jx0[s] = jxn0[s]; jx1[s] = jxn1[s]; jy0[s] = jyn0[s]; jy1[s] = jyn1[s];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) wc[s][v] = wn[s][v];
+        }
+        if (ch > 0) issue_bwd(ch - 1);
+#pragma unroll
+        for (int s = kRtCh - 1; s >= 0; --s) {
+            const int t = ch * kRtCh + s;                        // step t: from period t + 1 to period t (t = 0: the initial state)
+            if (t < T) {                                         // (uniform)
+                st_tile(bufA, w, lane, Ps);
+                __syncthreads();                                 // E3
+                const v4d PY0 = ld_tile(bufA, tY0, lane), PY1 = ld_tile(bufA, tY1, lane);
+                const v4d U = mm_tn(PY0, PY1, jx0[s], jx1[s], nks, zero4);      // U = P_s J' = Cov(f_t+1, f_t | X)
+                v4d Uaug = U;
+                if (c31) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Uaug[v] = fs[v];                // column 31 := f_t+1
+                }
+                st_tile(bufB, w, lane, Uaug);
+                __syncthreads();                                 // E4
+                const v4d UX0 = ld_tile(bufB, tX0, lane), UX1 = ld_tile(bufB, tX1, lane);
+                v4d Pn = mm_tn(jy0[s], jy1[s], UX0, UX1, nks, zc[s]);           // Z + J [U | f_t+1]
+                if (c31) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        fs[v] = wc[s][v] + (Pn[v] - zc[s][v]);                  // f_t = w_t + J f_t+1
+                        Pn[v] = zc[s][v];                                       // column 31 is padding: Z's own entries
+                    }
+                }
+                Ps = Pn;
+                if (em) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { SU[v] += U[v]; if (t > 0) SP[v] += Pn[v]; }
+                }
+                if (t > 0) emit(t - 1, Ps, fs);
+            }
+        }
+    }
+    if (!em) return;
+
+    // ---------------- EM sums: S11 = sum E[f_t f_t'], S10 = sum E[f_t f_t-1'], S00 (periods 1 .. T; f_0 = fs, P_0 = Ps) ----
+    // sum_t f_t f_t' etc. as products over time: k = 4 periods per MFMA, operands straight from f_smooth (this CU wrote it)
+    if (c31) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sm[kRtRed + rowv[v]] = fs[v];               // f_0 (32 doubles)
+    }
+    __threadfence();                                           // (f_smooth rows written by the column-31 lanes are read by every wave)
+    __syncthreads();
+    v4d G11 = zero4, G10 = zero4, G00 = zero4;
+    {
+        const double* F = a.f_smooth + (size_t)b * T * r;
+        const int ci = 16 * I + c, cj = 16 * J + c;              // this lane's column of F as A operand (I) and as B operand (J)
+        const bool oki = ci < r, okj = cj < r;
+        const double f0i = sm[kRtRed + ci], f0j = sm[kRtRed + cj];
+        for (int k0 = 0; k0 < T; k0 += 4) {
+            const int t = k0 + q;                                // F row t = period t + 1; "previous" = row t - 1, or f_0
+            const bool in = t < T;
+            const double fi = (in && oki) ? __hip_atomic_load(F + (size_t)t * r + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            const double fj = (in && okj) ? __hip_atomic_load(F + (size_t)t * r + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            double pi = 0.0, pj = 0.0;
+            if (in) {
+                pi = t == 0 ? f0i : (oki ? __hip_atomic_load(F + (size_t)(t - 1) * r + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
+                pj = t == 0 ? f0j : (okj ? __hip_atomic_load(F + (size_t)(t - 1) * r + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
+            }
+            G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, fj, G11, 0, 0, 0);
+            G10 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, pj, G10, 0, 0, 0);
+            G00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, pj, G00, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const size_t o = (size_t)b * RR + rowv[v] * R + col;
+        a.S11[o] = SP[v] + G11[v];
+        a.S10[o] = SU[v] + G10[v];
+        a.S00[o] = (SP[v] - PT[v] + Ps[v]) + G00[v];
+        a.P0s[o] = Ps[v];
+    }
+    if (c31) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a.f0s[(size_t)b * R + rowv[v]] = fs[v];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The transition M-step on the sums recursion_tile_kernel leaves in the workspace -- the epilogue of recursion_wave_kernel<32>
+// (element per thread, Grid<32>):  A = S10 S00^-1,  Q = sym(S11 - A S10') / T,  mu0 = f_0|T,  P0 = sym(P_0|T),  S11^-1.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024, 1) void tile_mstep_kernel(RecursionArgs a) {
+    constexpr int R = kRt, RR = R * R;
+    constexpr int TS = kTileStride<R>, RT = R * TS;
+    __shared__ __attribute__((aligned(16))) double wsm[2 * RT + kGridProw<R> + 2 * (RR / 64) * R + 2 * RT];
+    double* L0 = wsm;
+    double* L1 = L0 + RT;
+    Grid<R> G;
+    G.prow = L1 + RT;
+    G.red = G.prow + kGridProw<R>;
+    G.tt = G.red + 2 * (RR / 64) * R;
+    const int lane = threadIdx.x, i = lane / R, j = lane % R;
+    G.l = lane; G.i = i; G.j = j;
+    const int b = blockIdx.x;
+    const size_t o = (size_t)b * RR + lane;
+    const double S11 = a.S11[o], S10 = a.S10[o], S00 = a.S00[o], Ps = a.P0s[o];
+    const bool em_apply = a.active ? (a.active[b] != 0) : true;
+    double inv = S00;
+    (void)G.sweep_inverse(inv);
+    G.sync();
+    L0[TS * i + j] = S10;
+    L1[TS * i + j] = inv;                                      // symmetric: rows = columns
+    G.sync();
+    const double An = dot_rows<R>(L0, L1, i, j);
+    G.sync();
+    L1[TS * i + j] = An;
+    G.sync();
+    double Qn = (S11 - dot_rows<R>(L1, L0, i, j)) / (double)a.T;   // (A S10')_ij = row i of A . row j of S10
+    Qn = 0.5 * (Qn + G.transposed(Qn));
+    const double P0n = 0.5 * (Ps + G.transposed(Ps));
+    double inv2 = S11;
+    (void)G.sweep_inverse(inv2);
+    a.S11inv[o] = inv2;
+    if (em_apply) {
+        a.A_out[o] = An;
+        a.Q_out[o] = Qn;
+        a.P0_out[o] = P0n;
+        if (j == 0) a.mu0_out[(size_t)b * R + i] = a.f0s[(size_t)b * R + i];
+    }
+}
+
+// Rp = 32, information form, the plain factor model (loadings as wide as the state), 17 <= state width <= 31 (column 31 must
+// be padding).  DFM_NO_TILE=1: recursion_wave_kernel<32> instead (A/B, diagnostics).
+bool recursion_tile_supported(int Rpad, const RecursionArgs& a) {
+    static const bool off = [] { const char* v = route_env("DFM_NO_TILE"); return v && atoi(v) != 0; }();
+    if (off || Rpad != 32 || a.cov || a.Rc != 0 || a.rl != 0 || a.kdim != 0) return false;
+    if (a.rstate < 17 || a.rstate > 31 || a.T < 1) return false;
+    if (a.S11 && !a.A_out) return false;                       // (sums without the M-step: not a path the library takes)
+    return true;
+}
+
+hipError_t launch_recursion_tile(const RecursionArgs& a, hipStream_t s) {
+    note_kernel("recursion_tile_kernel");
+    hipLaunchKernelGGL(recursion_tile_kernel, dim3(a.B), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !a.S11) return e;
+    hipLaunchKernelGGL(tile_mstep_kernel, dim3(a.B), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace dfm

@@ -490,7 +490,7 @@ bool recursion_wave_supported(int Rpad, const RecursionArgs& a) {
     // Rp = 8, batch size: the lane-group kernel packs 8 replicates in a wave and stays at its ~3.3 ms latency floor up to
     // B ~ 8192; a wave per replicate costs 0.86 ms per 1024 replicates while a SIMD holds one wave (chunks of 8) and 0.63 ms
     // per 1024 once two share a SIMD (chunks of 4: 2.4 ms at B = 4096) -- it wins up to ~6000.
-    static const int bmax = [] { const char* v = getenv("DFM_WAVE_BMAX"); return v ? atoi(v) : 6144; }();
+    static const int bmax = [] { const char* v = diag_env("DFM_WAVE_BMAX"); return v ? atoi(v) : 6144; }();
     if (a.Rc == 0 && a.B > bmax) return false;
     return Rpad == 8 && wave_lds_bytes<8>(a.T) <= 60 * 1024;
 }
