@@ -4,8 +4,11 @@
 A "step" = one full Kalman-smoother pass (filter + RTS smoother + log-likelihood)
 over ONE batch of replicates already resident in HBM.  N=1: BASELINE configs[1] (batch = 1024
 replicates on 1 x MI355X).  N>1: one process per GPU (torch.distributed, backend nccl = RCCL), the
-replicate batch is sharded with the same 1024 replicates per GPU (weak scaling), and -- as
-north_star prescribes -- one all_gather of the per-replicate log-likelihoods closes every step.
+replicate batch is sharded with the same 1024 replicates per GPU (weak scaling: the N = 1 line equals the single-GPU
+bench); the per-replicate log-likelihoods are all-gathered ONCE per timed block (north_star prescribes the collective per EM
+iteration; `--gather step` / secondary.pass_gather_every_step = after every pass).  A default `--gpus N` run also times, as
+`secondary`: BASELINE configs[2]'s per-GPU shard (`c3`: 8192 replicates per GPU = 65 536 at N = 8) and the EM iteration with
+its all-gather of {loglik, active} (`em`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats 9] [--batch-per-gpu 1024] [--missing 0.0]
                   [--mode pass|em|pca] [--driver torch|lib] [--no-secondary] [--no-cpu-baseline]
@@ -269,7 +272,7 @@ def kernel_bytes_table(B, N, T, r):
     return {"collapse_mfma_kernel": B * panel_b, "collapse_dma_kernel": B * panel_b, "collapse_wide_kernel": B * panel_b,
             "collapse_wide2_kernel": B * panel_b, "collapse_kernel": B * panel_b, "collapse_miss_kernel": B * panel_b,
             "pass_fused_kernel": B * (b_in + b_out),
-            "recursion_kernel": seq, "recursion_wave_kernel": seq, "recursion_pair_kernel": seq,
+            "recursion_kernel": seq, "recursion_wave_kernel": seq, "recursion_pair_kernel": seq, "recursion_tile_kernel": seq,
             "meanscan_kernel": B * (b_in - panel_b + 8 * (T * r + 1)), "meanscan_mfma_kernel": B * (b_in - panel_b + 8 * (T * r + 1)),
             "pfill_kernel": B * 8 * T * npack,
             "mstep_mfma_kernel": B * 8 * (N * T + T * r), "mstep_wide_kernel": B * 8 * (N * T + T * r),
@@ -278,11 +281,32 @@ def kernel_bytes_table(B, N, T, r):
             "cov_grid_kernel": B * 8 * (3 * r * r + r), "ct_miss_wide_kernel": B * 8 * T * npack, "ct_miss_wide2_kernel": B * 8 * T * npack}
 
 
+def gram_flops(kernel, B, N, T):
+    """(executed, useful) flops per launch of the X'X kernels of the PCA start.  The product is symmetric: the matrix-pipe kernels
+    compute only the upper triangle of their tiling -- 16 x 16 tiles (gram_xx_mfma / gram_xx_dma_kernel, pca.hip) or pairs of
+    128-series blocks (gram_xx_wide_kernel) -- so `executed` is what the MFMA units retire and the figure `frac` is priced on
+    (counting the full 2 T N^2 B would let a symmetric-product kernel report frac > 1); `useful` = T N (N + 1) B,
+    the flops of the distinct entries."""
+    useful = float(T) * N * (N + 1) * B
+    if kernel in ("gram_xx_mfma_kernel", "gram_xx_dma_kernel"):
+        nt = (N + 15) // 16
+        return 2.0 * T * 256 * (nt * (nt + 1) // 2) * B, useful
+    if kernel == "gram_xx_wide_kernel":
+        nb = (N + 127) // 128
+        return 2.0 * T * 128 * 128 * (nb * (nb + 1) // 2) * B, useful
+    return 2.0 * T * N * N * B, useful                       # gram_xx_kernel (VALU): the full product
+
+
 class Workload:
     """One bench line: a batch resident in HBM, `step(k)` = k steps of the mode, timed as the contract prescribes."""
 
-    def __init__(self, torch, dist, ctx, shard, world, rank, dev, B, N, T, r, missing, mode, seed=20160415):
+    def __init__(self, torch, dist, ctx, shard, world, rank, dev, B, N, T, r, missing, mode, seed=20160415, gather="block"):
         self.torch, self.dist, self.ctx, self.shard = torch, dist, ctx, shard
+        # multi-rank pass mode: WHEN the replicates' log-likelihoods are all-gathered.  north_star prescribes the collective per EM
+        # iteration; a pass is not an iteration, so the default gathers ONCE per timed block of K passes ("block": the result of the
+        # job reaches every rank once); "step" = after every pass (on RCCL's stream beside the next pass) is the secondary line
+        # `pass_gather_every_step`.  EM mode always gathers {loglik, active} every iteration (shard.em_batch_sharded).
+        self.gather = gather
         self.world, self.rank, self.dev = world, rank, dev
         self.B, self.N, self.T, self.r, self.missing, self.mode = B, N, T, r, missing, mode
         # (DFM_BENCH_FORCE_DIST=1 under a 1-rank torchrun: the multi-rank step -- async all-gather on RCCL's stream, barrier fences --
@@ -330,7 +354,7 @@ class Workload:
                     pending[u].wait()                  # (the gather of step it - 2: long done; orders the buffer's reuse)
                     pending[u] = None
                 ctx.ks_pass_batch(self.panel, *self.params, may_have_missing=self.may_missing, out=(self.f, self.P, self.ll_pair[u]))
-                if self.distributed and not profile:   # north_star: a single RCCL all-gather of the replicates' log-likelihoods per step
+                if self.distributed and not profile and (self.gather == "step" or it == k - 1):
                     pending[u] = dist.all_gather_into_tensor(self.ll_all[u], self.ll_pair[u], async_op=True)
             for h in pending:
                 if h is not None:
@@ -402,16 +426,19 @@ class Workload:
         kernels_ms = {k: round(v, 4) for k, v in avg.items()}
         if self.mode == "pca":
             dom = max(avg, key=avg.get)
-            flops = {"gram_xx_kernel": 2.0 * T * N * N * B, "gram_xx_mfma_kernel": 2.0 * T * N * N * B, "gram_xx_dma_kernel": 2.0 * T * N * N * B, "gram_xx_wide_kernel": 2.0 * T * N * N * B}
-            gx = next((k for k in flops if k in avg), None)
+            gx = next((k for k in ("gram_xx_kernel", "gram_xx_mfma_kernel", "gram_xx_dma_kernel", "gram_xx_wide_kernel") if k in avg), None)
             out = dict(bound="mfma", kernel=dom, achieved=None, peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
                        avg_launch_ms=avg[dom], kernels_ms=kernels_ms,
-                       note="pca_kernel (subspace iteration, Rayleigh-Ritz, OLS start) is latency-bound small-matrix work on an "
-                            "L2-resident Gram matrix -- no roofline claim for it; `gram` = X'X of the batch on v_mfma_f64_16x16x4")
+                       note="pca_kernel (subspace iteration, Rayleigh-Ritz, scores, OLS / VAR start) is a chain of dependent small-matrix "
+                            "stages on an L2-resident Gram matrix: latency-bound, frac = null (no roofline claim; stage times by the "
+                            "diagnostics build's DFM_PCA_STOP, DESIGN.md section 10.9); `gram` = X'X of the batch on v_mfma_f64_16x16x4, "
+                            "priced on the flops the kernel EXECUTES (upper triangle of its tiling), not on 2 T N^2")
             if gx:
-                ach = flops[gx] / (avg[gx] * 1e-3) / 1e12
+                ex, useful = gram_flops(gx, B, N, T)
+                ach = ex / (avg[gx] * 1e-3) / 1e12
                 out["gram"] = dict(kernel=gx, achieved=ach, peak=FP64_MATRIX_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_MATRIX_PEAK_TFLOPS,
-                                   avg_launch_ms=avg[gx], flops_per_launch=flops[gx])
+                                   avg_launch_ms=avg[gx], flops_per_launch=ex, useful_flops_per_launch=useful,
+                                   useful_tflops=useful / (avg[gx] * 1e-3) / 1e12)
                 if dom == gx:
                     out.update(achieved=ach, frac=ach / FP64_MATRIX_PEAK_TFLOPS)
             return out
@@ -455,12 +482,135 @@ SECONDARY = [   # (key, dict(B, N, T, r, missing, mode), steps, warmup) -- three
     ("missing10", dict(B=1024, N=200, T=500, r=8, missing=0.1, mode="pass"), 10, 3),
     ("em", dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="em"), 10, 3),
     ("em_missing10", dict(B=1024, N=200, T=500, r=8, missing=0.1, mode="em"), 10, 3),
+    ("missing10_b8192", dict(B=8192, N=200, T=500, r=8, missing=0.1, mode="pass"), 3, 1),
+    ("em_missing10_b8192", dict(B=8192, N=200, T=500, r=8, missing=0.1, mode="em"), 3, 1),
     ("pca", dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="pca"), 3, 1),
     ("c4", dict(B=256, N=1000, T=2000, r=20, missing=0.0, mode="pass"), 5, 2),
     ("c4_em", dict(B=256, N=1000, T=2000, r=20, missing=0.0, mode="em"), 3, 1),
     ("c4_missing10", dict(B=256, N=1000, T=2000, r=20, missing=0.1, mode="pass"), 2, 1),
     ("c4_em_missing10", dict(B=256, N=1000, T=2000, r=20, missing=0.1, mode="em"), 2, 1),
 ]
+
+
+def config1_config5_lines(torch, ctx, dev, cpu_seconds=2.0):
+    """BASELINE configs[0] and configs[4] on one GPU, driver-visible (the lines of scripts/bench_extra.py):
+      c1_als  -- Stock-Watson real panel (tests/golden/sw_panel.npz, built from the reference's spreadsheet), r = 4, PCA start + 10
+                 ALS sweeps = the reference's `estimate_factor!(m, 10)` (dfm_functions.ipynb:328-382), 4096 independent runs in ONE
+                 dfm_als_batch_dev call; beside it oracle/als_oracle.py (NumPy, one thread) on the same problem, results compared;
+      c5_boot -- 10 000 wild-bootstrap draws of the 4-factor VAR(4) -> re-estimation -> Cholesky -> IRFs to 12 horizons -> 5 bands
+                 (dfm_functions.ipynb:444-492, 793-825), beside oracle/boot_oracle.py on a bounded sample of draws.
+    Both are latency-bound small-matrix work on L2-resident inputs: no roofline claim."""
+    import ctypes
+    import numpy as np
+    from dynamic_factor_models_amd import api
+    from oracle import als_oracle as ao
+    from oracle import boot_oracle as bo
+    out = {}
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sw_panel.npz"))
+    bp, inc, cat = d["bpdata"], d["inclcode"], d["bpcatcode"]
+    real = np.isin(np.floor(cat), [1, 2, 3, 5])
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    K = 5
+    # ---- config 1
+    t_line = time.perf_counter()
+    z, _ = api.standardize_data(bp[2:224][:, real][:, inc[real] == 1])
+    z = np.ascontiguousarray(z)
+    T, N = z.shape
+    F0 = api.pca_start(ctx, z, 4)
+    B = 4096
+    zt = torch.from_numpy(z).to(dev)
+    F_in = torch.from_numpy(np.repeat(F0[None], B, axis=0)).to(dev)
+    F = F_in.clone()
+    Lam = torch.empty((B, N, 4), dtype=torch.float64, device=dev)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+    ssr = torch.empty(B, dtype=torch.float64, device=dev)
+
+    def als_call():
+        F.copy_(F_in)
+        ctx._sync_stream()
+        rc = ctx._lib.dfm_als_batch_dev(ctx._h, B, T, N, 4, p(zt), 0, None, p(F), p(Lam), 20, 10, 1e-8, None, 0, p(iters), p(ssr), None)
+        assert rc == 0, rc
+    als_call(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        als_call()
+    torch.cuda.synchronize()
+    gpu_s = (time.perf_counter() - t0) / K
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < cpu_seconds:
+        o = ao.estimate_factor(bp[:, real], inc[real], 3, 224, 4, max_iter=10, solver="normal", compute_r2_flag=False, f0=F0)
+        n += 1
+    cpu_s = (time.perf_counter() - t0) / n
+    ok = abs(float(ssr[0]) - o["ssr"]) < 1e-8 * o["ssr"] and abs(float(ssr[-1]) - o["ssr"]) < 1e-8 * o["ssr"]
+    out["c1_als"] = dict(workload="BASELINE configs[0]: Stock-Watson real panel (222 x 58, 12 700 observed cells), r=4, PCA start + 10 ALS sweeps "
+                                  "(estimate_factor!(m, 10)), 4096 runs per dfm_als_batch_dev call",
+                         value=B / gpu_s, unit="ALS runs/s", ms_per_step=1e3 * gpu_s, batch=B, sweeps_per_s=10 * B / gpu_s, dominant="als_kernel",
+                         whole_step=None, matches_oracle_ssr=bool(ok),
+                         note="latency-bound (222 + 58 small dependent solves per sweep and run); the 103-KB panel is L2-resident",
+                         cpu_baseline=dict(value=1.0 / cpu_s, unit="ALS runs/s", cores=1, kind="port",
+                                           sample=f"{n} runs of oracle/als_oracle.py (NumPy normal equations) in {cpu_seconds:.0f} s"),
+                         seconds=round(time.perf_counter() - t_line, 2))
+    # ---- config 5
+    t_line = time.perf_counter()
+    m = api.DFMModel(bp, inc, 20, 40, 3, 224, 0, 4, 1e-8, 4, 4)
+    api.estimate(m, api.NonParametric(), ctx=ctx)
+    v = m.factor_var_model
+    rows = np.nonzero(~np.isnan(v.resid).any(axis=1))[0]
+    y = v.y[rows[0] - 4: rows[-1] + 1]
+    resid = np.zeros_like(y); resid[4:] = v.resid[rows]
+    Bd, H = 10000, 12
+    yt, bt, et = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (y, v.betahat, resid))
+    irf = torch.empty((Bd, 4, H, 4), dtype=torch.float64, device=dev)
+    q = torch.tensor([0.05, 0.16, 0.5, 0.84, 0.95], dtype=torch.float64, device=dev)
+    bands = torch.empty((5, 4 * H * 4), dtype=torch.float64, device=dev)
+
+    def boot_call():
+        ctx._sync_stream()
+        rc = ctx._lib.dfm_var_bootstrap_irf_dev(ctx._h, Bd, y.shape[0], 4, 4, H, p(yt), p(bt), p(et), None, ctypes.c_uint64(20160415),
+                                                ctypes.c_int64(0), None, p(irf))
+        assert rc == 0, rc
+        rc = ctx._lib.dfm_quantile_bands_dev(ctx._h, Bd, 4 * H * 4, 5, p(irf), p(q), p(bands))
+        assert rc == 0, rc
+    boot_call(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        boot_call()
+    torch.cuda.synchronize()
+    gpu_s = (time.perf_counter() - t0) / K
+    g = np.random.default_rng(0)
+    nd = 256
+    signs = np.where(g.random((nd, y.shape[0])) < 0.5, -1.0, 1.0)
+    t0 = time.perf_counter(); done = 0
+    while time.perf_counter() - t0 < cpu_seconds:
+        bo.var_bootstrap_irf(y, 4, H, signs); done += nd
+    cpu_s = (time.perf_counter() - t0) / done
+    out["c5_boot"] = dict(workload="BASELINE configs[4] on one GPU: 10000 wild-bootstrap draws x VAR(4) of the 4 Stock-Watson factors (T=222) -> "
+                                   "IRFs to 12 horizons -> 5/16/50/84/95 % bands",
+                          value=Bd / gpu_s, unit="bootstrap draws/s", ms_per_step=1e3 * gpu_s, draws=Bd, dominant="var_boot_kernel", whole_step=None,
+                          bands_finite=bool(torch.isfinite(bands).all()),
+                          note="latency-bound (218 dependent periods per draw, 17 x 17 normal equations); draw + re-estimation + Cholesky + IRF + bands",
+                          cpu_baseline=dict(value=1.0 / cpu_s, unit="bootstrap draws/s", cores=1, kind="port",
+                                            sample=f"{done} draws of oracle/boot_oracle.py (NumPy) in {cpu_s * done:.1f} s"),
+                          seconds=round(time.perf_counter() - t_line, 2))
+    return out
+
+
+def secondary_plan(world: int, default_line: bool, no_secondary: bool):
+    """Which secondary lines a run times (pure: tested on CPU).  One GPU, default invocation: the other lines of the path.
+    N > 1 GPUs, default invocation (what the driver's SCALE run launches): BASELINE configs[2]'s per-GPU shard (8192 replicates
+    per GPU = 65 536 at N = 8), the EM line with its all-gather per iteration, and the pass with the gather after EVERY step."""
+    if not default_line or no_secondary:
+        return []
+    if world == 1:
+        return [k for k, *_ in SECONDARY] + ["c1_als", "c5_boot"]
+    return ["c3", "em", "pass_gather_every_step"]
+
+
+MULTI_SECONDARY = {   # key -> (cfg, steps, warmup, gather)
+    "c3": (dict(B=8192, N=200, T=500, r=8, missing=0.0, mode="pass"), 5, 2, "block"),
+    "em": (dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="em"), 10, 3, "block"),
+    "pass_gather_every_step": (dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="pass"), 20, 3, "step"),
+}
 
 
 def workload_name(N, T, r, B):
@@ -534,6 +684,8 @@ def main():
     ap.add_argument("--mode", choices=("pass", "em", "pca"), default="pass")
     ap.add_argument("--driver", choices=("torch", "lib"), default="torch")
     ap.add_argument("--force-comm", action="store_true", help="--driver lib: build the RCCL communicator also for one GPU")
+    ap.add_argument("--gather", choices=("block", "step"), default="block",
+                    help="multi-rank pass mode: all-gather the log-likelihoods once per timed block (default) or after every pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -581,7 +733,7 @@ def main():
     B, N, T, r = args.batch_per_gpu, args.N, args.T, args.r
     default_line = (args.mode, B, N, T, r, args.missing) == ("pass", 1024, 200, 500, 8, 0.0)
 
-    wl = Workload(torch, dist, ctx, shard, world, rank, dev, B, N, T, r, args.missing, args.mode)
+    wl = Workload(torch, dist, ctx, shard, world, rank, dev, B, N, T, r, args.missing, args.mode, gather=args.gather)
     res = wl.run(args.steps, args.warmup, args.repeats)
     # clocks / power while the bench batch runs: enqueue ~0.5 s of steps, read rocm-smi meanwhile (rank 0)
     telemetry = None
@@ -614,7 +766,9 @@ def main():
             pr = [p[:S].cpu().numpy() for p in wl.params]
             cpu = cpu_baseline(ph, pr, args.cpu_seconds)
         name, unit, what_step = METRIC[args.mode]
-        coll = {"pass": " + all_gather(loglik) per step (on RCCL's stream, beside the next step's pass)", "em": " + all_gather({loglik, active}) per EM iteration", "pca": ""}[args.mode]
+        coll = {"pass": " + ONE all_gather(loglik) per timed block of K passes (north_star prescribes the collective per EM iteration, not per "
+                        "pass; secondary.pass_gather_every_step times the per-step form)",
+                "em": " + all_gather({loglik, active}) per EM iteration", "pca": ""}[args.mode]
         srt = res["sorted"]
         out = dict(metric=f"{name}, N={N} T={T} r={r} panel", value=res["value"], unit=unit, n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=res["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f64",
@@ -622,7 +776,11 @@ def main():
                    config=dict(workload=workload_name(N, T, r, B) + f": synthetic panel N={N} T={T} r={r}, batch={B} replicates per GPU, {what_step}"
                                         + (f", {args.missing:.0%} cells missing" if args.missing > 0 else ", balanced"),
                                N=N, T=T, r=r, batch_per_gpu=B, global_batch=world * B, missing=args.missing, mode=args.mode,
-                               parallelism=f"replicate-sharded x{world}" + (coll if world > 1 else "")),
+                               parallelism=f"replicate-sharded x{world}" + (coll if world > 1 else ""),
+                               process_group=(dict(backend=dist.get_backend(), world_size=dist.get_world_size(),
+                                                   ranks_per_node=int(os.environ.get("LOCAL_WORLD_SIZE", world)),
+                                                   nccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS"))
+                                              if (world > 1 or force_dist) else None)),
                    timing=dict(repeats=len(res["blocks"]), statistic="median of the timed blocks (each: K steps between fences, MAX over ranks)",
                                preheat=f">= {PREHEAT_MS:.0f} ms of untimed steps before the W warm-up steps ({res['preheat_steps']} steps)",
                                ms_per_step_min=1e3 * srt[0] / args.steps, ms_per_step_max=1e3 * srt[-1] / args.steps,
@@ -631,24 +789,42 @@ def main():
                    roofline=roofline, cpu_baseline=cpu, device=telemetry, host_cores=os.cpu_count(), source_hash=source_hash())
     wl.free()
 
-    # ---- the other lines of the path, driver-visible (default invocation on one GPU only; < 60 s together) ----
-    if default_line and world == 1 and not args.no_secondary:
-        sec = {}
-        for key, cfg, k, w in SECONDARY:
-            t0 = time.perf_counter()
-            try:
-                s = Workload(torch, dist, ctx, shard, 1, 0, dev, cfg["B"], cfg["N"], cfg["T"], cfg["r"], cfg["missing"], cfg["mode"])
-                rs = s.run(k, w, 3, preheat_ms=20.0)
+    # ---- the other lines of the path, driver-visible (default invocation only; about a minute together) ----
+    plan = secondary_plan(world, default_line, args.no_secondary)
+    sec = {}
+    for key in plan:
+        t0 = time.perf_counter()
+        try:
+            if key in ("c1_als", "c5_boot"):
+                continue                                          # (both measured by one call below)
+            if world == 1:
+                cfg, k, w = next((c, kk, ww) for kk_, c, kk, ww in SECONDARY if kk_ == key)
+                gather = "block"
+            else:
+                cfg, k, w, gather = MULTI_SECONDARY[key]
+            s = Workload(torch, dist, ctx, shard, world, rank, dev, cfg["B"], cfg["N"], cfg["T"], cfg["r"], cfg["missing"], cfg["mode"], gather=gather)
+            rs = s.run(k, w, 3, preheat_ms=20.0)
+            if rank == 0:
                 rf = s.roofline(rs)
                 sec[key] = dict(workload=workload_name(cfg["N"], cfg["T"], cfg["r"], cfg["B"]), **cfg, value=rs["value"], unit=METRIC[cfg["mode"]][1],
-                                ms_per_step=rs["ms_per_step"], ms_per_step_blocks=[round(1e3 * b / k, 5) for b in rs["blocks"]], steps=k,
+                                n_gpus=world, global_batch=world * cfg["B"], ms_per_step=rs["ms_per_step"],
+                                ms_per_step_blocks=[round(1e3 * b / k, 5) for b in rs["blocks"]], steps=k,
                                 whole_step=(rf.get("whole_step") or {}).get("frac"), dominant=rf["kernel"],
-                                dominant_frac=rf.get("frac"), kernels_ms=rf["kernels_ms"], gram=rf.get("gram"),
-                                seconds=None)
-                s.free()
-            except Exception as e:  # noqa: BLE001  (a secondary line must never take the headline down)
-                sec[key] = dict(error=f"{type(e).__name__}: {e}")
+                                dominant_frac=rf.get("frac"), kernels_ms=rf["kernels_ms"], gram=rf.get("gram"), seconds=None)
+                if world > 1:
+                    sec[key]["collective"] = ("all_gather({loglik, active}) per EM iteration" if cfg["mode"] == "em" else
+                                              "all_gather(loglik) after every pass" if gather == "step" else "one all_gather(loglik) per timed block")
+            s.free()
+        except Exception as e:  # noqa: BLE001  (a secondary line must never take the headline down)
+            sec[key] = dict(error=f"{type(e).__name__}: {e}")
+        if key in sec:
             sec[key]["seconds"] = round(time.perf_counter() - t0, 2)
+    if "c1_als" in plan and rank == 0:
+        try:
+            sec.update(config1_config5_lines(torch, ctx, dev))
+        except Exception as e:  # noqa: BLE001
+            sec["c1_als"] = dict(error=f"{type(e).__name__}: {e}")
+    if plan and rank == 0:
         out["secondary"] = sec
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -9,6 +9,13 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(HERE, "lib", "libdfmhip.so")
+# The diagnostics build (`python -m dynamic_factor_models_amd.build --diag`: -DDFM_DIAG, reads the ablation / stamp / *_OLD switches,
+# csrc/dfm_kernels.h diag_env) is a separate file that only scripts/dbg ask for: DFM_LIB=diag.  The product never loads it.
+# (scripts/dbg also pass the path of a development build: in-kernel span stamps, the previous round's library for an A/B)
+if os.environ.get("DFM_LIB") == "diag":
+    SO_PATH = os.path.join(HERE, "lib", "libdfmhip_diag.so")
+elif os.environ.get("DFM_LIB"):
+    SO_PATH = os.path.abspath(os.environ["DFM_LIB"])
 
 c_dp = ctypes.POINTER(ctypes.c_double)
 c_ip = ctypes.POINTER(ctypes.c_int)

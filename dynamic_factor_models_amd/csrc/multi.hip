@@ -332,7 +332,11 @@ int dfm_multi_create(dfm_multi** out, int ngpu, const int* device_ids, unsigned 
         if (rc != 0) return bail(m, g, rc, "dfm_create failed");
     });
     int rc = join_status(m);
-    const char* env = diag_env("DFM_MULTI_FORCE_COMM");
+#ifdef DFM_DIAG
+    const char* env = getenv("DFM_MULTI_FORCE_COMM");      // (diagnostics build only; callers use DFM_MULTI_F_FORCE_COMM)
+#else
+    const char* env = nullptr;
+#endif
     const bool want_comm = ngpu > 1 || (mflags & DFM_MULTI_F_FORCE_COMM) != 0 || (env && atoi(env) != 0);
     if (rc == 0 && want_comm) {
         Rccl& R = rccl();

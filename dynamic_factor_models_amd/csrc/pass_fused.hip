@@ -58,7 +58,10 @@ __device__ __forceinline__ void wait_vmf() {
 __device__ __forceinline__ void wait_lgkmf() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 constexpr int kPfR = 8;
-constexpr int kPfEcap = 6;                                  // transient covariance steps staged in LDS (later ones: global tab)
+#ifndef DFM_PF_ECAP
+#define DFM_PF_ECAP 8
+#endif
+constexpr int kPfEcap = DFM_PF_ECAP;                                  // transient covariance steps staged in LDS (later ones: global tab)
 constexpr int kPfNst = stead_mats(kPfR);                    // steady Z, J, G + the carry powers (256 scan threads)
 constexpr int kPfNlev = scan_levels(kPfR);
 constexpr int kPfScanWaves = kScanThreads / 64;             // 4
@@ -184,6 +187,7 @@ struct PfLds {
     int nsw, ncov, nbuf;
 };
 
+#if defined(DFM_DIAG) || defined(DFM_PF_FALLBACK_LDS)   // the round-2 scan: A/B against scan_reg in the diagnostics build only (DFM_SCAN_ABL bit 9); production: scan_reg, scan_seq
 // ------------------------------------------------------------------------------------------------------------------
 // The scan of one replicate, b_t in LDS, tables staged in LDS.  Called by the 4 scan waves (tid 0 .. 255); `sync` is their
 // barrier.  meanscan_kernel's algorithm (fastpath.hip).
@@ -327,6 +331,8 @@ __device__ __forceinline__ void scan_lds(const FastArgs& a, int b, int tid, doub
         a.loglik[b] = -0.5 * (llcp[0] + sq - d);
     }
 }
+
+#endif  // DFM_DIAG
 
 // ------------------------------------------------------------------------------------------------------------------
 // scan_reg (round 3): the same scan with every lane group owning ONE time range in BOTH directions, so that its b_t -> w_t
@@ -557,6 +563,82 @@ __device__ __forceinline__ void scan_reg(const FastArgs& a, int b, int tid, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// scan_seq: the plain sequential mean recursion by scan wave 0 (its eight lane groups redundantly, group 0 stores) -- the
+// fallback for a replicate whose Riccati transient is longer than the kPfEcap steps scan_reg keeps in LDS (E - 1 > kPfEcap:
+// slowly converging covariances; entries past the staged ones come from the workspace table).  ~4x the time of scan_reg for
+// that replicate (T dependent steps instead of 2 L + the carries), ~2 KB of code instead of the 36 KB of the round-2 scan_lds
+// that used to serve this case inside the production kernel.  The other scan waves only take part in the arrival count.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void scan_seq(const FastArgs& a, int b, int tid, double* bt, const double* s_tab, const double* tab_over,
+                                         const double* s_mat, const double* xi0p, const double* llcp, int E, const double* ssum, int nseg,
+                                         unsigned* arrive, unsigned arrive_last, unsigned* scan_done, unsigned done_value) {
+    constexpr int R = kPfR, NST = kPfNst;
+    const int lane = tid & 63, i = tid % R, c = tid / R;
+    const int T = a.T, r = a.r;
+    const int ts = E - 1;
+    const int nst = ts < kPfEcap ? ts : kPfEcap;
+    double dot = 0.0;
+    if (tid < 64) {
+        double* fout = a.f_smooth + (size_t)b * T * r;
+        double xi = xi0p[i];
+        double Zs[R], Gs[R];
+        load_xperm<R>(Zs, s_mat, i);
+        load_xperm<R>(Gs, s_mat + 2 * R * R, i);
+        for (int t = 0; t < T; ++t) {
+            double Zp[R], Gp[R];
+            if (t < ts) {                                       // (uniform) transient entry: LDS, or the workspace table
+                const double* ent = t < nst ? s_tab + (size_t)t * 3 * R * R : tab_over + (size_t)t * 3 * R * R;
+                load_xperm<R>(Zp, ent, i);
+                load_xperm<R>(Gp, ent + 2 * R * R, i);
+            } else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) { Zp[k] = Zs[k]; Gp[k] = Gs[k]; }
+            }
+            const double btv = bt[t * R + i];
+            const double w = matvec_x<R>(Zp, xi);
+            wave_lds_sync();                                    // every group has read b_t before group 0 overwrites it with w_t
+            if (c == 0) { dot = fma(xi, w, dot); bt[t * R + i] = w; }
+            xi = matvec_x<R>(Gp, xi, btv);
+        }
+        double PTp[R];
+        load_xperm<R>(PTp, s_mat + NST * R * R, i);
+        double v = matvec_x<R>(PTp, xi);                         // f_T
+        if (c == 0) {
+            dot = fma(xi, v, dot);
+            if (i < r) fout[(size_t)(T - 1) * r + i] = v;
+        }
+        wave_lds_sync();
+        double Js[R];
+        load_xperm<R>(Js, s_mat + R * R, i);
+        for (int t = T - 1; t >= 0; --t) {
+            double Jp[R];
+            if (t < ts) load_xperm<R>(Jp, (t < nst ? s_tab + (size_t)t * 3 * R * R : tab_over + (size_t)t * 3 * R * R) + R * R, i);
+            else {
+#pragma unroll
+                for (int k = 0; k < R; ++k) Jp[k] = Js[k];
+            }
+            v = matvec_x<R>(Jp, v, bt[t * R + i]);
+            if (c == 0 && t >= 1 && i < r) fout[(size_t)(t - 1) * r + i] = v;
+        }
+        if (a.f0s && c == 0) a.f0s[(size_t)b * R + i] = v;      // E[f_0 | X] (EM)
+        dot = (c == 0) ? dot : 0.0;
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, kWave);
+        if (lane == 0) {
+            double sq = 0.0;
+            for (int w = 0; w < nseg; ++w) sq += ssum[w];
+            a.loglik[b] = -0.5 * (llcp[0] + sq - dot);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    unsigned before = 0;
+    if (lane == 0) before = __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    before = __builtin_amdgcn_readfirstlane(before);
+    if (before + 1u == arrive_last && lane == 0)                 // (waves 1-3 arrive at once; whoever is last releases bt / the table set)
+        __hip_atomic_store(scan_done, done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Gram matrix C = Lam' R^-1 Lam of one replicate by ONE wave on the fp64 matrix pipe, in the collapse's own operand layout:
 // lane (K, g, h, q) holds W[c][4 h + q] = lam_c,4h+q / R_c for the series c = 8 s + 4 g + K (the B operands of the stream
 // waves).  Rows i = 4 p + (0..3) of Lam' play the part of the 4 periods of a row block: the A operand of block p is
@@ -641,12 +723,17 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
     const int N = a.N, T = a.T, B = a.B;
     const int G = (int)gridDim.x;
     const int nrep_wg = (B - (int)blockIdx.x + G - 1) / G;   // replicates of this workgroup
-    // P_smooth fills deferred to the tail (see the mover): DFM_SCAN_ABL bits 12-14 = count + 1 (diagnostics), default 1
+    // P_smooth fills deferred to the tail (see the mover)
+#ifdef DFM_DIAG   // DFM_SCAN_ABL bits 12-14 = count + 1
     const int ndefer = (fa.P_smooth == nullptr) ? 0 : (((fa.abl >> 12) & 7) ? ((fa.abl >> 12) & 7) - 1 : kPfDeferDefault);
+#else
+    const int ndefer = (fa.P_smooth == nullptr) ? 0 : kPfDeferDefault;
+#endif
 
     if (tid_wg < kFCount) flags[tid_wg] = 0u;
     __syncthreads();                                         // the only workgroup barrier of the kernel
 
+#ifdef DFM_DIAG
     // DFM_SCAN_ABL bit 8: s_memrealtime stamps (10 ns ticks) of the phases of every replicate into scol[b][0..31]
     const bool prof = (fa.abl & 256) != 0 && a.scol != nullptr && T >= 40;
     auto stamp = [&](int bb, int slot) {
@@ -660,6 +747,10 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
             if (lane == 0) a.scol[(size_t)bb * T + 40 + wave] = (double)hw;
         }
     }
+#else   // the production kernel carries no stamp code
+    constexpr bool prof = false;
+    auto stamp = [](int, int) {};
+#endif
 
     if (wave < nsw) {
         // ================= STREAM: segment [ta, tb) of every replicate -> bt[buf][t][0..7], ssum[buf][wave] ==========
@@ -894,7 +985,7 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
         for (int b = (int)blockIdx.x + cw * G; b < B; b += ncov * G) {
             stamp(b, 6);
             const double ld = gram_mfma8<STEPS, NDR>(fa.Lam + (size_t)b * N * R, fa.Rv + (size_t)b * N, N, lane, Cs,
-                                                     prof ? a.scol + (size_t)b * T + 36 : nullptr);
+                                                     prof ? a.scol + (size_t)b * T + 36 : nullptr);   // (null in the production build)
             wave_lds_sync();
             const double Cel = 0.5 * (Cs[lane] + Cs[(lane & 7) * 8 + (lane >> 3)]);   // exactly symmetric
             wave_lds_sync();
@@ -989,12 +1080,16 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
         double* s_a = reinterpret_cast<double*>(smem + ly.sa);
         double* s_b = reinterpret_cast<double*>(smem + ly.sb);
         PfScanSync sync{flags + kFScanBar, flags + kFAbort, 0u, lane};
-        const bool use_reg = fa.L <= kRegL && (fa.abl & 512) == 0;    // DFM_SCAN_ABL bit 9: the round-2 scan (A/B, diagnostics)
+#ifdef DFM_DIAG
+        const bool use_reg = fa.L <= kRegL && (fa.abl & 512) == 0;    // DFM_SCAN_ABL bit 9: the round-2 scan (A/B)
+        const int prio_mode = (fa.abl & 1024) ? 1 : (fa.abl & 2048) ? 2 : 0;   // bit 10: always 3; bit 11: always 0
+#else
+        constexpr int prio_mode = 0;                              // (the launcher admits L <= kRegL only: pass_fused_supported)
+#endif
         // Priority.  The scan is the pipeline's latency chain only while somebody waits for it: the first replicate of the
         // workgroup (everything behind it waits), or a stream that has run out of b_t buffers.  Otherwise it runs BESIDE a
         // stream that is the bottleneck, and at high priority its bursts delay the stream waves' DMA issue (measured at
-        // B = 8192: -4 % with the faster scan at priority 3 throughout).  DFM_SCAN_ABL bit 10: always 3; bit 11: always 0.
-        const int prio_mode = (fa.abl & 1024) ? 1 : (fa.abl & 2048) ? 2 : 0;
+        // B = 8192: -4 % with the faster scan at priority 3 throughout).
         auto set_prio = [&](int j) {
             const bool hot = prio_mode == 1 || (prio_mode == 0 && (j == 0 || ld_flag(flags + kFStreamWaits) != 0));
             if (hot) __builtin_amdgcn_s_setprio(3);
@@ -1012,13 +1107,8 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
             if (tid == 0) stamp(b, 12);
             set_prio(j);
             const int E = __builtin_amdgcn_readfirstlane((int)misc[kMiscE]);
-            if (use_reg && E - 1 <= kPfEcap) {
-                // (the arrival counter counts 4 per replicate on EITHER path, so the two can alternate between replicates)
-                scan_reg(fa, b, tid, bt, s_tab, s_mat, misc + kMiscXi0, misc + kMiscLlc, E, s_a, s_b, misc + kMiscRed,
-                         misc + kMiscSsum + buf * 8, nsw, sync, flags + kFScanArrive, (unsigned)(kPfScanWaves * (j + 1)),
-                         flags + kFScanDone, (unsigned)(j + 1), misc + kMiscWtr, [&]() { set_prio(j); }, (prof && tid == 0) ? a.scol + (size_t)b * T + 13 : nullptr);
-                if (tid == 0) stamp(b, 22);
-            } else {
+#ifdef DFM_DIAG
+            if (!use_reg) {
                 scan_lds(fa, b, tid, bt, s_tab, fa.tab + (size_t)b * T * 3 * 64, s_mat, misc + kMiscXi0, misc + kMiscLlc, E, s_a, s_b,
                          misc + kMiscVec, misc + kMiscRed, misc + kMiscSsum + buf * 8, nsw, sync,
                          (prof && tid == 0) ? a.scol + (size_t)b * T + 13 : nullptr);
@@ -1028,7 +1118,31 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
                     __hip_atomic_store(flags + kFScanDone, (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     stamp(b, 22);
                 }
+                continue;
             }
+            double* const pslot = (prof && tid == 0) ? a.scol + (size_t)b * T + 13 : nullptr;
+#else
+            double* const pslot = nullptr;
+#endif
+            // (the arrival counter counts 4 per replicate on EVERY path, so they can alternate between replicates)
+            if (E - 1 <= kPfEcap) {
+                scan_reg(fa, b, tid, bt, s_tab, s_mat, misc + kMiscXi0, misc + kMiscLlc, E, s_a, s_b, misc + kMiscRed,
+                         misc + kMiscSsum + buf * 8, nsw, sync, flags + kFScanArrive, (unsigned)(kPfScanWaves * (j + 1)),
+                         flags + kFScanDone, (unsigned)(j + 1), misc + kMiscWtr, [&]() { set_prio(j); }, pslot);
+            } else {                          // a Riccati transient longer than the staged tables: the sequential fallback
+#ifdef DFM_PF_FALLBACK_LDS                    // (development A/B: the round-2 scan as the fallback)
+                scan_lds(fa, b, tid, bt, s_tab, fa.tab + (size_t)b * T * 3 * 64, s_mat, misc + kMiscXi0, misc + kMiscLlc, E, s_a, s_b,
+                         misc + kMiscVec, misc + kMiscRed, misc + kMiscSsum + buf * 8, nsw, sync, nullptr);
+                sync();
+                if (lane == 0) __hip_atomic_fetch_add(flags + kFScanArrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (tid == 0) __hip_atomic_store(flags + kFScanDone, (unsigned)(j + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+#endif
+                scan_seq(fa, b, tid, bt, s_tab, fa.tab + (size_t)b * T * 3 * 64, s_mat, misc + kMiscXi0, misc + kMiscLlc, E,
+                         misc + kMiscSsum + buf * 8, nsw, flags + kFScanArrive, (unsigned)(kPfScanWaves * (j + 1)),
+                         flags + kFScanDone, (unsigned)(j + 1));
+            }
+            if (tid == 0) stamp(b, 22);
         }
     }
     if (lane == 0 && ld_flag(flags + kFAbort) != 0) atomicOr(a.status, 4);   // a bounded wait ran out
@@ -1083,6 +1197,11 @@ int pass_fused_pick_nsw(int T, int N, int want) { return pf_pick(T, N, want, 0).
 bool pass_fused_supported(int Rpad, int T, int N) {
     if (Rpad != 8 || !collapse_mfma_supported(8, N)) return false;
     if (T < 2) return false;
+#ifndef DFM_DIAG
+    // scan_reg keeps a lane group's chunk of L periods in registers (L <= kRegL: T <= 512); longer panels take the two-launch
+    // pass (collapse_mfma_kernel + meanscan_kernel).  The diagnostics build still has the round-2 scan_lds for them.
+    if (fast_chunk_len(8, T) > kRegL) return false;
+#endif
     return pf_pick(T, N, 0, 0).total <= kPfLdsLimit;
 }
 

@@ -32,6 +32,17 @@
 
 namespace dfm {
 
+// -DDFM_TILE_PROF (development builds): s_memrealtime spans (10 ns ticks) of replicate 5, printed by thread 0
+#ifdef DFM_TILE_PROF
+#define RT_NOW() ((long long)__builtin_amdgcn_s_memrealtime())
+#define RT_TICK(var) do { var -= RT_NOW(); } while (0)
+#define RT_TOCK(var) do { var += RT_NOW(); } while (0)
+#else
+#define RT_NOW() 0ll
+#define RT_TICK(var) do {} while (0)
+#define RT_TOCK(var) do {} while (0)
+#endif
+
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -53,6 +64,11 @@ struct RtCtx {
     int lane, w, I, J, q, c;
     int pp;                                        // pivot exchanges so far (buffer parity)
 };
+
+// Barrier of the workgroup's four waves that waits for this wave's LDS traffic ONLY.  __syncthreads() also drains vmcnt: every
+// one of the ~9 barriers of a period would then wait for the table stores (8 KB per wave and period) and for the prefetch of the
+// next chunk -- HBM round trips inside a chain whose steps are a few hundred cycles (the lesson of recursion_pair.hip).
+__device__ __forceinline__ void rt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ void st_tile(double* buf, int tile, int lane, const v4d& m) {
     double2* p = reinterpret_cast<double2*>(buf + tile * kRtTile);
@@ -112,38 +128,38 @@ __device__ __forceinline__ double rt_sweep_inverse(RtCtx& x, v4d& m, int npiv) {
                 }
                 praw[q * 32 + 16 * J + c] = val;
             }
-            __syncthreads();
-            // D^-1 by 2 x 2 blocks -- every lane, redundantly (the values are wave-uniform)
+            rt_barrier();
+            // D = L diag(d) L' (unit lower L) -- every lane, redundantly (the values are wave-uniform) -- and T~ = D^-1 R~ for the
+            // lane's column by two substitutions.  No explicit D^-1: the pivot columns of R~ are -I, so the same solve leaves -D^-1
+            // in the pivot block.  (A first version inverted D by 2 x 2 blocks and multiplied: ~90 fp64 instructions on a chain
+            // that issues one instruction per ~6 cycles -- 156 instructions per pivot, 60 % of the forward sweep; this is ~55.)
             const double2* d2 = reinterpret_cast<const double2*>(pD);
             const double2 r0a = d2[0], r0b = d2[1], r1a = d2[2], r1b = d2[3], r2b = d2[5], r3b = d2[7];
-            const double a00 = r0a.x, a01 = r0a.y, a11 = r1a.y;
-            const double b00 = r0b.x, b01 = r0b.y, b10 = r1b.x, b11 = r1b.y;
-            const double c00 = r2b.x, c01 = r2b.y, c11 = r3b.y;
-            const double detA = fma(a00, a11, -a01 * a01);
-            const double rA = fast_rcp(detA);
-            const double i00 = a11 * rA, i01 = -a01 * rA, i11 = a00 * rA;
-            const double w00 = fma(i00, b00, i01 * b10), w01 = fma(i00, b01, i01 * b11);
-            const double w10 = fma(i01, b00, i11 * b10), w11 = fma(i01, b01, i11 * b11);
-            const double s00 = c00 - fma(b00, w00, b10 * w10);
-            const double s01 = c01 - fma(b00, w01, b10 * w11);
-            const double s11 = c11 - fma(b01, w01, b11 * w11);
-            const double detS = fma(s00, s11, -s01 * s01);
-            const double rS = fast_rcp(detS);
-            const double t00 = s11 * rS, t01 = -s01 * rS, t11 = s00 * rS;
-            const double x00 = fma(w00, t00, w01 * t01), x01 = fma(w00, t01, w01 * t11);
-            const double x10 = fma(w10, t00, w11 * t01), x11 = fma(w10, t01, w11 * t11);
-            const double e00 = i00 + fma(x00, w00, x01 * w01);
-            const double e01 = i01 + fma(x00, w10, x01 * w11);
-            const double e11 = i11 + fma(x10, w10, x11 * w11);
-            det *= detA * detS;
-            // T~ = D^-1 R~ for the lane's column (all four rows; the lane keeps row q), A operand R~[q][16 I + c]
             const int col = 16 * J + c;
             const double p0 = praw[col], p1 = praw[32 + col], p2 = praw[64 + col], p3 = praw[96 + col];
-            const double aop = praw[q * 32 + 16 * I + c];
-            const double tq0 = fma(e00, p0, fma(e01, p1, fma(-x00, p2, -x01 * p3)));
-            const double tq1 = fma(e01, p0, fma(e11, p1, fma(-x10, p2, -x11 * p3)));
-            const double tq2 = fma(-x00, p0, fma(-x10, p1, fma(t00, p2, t01 * p3)));
-            const double tq3 = fma(-x01, p0, fma(-x11, p1, fma(t01, p2, t11 * p3)));
+            const double aop = praw[q * 32 + 16 * I + c];        // A operand R~[q][16 I + c]
+            const double D00 = r0a.x, D10 = r0a.y, D20 = r0b.x, D30 = r0b.y, D11 = r1a.y, D21 = r1b.x, D31 = r1b.y;
+            const double D22 = r2b.x, D32 = r2b.y, D33 = r3b.y;
+            const double i0 = fast_rcp3(D00);
+            const double l10 = D10 * i0, l20 = D20 * i0, l30 = D30 * i0;
+            const double e1 = fma(-l10, D10, D11);
+            const double i1 = fast_rcp3(e1);
+            const double u21 = fma(-l20, D10, D21), u31 = fma(-l30, D10, D31);
+            const double l21 = u21 * i1, l31 = u31 * i1;
+            const double e2 = fma(-l21, u21, fma(-l20, D20, D22));
+            const double i2 = fast_rcp3(e2);
+            const double u32 = fma(-l31, u21, fma(-l30, D20, D32));
+            const double l32 = u32 * i2;
+            const double e3 = fma(-l32, u32, fma(-l31, u31, fma(-l30, D30, D33)));
+            const double i3 = fast_rcp3(e3);
+            det *= (D00 * e1) * (e2 * e3);
+            const double y1 = fma(-l10, p0, p1);
+            const double y2 = fma(-l21, y1, fma(-l20, p0, p2));
+            const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, p0, p3)));
+            const double tq3 = y3 * i3;
+            const double tq2 = fma(-l32, tq3, y2 * i2);
+            const double tq1 = fma(-l31, tq3, fma(-l21, tq2, y1 * i1));
+            const double tq0 = fma(-l30, tq3, fma(-l20, tq2, fma(-l10, tq1, p0 * i0)));
             const double tq = (q & 2) ? ((q & 1) ? tq3 : tq2) : ((q & 1) ? tq1 : tq0);
             v4d acc = m;
             if (I == Ik) acc[vk] = 0.0;                           // pivot rows (a whole register of this wave) ...
@@ -181,6 +197,8 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     double* bufB = sm + kRtBufB;
     double* Xk = sm + kRtXk;
     const int tY0 = I, tY1 = 2 + I, tX0 = J, tX1 = 2 + J;      // tiles (0, I), (1, I), (0, J), (1, J)
+    long long p_inv = 0, p_p1 = 0, p_p2 = 0; (void)p_inv; (void)p_p1; (void)p_p2;
+    const long long t_start = RT_NOW(); (void)t_start;
     // column 31 of an LDS tile buffer, rows of this wave's row block: element v of lane (q, 15) of tile (I, 1)
     auto put_c31 = [&](double* buf, const double (&vec)[4]) {
         if (c31) {
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     const double detP0 = rt_sweep_inverse(x, Omf, npiv);
     st_tile(bufA, w, lane, Ael);
     st_tile(bufB, w, lane, Qi);
-    __syncthreads();
+    rt_barrier();
     v4d KtY0, KtY1, Phi;
     {
         const v4d A0i = ld_tile(bufA, tY0, lane), A1i = ld_tile(bufA, tY1, lane);   // A as Y: tiles (kb, I)
@@ -230,17 +248,17 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
         const v4d Kt = mm_tn(A0i, A1i, Q0j, Q1j, nks, zero4);                       // K' = A'Qi
         const v4d Km = mm_tn(Q0i, Q1i, A0j, A1j, nks, zero4);                       // K  = Qi A
         st_tile(Xk, w, lane, Kt);
-        __syncthreads();                                                             // (bufA / bufB are read; Xk is complete)
+        rt_barrier();                                                             // (bufA / bufB are read; Xk is complete)
         st_tile(bufB, w, lane, Km);
-        __syncthreads();
+        rt_barrier();
         const v4d K0i = ld_tile(bufB, tY0, lane), K1i = ld_tile(bufB, tY1, lane);
         Phi = mm_tn(K0i, K1i, A0j, A1j, nks, zero4);                                // Phi = K'A
         KtY0 = ld_tile(Xk, tY0, lane); KtY1 = ld_tile(Xk, tY1, lane);               // K' as Y: constant for the whole kernel
         st_tile(bufA, w, lane, Omf);
-        __syncthreads();                                                             // (K' tiles are read before column 31 is patched)
+        rt_barrier();                                                             // (K' tiles are read before column 31 is patched)
     }
     put_c31(Xk, mu0v);
-    __syncthreads();
+    rt_barrier();
     double xi[4];                                              // (column-31 lanes) xi_t, rows of this wave's row block
     double qacc = 0.0;                                         // (column-31 lanes) mu0'xi_0 - xi_T'f_T - sum_t xi_t'w_t
     {
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
 #pragma unroll
         for (int v = 0; v < 4; ++v) { xi[v] = x0[v]; qacc = fma(mu0v[v], x0[v], qacc); }
     }
-    __syncthreads();                                           // (every wave has read Xk before the next patch)
+    rt_barrier();                                           // (every wave has read Xk before the next patch)
     put_c31(Xk, xi);
 
     // ---------------- forward sweep (t = T: the terminal inverse P_T = Om_f,T^-1 and f_T = P_T xi_T) ----------------------
@@ -294,13 +312,17 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                 v4d Z;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Z[v] = last ? Omf[v] : Omf[v] + Phi[v];
+                RT_TICK(p_inv);
                 const double dM = rt_sweep_inverse(x, Z, npiv);
+                RT_TOCK(p_inv);
+                RT_TICK(p_p1);
                 st_tile(bufA, w, lane, Z);
-                __syncthreads();                                 // E1: Z in LDS; column 31 of Xk holds xi_t
+                rt_barrier();                                 // E1: Z in LDS; column 31 of Xk holds xi_t
                 const v4d ZY0 = ld_tile(bufA, tY0, lane), ZY1 = ld_tile(bufA, tY1, lane);
                 const v4d X0 = ld_tile(Xk, tX0, lane), X1 = ld_tile(Xk, tX1, lane);
                 const v4d Jaug = mm_tn(ZY0, ZY1, X0, X1, nks, zero4);          // [J | w] = Z'[K' | xi]
                 if (last) {
+                    RT_TOCK(p_p1);
                     detOmT = dM;
                     Ps = Z;
 #pragma unroll
@@ -317,7 +339,9 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
 #pragma unroll
                         for (int v = 0; v < 4; ++v) wtab[(size_t)t * R + rowv[v]] = Jaug[v];
                     }
-                    __syncthreads();                             // E2: [J | w] in LDS
+                    RT_TOCK(p_p1);
+                    RT_TICK(p_p2);
+                    rt_barrier();                             // E2: [J | w] in LDS
                     const v4d JX0 = ld_tile(bufB, tX0, lane), JX1 = ld_tile(bufB, tX1, lane);
                     const v4d prod = mm_tn(KtY0, KtY1, JX0, JX1, nks, zero4);  // K [J | w]
                     const bool full = (cn[s] == N);
@@ -337,15 +361,17 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                     ssum += cs[s];
                     nsum += (double)cn[s];
                     ldsum += full ? ldfull : cl[s];
+                    RT_TOCK(p_p2);
                 }
             }
         }
     }
 
+    const long long t_fwd = RT_NOW(); (void)t_fwd;
     // ---------------- log-likelihood, EM bookkeeping ------------------------------------------------------------------
     {
         if (c31) sm[kRtRed + 4 * I + q] = qacc;
-        __syncthreads();
+        rt_barrier();
         if (tid == 0) {
             double qd = 0.0;
 #pragma unroll
@@ -421,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
             const int t = ch * kRtCh + s;                        // step t: from period t + 1 to period t (t = 0: the initial state)
             if (t < T) {                                         // (uniform)
                 st_tile(bufA, w, lane, Ps);
-                __syncthreads();                                 // E3
+                rt_barrier();                                 // E3
                 const v4d PY0 = ld_tile(bufA, tY0, lane), PY1 = ld_tile(bufA, tY1, lane);
                 const v4d U = mm_tn(PY0, PY1, jx0[s], jx1[s], nks, zero4);      // U = P_s J' = Cov(f_t+1, f_t | X)
                 v4d Uaug = U;
@@ -430,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                     for (int v = 0; v < 4; ++v) Uaug[v] = fs[v];                // column 31 := f_t+1
                 }
                 st_tile(bufB, w, lane, Uaug);
-                __syncthreads();                                 // E4
+                rt_barrier();                                 // E4
                 const v4d UX0 = ld_tile(bufB, tX0, lane), UX1 = ld_tile(bufB, tX1, lane);
                 v4d Pn = mm_tn(jy0[s], jy1[s], UX0, UX1, nks, zc[s]);           // Z + J [U | f_t+1]
                 if (c31) {
@@ -449,6 +475,11 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
             }
         }
     }
+#ifdef DFM_TILE_PROF
+    if (b == 5 && tid == 0)
+        printf("TILEPROF T=%d (10 ns ticks): total %lld  forward %lld (inverse %lld, Z exchange + 2 products %lld, J exchange + product + update %lld)  backward %lld\n",
+               T, RT_NOW() - t_start, t_fwd - t_start, p_inv, p_p1, p_p2, RT_NOW() - t_fwd);
+#endif
     if (!em) return;
 
     // ---------------- EM sums: S11 = sum E[f_t f_t'], S10 = sum E[f_t f_t-1'], S00 (periods 1 .. T; f_0 = fs, P_0 = Ps) ----

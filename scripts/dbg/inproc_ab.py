@@ -1,12 +1,16 @@
 #!/usr/bin/env python
 """A/B of two DFM_SCAN_ABL settings of the one-launch pass INSIDE one process on the same buffers (processes of this pool
 differ by +-3 % on identical code -- physical placement of the 819 MB panel -- so cross-process A/B needs many repeats).
-Usage: python scripts/dbg/inproc_ab.py <A> <B> [<C> ...] [batch=N]   with A, B, ... = a DFM_SCAN_ABL value or "ENV=VAL,ENV=VAL" """
+Usage: python scripts/dbg/inproc_ab.py <A> <B> [<C> ...] [batch=N]   with A, B, ... = a DFM_SCAN_ABL value or "ENV=VAL,ENV=VAL";
+the pseudo-variable LIB=<path of a libdfmhip build> loads ANOTHER library for that variant (e.g. the previous round's build
+under gpurun_tmp/, or lib/libdfmhip_diag.so): both live in this process, each context keeps the one it was created with. """
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from dynamic_factor_models_amd import DfmContext
+from dynamic_factor_models_amd import _lib as _L
+DEFAULT_SO = _L.SO_PATH
 VARS = [a for a in sys.argv[1:] if not a.startswith("batch=")]
 Brep = ([int(a[6:]) for a in sys.argv[1:] if a.startswith("batch=")] or [1024])[0]
 ctxs = []
@@ -14,11 +18,16 @@ KNOBS = ("DFM_SCAN_ABL", "DFM_PASS_NSW", "DFM_PASS_NCOV", "DFM_PASS_FUSED", "DFM
 for v in VARS:
     for k in KNOBS:
         os.environ.pop(k, None)
+    so = DEFAULT_SO
     if "=" in v:
         for kv in v.split(","):
-            k, x = kv.split("="); os.environ[k] = x
+            k, x = kv.split("=")
+            if k == "LIB": so = x if os.path.isabs(x) else os.path.join(ROOT, x)
+            else: os.environ[k] = x
     else:
         os.environ["DFM_SCAN_ABL"] = v
+    if so != _L.SO_PATH:
+        _L.SO_PATH = so; _L._lib = None
     ctxs.append(DfmContext(0))
 panel, par = ctxs[0].synth_panels(20160415, 0, Brep, 500, 200, 8)
 dev = panel.device

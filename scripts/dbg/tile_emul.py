@@ -106,12 +106,32 @@ def sweep_inverse(m, npiv):
                 pD[Q4[inblk], C16[inblk] - ck] = val[inblk]
                 val = np.where(inblk, np.where(C16 - ck == Q4, -1.0, 0.0), val)
             praw[Q4, 16 * J + C16] = val
-        Dinv, dd = inv4(pD)                                   # c. every lane: D^-1, det
+        Dinv, dd = inv4(pD)                                   # (first version: explicit D^-1 by 2 x 2 blocks)
         det *= dd
+        # the kernel: D = L diag(e) L' and two substitutions per column (uses the UPPER triangle of the published block)
+        D00, D10, D20, D30, D11, D21, D31, D22, D32, D33 = pD[0, 0], pD[0, 1], pD[0, 2], pD[0, 3], pD[1, 1], pD[1, 2], pD[1, 3], pD[2, 2], pD[2, 3], pD[3, 3]
+        i0 = 1 / D00; l10, l20, l30 = D10 * i0, D20 * i0, D30 * i0
+        e1 = D11 - l10 * D10; i1 = 1 / e1
+        u21 = D21 - l20 * D10; u31 = D31 - l30 * D10; l21, l31 = u21 * i1, u31 * i1
+        e2 = D22 - l20 * D20 - l21 * u21; i2 = 1 / e2
+        u32 = D32 - l30 * D20 - l31 * u21; l32 = u32 * i2
+        e3 = D33 - l30 * D30 - l31 * u31 - l32 * u32; i3 = 1 / e3
+        assert np.isclose(D00 * e1 * e2 * e3, dd, rtol=1e-12)
+
+        def solve(pc):
+            y1 = pc[1] - l10 * pc[0]
+            y2 = pc[2] - l20 * pc[0] - l21 * y1
+            y3 = pc[3] - l30 * pc[0] - l31 * y1 - l32 * y2
+            t3 = y3 * i3
+            t2 = y2 * i2 - l32 * t3
+            t1 = y1 * i1 - l21 * t2 - l31 * t3
+            t0 = pc[0] * i0 - l10 * t1 - l20 * t2 - l30 * t3
+            return np.array([t0, t1, t2, t3])
         for w in range(4):
             I, J = w >> 1, w & 1
             col = 16 * J + C16
-            T = Dinv @ praw[:, col]                           # all four rows for the lane's column ...
+            T = solve(praw[:, col])                           # all four rows for the lane's column ...
+            assert np.allclose(T, Dinv @ praw[:, col], rtol=1e-9, atol=1e-12)
             bop = -T[Q4, L]                                   # ... the lane keeps row q:  B operand = -T~[q][16 J + c]
             aop = praw[Q4, 16 * I + C16]                      # A operand = R~[q][16 I + c]
             acc = m[w].copy()

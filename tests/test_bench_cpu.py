@@ -85,3 +85,30 @@ def test_the_json_line_is_alone_on_stdout_when_a_library_prints_with_c_stdio():
         "print('{\"metric\": 1}', flush=True)\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.stdout == '{"metric": 1}\n' and "banner" in r.stderr
+
+
+def test_secondary_plan_covers_every_config_and_the_scale_run():
+    """a default one-GPU run times every other line of the path incl. BASELINE configs[0] and [4]; a default
+    N-GPU run (the driver's SCALE launch) times configs[2]'s per-GPU shard and the EM line with its per-iteration all-gather."""
+    one = bench.secondary_plan(1, True, False)
+    for key in ("b8192", "missing10", "missing10_b8192", "em", "em_missing10", "em_missing10_b8192", "pca", "c4", "c4_em", "c4_missing10",
+                "c4_em_missing10", "c1_als", "c5_boot"):
+        assert key in one
+    eight = bench.secondary_plan(8, True, False)
+    assert eight == ["c3", "em", "pass_gather_every_step"]
+    cfg, steps, warm, gather = bench.MULTI_SECONDARY["c3"]
+    assert cfg["B"] == 8192 and 8 * cfg["B"] == 65536 and gather == "block" and cfg["mode"] == "pass"
+    assert bench.MULTI_SECONDARY["pass_gather_every_step"][3] == "step"
+    assert bench.secondary_plan(8, False, False) == [] and bench.secondary_plan(1, True, True) == []
+
+
+def test_gram_flops_are_the_executed_ones():
+    """the X'X kernels compute the upper triangle of their tiling; pricing them on 2 T N^2 over-states the
+    matrix-pipe fraction by 1.7-1.9x (and could exceed 1)."""
+    ex, useful = bench.gram_flops("gram_xx_dma_kernel", 1024, 200, 500)
+    assert ex == 2.0 * 500 * 256 * 91 * 1024                     # 13 x 13 tiles of 16 series: 91 upper-triangle tiles
+    assert useful == 500.0 * 200 * 201 * 1024
+    assert useful < ex < 2.0 * 500 * 200 * 200 * 1024
+    exw, _ = bench.gram_flops("gram_xx_wide_kernel", 256, 1000, 2000)
+    assert exw == 2.0 * 2000 * 128 * 128 * 36 * 256              # 8 blocks of 128 series: 36 pairs
+    assert bench.gram_flops("gram_xx_kernel", 1, 10, 10)[0] == 2000.0

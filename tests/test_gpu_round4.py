@@ -189,3 +189,39 @@ def test_a_stale_status_bit_does_not_fail_the_next_host_call(ctx):
     fo, Po, llo = _oracle(x, dict(zip(KEYS, st)))
     np.testing.assert_allclose(ll, llo, rtol=1e-9)
     ctx.check_status()                                             # and nothing is left behind
+
+
+def test_multi_object_on_every_visible_device(ctx):
+    """The library's multi-GPU object over ALL the devices of the box (skips on a one-GPU box: it runs the day a node appears --
+    VERDICT r3 item 5).  Shards, per-device LDS opt-in, the RCCL communicator and the per-iteration ncclAllGather over > 1 rank
+    must reproduce the single-handle results bit for bit (replicates are independent; the collective carries convergence state only)."""
+    import torch
+    from dynamic_factor_models_amd import DfmMulti
+    G = torch.cuda.device_count()
+    if G < 2:
+        pytest.skip("one visible device: the multi-rank branch is covered by the forced 1-rank communicator (test_gpu_round3)")
+    B, N, T, r, iters = 8 * G + 3, 200, 120, 8, 4                 # (uneven shards)
+    seed, first = 99, 10
+    m = DfmMulti(G)
+    try:
+        assert m.ngpu == G and m.has_comm
+        m.synth(seed, first, B, T, N, r)
+        panel, par = ctx.synth_panels(seed, first, B, T, N, r)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(m.fetch("panel"), panel.cpu().numpy())
+        m.ks_pass(want_P=True)
+        f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=False)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(m.fetch("loglik"), ll.cpu().numpy())
+        np.testing.assert_array_equal(m.fetch("P_smooth"), P.cpu().numpy())
+        ran = m.em(max_iter=iters, tol=1e-5, want_smooth=True, want_P=False)
+        q = [p.clone() for p in par]
+        path, its, f2, _ = ctx.em_batch(panel, *q, max_iter=iters, tol=1e-5, may_have_missing=False)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(m.fetch("iters"), its.cpu().numpy())
+        for k, p in zip(KEYS, q):
+            np.testing.assert_array_equal(m.fetch(k), p.cpu().numpy())
+        np.testing.assert_array_equal(m.fetch("f_smooth"), f2.cpu().numpy())
+        assert ran == int(its.max().item())
+    finally:
+        m.close()
