@@ -84,7 +84,7 @@ def source_hash():
 def measured_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes (scripts/gpu_profile.sh -> profiles/rNN/
     pmc_traffic*.json), ONLY when that file was produced by exactly this source tree on this workload; else None."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         for name in ("pmc_traffic.json", "pmc_traffic_c4.json"):      # headline workload; BASELINE config 4
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, name)) as fh:

@@ -42,6 +42,7 @@ struct dfm_handle {
     bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
     bool fused_gram = true;                // DFM_FUSED_GRAM=0: gram_kernel as its own launch in front of the fused collapse launch
     bool no_fuse_cov = false;              // DFM_NO_FUSE_COV=1: cov_kernel / pfill_kernel as their own launches on a forked stream
+    bool no_defer_em = false;              // DFM_NO_DEFER_EM=1 (route): em_update_kernel as its own launch behind the E-step
     bool no_mstep_mfma = false;            // DFM_NO_MSTEP_MFMA=1: VALU M-step for balanced panels too (diagnostics)
     bool em_general = false;               // DFM_EM_GENERAL=1: EM of balanced panels on the general path too (diagnostics)
     bool fuse_gram = false;                // DFM_FUSE_GRAM=1: Gram matrices inside cov_kernel instead of gram_kernel (slower: its
@@ -55,6 +56,11 @@ struct dfm_handle {
     bool cov_wave = false;                 // DFM_COV_WAVE=1: one-wave-per-replicate covariance recursion on the separate-launch path
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    // EM on the fast path at Rp <= 8: the transition M-step is not launched behind the E-step but handed to the loadings step's
+    // streaming launch (mstep_mfma.hip runs it as extra workgroups): em_iteration sets defer_em, enqueue_pass_fast parks the
+    // arguments here
+    bool defer_em = false, have_deferred_em = false;
+    dfm::EmUpdArgs deferred_em;
     void* odd = nullptr;                   // panel / loadings / R with one all-missing series appended (odd N beyond the tilings, odd_pad)
     size_t odd_bytes = 0;
     std::string prof_file;                 // DFM_PF_PROF_FILE with DFM_SCAN_ABL=256: phase stamps of the fused pass
@@ -453,6 +459,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         ua.A_out = em->A_out; ua.Q_out = em->Q_out; ua.mu0_out = em->mu0_out; ua.P0_out = em->P0_out;
         ua.active = em->active; ua.iters = em->iters; ua.ll_path = em->ll_path; ua.k = em->k; ua.max_iter = em->max_iter;
         ua.tol = em->tol;
+        if (h->defer_em) { h->deferred_em = ua; h->have_deferred_em = true; return 0; }
         { ProfScope ps(h, K_EM_UPDATE); HIP_TRY(h, launch_em_update(p.Rp, ua, h->stream)); }
         return 0;
     };
@@ -633,16 +640,6 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ca.bcol = at<double>(h, p.bcol); ca.scol = at<double>(h, p.scol); ca.nobs = at<int>(h, p.nobs);
     ca.ldrow = at<double>(h, p.ldrow); ca.Ct = at<double>(h, p.Ct); ca.Cfull = at<double>(h, p.Cfull);
     ca.ldfull = at<double>(h, p.ldfull); ca.status = h->status_dev;
-    {
-        const int Rcol = p.Rc ? p.Rc : p.Rp;
-        if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream)); }
-        else if (p.Wwide != (size_t)-1 && N > collapse_max_n(Rcol)) {   // Rp = 32 beyond the register tiling (config 4 with missing cells)
-            double* W = at<double>(h, p.Wwide);
-            { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(ca, W, 32, h->stream)); }
-            { ProfScope ps(h, K_COLLAPSE_WIDE); HIP_TRY(h, launch_collapse_wide2(ca, W, 32, p.r, h->num_cu, h->stream)); }
-            { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_ct_miss_wide(ca, W, p.r, h->stream)); }
-        } else { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(Rcol, ca, h->stream)); }
-    }
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
@@ -660,6 +657,21 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
         ra.A_out = em->A_out; ra.Q_out = em->Q_out; ra.mu0_out = em->mu0_out; ra.P0_out = em->P0_out;
         ra.active = em->active; ra.iters = em->iters; ra.ll_path = em->ll_path;
         ra.k = em->k; ra.max_iter = em->max_iter; ra.tol = em->tol;
+    }
+    // C_t rows: the packed leading block when recursion_tile_kernel reads them (it executes ceil(r / 4) block pivots of the 32-wide
+    // state: the rest is padding whose entries equal Cfull's), the full Rp (Rp + 1) / 2 layout for the other recursion kernels
+    ca.ct_r = 0;
+    if (ra.wave && p.Wwide != (size_t)-1 && N > collapse_max_n(p.Rc ? p.Rc : p.Rp) && recursion_tile_supported(p.Rp, ra)) ca.ct_r = 4 * ((p.r + 3) / 4);
+    ra.ct_r = ca.ct_r;
+    {
+        const int Rcol = p.Rc ? p.Rc : p.Rp;
+        if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream)); }
+        else if (p.Wwide != (size_t)-1 && N > collapse_max_n(Rcol)) {   // Rp = 32 beyond the register tiling (config 4 with missing cells)
+            double* W = at<double>(h, p.Wwide);
+            { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(ca, W, 32, h->stream)); }
+            { ProfScope ps(h, K_COLLAPSE_WIDE); HIP_TRY(h, launch_collapse_wide2(ca, W, 32, p.r, h->num_cu, h->stream)); }
+            { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_ct_miss_wide(ca, W, p.r, h->stream)); }
+        } else { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(Rcol, ca, h->stream)); }
     }
     { ProfScope ps(h, K_RECURSION); HIP_TRY(h, launch_recursion(p.Rp, ra, h->stream)); }
     return 0;
@@ -690,7 +702,12 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
     const int Rp = p.Rc ? p.Rc : p.Rp;          // width of the loadings (narrower than the state for a companion model)
     PaddedParams pp{LamP, AP, QP, mu0P, P0P};
     eo.A_out = AP; eo.Q_out = QP; eo.mu0_out = mu0P; eo.P0_out = P0P;
-    if (int rc = enqueue_pass(h, p, B, T, N, Rp, panel, pp, Rv, fsm, Psm, loglik, &eo)) return rc;
+    const bool ms_mfma = p.fast && p.ms_ws != (size_t)-1 && !h->no_mstep_mfma;
+    h->defer_em = ms_mfma && p.Rp <= 8 && !h->no_defer_em;  // the transition M-step rides in the loadings step's launch
+    h->have_deferred_em = false;
+    const int rc_pass = enqueue_pass(h, p, B, T, N, Rp, panel, pp, Rv, fsm, Psm, loglik, &eo);
+    h->defer_em = false;
+    if (rc_pass) return rc_pass;
     MstepArgs ma;
     ma.B = B; ma.T = T; ma.N = N; ma.r = Rp;
     ma.panel = panel; ma.fsm = fsm; ma.Psm = Psm;
@@ -699,7 +716,8 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
     ma.active = eo.active; ma.Lam_out = LamP; ma.R_out = Rv; ma.lam_stride = Rp;
     if (p.fast && p.ms_ws != (size_t)-1 && !h->no_mstep_mfma) {   // balanced panel: second panel read on the matrix pipe
         ProfScope ps(h, K_MSTEP_MFMA);
-        HIP_TRY(h, launch_mstep_mfma(Rp, ma, p.ms_wpr, at<double>(h, p.ms_ws), h->stream));
+        HIP_TRY(h, launch_mstep_mfma(Rp, ma, p.ms_wpr, at<double>(h, p.ms_ws), h->stream, h->have_deferred_em ? &h->deferred_em : nullptr));
+        h->have_deferred_em = false;
         return 0;
     }
     if (p.fast && p.mw_ws != (size_t)-1 && !h->no_mstep_mfma) {   // ... Rp = 32 (config 4): the same on the streaming machinery of its collapse
@@ -1167,6 +1185,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = diag_env("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
     if (const char* v = route_env("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;
     if (const char* v = diag_env("DFM_NO_MSTEP_MFMA")) h->no_mstep_mfma = atoi(v) != 0;
+    if (const char* v = route_env("DFM_NO_DEFER_EM")) h->no_defer_em = atoi(v) != 0;
     if (const char* v = diag_env("DFM_EM_GENERAL")) h->em_general = atoi(v) != 0;
     if (const char* v = diag_env("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
     if (const char* v = diag_env("DFM_SUBBATCH")) h->subbatch = atoi(v);

@@ -563,40 +563,73 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide_kernel(CollapseArgs a
 // bytes and 9 FMAs on every lane (the packed-entry-per-lane form was LDS-bound: two operand reads per FMA).  The slots'
 // partial sums meet in two butterfly steps per accumulator at the end of the tile.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall, int ntile16, int r) {
-    constexpr int R = kW2R, NP = R * (R + 1) / 2, SE = kW2Chunk * R;        // SE: elements of a stage (32 series x 32)
-    constexpr unsigned kStagesB = 3u * 2u * 8u * 1088u;       // three stage buffers (see the stage loop)
+// Round 4 (third version).  Measured on the round-3 kernel: 6.0 ms per config-4 batch -- a third of the whole pass once the
+// recursion moved to the matrix pipe -- and neither arithmetic (48 M FMAs per replicate: 0.1 ms of a CU) nor HBM (4.1 GB of panel
+// + 2.2 GB of output: 1.5 ms) explains it: one workgroup per CU (128 KB of LDS) walks 32 stage hand-overs per tile of 16 periods,
+// each waiting ~2 us for an L2 -> LDS DMA with two stages in flight, in front of ~3 missing series per wave and stage; the mask
+// build in front of the stage loop and the output behind it are serial phases of the same workgroup.  Now:
+//   * PPW = 2 periods per wave (a tile = 32 periods): half the hand-overs and half the re-streaming per period;
+//   * a stage = 64 series of W ONLY (16 KB, one DMA per wave): lam_i = w_i R_i with R in LDS -- the loadings are not streamed a
+//     second time (L2 -> LDS traffic 16 GB -> 4 GB per batch), and a stage carries twice the series: 16 hand-overs per tile;
+//   * the first stages are requested BEFORE the mask build, so their latency hides behind the panel reads;
+//   * output rows are the packed leading ct_r x ct_r block when the recursion kernel reads that (a.ct_r > 0: 210 instead of 528
+//     doubles per period at r = 20 -- 0.86 instead of 2.2 GB written, and read back).
+template <int PPW>
+__global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall, int ntile, int r) {
+    constexpr int R = kW2R, NPfull = R * (R + 1) / 2;
+    constexpr int P = kCtP * PPW;                             // periods of a tile
+    constexpr int SS = 64;                                    // series per stage
+    constexpr unsigned kPieceB = 1088, kStageB = 16 * kPieceB;   // a stage: 16 pieces (4 series rows of 256 bytes) 1024 + 64 bytes apart
+    constexpr unsigned kStagesB = 3u * kStageB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, T = a.T;
-    const int npad = ((N + kW2Chunk - 1) / kW2Chunk) * kW2Chunk;
-    unsigned short* mask = reinterpret_cast<unsigned short*>(smem + kStagesB);   // [npad]
-    unsigned* anyS = reinterpret_cast<unsigned*>(mask + npad);
-    const size_t cs_off = ((size_t)kStagesB + (size_t)npad * sizeof(unsigned short) + 16 + 15) & ~(size_t)15;   // [16][NP] output tiles
+    const int npad = ((N + SS - 1) / SS) * SS;
+    double* Rs = reinterpret_cast<double*>(smem + kStagesB);                              // [npad] R_i
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(Rs + npad);         // [npad]: bit t = cell (t0 + t, i) is missing
+    unsigned long long* anyS = mask + npad;
+    const int ctr = a.ct_r > 0 ? a.ct_r : R;                  // rows / columns of the packed output block
+    const int NPo = ctr * (ctr + 1) / 2;
+    double* CsAll = reinterpret_cast<double*>(anyS + 2);      // [16 waves][NPo] output rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = (int)blockIdx.x / ntile16, t0 = ((int)blockIdx.x % ntile16) * kCtP;
+    const int b = (int)blockIdx.x / ntile, t0 = ((int)blockIdx.x % ntile) * P;
     const double* __restrict__ X = a.panel + (size_t)b * T * N;
-    if (tid == 0) *anyS = 0u;
-    __syncthreads();
-    unsigned many = 0u;
+    const char* __restrict__ Wb = reinterpret_cast<const char*>(Wall + (size_t)b * N * R);
+    const int nch = npad / SS;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_w)(smem));
+    const unsigned wbytes = (unsigned)N * R * 8u;
+    auto issue = [&](int ch, int buf) {                        // wave w moves piece w of stage ch: ONE global_load_lds_dwordx4
+        unsigned o = (unsigned)ch * (SS * R * 8u) + (unsigned)wave * 1024u + 16u * lane;
+        o = o < wbytes ? o : wbytes - 16u;                    // the last stage may be partial: its rows past N are never selected
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * kStageB + (unsigned)wave * kPieceB);
+        dma16w(Wb + o, dst);
+    };
+    issue(0, 0);
+    if (nch > 1) issue(1, 1);
+    if (tid == 0) *anyS = 0ull;
+    for (int i = tid; i < npad; i += kCtThreads) Rs[i] = i < N ? a.Rv[(size_t)b * N + i] : 1.0;
+    __syncthreads();                                          // (drains this wave's DMAs too: counted waits start from zero below)
+    unsigned long long many = 0ull;
     for (int i = tid; i < npad; i += kCtThreads) {
-        unsigned m = 0u;
+        unsigned long long m = 0ull;
         if (i < N) {
-#pragma unroll
-            for (int t = 0; t < kCtP; ++t) {
+#pragma unroll 8
+            for (int t = 0; t < P; ++t) {
                 const int tt = t0 + t < T ? t0 + t : T - 1;
                 const double x = X[(size_t)tt * N + i];
-                m |= (x != x && t0 + t < T) ? (1u << t) : 0u;
+                m |= (x != x && t0 + t < T) ? (1ull << t) : 0ull;
             }
         }
-        mask[i] = (unsigned short)m;
+        mask[i] = m;
         many |= m;
     }
     if (many) atomicOr(anyS, many);
     __syncthreads();
-    const unsigned tilemask = *anyS;                          // periods of the tile with a missing cell
-    if (tilemask == 0u) return;
-    const bool mine = (tilemask >> wave) & 1u;                // (wave-uniform) this wave's period has a missing cell
+    const unsigned long long tilemask = *anyS;                // periods of the tile with a missing cell
+    if (tilemask == 0ull) return;
+    const int tw0 = wave * PPW;                               // this wave's periods: t0 + tw0 + pp
+    const unsigned wmask = (unsigned)((tilemask >> tw0) & ((1ull << PPW) - 1ull));   // (wave-uniform) which of them have a missing cell
+    const bool mine = wmask != 0u;
     // blocks: nb x nb of 4 x 4 over the r x r matrix, lower triangle; LS lanes per slot
     const int nb = (r + 3) / 4, nlt = nb * (nb + 1) / 2;
     const int LS = nlt <= 16 ? 16 : (nlt <= 32 ? 32 : 64), NS = 64 / LS;
@@ -605,102 +638,101 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs 
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= (act ? bl : 0)) ++bi;
     const int bj = (act ? bl : 0) - bi * (bi + 1) / 2;
-    double E[4][4];
+    double E[PPW][4][4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+    for (int pp = 0; pp < PPW; ++pp)
 #pragma unroll
-        for (int y = 0; y < 4; ++y) E[x][y] = 0.0;
-    const double* __restrict__ Wb = Wall + (size_t)b * N * R;
-    const double* __restrict__ Lb = a.Lam + (size_t)b * N * R;
-    const int nch = npad / kW2Chunk;
-    // Stage ch = W and lam of series 32 ch .. 32 ch + 31 (8 KB each, contiguous in global memory): 16 pieces of 1 KB, ONE
-    // global_load_lds_dwordx4 per wave and stage, three stage buffers, counted waits (the compiler's own scoreboard put a
-    // vmcnt(0) in front of every register-staged LDS write, i.e. one L2 round trip per stage -- ~1.2 us x 32 stages per tile).
-    // A piece = 4 series rows of 256 bytes; pieces sit 1024 + 64 bytes apart so that rows of different pieces start on
-    // different banks (the slots read different series at the same column block).
-    constexpr unsigned kPieceB = 1088, kHalfB = 8 * kPieceB, kStageB = 2 * kHalfB;       // W half | lam half
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_w)(smem));
-    const unsigned wbytes = (unsigned)N * R * 8u;
-    const char* srcb = reinterpret_cast<const char*>(wave < 8 ? Wb : Lb);
-    auto issue = [&](int ch, int buf) {
-        unsigned o = (unsigned)ch * 8192u + (unsigned)(wave & 7) * 1024u + 16u * lane;
-        o = o < wbytes ? o : wbytes - 16u;                    // the last stage may be partial: its rows past N are never selected
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * kStageB + (wave < 8 ? 0u : kHalfB) + (unsigned)(wave & 7) * kPieceB);
-        dma16w(srcb + o, dst);
-    };
-    issue(0, 0);
-    if (nch > 1) issue(1, 1);
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) E[pp][x][y] = 0.0;
+    // three stage buffers, counted waits (the compiler's own scoreboard put a vmcnt(0) in front of every register-staged LDS
+    // write, i.e. one L2 round trip per stage); rows of different pieces start on different banks (the slots read different
+    // series at the same column block)
+    if (nch > 2) issue(2, 2);
     for (int ch = 0; ch < nch; ++ch) {
-        if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // this wave's piece of stage ch has landed
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // ... and everybody's; every wave is done with stage ch - 1
-        if (ch + 2 < nch) issue(ch + 2, (ch + 2) % 3);        // into the buffer stage ch - 1 used
+        // stages 0 and 1 landed before the barrier above; from stage 2 on, at most ONE younger DMA of this wave is in flight
+        if (ch >= 2) {
+            if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everybody's piece has landed; every wave is done with stage ch - 1
+        if (ch >= 1 && ch + 2 < nch) issue(ch + 2, (ch + 2) % 3);             // into the buffer stage ch - 1 used
         if (!mine) continue;
         const char* st = smem + (size_t)(ch % 3) * kStageB;
-        unsigned long long bits = __ballot(lane < kW2Chunk && ((mask[ch * kW2Chunk + (lane & (kW2Chunk - 1))] >> wave) & 1u) != 0u);
+        const unsigned long long mrow = mask[ch * SS + lane];  // the lane's series of this stage
+#pragma unroll
+        for (int pp = 0; pp < PPW; ++pp) {
+            unsigned long long bits = __ballot(((mrow >> (tw0 + pp)) & 1ull) != 0ull);
 #pragma unroll 1
-        while (bits != 0ull) {
-            int my = -1;
+            while (bits != 0ull) {
+                int my = -1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                     // the next NS missing series of the stage, one per slot
-                if (q < NS && bits != 0ull) {
-                    const int ii = __builtin_ctzll(bits);
-                    bits &= bits - 1ull;
-                    my = (slot == q) ? ii : my;
+                for (int q = 0; q < 4; ++q) {                 // the next NS missing series of the stage, one per slot
+                    if (q < NS && bits != 0ull) {
+                        const int ii = __builtin_ctzll(bits);
+                        bits &= bits - 1ull;
+                        my = (slot == q) ? ii : my;
+                    }
                 }
-            }
-            if (act && my >= 0) {
-                const int sw = 16 * (my & 1);                 // (stage start is a multiple of 32: parity of ii = parity of the series)
-                const char* row = st + (unsigned)(my >> 2) * kPieceB + (unsigned)(my & 3) * 256u;
-                const double2* wp = reinterpret_cast<const double2*>(row + 8 * ((4 * bi) ^ sw));
-                const double2* lp = reinterpret_cast<const double2*>(row + kHalfB + 8 * (4 * bj));
-                const double2 w01 = wp[0], w23 = wp[1], l01 = lp[0], l23 = lp[1];
-                const double wv[4] = {w01.x, w01.y, w23.x, w23.y}, lv[4] = {l01.x, l01.y, l23.x, l23.y};
+                if (act && my >= 0) {
+                    const int sw = 16 * (my & 1);             // (stage start is even: parity of ii = parity of the series; odd rows of W have their halves swapped)
+                    const char* row = st + (unsigned)(my >> 2) * kPieceB + (unsigned)(my & 3) * 256u;
+                    const double2* wp = reinterpret_cast<const double2*>(row + 8 * ((4 * bi) ^ sw));
+                    const double2* lp = reinterpret_cast<const double2*>(row + 8 * ((4 * bj) ^ sw));
+                    const double ri = Rs[ch * SS + my];
+                    const double2 w01 = wp[0], w23 = wp[1], l01 = lp[0], l23 = lp[1];
+                    const double wv[4] = {w01.x, w01.y, w23.x, w23.y};
+                    const double lv[4] = {l01.x * ri, l01.y * ri, l23.x * ri, l23.y * ri};   // lam_i = w_i R_i
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+                    for (int x = 0; x < 4; ++x)
 #pragma unroll
-                    for (int y = 0; y < 4; ++y) E[x][y] = fma(wv[x], lv[y], E[x][y]);
+                        for (int y = 0; y < 4; ++y) E[pp][x][y] = fma(wv[x], lv[y], E[pp][x][y]);
+                }
             }
         }
     }
     if (!mine) return;
-    // fold the slots (lanes bl, bl + LS, ...)
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            double e = E[x][y];
-            if (NS >= 2) e += __shfl_xor(e, 32, 64);
-            if (NS >= 4) e += __shfl_xor(e, 16, 64);
-            E[x][y] = e;
-        }
-    // The period's packed C_t is assembled in LDS and leaves as whole 16-byte pieces, 1 KB per store instruction: written
-    // straight from the blocks it was 16 scattered 8-byte stores per lane -- 270 M partial-sector writes per config-4 batch,
-    // which (not the arithmetic) then bounded the kernel.
-    const int t = t0 + wave;
-    double* Co = a.Ct + ((size_t)b * T + t) * NP;
     const double* Cf = a.Cfull + (size_t)b * R * R;
-    double* Cs = reinterpret_cast<double*>(smem + cs_off) + (size_t)wave * NP;   // (its own LDS: slower waves still read the stage buffers)
-    if (act && slot == 0) {
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) {
-                const int jj = 4 * bi + x, kk = 4 * bj + y;
-                if (kk <= jj && jj < R) Cs[jj * (jj + 1) / 2 + kk] = Cf[jj * R + kk] - E[x][y];
-            }
-    }
-    // rows past the blocks (padding of the state): no series loads on them, C_t = C
-    const int j0 = 4 * nb < R ? 4 * nb : R;
-    for (int v = j0 * (j0 + 1) / 2 + lane; v < NP; v += 64) {
+    double* Cs = CsAll + (size_t)wave * NPo;                  // (its own LDS: slower waves still read the stage buffers)
+    // rows past the blocks (padding inside the output block): no series loads on them, C_t = C -- the same for every period
+    const int j0 = 4 * nb < ctr ? 4 * nb : ctr;
+    for (int v = j0 * (j0 + 1) / 2 + lane; v < NPo; v += 64) {
         int jj = j0;
         while ((jj + 1) * (jj + 2) / 2 <= v) ++jj;
         Cs[v] = Cf[jj * R + (v - jj * (jj + 1) / 2)];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    static_assert(NP % 2 == 0, "packed rows leave in 16-byte pieces");
-    for (int v = 2 * lane; v < NP; v += 128) *reinterpret_cast<double2*>(Co + v) = *reinterpret_cast<const double2*>(Cs + v);
+    double cfv[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const int jj = 4 * bi + x, kk = 4 * bj + y;
+            cfv[x][y] = (act && kk <= jj && jj < ctr) ? Cf[jj * R + kk] : 0.0;
+        }
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+        if (!((wmask >> pp) & 1u)) continue;                  // (wave-uniform) a period without a missing cell keeps Cfull
+        // fold the slots (lanes bl, bl + LS, ...).  The period's packed C_t is assembled in LDS and leaves as whole 16-byte
+        // pieces, 1 KB per store instruction: written straight from the blocks it was 16 scattered 8-byte stores per lane --
+        // 270 M partial-sector writes per config-4 batch, which (not the arithmetic) then bounded the kernel.
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                double e = E[pp][x][y];
+                if (NS >= 2) e += __shfl_xor(e, 32, 64);
+                if (NS >= 4) e += __shfl_xor(e, 16, 64);
+                const int jj = 4 * bi + x, kk = 4 * bj + y;
+                if (act && slot == 0 && kk <= jj && jj < ctr) Cs[jj * (jj + 1) / 2 + kk] = cfv[x][y] - e;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double* Co = a.Ct + ((size_t)b * T + (t0 + tw0 + pp)) * NPo;          // (NPo is even: rows are 16-byte aligned)
+        for (int v = 2 * lane; v < NPo; v += 128) *reinterpret_cast<double2*>(Co + v) = *reinterpret_cast<const double2*>(Cs + v);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the row is read before the next period overwrites it)
+        __builtin_amdgcn_wave_barrier();
+    }
+    (void)NPfull;
 }
 
 int collapse_wide2_tiles(int T) { return (T + kW2Rows - 1) / kW2Rows; }
@@ -792,16 +824,24 @@ hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStre
     static const int old = [] { const char* v = diag_env("DFM_CT_OLD"); return v ? atoi(v) : 0; }();     // A/B: the round-2 kernel
     if (!old) {
         note_kernel("ct_miss_wide2_kernel");
-        const size_t lds2 = (((size_t)3 * 2 * 8 * 1088 + (size_t)w.npad * sizeof(unsigned short) + 16 + 15) & ~(size_t)15)
-                            + (size_t)kCtP * (kW2R * (kW2R + 1) / 2) * sizeof(double);      // stage buffers | masks | [16][528] output tiles
+        static const int ppw_env = [] { const char* v = diag_env("DFM_CT_PPW"); return v ? atoi(v) : 0; }();   // A/B: 1 = the round-3 tiling
+        const int ppw = ppw_env == 1 ? 1 : 2;
+        const int ntile = (a.T + kCtP * ppw - 1) / (kCtP * ppw);
+        const size_t npad64 = (size_t)((a.N + 63) / 64) * 64;
+        const int ctr = a.ct_r > 0 ? a.ct_r : kW2R;
+        const size_t lds2 = (size_t)3 * 16 * 1088 + npad64 * (sizeof(double) + sizeof(unsigned long long)) + 16
+                            + (size_t)kCtP * (ctr * (ctr + 1) / 2) * sizeof(double);      // W stages | R | masks | [16 waves] output rows
         static LdsOptIn attr_ct;
         if (!attr_ct) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_ct = true;
         }
-        hipLaunchKernelGGL(ct_miss_wide2_kernel, dim3((unsigned)((long long)a.B * ntile16)), dim3(kCtThreads), lds2, s, a, w.W, ntile16,
-                           r > 0 && r <= kW2R ? r : kW2R);
+        const int rr = r > 0 && r <= kW2R ? r : kW2R;
+        const dim3 grid((unsigned)((long long)a.B * ntile));
+        if (ppw == 1) hipLaunchKernelGGL(ct_miss_wide2_kernel<1>, grid, dim3(kCtThreads), lds2, s, a, w.W, ntile, rr);
+        else hipLaunchKernelGGL(ct_miss_wide2_kernel<2>, grid, dim3(kCtThreads), lds2, s, a, w.W, ntile, rr);
         return hipGetLastError();
     }
     note_kernel("ct_miss_wide_kernel");

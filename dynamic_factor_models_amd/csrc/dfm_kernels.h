@@ -55,6 +55,9 @@ struct CollapseArgs {
     const void* fuse_cov; // collapse_mfma only, HOST pointer read by the launcher (not by the kernel): FastArgs of the pass whose
                           // covariance workgroups + P_smooth fill ride at the front of this launch, or null
     int wpr;              // collapse_mfma only: waves (period segments) per replicate (0 = 4); nseg = wpr <= kSsumSlots
+    int ct_r;             // ct_miss_wide2 only: > 0 = Ct rows are the packed LEADING ct_r x ct_r block (ct_r (ct_r + 1) / 2 doubles; the
+                          // padding of the state carries no loadings, its entries equal Cfull's) -- what recursion_tile_kernel reads;
+                          // 0 = the full Rp (Rp + 1) / 2 layout of the other recursion kernels
 };
 
 struct RecursionArgs {
@@ -95,6 +98,7 @@ struct RecursionArgs {
                           // (recursion_pair.hip); 0: never
     int ka;               // > 0 with kdim: only the first ka = r p columns of the transition rows are free (a VAR(p) inside a
                           // state that carries m > p lags); 0: all kdim columns
+    int ct_r;             // > 0: Ct holds the packed leading ct_r x ct_r block per period (see CollapseArgs::ct_r; recursion_tile only)
     int rstate;           // the model's state width before padding (0: unknown) -- recursion_tile.hip executes ceil(rstate / 4) of
                           // the 8 block pivots / k-steps of a 32-wide state and keeps the mean vectors in (padding) column 31
 };
@@ -169,7 +173,10 @@ bool mstep_needs_dmiss(int Rpad, int N);
 // per-segment partial sums
 bool mstep_mfma_supported(int Rpad, int N);
 size_t mstep_mfma_workspace(int B, int N, int Rpad, int wpr);
-hipError_t launch_mstep_mfma(int Rpad, const MstepArgs& a, int wpr, double* workspace, hipStream_t s);
+struct EmUpdArgs;
+// ua != nullptr (Rp <= 8): the transition M-step of every replicate runs as extra workgroups at the front of the streaming launch
+// (dfm_em_update.h) instead of as em_update_kernel's own launch
+hipError_t launch_mstep_mfma(int Rpad, const MstepArgs& a, int wpr, double* workspace, hipStream_t s, const EmUpdArgs* ua = nullptr);
 
 // Series block of the ECM iteration with AR(q) idiosyncratic terms (mstep_ar.hip): loadings, AR coefficients and innovation
 // variances from the smoothed moments of the companion state of the quasi-differenced model.

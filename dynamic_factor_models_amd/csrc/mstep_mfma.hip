@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "dfm_gram.h"
+#include "dfm_em_update.h"
 #include "dfm_kernels.h"
 
 namespace dfm {
@@ -52,16 +53,31 @@ __host__ __device__ inline unsigned ms_slot_bytes(int N) {   // as collapse_mfma
 }
 
 template <int R, int STEPS, int NDR>
-__global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigned SB, int wpr, double* part_sxf, double* part_sxx) {
+__global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigned SB, int wpr, double* part_sxf, double* part_sxx, EmUpdArgs ua,
+                                                            int nfront_) {
     using G = MsGeo<R>;
     constexpr int NB = 2, NS = 4 * NB, CS = G::CS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gw = (int)blockIdx.x * 4 + wave;
+    // The first nfront workgroups are not streaming workgroups: each of their waves runs the TRANSITION half of the M-step of one
+    // replicate (dfm_em_update.h: sums of f f', A, Q, mu0, P0, S11^-1, the EM bookkeeping).  It depends on the E-step only, so it
+    // hides behind the second panel stream instead of being a 33-us launch in front of it; mstep_finish_kernel (the next launch)
+    // is its only consumer.  Streaming waves may read `active` before or after its update: a replicate that stops in this
+    // iteration then computes sums nobody uses -- except in iteration 0, where the array is still UNINITIALISED until the front
+    // waves have written it (every replicate is active then by definition): nfront < 0 says "do not look at it".
+    const int nfront = nfront_ < 0 ? -nfront_ : nfront_;
+    const bool trust_active = nfront_ >= 0;
+    if ((int)blockIdx.x < nfront) {
+        const int be = (int)blockIdx.x * 4 + wave;
+        constexpr int kEmDoubles = (64 / R) * (R * R + 2 * R);
+        em_update_wave<R>(ua, be < ua.B ? be : ua.B - 1, be < ua.B, lane, reinterpret_cast<double*>(smem) + wave * kEmDoubles);
+        return;
+    }
+    const int gw = ((int)blockIdx.x - nfront) * 4 + wave;
     if (gw >= a.B * wpr) return;
     const int b = gw / wpr, segi = gw % wpr;
-    if (a.active && !a.active[b]) return;
+    if (trust_active && a.active && !a.active[b]) return;
     const int N = a.N, T = a.T;
     const unsigned rowB = (unsigned)N * 8u;
     const int K = lane >> 4, blk = (lane >> 2) & 3, q = lane & 3;
@@ -271,9 +287,10 @@ __global__ __launch_bounds__(256, 2) void mstep_finish_kernel(MstepArgs a, int w
 constexpr int kMsMaxSteps = 32;
 
 template <int R, int STEPS, int NDR>
-static hipError_t launch_ms_one(const MstepArgs& a, int wpr, double* pf, double* px, hipStream_t s) {
+static hipError_t launch_ms_one(const MstepArgs& a, int wpr, double* pf, double* px, hipStream_t s, const EmUpdArgs* ua) {
     const unsigned SB = ms_slot_bytes(a.N);
-    const size_t lds = (size_t)4 * (8 * SB + 2 * 4 * R * 8);
+    size_t lds = (size_t)4 * (8 * SB + 2 * 4 * R * 8);
+    if (ua && lds < (size_t)4 * (64 / R) * (R * R + 2 * R) * sizeof(double)) lds = (size_t)4 * (64 / R) * (R * R + 2 * R) * sizeof(double);   // (the front waves' scratch)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
@@ -282,7 +299,11 @@ static hipError_t launch_ms_one(const MstepArgs& a, int wpr, double* pf, double*
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((mstep_mfma_kernel<R, STEPS, NDR>), dim3((a.B * wpr + 3) / 4), dim3(256), lds, s, a, SB, wpr, pf, px);
+    EmUpdArgs u0;
+    memset(&u0, 0, sizeof(u0));
+    const int nfront = ua ? (a.B + 3) / 4 : 0;                // transition M-step waves in front of the streaming workgroups
+    hipLaunchKernelGGL((mstep_mfma_kernel<R, STEPS, NDR>), dim3((a.B * wpr + 3) / 4 + nfront), dim3(256), lds, s, a, SB, wpr, pf, px, ua ? *ua : u0,
+                       (ua && ua->k == 0) ? -nfront : nfront);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((mstep_finish_kernel<R>), dim3(a.B), dim3(256), 0, s, a, wpr, (const double*)pf, (const double*)px);
@@ -290,20 +311,20 @@ static hipError_t launch_ms_one(const MstepArgs& a, int wpr, double* pf, double*
 }
 
 template <int R, int S>
-static hipError_t launch_ms_pick(const MstepArgs& a, int wpr, double* pf, double* px, hipStream_t s, int steps) {
+static hipError_t launch_ms_pick(const MstepArgs& a, int wpr, double* pf, double* px, hipStream_t s, int steps, const EmUpdArgs* ua) {
     if constexpr (S > kMsMaxSteps) {
         return hipErrorInvalidValue;
     } else {
         if (steps == S) {
             const int ndr = (a.N * 8 + 1023) / 1024;
             constexpr int lo = (MsGeo<R>::CS * (S - 1) * 8 + 8 + 1023) / 1024, hi = (MsGeo<R>::CS * S * 8 + 1023) / 1024;
-            if constexpr (lo <= 1 && 1 <= hi) { if (ndr == 1) return launch_ms_one<R, S, 1>(a, wpr, pf, px, s); }
-            if constexpr (lo <= 2 && 2 <= hi) { if (ndr == 2) return launch_ms_one<R, S, 2>(a, wpr, pf, px, s); }
-            if constexpr (lo <= 3 && 3 <= hi) { if (ndr == 3) return launch_ms_one<R, S, 3>(a, wpr, pf, px, s); }
-            if constexpr (lo <= 4 && 4 <= hi) { if (ndr == 4) return launch_ms_one<R, S, 4>(a, wpr, pf, px, s); }
+            if constexpr (lo <= 1 && 1 <= hi) { if (ndr == 1) return launch_ms_one<R, S, 1>(a, wpr, pf, px, s, ua); }
+            if constexpr (lo <= 2 && 2 <= hi) { if (ndr == 2) return launch_ms_one<R, S, 2>(a, wpr, pf, px, s, ua); }
+            if constexpr (lo <= 3 && 3 <= hi) { if (ndr == 3) return launch_ms_one<R, S, 3>(a, wpr, pf, px, s, ua); }
+            if constexpr (lo <= 4 && 4 <= hi) { if (ndr == 4) return launch_ms_one<R, S, 4>(a, wpr, pf, px, s, ua); }
             return hipErrorInvalidValue;
         }
-        return launch_ms_pick<R, S + 1>(a, wpr, pf, px, s, steps);
+        return launch_ms_pick<R, S + 1>(a, wpr, pf, px, s, steps, ua);
     }
 }
 
@@ -316,11 +337,11 @@ bool mstep_mfma_supported(int Rpad, int N) {
 }
 size_t mstep_mfma_workspace(int B, int N, int Rpad, int wpr) { return (size_t)B * wpr * ((size_t)N * Rpad + N) * sizeof(double); }
 
-hipError_t launch_mstep_mfma(int Rpad, const MstepArgs& a, int wpr, double* workspace, hipStream_t s) {
+hipError_t launch_mstep_mfma(int Rpad, const MstepArgs& a, int wpr, double* workspace, hipStream_t s, const EmUpdArgs* ua) {
     double* pf = workspace;
     double* px = workspace + (size_t)a.B * wpr * a.N * Rpad;
-    if (Rpad == 4) return launch_ms_pick<4, 1>(a, wpr, pf, px, s, (a.N + MsGeo<4>::CS - 1) / MsGeo<4>::CS);
-    if (Rpad == 8) return launch_ms_pick<8, 1>(a, wpr, pf, px, s, (a.N + MsGeo<8>::CS - 1) / MsGeo<8>::CS);
+    if (Rpad == 4) return launch_ms_pick<4, 1>(a, wpr, pf, px, s, (a.N + MsGeo<4>::CS - 1) / MsGeo<4>::CS, ua);
+    if (Rpad == 8) return launch_ms_pick<8, 1>(a, wpr, pf, px, s, (a.N + MsGeo<8>::CS - 1) / MsGeo<8>::CS, ua);
     return hipErrorInvalidValue;
 }
 

@@ -215,12 +215,17 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     const double ldfull = a.ldfull[b];
     double* ZJ = a.ZJtab + (size_t)b * (T + 1) * 2 * RR;       // per period: Z (4 tiles), J' (4 tiles), register-pair layout
     double* wtab = a.wtab + (size_t)b * T * R;
-    constexpr int NPc = R * (R + 1) / 2;
+    // C_t rows: the packed leading ct_r x ct_r block (ct_miss_wide2_kernel writes that for this kernel: the padding beyond it carries
+    // no loadings, its entries are Cfull's), or the full packed 32 x 32 layout of the other collapse kernels (ct_r = 0)
+    const int ctr = a.ct_r > 0 ? a.ct_r : R;
+    const int NPc = ctr * (ctr + 1) / 2;
     int pk[4];
+    bool cin[4];                                               // the lane's element (i, j) lies inside the block
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int i = rowv[v], j = col;
-        pk[v] = (i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i;
+        cin[v] = i < ctr && j < ctr;
+        pk[v] = cin[v] ? ((i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i) : 0;
     }
 
     // ---------------- prologue: Qi = Q^-1, Om_f,0 = P0^-1, K' = A'Qi, Phi = A'Qi A, xi_0 = P0^-1 mu0 -----------------------
@@ -272,20 +277,21 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     put_c31(Xk, xi);
 
     // ---------------- forward sweep (t = T: the terminal inverse P_T = Om_f,T^-1 and f_T = P_T xi_T) ----------------------
-    double cbn[kRtCh][4], ccn[kRtCh][4], csn[kRtCh], cln[kRtCh];
-    int cnn[kRtCh];
-    auto issue_fwd = [&](int ch) {
+    // Operands of period t live in register set t & 1 and are RE-LOADED for period t + 2 right behind their last use (they are
+    // consumed at the very end of a period): two periods of lead, no staging copies (a first version prefetched a chunk into a
+    // second set and copied it over: 22 v_mov per two periods on a chain that is bound by its instruction count).
+    static_assert(kRtCh == 2, "register sets alternate by the parity of the period");
+    double cb[kRtCh][4], cc[kRtCh][4], cs[kRtCh], cl[kRtCh];
+    int cn[kRtCh];
+    const double* Ctb = a.Ct ? a.Ct + (size_t)b * T * NPc : nullptr;
+    auto load_fwd = [&](int s, int t) {
+        t = t < T ? t : T - 1;
 #pragma unroll
-        for (int s = 0; s < kRtCh; ++s) {
-            int t = ch * kRtCh + s;
-            t = t < T ? t : T - 1;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                cbn[s][v] = bcol[(size_t)t * R + rowv[v]];
-                ccn[s][v] = a.Ct ? a.Ct[((size_t)b * T + t) * NPc + pk[v]] : 0.0;
-            }
-            csn[s] = scol[t]; cnn[s] = nobs[t]; cln[s] = ldrow[t];
+        for (int v = 0; v < 4; ++v) {
+            cb[s][v] = bcol[(size_t)t * R + rowv[v]];
+            cc[s][v] = Ctb ? Ctb[(size_t)t * NPc + pk[v]] : 0.0;
         }
+        cs[s] = scol[t]; cn[s] = nobs[t]; cl[s] = ldrow[t];
     };
     double ssum = 0.0, nsum = 0.0, ldsum = 0.0;
     LogProd detprod;
@@ -293,17 +299,9 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     double fs[4] = {0.0, 0.0, 0.0, 0.0};
     double detOmT = 1.0;
     const int nchf = (T + 1 + kRtCh - 1) / kRtCh;              // T + 1 steps
-    issue_fwd(0);
+    load_fwd(0, 0);
+    load_fwd(1, 1);
     for (int ch = 0; ch < nchf; ++ch) {
-        double cb[kRtCh][4], cc[kRtCh][4], cs[kRtCh], cl[kRtCh];
-        int cn[kRtCh];
-#pragma unroll
-        for (int s = 0; s < kRtCh; ++s) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) { cb[s][v] = cbn[s][v]; cc[s][v] = ccn[s][v]; }
-            cs[s] = csn[s]; cl[s] = cln[s]; cn[s] = cnn[s];
-        }
-        if (ch + 1 < nchf) issue_fwd(ch + 1);
 #pragma unroll
         for (int s = 0; s < kRtCh; ++s) {
             const int t = ch * kRtCh + s;
@@ -348,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const double omp = c31 ? Qi[v] : Qi[v] - prod[v];     // column 31 is padding: Qi's own entries
-                        Omf[v] = omp + (full ? Cf[v] : cc[s][v]);
+                        Omf[v] = omp + ((full || !cin[v]) ? Cf[v] : cc[s][v]);
                     }
                     if (c31) {
 #pragma unroll
@@ -361,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                     ssum += cs[s];
                     nsum += (double)cn[s];
                     ldsum += full ? ldfull : cl[s];
+                    load_fwd(s, t + 2);                          // (this set's operands are consumed)
                     RT_TOCK(p_p2);
                 }
             }
@@ -395,53 +394,52 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
 
     // ---------------- backward sweep -------------------------------------------------------------------------------------
     const int npr = r * (r + 1) / 2;
+    int poff[4];                                               // packed offset of the lane's element (i, col), -1: not in the output
+#pragma unroll
+    for (int v = 0; v < 4; ++v) poff[v] = (rowv[v] < r && col <= rowv[v]) ? rowv[v] * (rowv[v] + 1) / 2 + col : -1;
+    double* const fsm = a.f_smooth + (size_t)b * T * r;
+    double* const Psm = a.P_smooth ? a.P_smooth + (size_t)b * T * npr : nullptr;
     auto emit = [&](int trow, const v4d& P, const double (&f)[4]) {   // smoothed moments of period trow + 1
         if (c31) {
+            double* fr = fsm + (size_t)trow * r;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
-                if (rowv[v] < r) a.f_smooth[((size_t)b * T + trow) * r + rowv[v]] = f[v];
+                if (rowv[v] < r) fr[rowv[v]] = f[v];
         }
-        if (a.P_smooth) {
+        if (Psm) {
+            double* pr = Psm + (size_t)trow * npr;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int i = rowv[v];
-                if (i < r && col <= i) a.P_smooth[((size_t)b * T + trow) * npr + i * (i + 1) / 2 + col] = P[v];
-            }
+            for (int v = 0; v < 4; ++v)
+                if (poff[v] >= 0) pr[poff[v]] = P[v];
         }
     };
     emit(T - 1, Ps, fs);
     const bool em = a.S11 != nullptr;
     const v4d PT = Ps;
     v4d SP = Ps, SU = zero4;                                   // sum_t P_t (periods 1 .. T), sum of the lag-one covariances
-    v4d zn[kRtCh], jxn0[kRtCh], jxn1[kRtCh], jyn0[kRtCh], jyn1[kRtCh];
-    double wn[kRtCh][4];
-    auto issue_bwd = [&](int ch) {
+    // (Z, J') of step t and w_t in register set t & 1, re-loaded for step t - 2 behind their last use: the B operands of the
+    // first product early in the step, Z / the A operands / w_t behind the second
+    v4d zc[kRtCh], jx0[kRtCh], jx1[kRtCh], jy0[kRtCh], jy1[kRtCh];
+    double wc[kRtCh][4];
+    auto load_bwd_x = [&](int s, int t) {
+        t = t > 0 ? t : 0;
+        const double* ent = ZJ + (size_t)t * 2 * RR + RR;
+        jx0[s] = ld_tile_g(ent, tX0, lane); jx1[s] = ld_tile_g(ent, tX1, lane);
+    };
+    auto load_bwd_y = [&](int s, int t) {
+        t = t > 0 ? t : 0;
+        const double* ent = ZJ + (size_t)t * 2 * RR;
+        zc[s] = ld_tile_g(ent, w, lane);
+        jy0[s] = ld_tile_g(ent + RR, tY0, lane); jy1[s] = ld_tile_g(ent + RR, tY1, lane);
 #pragma unroll
-        for (int s = 0; s < kRtCh; ++s) {
-            int t = ch * kRtCh + s;
-            t = t < T ? t : T - 1;
-            const double* ent = ZJ + (size_t)t * 2 * RR;
-            zn[s] = ld_tile_g(ent, w, lane);
-            jxn0[s] = ld_tile_g(ent + RR, tX0, lane); jxn1[s] = ld_tile_g(ent + RR, tX1, lane);
-            jyn0[s] = ld_tile_g(ent + RR, tY0, lane); jyn1[s] = ld_tile_g(ent + RR, tY1, lane);
-#pragma unroll
-            for (int v = 0; v < 4; ++v) wn[s][v] = wtab[(size_t)t * R + rowv[v]];
-        }
+        for (int v = 0; v < 4; ++v) wc[s][v] = wtab[(size_t)t * R + rowv[v]];
     };
     const int nchb = (T + kRtCh - 1) / kRtCh;
     __threadfence();
     __syncthreads();                                           // (table and w_t stores of the forward sweep are visible: one CU, one L1)
-    issue_bwd(nchb - 1);
+    load_bwd_x((T - 1) & 1, T - 1); load_bwd_y((T - 1) & 1, T - 1);
+    load_bwd_x((T - 2) & 1, T - 2); load_bwd_y((T - 2) & 1, T - 2);   // (T = 1: step 0 again, unused)
     for (int ch = nchb - 1; ch >= 0; --ch) {
-        v4d zc[kRtCh], jx0[kRtCh], jx1[kRtCh], jy0[kRtCh], jy1[kRtCh];
-        double wc[kRtCh][4];
-#pragma unroll
-        for (int s = 0; s < kRtCh; ++s) {
-            zc[s] = zn[s]; jx0[s] = jxn0[s]; jx1[s] = jxn1[s]; jy0[s] = jyn0[s]; jy1[s] = jyn1[s];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) wc[s][v] = wn[s][v];
-        }
-        if (ch > 0) issue_bwd(ch - 1);
 #pragma unroll
         for (int s = kRtCh - 1; s >= 0; --s) {
             const int t = ch * kRtCh + s;                        // step t: from period t + 1 to period t (t = 0: the initial state)
@@ -450,6 +448,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                 rt_barrier();                                 // E3
                 const v4d PY0 = ld_tile(bufA, tY0, lane), PY1 = ld_tile(bufA, tY1, lane);
                 const v4d U = mm_tn(PY0, PY1, jx0[s], jx1[s], nks, zero4);      // U = P_s J' = Cov(f_t+1, f_t | X)
+                load_bwd_x(s, t - 2);
                 v4d Uaug = U;
                 if (c31) {
 #pragma unroll
@@ -467,6 +466,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                     }
                 }
                 Ps = Pn;
+                load_bwd_y(s, t - 2);
                 if (em) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) { SU[v] += U[v]; if (t > 0) SP[v] += Pn[v]; }

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("DFM_LIB", "diag")   # the stamps exist only in the diagnostics build: python -m dynamic_factor_models_amd.build --diag
 os.environ["DFM_PASS_FUSED"] = "1"
 os.environ["DFM_SCAN_ABL"] = str(256 | int(os.environ.get("PF_ABL", "0")))   # PF_ABL=512: the round-2 scan
 os.environ["DFM_PF_PROF_FILE"] = "/tmp/pf_prof.txt"
