@@ -661,7 +661,8 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     // C_t rows: the packed leading block when recursion_tile_kernel reads them (it executes ceil(r / 4) block pivots of the 32-wide
     // state: the rest is padding whose entries equal Cfull's), the full Rp (Rp + 1) / 2 layout for the other recursion kernels
     ca.ct_r = 0;
-    if (ra.wave && p.Wwide != (size_t)-1 && N > collapse_max_n(p.Rc ? p.Rc : p.Rp) && recursion_tile_supported(p.Rp, ra)) ca.ct_r = 4 * ((p.r + 3) / 4);
+    if (ra.wave && p.Wwide != (size_t)-1 && N > collapse_max_n(p.Rc ? p.Rc : p.Rp) && recursion_tile_supported(p.Rp, ra) &&
+        ct_miss_wide_compact_ok(N, 4 * ((p.r + 3) / 4))) ca.ct_r = 4 * ((p.r + 3) / 4);
     ra.ct_r = ca.ct_r;
     {
         const int Rcol = p.Rc ? p.Rc : p.Rp;

@@ -574,13 +574,14 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide_kernel(CollapseArgs a
 //   * the first stages are requested BEFORE the mask build, so their latency hides behind the panel reads;
 //   * output rows are the packed leading ct_r x ct_r block when the recursion kernel reads that (a.ct_r > 0: 210 instead of 528
 //     doubles per period at r = 20 -- 0.86 instead of 2.2 GB written, and read back).
-template <int PPW>
+template <int PPW, int NBUF>
 __global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall, int ntile, int r) {
     constexpr int R = kW2R, NPfull = R * (R + 1) / 2;
     constexpr int P = kCtP * PPW;                             // periods of a tile
     constexpr int SS = 64;                                    // series per stage
     constexpr unsigned kPieceB = 1088, kStageB = 16 * kPieceB;   // a stage: 16 pieces (4 series rows of 256 bytes) 1024 + 64 bytes apart
-    constexpr unsigned kStagesB = 3u * kStageB;
+    // NBUF stage buffers: NBUF - 1 stages in flight behind the one in use (5 where the compact output rows leave the LDS for them)
+    constexpr unsigned kStagesB = (unsigned)NBUF * kStageB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, T = a.T;
     const int npad = ((N + SS - 1) / SS) * SS;
@@ -604,8 +605,9 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs 
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * kStageB + (unsigned)wave * kPieceB);
         dma16w(Wb + o, dst);
     };
-    issue(0, 0);
-    if (nch > 1) issue(1, 1);
+#pragma unroll
+    for (int u = 0; u < NBUF - 1; ++u)
+        if (u < nch) issue(u, u);
     if (tid == 0) *anyS = 0ull;
     for (int i = tid; i < npad; i += kCtThreads) Rs[i] = i < N ? a.Rv[(size_t)b * N + i] : 1.0;
     __syncthreads();                                          // (drains this wave's DMAs too: counted waits start from zero below)
@@ -645,20 +647,26 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs 
         for (int x = 0; x < 4; ++x)
 #pragma unroll
             for (int y = 0; y < 4; ++y) E[pp][x][y] = 0.0;
-    // three stage buffers, counted waits (the compiler's own scoreboard put a vmcnt(0) in front of every register-staged LDS
+    // NBUF stage buffers, counted waits (the compiler's own scoreboard put a vmcnt(0) in front of every register-staged LDS
     // write, i.e. one L2 round trip per stage); rows of different pieces start on different banks (the slots read different
-    // series at the same column block)
-    if (nch > 2) issue(2, 2);
+    // series at the same column block).  Stages 0 .. NBUF - 2 were requested before the mask build and have landed (the
+    // barriers above drain vmcnt); from then on stage ch + NBUF - 1 is requested when stage ch is taken up, so at most
+    // NBUF - 2 YOUNGER requests of this wave are in flight when it needs stage ch.
     for (int ch = 0; ch < nch; ++ch) {
-        // stages 0 and 1 landed before the barrier above; from stage 2 on, at most ONE younger DMA of this wave is in flight
-        if (ch >= 2) {
-            if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ch >= NBUF - 1) {
+            const int younger = nch - 1 - ch < NBUF - 2 ? nch - 1 - ch : NBUF - 2;
+            switch (younger) {                                    // (wave-uniform; the immediate must be a constant)
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // everybody's piece has landed; every wave is done with stage ch - 1
-        if (ch >= 1 && ch + 2 < nch) issue(ch + 2, (ch + 2) % 3);             // into the buffer stage ch - 1 used
+        if (ch + NBUF - 1 < nch) issue(ch + NBUF - 1, (ch + NBUF - 1) % NBUF);   // into the buffer stage ch - 1 used (ch = 0: a fresh one)
         if (!mine) continue;
-        const char* st = smem + (size_t)(ch % 3) * kStageB;
+        const char* st = smem + (size_t)(ch % NBUF) * kStageB;
         const unsigned long long mrow = mask[ch * SS + lane];  // the lane's series of this stage
 #pragma unroll
         for (int pp = 0; pp < PPW; ++pp) {
@@ -816,6 +824,13 @@ hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, in
 
 // C_t of the periods with missing cells (a.Ct, packed; the other periods keep Cfull): after launch_wide_prep, beside or after
 // the collapse (it reads the panel itself)
+// compact C_t rows (CollapseArgs::ct_r) fit the LDS of ct_miss_wide2_kernel for this cross-section
+bool ct_miss_wide_compact_ok(int N, int ct_r) {
+    const size_t npad64 = (size_t)((N + 63) / 64) * 64;
+    return (size_t)3 * 16 * 1088 + npad64 * (sizeof(double) + sizeof(unsigned long long)) + 16
+           + (size_t)kCtP * (ct_r * (ct_r + 1) / 2) * sizeof(double) <= 160 * 1024;
+}
+
 hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s) {
     static const int skip = [] { const char* v = diag_env("DFM_CT_SKIP"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
     if (skip) return hipSuccess;
@@ -829,19 +844,36 @@ hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStre
         const int ntile = (a.T + kCtP * ppw - 1) / (kCtP * ppw);
         const size_t npad64 = (size_t)((a.N + 63) / 64) * 64;
         const int ctr = a.ct_r > 0 ? a.ct_r : kW2R;
-        const size_t lds2 = (size_t)3 * 16 * 1088 + npad64 * (sizeof(double) + sizeof(unsigned long long)) + 16
-                            + (size_t)kCtP * (ctr * (ctr + 1) / 2) * sizeof(double);      // W stages | R | masks | [16 waves] output rows
+        auto lds_for = [&](int nb) {                              // W stages | R | masks | [16 waves] output rows
+            return (size_t)nb * 16 * 1088 + npad64 * (sizeof(double) + sizeof(unsigned long long)) + 16
+                   + (size_t)kCtP * (ctr * (ctr + 1) / 2) * sizeof(double);
+        };
+        // (five stage buffers -- four stages in flight -- measured the same 4.4-4.5 ms as three at config 4: the stage loop is bound by
+        //  the waves' instruction issue, ~300 instructions per wave and stage at four waves per SIMD, not by the DMA latency)
+        const int nbuf = 3;
+        const size_t lds2 = lds_for(nbuf);
+        if (lds2 > 160 * 1024) {
+            // a very wide cross-section (16 bytes of LDS per series here): the round-2 kernel, whose masks are 2 bytes per series --
+            // full rows only (capi.hip asks ct_miss_wide_compact_ok before it promises the recursion compact rows)
+            if (a.ct_r > 0) return hipErrorInvalidValue;
+            note_kernel("ct_miss_wide_kernel");
+            const size_t lds = (size_t)2 * kW2Chunk * kW2R * sizeof(double) + (size_t)w.npad * sizeof(unsigned short) + 16;
+            hipLaunchKernelGGL(ct_miss_wide_kernel, dim3((unsigned)((long long)a.B * ntile16)), dim3(kCtThreads), lds, s, a, w.W, ntile16);
+            return hipGetLastError();
+        }
         static LdsOptIn attr_ct;
         if (!attr_ct) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel<2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel<2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_wide2_kernel<1, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
             attr_ct = true;
         }
         const int rr = r > 0 && r <= kW2R ? r : kW2R;
         const dim3 grid((unsigned)((long long)a.B * ntile));
-        if (ppw == 1) hipLaunchKernelGGL(ct_miss_wide2_kernel<1>, grid, dim3(kCtThreads), lds2, s, a, w.W, ntile, rr);
-        else hipLaunchKernelGGL(ct_miss_wide2_kernel<2>, grid, dim3(kCtThreads), lds2, s, a, w.W, ntile, rr);
+        if (ppw == 1) hipLaunchKernelGGL((ct_miss_wide2_kernel<1, 3>), grid, dim3(kCtThreads), lds2, s, a, w.W, ntile, rr);
+        else if (nbuf == 5) hipLaunchKernelGGL((ct_miss_wide2_kernel<2, 5>), grid, dim3(kCtThreads), lds2, s, a, w.W, ntile, rr);
+        else hipLaunchKernelGGL((ct_miss_wide2_kernel<2, 3>), grid, dim3(kCtThreads), lds2, s, a, w.W, ntile, rr);
         return hipGetLastError();
     }
     note_kernel("ct_miss_wide_kernel");

@@ -164,6 +164,7 @@ size_t collapse_wide2_ws_bytes(int B, int N, int Rpad);    // W [B][N][Rp] | 1 /
 hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s);
 hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s);
 // a.nobs != nullptr selects the variant for panels with missing cells (per-period scol / nobs / ldrow); their C_t:
+bool ct_miss_wide_compact_ok(int N, int ct_r);   // compact C_t rows (CollapseArgs::ct_r) are available for this cross-section
 hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s);   // r: the caller's factor count
 bool gram_supported(int Rpad, int N);       // launch_gram's register tilings
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);

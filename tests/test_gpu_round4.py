@@ -225,3 +225,19 @@ def test_multi_object_on_every_visible_device(ctx):
         assert ran == int(its.max().item())
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("N", [3000, 6400])
+def test_very_wide_cross_section_with_missing_cells(ctx, N):
+    """The C_t kernel of the wide path keeps 16 bytes of LDS per series (mask + R): N = 3000 still gets the compact rows the tile
+    recursion reads (three stage buffers instead of five), N = 6400 falls back to the round-2 kernel with full rows."""
+    import torch
+    B, T, r = 2, 10, 18
+    reps = [ko.synth_replicate(b, N, T, r, seed=5, missing=0.05) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    st = {k: np.stack([p[k] for _, p in reps]) for k in KEYS}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_batch(t(panel), *[t(st[k]) for k in KEYS], may_have_missing=True)
+    torch.cuda.synchronize()
+    _compare((f.cpu().numpy(), P.cpu().numpy(), ll.cpu().numpy()), _oracle(panel, st), f"N = {N}, r = {r}, missing cells")
