@@ -68,8 +68,9 @@ int dfm_set_stream(dfm_handle* h, void* stream);
  * converged).  The word is STICKY: kernels only ever set bits, and the call that reads a non-zero value reports it once and
  * clears it -- so it covers every call enqueued since the previous check (no per-call reset: that was a fill kernel in front
  * of every pass).  The "_dev" entry points only enqueue, so this is where a device-pointer caller learns that a call went
- * wrong; the host-pointer entry points make the same check themselves.  dfm_check_status is the same call under the name a
- * reader looks for. */
+ * wrong; the host-pointer entry points make the same check themselves -- and open a new EPOCH when they start: they read and
+ * clear the word at entry, so what they report at the end is their own kernels' (a bit left by an earlier unchecked "_dev" call
+ * is discarded there, with a note in dfm_last_error).  dfm_check_status is the same call under the name a reader looks for. */
 int dfm_synchronize(dfm_handle* h);
 int dfm_check_status(dfm_handle* h);
 const char* dfm_last_error(const dfm_handle* h);
