@@ -1789,12 +1789,14 @@ int dfm_synth_panels_dev(dfm_handle* h, uint64_t seed, int64_t first_replicate, 
     HIP_TRY(h, hipSetDevice(h->device));
     size_t off = 0;
     const size_t oF = take(off, (size_t)B * (T + 1) * r * sizeof(double));
+    const size_t oC = take(off, (size_t)B * synth_tiles(T) * 2 * N * sizeof(double));
     if (int rc = ensure_ws(h, off)) return rc;
     SynthArgs sa;
     sa.B = B; sa.T = T; sa.N = N; sa.r = r; sa.seed = seed; sa.first_replicate = first_replicate;
     sa.missing_prob = missing_prob;
     sa.panel = panel; sa.Lam = Lam; sa.R = R; sa.A = A; sa.Q = Q; sa.mu0 = mu0; sa.P0 = P0;
     sa.fscratch = at<double>(h, oF);
+    sa.colstats = at<double>(h, oC);
     { ProfScope ps(h, K_SYNTH); HIP_TRY(h, launch_synth(sa, h->stream)); }
     return 0;
 }

@@ -355,7 +355,9 @@ struct SynthArgs {
     uint64_t seed; int64_t first_replicate; double missing_prob;
     double* panel; double* Lam; double* R; double* A; double* Q; double* mu0; double* P0;
     double* fscratch;           // [B][T+1][r]
+    double* colstats;           // [B][synth_tiles(T)][2][N]  per-tile column sums (sum x, sum x^2) of the raw cells
 };
+int synth_tiles(int T);
 hipError_t launch_synth(const SynthArgs& a, hipStream_t s);
 
 }  // namespace dfm

@@ -34,20 +34,29 @@ __device__ __forceinline__ double uniform1(uint64_t key, uint64_t stream, uint64
 }
 
 constexpr int kSynThreads = 256;
+constexpr int kSynTile = 32;                                 // periods per tile of the cell / standardisation kernels
 enum : uint64_t { kStrLam = 1, kStrR = 2, kStrF = 3, kStrEps = 4, kStrMiss = 5 };
 
-__global__ __launch_bounds__(kSynThreads) void synth_kernel(SynthArgs a) {
+// Round 4: three launches instead of one workgroup per replicate.  The round-1 kernel gave a replicate ONE workgroup of 256
+// threads (256 workgroups for config 4: one wave per SIMD), re-read the loadings from L2 for every cell and made three
+// column-strided passes over the panel to standardise it: 85 GB fetched to write 10.8 GB at config 4, 44 ms.
+// Now: (1) parameters and factor paths, one workgroup per replicate (tiny); (2) cells: a thread owns a column PAIR for a tile of
+// 32 periods -- its two rows of loadings in registers, the tile's factors in LDS, one Philox counter per pair of cells as
+// before -- writes the raw cells once and leaves per-tile column sums (sum x, sum x^2); (3) standardisation: every workgroup
+// reduces the tiles' sums for its columns (mean, population s.d. = sqrt(sum x^2 / T - mean^2): the columns have mean ~ 0, so
+// the one-pass form loses nothing), rescales its tile in place and punches the missing cells; the workgroups of tile 0 rescale
+// the parameters.  HBM: panel written once, read once, written once.  Every number is still a pure function of
+// (seed, replicate, stream, index): results do not depend on the launch geometry (oracle/synth_oracle.py restates them).
+
+__global__ __launch_bounds__(kSynThreads) void synth_params_kernel(SynthArgs a) {
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int N = a.N, T = a.T, r = a.r;
     const uint64_t key = a.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(a.first_replicate + b + 1));
-    double* X = a.panel + (size_t)b * T * N;
     double* Lam = a.Lam + (size_t)b * N * r;
     double* Rv = a.R + (size_t)b * N;
     double* F = a.fscratch + (size_t)b * (T + 1) * r;        // f_1 .. f_T (row t-1) -- scratch
-
-    // loadings and idiosyncratic variances
-    for (int idx = tid; idx < (N * r + 1) / 2; idx += kSynThreads) {
+    for (int idx = tid; idx < (N * r + 1) / 2; idx += kSynThreads) {   // loadings (raw; rescaled by the standardisation kernel)
         double z0, z1;
         normal2(key, kStrLam, idx, z0, z1);
         Lam[2 * idx] = z0;
@@ -71,42 +80,6 @@ __global__ __launch_bounds__(kSynThreads) void synth_kernel(SynthArgs a) {
             }
         }
     }
-    __syncthreads();
-    // x_ti = lam_i' f_t + sqrt(R_i) eps_ti     (two cells per counter)
-    const size_t ncell = (size_t)T * N;
-    for (size_t p = tid; p < (ncell + 1) / 2; p += kSynThreads) {
-        double z[2];
-        normal2(key, kStrEps, p, z[0], z[1]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const size_t cell = 2 * p + e;
-            if (cell < ncell) {
-                const int t = (int)(cell / N), i = (int)(cell % N);
-                double s = 0.0;
-                for (int k = 0; k < r; ++k) s = fma(Lam[(size_t)i * r + k], F[(size_t)t * r + k], s);
-                X[cell] = s + sqrt(Rv[i]) * z[e];
-            }
-        }
-    }
-    __syncthreads();
-    // standardise columns (mean, population s.d.), rescale the parameters, punch the missing cells
-    for (int i = tid; i < N; i += kSynThreads) {
-        double m = 0.0;
-        for (int t = 0; t < T; ++t) m += X[(size_t)t * N + i];
-        m /= (double)T;
-        double v = 0.0;
-        for (int t = 0; t < T; ++t) { const double d = X[(size_t)t * N + i] - m; v = fma(d, d, v); }
-        const double sd = sqrt(v / (double)T);
-        const double inv = 1.0 / sd;
-        for (int t = 0; t < T; ++t) {
-            double x = (X[(size_t)t * N + i] - m) * inv;
-            if (a.missing_prob > 0.0 && uniform1(key, kStrMiss, (uint64_t)t * N + i) < a.missing_prob)
-                x = __longlong_as_double(0x7FF8000000000000ll);
-            X[(size_t)t * N + i] = x;
-        }
-        for (int k = 0; k < r; ++k) Lam[(size_t)i * r + k] *= inv;
-        Rv[i] *= inv * inv;
-    }
     // transition parameters of the DGP
     for (int idx = tid; idx < r * r; idx += kSynThreads) {
         const int i = idx / r, j = idx % r;
@@ -118,8 +91,115 @@ __global__ __launch_bounds__(kSynThreads) void synth_kernel(SynthArgs a) {
     for (int i = tid; i < r; i += kSynThreads) a.mu0[(size_t)b * r + i] = 0.0;
 }
 
+// x_ti = lam_i' f_t + sqrt(R_i) eps_ti for the tile's periods and the thread's two columns (two cells per counter: cell c and
+// c + 1 share counter c / 2 when c is even)
+__global__ __launch_bounds__(kSynThreads) void synth_cells_kernel(SynthArgs a, int ntile) {
+    __shared__ double Fs[kSynTile * 32];
+    const int b = blockIdx.z, tile = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int N = a.N, T = a.T, r = a.r;
+    const uint64_t key = a.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(a.first_replicate + b + 1));
+    const int t0 = tile * kSynTile, t1 = t0 + kSynTile < T ? t0 + kSynTile : T;
+    const double* F = a.fscratch + (size_t)b * (T + 1) * r;
+    for (int e = tid; e < (t1 - t0) * r; e += kSynThreads) Fs[e] = F[(size_t)t0 * r + e];
+    __syncthreads();
+    const int i0 = 2 * ((int)blockIdx.x * kSynThreads + tid);
+    if (i0 >= N) return;
+    const bool two = i0 + 1 < N;
+    const double* Lam = a.Lam + (size_t)b * N * r;
+    double l0[32], l1[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        l0[k] = k < r ? Lam[(size_t)i0 * r + k] : 0.0;
+        l1[k] = (k < r && two) ? Lam[(size_t)(i0 + 1) * r + k] : 0.0;
+    }
+    const double s0 = sqrt(a.R[(size_t)b * N + i0]), s1 = two ? sqrt(a.R[(size_t)b * N + i0 + 1]) : 0.0;
+    double* X = a.panel + (size_t)b * T * N;
+    double sum0 = 0.0, sq0 = 0.0, sum1 = 0.0, sq1 = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const size_t c = (size_t)t * N + i0;
+        double za, zb, e0, e1;
+        normal2(key, kStrEps, c >> 1, za, zb);
+        if ((c & 1) == 0) { e0 = za; e1 = zb; }
+        else {                                                // (odd N, odd row: the pair straddles two counters)
+            e0 = zb;
+            double zc, zd;
+            normal2(key, kStrEps, (c + 1) >> 1, zc, zd);
+            e1 = zc;
+        }
+        const double* f = Fs + (t - t0) * r;
+        double x0 = 0.0, x1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if (k < r) { const double fk = f[k]; x0 = fma(l0[k], fk, x0); x1 = fma(l1[k], fk, x1); }
+        }
+        x0 += s0 * e0; x1 += s1 * e1;
+        X[c] = x0;
+        if (two) X[c + 1] = x1;
+        sum0 += x0; sq0 = fma(x0, x0, sq0);
+        sum1 += x1; sq1 = fma(x1, x1, sq1);
+    }
+    double* cs = a.colstats + ((size_t)b * ntile + tile) * 2 * N;
+    cs[i0] = sum0; cs[N + i0] = sq0;
+    if (two) { cs[i0 + 1] = sum1; cs[N + i0 + 1] = sq1; }
+}
+
+// standardise the tile's rows of the thread's two columns (mean, population s.d.), punch the missing cells; tile 0 also rescales
+// the parameters to the standardised panel
+__global__ __launch_bounds__(kSynThreads) void synth_standardize_kernel(SynthArgs a, int ntile) {
+    const int b = blockIdx.z, tile = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int N = a.N, T = a.T, r = a.r;
+    const int i0 = 2 * ((int)blockIdx.x * kSynThreads + tid);
+    if (i0 >= N) return;
+    const bool two = i0 + 1 < N;
+    const uint64_t key = a.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(a.first_replicate + b + 1));
+    const double* cs = a.colstats + (size_t)b * ntile * 2 * N;
+    double sum0 = 0.0, sq0 = 0.0, sum1 = 0.0, sq1 = 0.0;
+    for (int q = 0; q < ntile; ++q) {
+        const double* c = cs + (size_t)q * 2 * N;
+        sum0 += c[i0]; sq0 += c[N + i0];
+        if (two) { sum1 += c[i0 + 1]; sq1 += c[N + i0 + 1]; }
+    }
+    const double m0 = sum0 / (double)T, m1 = sum1 / (double)T;
+    const double inv0 = 1.0 / sqrt(sq0 / (double)T - m0 * m0);
+    const double inv1 = two ? 1.0 / sqrt(sq1 / (double)T - m1 * m1) : 0.0;
+    double* X = a.panel + (size_t)b * T * N;
+    const int t0 = tile * kSynTile, t1 = t0 + kSynTile < T ? t0 + kSynTile : T;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    for (int t = t0; t < t1; ++t) {
+        const size_t c = (size_t)t * N + i0;
+        double x0 = (X[c] - m0) * inv0;
+        if (a.missing_prob > 0.0 && uniform1(key, kStrMiss, c) < a.missing_prob) x0 = qnan;
+        X[c] = x0;
+        if (two) {
+            double x1 = (X[c + 1] - m1) * inv1;
+            if (a.missing_prob > 0.0 && uniform1(key, kStrMiss, c + 1) < a.missing_prob) x1 = qnan;
+            X[c + 1] = x1;
+        }
+    }
+    if (tile == 0) {
+        double* Lam = a.Lam + (size_t)b * N * r;
+        double* Rv = a.R + (size_t)b * N;
+        for (int k = 0; k < r; ++k) {
+            Lam[(size_t)i0 * r + k] *= inv0;
+            if (two) Lam[(size_t)(i0 + 1) * r + k] *= inv1;
+        }
+        Rv[i0] *= inv0 * inv0;
+        if (two) Rv[i0 + 1] *= inv1 * inv1;
+    }
+}
+
+int synth_tiles(int T) { return (T + kSynTile - 1) / kSynTile; }
+
 hipError_t launch_synth(const SynthArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(synth_kernel, dim3(a.B), dim3(kSynThreads), 0, s, a);
+    note_kernel("synth_cells_kernel");
+    const int ntile = synth_tiles(a.T);
+    const int npair = (a.N + 1) / 2;
+    hipLaunchKernelGGL(synth_params_kernel, dim3(a.B), dim3(kSynThreads), 0, s, a);
+    const dim3 grid((npair + kSynThreads - 1) / kSynThreads, ntile, a.B);
+    hipLaunchKernelGGL(synth_cells_kernel, grid, dim3(kSynThreads), 0, s, a, ntile);
+    hipLaunchKernelGGL(synth_standardize_kernel, grid, dim3(kSynThreads), 0, s, a, ntile);
     return hipGetLastError();
 }
 

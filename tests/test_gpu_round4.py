@@ -241,3 +241,20 @@ def test_very_wide_cross_section_with_missing_cells(ctx, N):
     f, P, ll = ctx.ks_pass_batch(t(panel), *[t(st[k]) for k in KEYS], may_have_missing=True)
     torch.cuda.synchronize()
     _compare((f.cpu().numpy(), P.cpu().numpy(), ll.cpu().numpy()), _oracle(panel, st), f"N = {N}, r = {r}, missing cells")
+
+
+@pytest.mark.parametrize("T,r,N,miss", [(1, 20, 40, 0.2), (2, 17, 300, 0.1), (5, 31, 64, 0.3), (3, 24, 258, 0.0)])
+def test_tile_recursion_edges(ctx, T, r, N, miss):
+    """recursion_tile_kernel at the edges of its loops: one and two periods (its operand sets alternate by the parity of the
+    period and are re-loaded two periods ahead), the widest state it takes (r = 31: column 31 is the only padding), a panel declared
+    with missing cells that has none (every row takes Cfull)."""
+    import torch
+    B = 3
+    reps = [ko.synth_replicate(b, N, max(T, 6), r, seed=1234 + T, missing=miss) for b in range(B)]   # (a one-period panel cannot be standardised: cut a longer one)
+    panel = np.ascontiguousarray(np.stack([x for x, _ in reps])[:, :T])
+    st = {k: np.stack([p[k] for _, p in reps]) for k in KEYS}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_batch(t(panel), *[t(st[k]) for k in KEYS], may_have_missing=True)
+    torch.cuda.synchronize()
+    _compare((f.cpu().numpy(), P.cpu().numpy(), ll.cpu().numpy()), _oracle(panel, st), f"T = {T}, r = {r}")
