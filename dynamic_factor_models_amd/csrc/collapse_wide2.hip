@@ -29,6 +29,11 @@
 #include "dfm_gram.h"
 #include "dfm_kernels.h"
 
+// cache-policy modifiers of the streaming LDS-DMA loads (development A/B: -DDFM_DMA_MOD='" nt"', '" sc1"', ...); default: none
+#ifndef DFM_DMA_MOD
+#define DFM_DMA_MOD ""
+#endif
+
 namespace dfm {
 
 namespace {
@@ -45,7 +50,7 @@ __device__ __forceinline__ void dma16w(const void* gsrc, unsigned lds_dst) {
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %1, off" DFM_DMA_MOD "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_dst)

@@ -28,6 +28,15 @@ inline const char* diag_env(const char* name) { return getenv(name); }
 inline const char* diag_env(const char*) { return nullptr; }
 #endif
 
+// Non-temporal hint on a kernel's ONE-PASS panel stream (pass_fused.hip dma16f, mstep_mfma.hip): on for batches whose panels are
+// <= 2 GiB, where part of the pass's working set survives in the 256-MB Infinity Cache between launches (measured gains up to
+// B = 4096 at the C2 shape, a loss at 8192).  DFM_DMA_NT=0 | 1 (route switch: same results either way) overrides.
+inline bool stream_nt_hint(size_t panel_bytes) {
+    static const int force = [] { const char* v = route_env("DFM_DMA_NT"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
+    if (force >= 0) return force != 0;
+    return panel_bytes <= ((size_t)2 << 30);
+}
+
 inline void note_kernel(const char* name) { t_launched_kernel = name; }
 
 

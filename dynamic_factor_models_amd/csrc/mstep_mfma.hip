@@ -22,17 +22,29 @@
 namespace dfm {
 
 using lds_char_ptr_ms = __attribute__((address_space(3))) char*;
-__device__ __forceinline__ void dma16s(const void* gsrc, unsigned lds_dst) {
+__device__ __forceinline__ void dma16s(const void* gsrc, unsigned lds_dst, bool nt) {   // nt: see pass_fused.hip dma16f
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
+    if (nt) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    }
 }
 template <int K>
 __device__ __forceinline__ void wait_vms() {
@@ -54,7 +66,7 @@ __host__ __device__ inline unsigned ms_slot_bytes(int N) {   // as collapse_mfma
 
 template <int R, int STEPS, int NDR>
 __global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigned SB, int wpr, double* part_sxf, double* part_sxx, EmUpdArgs ua,
-                                                            int nfront_) {
+                                                            int nfront_, int dma_nt) {
     using G = MsGeo<R>;
     constexpr int NB = 2, NS = 4 * NB, CS = G::CS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigne
         const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)slot * SB);
 #pragma unroll
         for (int p = 0; p < NDR; ++p)
-            if (pact[p]) dma16s(src + 1024 * p, dst + 1024u * p);
+            if (pact[p]) dma16s(src + 1024 * p, dst + 1024u * p, dma_nt != 0);
     };
     // the factors of row block j (periods 4j .. 4j+3, R doubles each, contiguous) ride the same DMA stream into the
     // block's slot of the factor ring -- every load of the steady state is an LDS-DMA, so one counted vmcnt orders them
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigne
     auto issue_f = [&](int j, int bslot_) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + NS * SB + (unsigned)bslot_ * FB);
         const int row = 4 * j + (int)(lane16 / (8u * R));
-        if (lane16 < FB && row < nrows) dma16s(fbytes + (size_t)j * FB + lane16, dst);
+        if (lane16 < FB && row < nrows) dma16s(fbytes + (size_t)j * FB + lane16, dst, false);   // (the factors were just written: they are wanted in cache)
     };
     int issued = 0;
     if (nrows > 0) {
@@ -303,7 +315,7 @@ static hipError_t launch_ms_one(const MstepArgs& a, int wpr, double* pf, double*
     memset(&u0, 0, sizeof(u0));
     const int nfront = ua ? (a.B + 3) / 4 : 0;                // transition M-step waves in front of the streaming workgroups
     hipLaunchKernelGGL((mstep_mfma_kernel<R, STEPS, NDR>), dim3((a.B * wpr + 3) / 4 + nfront), dim3(256), lds, s, a, SB, wpr, pf, px, ua ? *ua : u0,
-                       (ua && ua->k == 0) ? -nfront : nfront);
+                       (ua && ua->k == 0) ? -nfront : nfront, stream_nt_hint((size_t)a.B * a.T * a.N * sizeof(double)) ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((mstep_finish_kernel<R>), dim3(a.B), dim3(256), 0, s, a, wpr, (const double*)pf, (const double*)px);

@@ -33,23 +33,46 @@
 #include "dfm_kernels.h"
 #include "dfm_scan.h"
 
+// cache-policy modifiers of the streaming LDS-DMA loads (development A/B: -DDFM_DMA_MOD='" nt"', '" sc1"', ...); default: none
+#ifndef DFM_DMA_MOD
+#define DFM_DMA_MOD ""
+#endif
+
 namespace dfm {
 
 namespace {
 
 using lds_char_ptr_f = __attribute__((address_space(3))) char*;
 
-__device__ __forceinline__ void dma16f(const void* gsrc, unsigned lds_dst) {
+// nt: the non-temporal hint on the panel stream.  The panel is read ONCE per pass; with the hint its lines do not displace the
+// rest of the pass's working set from the 256-MB Infinity Cache -- the outputs (P_smooth, f_smooth: 180 MB per 1024 replicates),
+// which the next pass or the M-step behind this one overwrites or reads again, and the covariance tables.  Measured in one
+// process (profiles/r04/ab_dma_nt_*.txt): +12 % at B = 512, +13..15 % at 1024, +8 % at 1536, +6 % at 2048, +1 % at 4096, -2 % at
+// 8192 (nothing of a 6.6-GB batch stays on chip, and the hint costs the L2 its write-combining of neighbouring rows): the
+// launcher sets it for batches whose panels are <= 2 GiB.
+__device__ __forceinline__ void dma16f(const void* gsrc, unsigned lds_dst, bool nt) {
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
+    if (nt) {                                                  // (wave-uniform)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off" DFM_DMA_MOD "\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(gsrc), "s"(lds_dst)
+            : "memory");
+    }
 }
 template <int K>
 __device__ __forceinline__ void wait_vmf() {
@@ -185,6 +208,7 @@ struct PfLds {
     unsigned ring;    // nsw x 8 slots x SB bytes
     unsigned total;
     int nsw, ncov, nbuf;
+    int nt;           // non-temporal hint on the panel stream (dma16f)
 };
 
 #if defined(DFM_DIAG) || defined(DFM_PF_FALLBACK_LDS)   // the round-2 scan: A/B against scan_reg in the diagnostics build only (DFM_SCAN_ABL bit 9); production: scan_reg, scan_seq
@@ -717,6 +741,7 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
     const int lane = tid_wg & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid_wg >> 6);
     const int nsw = ly.nsw, ncov = ly.ncov, nbuf = ly.nbuf;
+    const bool dma_nt = ly.nt != 0;
     unsigned* flags = reinterpret_cast<unsigned*>(smem + ly.flags);
     double* misc = reinterpret_cast<double*>(smem + ly.misc);
     double* bt0 = reinterpret_cast<double*>(smem + ly.bt);
@@ -800,7 +825,7 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
                 const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)(bslot * 4 + rr) * SB);
 #pragma unroll
                 for (int p = 0; p < NDR; ++p) {
-                    if (pact[p]) dma16f(src + 1024 * p, dst + 1024u * p);
+                    if (pact[p]) dma16f(src + 1024 * p, dst + 1024u * p, dma_nt);
                 }
             }
         };
@@ -1165,7 +1190,7 @@ static PfLds pf_layout(int T, int N, int nsw, int ncov, int nbuf) {
     l.bt = take(l.bt_stride * 8 * (unsigned)nbuf);
     l.ring = take((unsigned)nsw * 8u * pf_slot_bytes(N));
     l.total = off;
-    l.nsw = nsw; l.ncov = ncov; l.nbuf = nbuf;
+    l.nsw = nsw; l.ncov = ncov; l.nbuf = nbuf; l.nt = 0;
     return l;
 }
 
@@ -1207,8 +1232,9 @@ bool pass_fused_supported(int Rpad, int T, int N) {
 
 template <int STEPS, int NDR>
 static hipError_t launch_pf_one(const CollapseArgs& a, const FastArgs& fa, int nsw, int ncov, int num_cu, hipStream_t s) {
-    const PfLds ly = pf_pick(a.T, a.N, nsw, ncov);
+    PfLds ly = pf_pick(a.T, a.N, nsw, ncov);
     if (ly.total > kPfLdsLimit) return hipErrorInvalidValue;
+    ly.nt = stream_nt_hint((size_t)a.B * a.T * a.N * sizeof(double)) ? 1 : 0;
     static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pass_fused_kernel<STEPS, NDR>),
