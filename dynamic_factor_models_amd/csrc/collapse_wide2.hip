@@ -56,6 +56,23 @@ __device__ __forceinline__ void dma16w(const void* gsrc, unsigned lds_dst) {
         : "v"(gsrc), "s"(lds_dst)
         : "memory");
 }
+// the PANEL rows of collapse_wide2_kernel (development A/B: -DDFM_W2_PANEL_MOD='" nt"' puts a modifier on them alone -- the W / R
+// tables of a replicate are re-read from L2 by every CU of its XCD and must stay cacheable)
+#ifndef DFM_W2_PANEL_MOD
+#define DFM_W2_PANEL_MOD DFM_DMA_MOD
+#endif
+__device__ __forceinline__ void dma16wp(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off" DFM_W2_PANEL_MOD "\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
 __device__ __forceinline__ void wait_all_w() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 constexpr int kW2R = 32;          // padded factors (widest; the kernels are templates in R = 16 | 32, the stage layout is R = 32's)
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
                 t = t < T ? t : T - 1;
                 const char* src = Xb + (size_t)t * rowB + colB;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + (unsigned)(pw * 8 + k) * kW2GroupB);
-                if (act) dma16w(src, dst);
+                if (act) dma16wp(src, dst);
             }
 #pragma unroll
             for (int u = 0; u < GEO::WPieces; ++u) {   // past the end of W -- the last, partial stage -- the lanes re-read its last 16 bytes; those rows only ever meet a zeroed A

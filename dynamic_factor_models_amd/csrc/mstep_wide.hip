@@ -47,6 +47,23 @@ __device__ __forceinline__ void dma16mw(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
+// the PANEL rows (development A/B: -DDFM_MW_PANEL_MOD='" nt"'); the factor rows are re-read by the 8 series blocks of a replicate
+#ifndef DFM_MW_PANEL_MOD
+#define DFM_MW_PANEL_MOD ""
+#endif
+__device__ __forceinline__ void dma16mwp(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off" DFM_MW_PANEL_MOD "\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
 constexpr int kMwR = 32;
 constexpr int kMwSer = 128;                              // series per item: 8 consumer waves x 16
 constexpr int kMwPer = 32;                               // periods per stage
@@ -138,7 +155,7 @@ __global__ __launch_bounds__(kMwThreads) void mstep_wide_kernel(MstepArgs a, dou
                 t = t < T ? t : T - 1;
                 const char* src = Xb + ((size_t)t * N + ser) * 8;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + (unsigned)row * kMwRowB);
-                if (act) dma16mw(src, dst);
+                if (act) dma16mwp(src, dst);
             }
 #pragma unroll
             for (int u = 0; u < GEO::FPieces; ++u) {
