@@ -403,6 +403,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     FastArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.B = B; fa.T = T; fa.N = N; fa.r = out_r; fa.L = fast_chunk_len(p.Rp, T);
+    fa.rstate = p.r;
     fa.A = pp.A; fa.Q = pp.Q; fa.mu0 = pp.mu0; fa.P0 = pp.P0;
     fa.Cfull = ca.Cfull; fa.ldfull = ca.ldfull;
     fa.tab = at<double>(h, p.f_tab); fa.E = at<int>(h, p.f_E); fa.stead = at<double>(h, p.f_stead);
@@ -575,6 +576,9 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         // Rp = 32 (config 4): the fill is 0.86 GB of stores -- beside the collapse they cost it 0.4 ms of its 1.13; beside the
         // latency-bound scan they are free.  So: cov -> [event] ; collapse (side) -> [event] ; fill on the third stream
         // after both, scan on the caller's stream after the collapse, join at the end.
+        // DFM_PFILL_TRICKLE=n (route; experiment): the fill from n persistent workgroups, started behind the covariance kernel --
+        // a trickle of stores under the whole collapse, not a burst beside the scan
+        static const int trickle = [] { const char* v = route_env("DFM_PFILL_TRICKLE"); return v ? atoi(v) : 0; }();
         const bool fill_late = fill && use_wide2;
         if (fill && !fill_late) {         // the data-independent rows of P_smooth, beside the collapse
             ProfScope ps(h, K_PFILL);
@@ -589,8 +593,8 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
             }
             HIP_TRY(h, hipEventRecord(h->ev_sub[0], h->stream));            // cov_kernel's outputs
             HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_sub[0], 0));
-            HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));        // ... and not before the collapse is done
-            { ProfScope ps(h, K_PFILL, h->post); HIP_TRY(h, launch_pfill(p.Rp, fa, h->post)); }
+            if (trickle <= 0) HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));        // ... and not before the collapse is done
+            { ProfScope ps(h, K_PFILL, h->post); HIP_TRY(h, launch_pfill(p.Rp, fa, h->post, trickle)); }
             HIP_TRY(h, hipEventRecord(h->ev_post, h->post));
             fa.abl |= 1;
         }

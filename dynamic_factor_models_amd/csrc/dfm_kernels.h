@@ -247,6 +247,7 @@ struct FastArgs {
     double* f0s;                // [B][Rp] E[f_0 | X] (EM) or null
     int b0;                     // meanscan: first replicate of this launch (sub-batch pipelining)
     int abl;                    // diagnostics (DFM_SCAN_ABL): bit0 skip the P_smooth fill, bit1 skip the scans
+    int rstate;                 // the model's state width (<= Rp; 0 = unknown: Rp) -- cov_tile_kernel executes ceil(rstate / 4) block pivots
 };
 struct EmUpdArgs {               // transition M-step + EM bookkeeping after a fast-path E-step (all padded, Rp)
     int B, T;
@@ -265,7 +266,7 @@ hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
 bool cov_fuses_gram(int Rpad, int N);   // launch_cov with a.Lam != nullptr is supported for this shape
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);
 hipError_t launch_meanscan_mfma(int Rpad, const FastArgs& a, hipStream_t s);   // Rp = 16, 32: the steady scans on the matrix pipe (scan_mfma32.hip)
-hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s);   // the P_smooth fill of meanscan (then run it with abl bit 0)
+hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s, int trickle_wgs = 0);   // the P_smooth fill of meanscan (then run it with abl bit 0)
 // The whole balanced pass in one launch (pass_fused.hip: persistent workgroups, stream / covariance / scan waves) and the
 // one-wave-per-replicate covariance recursion as a drop-in for launch_cov (Rp = 8, Cfull / ldfull from gram_kernel).
 bool pass_fused_supported(int Rpad, int T, int N);
@@ -276,6 +277,9 @@ hipError_t launch_cov_wave(const FastArgs& a, hipStream_t s);
 // the element-per-thread covariance recursion for Rp = 16 / 32 (a workgroup of Rp x Rp threads per replicate; Cfull / ldfull
 // from the Gram kernel): what launch_cov runs for those widths unless DFM_COV_ROWS=1
 bool cov_grid_supported(int Rpad);
+// Rp = 32: the same recursion with four waves per replicate on the matrix pipe (recursion_tile.hip); rstate = the model's state width
+bool cov_tile_supported(int Rpad, const FastArgs& a, int rstate);
+hipError_t launch_cov_tile(const FastArgs& a, int rstate, hipStream_t s);
 hipError_t launch_cov_grid(int Rpad, const FastArgs& a, hipStream_t s);
 int fast_chunk_len(int Rpad, int T);
 int fast_stead_mats(int Rpad);

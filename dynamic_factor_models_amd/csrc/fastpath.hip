@@ -72,6 +72,30 @@ __global__ __launch_bounds__(256) void pfill_kernel(FastArgs a) {
     fill_psmooth_range(a, b, tid, 256, s_ps, lo + (int)(span * sl / ns), lo + (int)(span * (sl + 1) / ns));
 }
 
+// The same rows from a FEW persistent workgroups (gridDim.x of them take the (replicate, slice) items in turn): a trickle of
+// stores beside the streaming collapse of the wide path instead of a burst beside the mean scan behind it -- see
+// enqueue_pass_fast in capi.hip.
+template <int R>
+__global__ __launch_bounds__(256) void pfill_trickle_kernel(FastArgs a, int ns) {
+    __shared__ double s_ps[R * (R + 1) / 2];
+    const int tid = threadIdx.x;
+    const int npr = a.r * (a.r + 1) / 2;
+    for (int item = blockIdx.x; item < a.B * ns; item += gridDim.x) {
+        // slice-major: the first replicates' rows are not all written first (every replicate's scan may start early)
+        const int b = item % a.B, sl = item / a.B;
+        __syncthreads();
+        for (int v = tid; v < npr; v += 256) {
+            int ri = 0;
+            while ((ri + 1) * (ri + 2) / 2 <= v) ++ri;
+            s_ps[v] = a.PsInf[(size_t)b * R * R + ri * R + (v - ri * (ri + 1) / 2)];
+        }
+        __syncthreads();
+        const int lo = a.fill[2 * b], hi = a.fill[2 * b + 1];
+        const long long span = hi > lo ? hi - lo : 0;
+        fill_psmooth_range(a, b, tid, 256, s_ps, lo + (int)(span * sl / ns), lo + (int)(span * (sl + 1) / ns));
+    }
+}
+
 template <int R>
 struct ScanLds {   // dynamic LDS of meanscan_kernel, in doubles
     static constexpr int ST = scan_threads(R);
@@ -497,6 +521,7 @@ int fast_chunk_len(int Rpad, int T) {
 
 hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s) {
     static const bool rows_only = [] { const char* v = diag_env("DFM_COV_ROWS"); return v && atoi(v) != 0; }();
+    if (!rows_only && cov_tile_supported(Rpad, a, a.rstate > 0 ? a.rstate : Rpad)) return launch_cov_tile(a, a.rstate > 0 ? a.rstate : Rpad, s);
     if (!rows_only && a.Lam == nullptr && cov_grid_supported(Rpad)) return launch_cov_grid(Rpad, a, s);
     switch (Rpad) {
         case 2: return launch_cov_r<2>(a, s);
@@ -507,13 +532,17 @@ hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 }
-hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s) {
+hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s, int trickle_wgs) {
     if (!a.P_smooth) return hipSuccess;
     // slices per replicate: enough workgroups to fill the chip, each with at least ~64 KB of rows
     const long long bytes = (long long)a.T * (a.r * (a.r + 1) / 2) * 8;
     int ns = (int)((2048 + a.B - 1) / a.B);
     while (ns > 1 && bytes / ns < 65536) --ns;
     if (ns < 1) ns = 1;
+    if (trickle_wgs > 0 && Rpad == 32) {
+        hipLaunchKernelGGL((pfill_trickle_kernel<32>), dim3(trickle_wgs), dim3(256), 0, s, a, ns);
+        return hipGetLastError();
+    }
     const dim3 grid(a.B, ns);
     switch (Rpad) {
         case 2: hipLaunchKernelGGL((pfill_kernel<2>), grid, dim3(256), 0, s, a); break;

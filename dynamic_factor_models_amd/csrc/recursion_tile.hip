@@ -26,6 +26,8 @@
 // The reference has no counterpart (dfm_functions.ipynb:21-23 declares `Parametric` only).
 #include <stdlib.h>
 
+#include "dfm_cov.h"
+#include "dfm_gram.h"
 #include "dfm_grid.h"
 #include "dfm_kernels.h"
 #include "dfm_smallmat.h"
@@ -567,6 +569,272 @@ __global__ __launch_bounds__(1024, 1) void tile_mstep_kernel(RecursionArgs a) {
         a.P0_out[o] = P0n;
         if (j == 0) a.mu0_out[(size_t)b * R + i] = a.f0s[(size_t)b * R + i];
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// cov_tile_kernel: the data-independent covariance half of the BALANCED fast path at Rp = 32 (dfm_cov8.h cov_grid: the forward
+// steps to the fixed point, terminal, backward steps, carry powers -- same tables, same bookkeeping) in the tile layout: four
+// waves per replicate instead of the 1024 threads of cov_grid_kernel<32>.  That kernel (128 VGPRs x 16 waves) fills a CU, so
+// the streaming collapse of the pass cannot start beside it: its 0.19 ms at BASELINE config 4 are serial time in front of the
+// 0.89 ms of the collapse, ~50 dependent 32 x 32 operations each behind 16-wave barriers.  Here a product is <= 8 MFMAs per
+// wave behind a 4-wave barrier and an inverse executes ceil(r / 4) block pivots.
+//   forward   Z = (Om_f + Phi)^-1,  J = Z K',  G = K Z (= J'),  Om_f <- Qi - K J + C       (K' = A'Qi, Phi = K'A)
+//   backward  U = P_s J' = P'G,  P_s <- Z + J U = Z + G'U
+//   powers    (G^2, J^2) <- (J'G, G'J): the pair stays each other's transpose, every product has the form Y'X
+// Matrices leave in the row-major [32][32] layout of the tables (4 rows x 128 bytes per store instruction).
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+// AND over the workgroup's 256 threads (one barrier; flag slots alternate so that the next call cannot overtake this one's reads)
+__device__ __forceinline__ bool rt_all(RtCtx& x, bool pred, int& par) {
+    const bool wv = __all(pred ? 1 : 0) != 0;
+    double* fl = x.sm + kRtRed + 8 * (par & 1);
+    par ^= 1;
+    if (x.lane == 0) fl[x.w] = wv ? 1.0 : 0.0;
+    rt_barrier();
+    return fl[0] != 0.0 && fl[1] != 0.0 && fl[2] != 0.0 && fl[3] != 0.0;
+}
+// element (i, j) of a matrix st_tile() left in an LDS tile buffer
+__device__ __forceinline__ double tl_elem(const double* buf, int i, int j) {
+    const int ri = i & 15, v = ri >> 2, qq = ri & 3;
+    return buf[(2 * (i >> 4) + (j >> 4)) * kRtTile + (v >> 1) * 128 + (qq * 16 + (j & 15)) * 2 + (v & 1)];
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 1) void cov_tile_kernel(FastArgs a, int rstate) {
+    constexpr int R = kRt, RR = R * R, NLEV = scan_levels(R), KEEP = 4;
+    __shared__ __attribute__((aligned(16))) double sm[kRtLds];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    RtCtx x;
+    x.sm = sm; x.lane = lane; x.w = w; x.I = w >> 1; x.J = w & 1; x.q = lane >> 4; x.c = lane & 15; x.pp = 0;
+    const int I = x.I, J = x.J, q = x.q, c = x.c;
+    const int b = blockIdx.x;
+    const int T = a.T, r = a.r;
+    const int npiv = (rstate + 3) >> 2, nks = npiv;
+    const int col = 16 * J + c;
+    int rowv[4], rm[4];                                        // rows of the lane's elements; their row-major offsets
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { rowv[v] = 16 * I + q + 4 * v; rm[v] = rowv[v] * R + col; }
+    double* bufA = sm + kRtBufA;
+    double* bufB = sm + kRtBufB;
+    double* Xk = sm + kRtXk;
+    const int tY0 = I, tY1 = 2 + I, tX0 = J, tX1 = 2 + J;
+    auto put_rm = [&](double* dst, const v4d& m) {             // TL -> row-major [32][32]
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dst[rm[v]] = m[v];
+    };
+    int apar = 0;
+
+    // ---------------- prologue: Qi = Q^-1, Om_f,0 = P0^-1, K' = A'Qi, Phi = K'A, xi_0 = P0^-1 mu0 ------------------------------
+    v4d Qi, Omf, Ael, Cel, zero4;
+    {
+        const double* Cf = a.Cfull + (size_t)b * RR;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const size_t o = (size_t)b * RR + rm[v];
+            Qi[v] = a.Q[o]; Omf[v] = a.P0[o]; Ael[v] = a.A[o];
+            Cel[v] = 0.5 * (Cf[rm[v]] + Cf[col * R + rowv[v]]);  // exactly symmetric (the matrix-pipe Gram is symmetric to rounding)
+            zero4[v] = 0.0;
+        }
+    }
+    const double mu0t = tid < R ? a.mu0[(size_t)b * R + tid] : 0.0;
+    const double detQ = rt_sweep_inverse(x, Qi, npiv);
+    const double detP0 = rt_sweep_inverse(x, Omf, npiv);
+    st_tile(bufA, w, lane, Ael);
+    st_tile(bufB, w, lane, Qi);
+    if (tid < R) sm[kRtRed + 16 + tid] = mu0t;
+    rt_barrier();
+    v4d KtY0, KtY1, Phi;
+    {
+        const v4d A0i = ld_tile(bufA, tY0, lane), A1i = ld_tile(bufA, tY1, lane);
+        const v4d A0j = ld_tile(bufA, tX0, lane), A1j = ld_tile(bufA, tX1, lane);
+        const v4d Q0i = ld_tile(bufB, tY0, lane), Q1i = ld_tile(bufB, tY1, lane);
+        const v4d Q0j = ld_tile(bufB, tX0, lane), Q1j = ld_tile(bufB, tX1, lane);
+        const v4d Kt = mm_tn(A0i, A1i, Q0j, Q1j, nks, zero4);                       // K' = A'Qi
+        const v4d Km = mm_tn(Q0i, Q1i, A0j, A1j, nks, zero4);                       // K  = Qi A
+        st_tile(Xk, w, lane, Kt);
+        rt_barrier();
+        st_tile(bufB, w, lane, Km);
+        rt_barrier();
+        const v4d K0i = ld_tile(bufB, tY0, lane), K1i = ld_tile(bufB, tY1, lane);
+        Phi = mm_tn(K0i, K1i, A0j, A1j, nks, zero4);                                // Phi = K'A
+        KtY0 = ld_tile(Xk, tY0, lane); KtY1 = ld_tile(Xk, tY1, lane);               // K' as Y: constant
+        st_tile(bufA, w, lane, Omf);
+        rt_barrier();
+    }
+    double q0 = 0.0;
+    if (w == 0) {                                              // xi_0 = Om_f,0 mu0 and mu0'xi_0: one row per lane (lanes 32.. idle)
+        double xr = 0.0;
+        if (lane < R) {
+            for (int j = 0; j < R; ++j) xr = fma(tl_elem(bufA, lane, j), sm[kRtRed + 16 + j], xr);
+            a.xi0[(size_t)b * R + lane] = xr;
+        }
+        q0 = wave_allsum(lane < R ? xr * mu0t : 0.0);
+    }
+
+    // ---------------- forward covariance steps until the fixed point ---------------------------------------------------------
+    LogProd detprod;
+    double detM_last = 1.0;
+    int E = 0;
+    v4d Zk[KEEP], Gk[KEEP];                                    // own tiles of Z_e and of J_e' = G_e of the first steps (backward sweep)
+#pragma unroll
+    for (int u = 0; u < KEEP; ++u) { Zk[u] = zero4; Gk[u] = zero4; }
+    v4d Zlast = zero4, Jlast = zero4, Glast = zero4;
+    double* tabb = a.tab + (size_t)b * T * 3 * RR;
+    for (int e = 0;; ++e) {
+        v4d Z;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Z[v] = Omf[v] + Phi[v];
+        const double detM = rt_sweep_inverse(x, Z, npiv);       // (its barriers: every wave is done with bufA / bufB of the last step)
+        st_tile(bufA, w, lane, Z);
+        rt_barrier();
+        const v4d ZY0 = ld_tile(bufA, tY0, lane), ZY1 = ld_tile(bufA, tY1, lane);
+        const v4d ZX0 = ld_tile(bufA, tX0, lane), ZX1 = ld_tile(bufA, tX1, lane);
+        const v4d X0 = ld_tile(Xk, tX0, lane), X1 = ld_tile(Xk, tX1, lane);
+        const v4d Jm = mm_tn(ZY0, ZY1, X0, X1, nks, zero4);    // J = Z K'
+        const v4d Gm = mm_tn(KtY0, KtY1, ZX0, ZX1, nks, zero4);   // G = K Z
+        st_tile(bufB, w, lane, Jm);
+        rt_barrier();
+        const v4d JX0 = ld_tile(bufB, tX0, lane), JX1 = ld_tile(bufB, tX1, lane);
+        const v4d KJ = mm_tn(KtY0, KtY1, JX0, JX1, nks, zero4);
+        v4d Omn;
+        bool same = true;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            Omn[v] = (Qi[v] - KJ[v]) + Cel[v];
+            same = same && close_enough(Omn[v], Omf[v]);
+        }
+        const bool gsame = rt_all(x, same, apar);
+        double* te = tabb + (size_t)e * 3 * RR;
+        put_rm(te, Z); put_rm(te + RR, Jm); put_rm(te + 2 * RR, Gm);
+#pragma unroll
+        for (int u = 0; u < KEEP; ++u)
+            if (u == e) { Zk[u] = Z; Gk[u] = Gm; }              // (uniform)
+        Zlast = Z; Jlast = Jm; Glast = Gm;
+        E = e + 1;
+        detprod.mul(detM);
+        detM_last = detM;
+        Omf = Omn;
+        if (gsame || e + 1 >= T) break;
+    }
+    const int ts = E - 1;
+
+    // ---------------- terminal ---------------------------------------------------------------------------------------------
+    v4d Ps = Omf;
+    const double detOmT = rt_sweep_inverse(x, Ps, npiv);
+    put_rm(a.PT + (size_t)b * RR, Ps);
+    if (tid == 0) {
+        const double sum_ldz = -(detprod.log_value() + (double)(T - E) * log(detM_last));
+        const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) - sum_ldz;
+        a.llc[b] = (double)a.N * (double)T * kLog2PiF + (double)T * a.ldfull[b] + LD + q0;
+        a.E[b] = E;
+    }
+
+    // ---------------- backward covariance steps ----------------------------------------------------------------------------
+    const int npr = r * (r + 1) / 2;
+    int poff[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) poff[v] = (a.P_smooth && rowv[v] < r && col <= rowv[v]) ? rowv[v] * (rowv[v] + 1) / 2 + col : -1;
+    double* Psm = a.P_smooth ? a.P_smooth + (size_t)b * T * npr : nullptr;
+    auto emit = [&](int trow, const v4d& P) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            if (poff[v] >= 0) Psm[(size_t)trow * npr + poff[v]] = P[v];
+    };
+    emit(T - 1, Ps);
+    v4d SP = Ps, SU = zero4;
+    int fill_lo = 0, fill_hi = 0;
+    int t = T - 1, cur_e = -2;
+    v4d Zc = zero4, GX0 = zero4, GX1 = zero4, GY0 = zero4, GY1 = zero4;
+    while (t >= 0) {
+        const int e = t < ts ? t : ts;
+        const bool reload = e != cur_e;                          // (uniform)
+        if (reload) {
+            v4d Gc = zero4;
+            if (e == ts) {
+                Zc = Zlast; Gc = Glast;
+            } else if (e < KEEP) {
+#pragma unroll
+                for (int u = 0; u < KEEP; ++u)
+                    if (u == e) { Zc = Zk[u]; Gc = Gk[u]; }
+            } else {
+                const double* te = tabb + (size_t)e * 3 * RR;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { Zc[v] = te[rm[v]]; Gc[v] = te[2 * RR + rm[v]]; }
+            }
+            cur_e = e;
+            st_tile(Xk, w, lane, Gc);                            // (K' is done with)
+        }
+        st_tile(bufA, w, lane, Ps);
+        rt_barrier();
+        if (reload) {
+            GX0 = ld_tile(Xk, tX0, lane); GX1 = ld_tile(Xk, tX1, lane);
+            GY0 = ld_tile(Xk, tY0, lane); GY1 = ld_tile(Xk, tY1, lane);
+        }
+        const v4d PY0 = ld_tile(bufA, tY0, lane), PY1 = ld_tile(bufA, tY1, lane);
+        const v4d U = mm_tn(PY0, PY1, GX0, GX1, nks, zero4);   // U = P_s J'
+        st_tile(bufB, w, lane, U);
+        rt_barrier();
+        const v4d UX0 = ld_tile(bufB, tX0, lane), UX1 = ld_tile(bufB, tX1, lane);
+        const v4d Psn = mm_tn(GY0, GY1, UX0, UX1, nks, Zc);    // Z + J U
+        bool same = true;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) same = same && close_enough(Psn[v], Ps[v]);
+        const bool gsame = rt_all(x, same, apar);
+        const bool skip = (e == ts && t > ts && gsame);          // steps t-1 .. ts repeat this (U, P_s)
+        const int plo = ts >= 1 ? ts : 1;                        // periods plo .. t-1 carry P_s,inf
+        const double cu = skip ? (double)(t - ts + 1) : 1.0;
+        const double cp = (t >= 1 ? 1.0 : 0.0) + (skip ? (double)(t - plo) : 0.0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { SU[v] = fma(cu, U[v], SU[v]); SP[v] = fma(cp, Psn[v], SP[v]); }
+        if (t >= 1) emit(t - 1, Psn);
+        if ((t == 0 || (skip && ts == 0)) && a.SP11) put_rm(a.P0s + (size_t)b * RR, Psn);
+        if (skip) {
+            put_rm(a.PsInf + (size_t)b * RR, Psn);
+            fill_lo = plo - 1;
+            fill_hi = t - 1;
+            t = ts - 1;
+        } else {
+            t -= 1;
+        }
+        Ps = Psn;
+    }
+    if (tid == 0) { a.fill[2 * b] = fill_lo; a.fill[2 * b + 1] = fill_hi; }
+    if (a.SP11) { put_rm(a.SP11 + (size_t)b * RR, SP); put_rm(a.SU + (size_t)b * RR, SU); }
+
+    // ---------------- steady Z, J, G and the powers G^(L 2^k), J^(L 2^k) for the chunk carries ----------------------------------
+    {
+        double* st = a.stead + (size_t)b * stead_mats(R) * RR;
+        put_rm(st, Zlast); put_rm(st + RR, Jlast); put_rm(st + 2 * RR, Glast);
+        v4d MG = Glast, MJ = Jlast;
+        auto square2 = [&]() {
+            st_tile(bufA, w, lane, MG);
+            st_tile(bufB, w, lane, MJ);
+            rt_barrier();
+            const v4d gY0 = ld_tile(bufA, tY0, lane), gY1 = ld_tile(bufA, tY1, lane), gX0 = ld_tile(bufA, tX0, lane), gX1 = ld_tile(bufA, tX1, lane);
+            const v4d jY0 = ld_tile(bufB, tY0, lane), jY1 = ld_tile(bufB, tY1, lane), jX0 = ld_tile(bufB, tX0, lane), jX1 = ld_tile(bufB, tX1, lane);
+            MG = mm_tn(jY0, jY1, gX0, gX1, nks, zero4);        // J'G = G G
+            MJ = mm_tn(gY0, gY1, jX0, jX1, nks, zero4);        // G'J = J J
+            rt_barrier();                                      // (the buffers are free again)
+        };
+        for (int l = 1; l < a.L; l <<= 1) square2();             // M^L
+#pragma unroll 1
+        for (int k = 0; k < NLEV; ++k) {
+            put_rm(st + (size_t)(3 + k) * RR, MG);
+            put_rm(st + (size_t)(3 + NLEV + k) * RR, MJ);
+            if (k + 1 < NLEV) square2();
+        }
+    }
+}
+
+bool cov_tile_supported(int Rpad, const FastArgs& a, int rstate) {
+    static const bool off = [] { const char* v = route_env("DFM_NO_COV_TILE"); return v && atoi(v) != 0; }();
+    return !off && Rpad == 32 && a.Lam == nullptr && rstate >= 1 && rstate <= 32 && a.T >= 1;
+}
+hipError_t launch_cov_tile(const FastArgs& a, int rstate, hipStream_t s) {
+    note_kernel("cov_tile_kernel");
+    hipLaunchKernelGGL(cov_tile_kernel, dim3(a.B), dim3(256), 0, s, a, rstate);
+    return hipGetLastError();
 }
 
 // Rp = 32, information form, the plain factor model (loadings as wide as the state), 17 <= state width <= 31 (column 31 must

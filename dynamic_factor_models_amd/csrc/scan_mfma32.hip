@@ -32,8 +32,29 @@ namespace dfm {
 
 namespace {
 
-constexpr int kS3PF = 4;                           // steps per operand prefetch block
+constexpr int kS3PF = 4;                           // operand prefetch distance (steps) of the emitting runs
+#ifndef DFM_S3_PF1
+#define DFM_S3_PF1 8
+#endif
+constexpr int kS3PF1 = DFM_S3_PF1;                 // ... of the zero-state runs (no Z operand, no emission: registers to spare)
 typedef double s3_v4 __attribute__((ext_vector_type(4)));
+// workgroup barrier for data that travels through LDS only: __syncthreads() also waits for every outstanding global access
+// (vmcnt(0)) -- here that would be the prefetched operands of later steps and the asynchronous staging
+__device__ __forceinline__ void s3_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+using s3_lds_ptr = __attribute__((address_space(3))) char*;
+// 64 lanes x 16 bytes, global -> LDS (1 KB back to back from byte address `lds_dst`), asynchronous: counted by vmcnt
+__device__ __forceinline__ void s3_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
 
 template <int R>
 struct S3Geo {
@@ -54,11 +75,14 @@ struct S3Geo {
 };
 
 // State order.  The MFMA fixes which PHYSICAL row m = K + 4 v + 16 io of the state a lane (K, j) holds in register (io, v); it
-// does not care which component of the state that row is.  Row m carries component pi(m) = (R / 4) K + 4 io + v: a lane's R / 4
-// registers are CONSECUTIVE components -- 64 (R = 32) or 32 (R = 16) contiguous bytes of b_t / w_t / f_t per lane and period
-// instead of 8-byte accesses 32 bytes apart.  Only the matrices have to follow: A[m][n] = M[pi(m)][pi(n)].
+// does not care which component of the state that row is.  Row m carries component pi(m) = 16 io + 8 (v / 2) + 2 K + v % 2: a
+// register PAIR of a lane is 16 contiguous bytes of b_t / w_t / f_t, and the four K lanes of a column read 64 contiguous bytes with
+// ONE 16-byte load each -- an instruction touches 16 rows x 64 bytes.  (Round 2 gave a lane 8 consecutive components: every 16-byte
+// load then touched 16 rows x 4 pieces 64 bytes apart, each 64-byte sector was asked for by four different instructions, and the
+// forward runs over the cold b_t sat at 3.3 us per step against 0.85 us of MFMA time.)  Only the matrices have to follow:
+// A[m][n] = M[pi(m)][pi(n)].
 template <int R>
-__device__ __forceinline__ constexpr int s3_pi(int K, int v, int io) { return (R / 4) * K + 4 * io + v; }
+__device__ __forceinline__ constexpr int s3_pi(int K, int v, int io) { return 16 * io + 8 * (v >> 1) + 2 * K + (v & 1); }
 // A operand of the 16x16x4 MFMA for matrix M (row-major, row stride `ld` doubles): lane (k4 = l / 16, c16 = l % 16) holds
 // physical element (16 io + c16, 4 s + k4) in A[io][s]
 template <int R>
@@ -110,54 +134,97 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
     const double* stead = a.stead + (size_t)b * stead_mats(R) * R * R;
     double* fout = a.f_smooth + (size_t)b * T * r;
     const int npr = r * (r + 1) / 2;
+    const bool fpair = (r & 1) == 0 && (reinterpret_cast<size_t>(fout) & 15) == 0;   // f_t rows can be stored as 16-byte pairs
     unsigned long long stamps[10];                            // DFM_SCAN_ABL & 256: phase stamps of workgroup 0 (diagnostics)
     int nstamp = 0;
     auto stamp = [&]() { if ((a.abl & 256) && blockIdx.x == 0 && tid == 0 && nstamp < 10) stamps[nstamp++] = __builtin_amdgcn_s_memrealtime(); };
     stamp();
 
-    // carry powers of one direction -> LDS (row stride kS3PS)
+    constexpr int NW = kS3Threads / 64;
+    const unsigned lds_dsm = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(s3_lds_ptr)dsm);
+    // carry powers of one direction -> LDS (row stride kS3PS), ASYNCHRONOUSLY: 1-KB LDS-DMA pieces dealt to the waves; the 16 bytes
+    // of lane l of piece i are LDS doubles 128 i + 2 l, 128 i + 2 l + 1 = columns (c, c + 1) of row (level k, r) -- c = R is the
+    // padding pair, it re-reads the row's last pair.  The carry scan waits for them (vmcnt(0) + barrier) a whole phase later; the
+    // backward powers are requested when the forward carry scan is done with the table, under the forward re-run.
     auto stage_powers = [&](int first) {
-        for (int e = tid; e < kS3Lev * R * R; e += kS3Threads) {
-            const int k = e / (R * R), rc = e % (R * R);
-            s_pow[(size_t)k * R * kS3PS + (rc / R) * kS3PS + (rc % R)] = stead[(size_t)(first + k) * R * R + rc];
+        constexpr int bytes = kS3Lev * R * kS3PS * 8;
+        constexpr int npiece = (bytes + 1023) / 1024;
+        const double* src0 = stead + (size_t)first * R * R;
+        for (int i = wave; i < npiece; i += NW) {
+            const int byte = 1024 * i + 16 * lane;
+            const int e = byte >> 3;
+            const int kr = e / kS3PS, col = e % kS3PS;
+            const int krc = kr < kS3Lev * R ? kr : kS3Lev * R - 1;
+            const double* src = src0 + (size_t)krc * R + (col < R ? col : R - 2);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dsm + (unsigned)(S3Lds::oPow * 8 + 1024 * i));
+            if (byte < bytes) s3_dma16(src, dst);
         }
     };
-    stage_powers(3);
-    if (a.P_smooth) {
+    auto powers_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };   // (then a barrier: every wave's pieces)
+    // ---- forward transient, steps 0 .. ts - 1 (time-varying Z_t, G_t: 8 KB each per step): the chain xi_(t+1) = G_t xi_t + b_t on
+    // the even waves, w_t = Z_t xi_t (off the chain) on the odd ones, step t on waves 2 t and 2 t + 1 (mod NW) -- every wave
+    // fetches the one matrix of its first step NOW, all at once, and the one of its next step as soon as it has used the last
+    // (round 2: wave 0 alone, two dependent 8-KB fetches + two products per step, 6.4 us per step).  xi_t travels through LDS,
+    // ping-pong between s_vec[0 ..) and s_vec[3 R ..) so that xi_ts ends in s_vec[0 ..).
+    double Mp[R];                                             // (forward transient only; the backward one has its own: Mb)
+    double btv = 0.0;
+    const bool isG = (wave & 1) == 0;
+    int tn = wave >> 1;                                       // the next step of this wave
+    auto xi_slot = [&](int t) { return ((ts - t) & 1) ? 3 * R : 0; };
+    auto preload_fwd = [&](int t) {
+        if (t < ts) {
+            load_xperm<R>(Mp, tab + (size_t)t * 3 * R * R + (isG ? 2 * R * R : 0), i32);
+            if (isG) btv = bcol[(size_t)t * R + i32];
+        }
+    };
+    const double xi00 = a.xi0[(size_t)b * R + i32];
+    preload_fwd(tn);
+    stage_powers(3);                                          // (behind the transient's fetches: loads return in order)
+    if (wave == 0 && cg == 0) s_vec[xi_slot(0) + i32] = xi00;
+    if (a.P_smooth && !(a.abl & 1)) {
         for (int v = tid; v < npr; v += kS3Threads) {         // packed (caller's r) copy of P_s,inf
             int ri = 0;
             while ((ri + 1) * (ri + 2) / 2 <= v) ++ri;
             s_ps[v] = a.PsInf[(size_t)b * R * R + ri * R + (v - ri * (ri + 1) / 2)];
         }
+        __syncthreads();
+        // ---- P_smooth rows inside the fixed-point range: fire-and-forget stores (unless pfill_kernel wrote them)
+        fill_psmooth_rows(a, b, tid, kS3Threads, s_ps);
     }
-    __syncthreads();
-    // ---- P_smooth rows inside the fixed-point range: fire-and-forget stores (unless pfill_kernel wrote them)
-    if (a.P_smooth && !(a.abl & 1)) fill_psmooth_rows(a, b, tid, kS3Threads, s_ps);
-    if (a.abl & 2) return;
+    if (a.abl & 2) { powers_landed(); return; }
+    s3_barrier_lds();
 
     stamp();   // 1: staging done
-    // ---- forward transient: steps 0 .. ts - 1 on wave 0 (its two lane groups redundantly) ------------------------------
     double dot = 0.0;                                         // lane part of sum_t xi_t' w_t
-    if (wave == 0) {
-        double xi = a.xi0[(size_t)b * R + i32];
-        for (int t = 0; t < ts; ++t) {
-            double Zp[R], Gp[R];
-            const double* ent = tab + (size_t)t * 3 * R * R;
-            load_xperm<R>(Zp, ent, i32);
-            load_xperm<R>(Gp, ent + 2 * R * R, i32);
-            const double bt = bcol[(size_t)t * R + i32];
-            const double w = matvec_x<R>(Zp, xi);
-            if (cg == 0) {
-                dot = fma(xi, w, dot);
-                wtab[(size_t)t * R + i32] = w;
+    for (int t = 0; t < ts; ++t) {
+        if (tn == t) {                                        // (wave-uniform)
+            const double xi = s_vec[xi_slot(t) + i32];
+            if (isG) {
+                const double xn = matvec_x<R>(Mp, xi, btv);
+                if (cg == 0) s_vec[xi_slot(t + 1) + i32] = xn;
+            } else {
+                const double w = matvec_x<R>(Mp, xi);
+                if (cg == 0) {
+                    dot = fma(xi, w, dot);
+                    wtab[(size_t)t * R + i32] = w;
+                }
             }
-            xi = matvec_x<R>(Gp, xi, bt);
+            tn += NW / 2;
+            preload_fwd(tn);
         }
-        if (cg == 0) s_vec[i32] = xi;                         // xi_ts
+        s3_barrier_lds();
     }
-    __syncthreads();
 
     stamp();   // 2: forward transient done
+    int kn = wave;                                            // backward transient: the next step of this wave
+    double Mb[R], wtv;                                        // (not initialised: nothing to keep alive across the forward scan)
+    auto preload_bwd = [&](int k) {
+        if (k < ts) {
+            const int t = ts - 1 - k;
+            load_xperm<R>(Mb, tab + (size_t)t * 3 * R * R + R * R, i32);
+            wtv = wtab[(size_t)t * R + i32];
+        }
+    };
     const int clast = (T - 1 - ts) / L;                       // chunk that holds step T - 1 (forward) / step ts (backward)
     // One chunked scan.  dir = +1: steps t = ts + ch L + j, operands b_t, emits w_t and xi' w;  dir = -1:
     // steps t = T - 1 - ch L - j, operands w_t, emits f.  head = s_vec offset of the start vector of chunk 0,
@@ -171,21 +238,22 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
         auto load_u = [&](s3_v4 (&U)[NIO], int j) {
             int t = step_t(j);
             t = t < ts ? ts : (t >= T ? T - 1 : t);           // (a row that exists; the step is skipped when invalid)
-            const double2* p = reinterpret_cast<const double2*>((FWD ? bcol : wtab) + (size_t)t * R + (R / 4) * K);
+            const double2* p = reinterpret_cast<const double2*>((FWD ? bcol : wtab) + (size_t)t * R) + K;
 #pragma unroll
-            for (int io = 0; io < NIO; ++io) {
-                const double2 x = p[2 * io], y = p[2 * io + 1];
+            for (int io = 0; io < NIO; ++io) {                // components 16 io + 2 K (+ 1) and 16 io + 8 + 2 K (+ 1)
+                const double2 x = p[8 * io], y = p[8 * io + 4];
                 U[io][0] = x.x; U[io][1] = x.y; U[io][2] = y.x; U[io][3] = y.y;
             }
         };
         auto run = [&](s3_v4 (&X)[NIO], auto emit_tag) {
             constexpr bool EMIT = decltype(emit_tag)::value;
-            s3_v4 cur[kS3PF][NIO];                              // ring of operands, kS3PF steps ahead (slot u refilled once consumed)
+            constexpr int PF = (EMIT || R < 32) ? kS3PF : kS3PF1;
+            s3_v4 cur[PF][NIO];                                 // ring of operands, PF steps ahead (slot u refilled once consumed)
 #pragma unroll
-            for (int u = 0; u < kS3PF; ++u) load_u(cur[u], u);
-            for (int j0 = 0; j0 < L; j0 += kS3PF) {
+            for (int u = 0; u < PF; ++u) load_u(cur[u], u);
+            for (int j0 = 0; j0 < L; j0 += PF) {
 #pragma unroll
-                for (int u = 0; u < kS3PF; ++u) {
+                for (int u = 0; u < PF; ++u) {
                     const int j = j0 + u;
                     if (j < L) {                              // wave-uniform
                         const bool ok = valid_t(j);
@@ -196,20 +264,20 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
                             for (int io = 0; io < NIO; ++io) W[io] = s3_v4{0.0, 0.0, 0.0, 0.0};
                             mm_step<R>(AZ, X, W);
                             if (ok) {
-                                double2* q = reinterpret_cast<double2*>(wtab + (size_t)t * R + (R / 4) * K);
+                                double2* q = reinterpret_cast<double2*>(wtab + (size_t)t * R) + K;
 #pragma unroll
                                 for (int io = 0; io < NIO; ++io) {
 #pragma unroll
                                     for (int v = 0; v < 4; ++v) dot = fma(X[io][v], W[io][v], dot);
-                                    q[2 * io] = make_double2(W[io][0], W[io][1]);
-                                    q[2 * io + 1] = make_double2(W[io][2], W[io][3]);
+                                    q[8 * io] = make_double2(W[io][0], W[io][1]);
+                                    q[8 * io + 4] = make_double2(W[io][2], W[io][3]);
                                 }
                             }
                         }
                         s3_v4 Y[NIO];
 #pragma unroll
                         for (int io = 0; io < NIO; ++io) Y[io] = cur[u][io];
-                        load_u(cur[u], j + kS3PF);
+                        load_u(cur[u], j + PF);
                         mm_step<R>(AM, X, Y);
 #pragma unroll
                         for (int io = 0; io < NIO; ++io)
@@ -217,12 +285,18 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
                             for (int v = 0; v < 4; ++v) X[io][v] = ok ? Y[io][v] : X[io][v];
                         if constexpr (EMIT && !FWD) {         // f of period t - 1
                             if (ok && t >= 1) {
+                                double* fo = fout + (size_t)(t - 1) * r;
 #pragma unroll
                                 for (int io = 0; io < NIO; ++io)
 #pragma unroll
-                                    for (int v = 0; v < 4; ++v) {
-                                        const int row = s3_pi<R>(K, v, io);
-                                        if (row < r) fout[(size_t)(t - 1) * r + row] = X[io][v];
+                                    for (int hh = 0; hh < 2; ++hh) {
+                                        const int c = s3_pi<R>(K, 2 * hh, io);      // even; the pair (c, c + 1)
+                                        if (fpair) {                              // r even, rows 16-byte aligned: c < r implies c + 1 < r
+                                            if (c < r) *reinterpret_cast<double2*>(fo + c) = make_double2(X[io][2 * hh], X[io][2 * hh + 1]);
+                                        } else {
+                                            if (c < r) fo[c] = X[io][2 * hh];
+                                            if (c + 1 < r) fo[c + 1] = X[io][2 * hh + 1];
+                                        }
                                     }
                             }
                         }
@@ -249,6 +323,7 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
                 for (int v = 0; v < 4; ++v) s_P[ch * kS3PS + K + 4 * v + 16 * io] = X[io][v];
         };
         put_state();
+        powers_landed();
         __syncthreads();
 #pragma unroll 1
         for (int k = 0; k < kS3Lev; ++k) {
@@ -265,6 +340,8 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
             put_state();
             __syncthreads();
         }
+        if constexpr (FWD) stage_powers(3 + kS3Lev);           // J^(L 2^k): every wave is past its last read of the table
+        else preload_bwd(kn);                                  // first J_t of this wave for the backward transient (w_t, t < ts: written long ago)
         // start state of chunk c: P_(c - 1); chunk 0: the head
         if (ch == 0) from_vec(X, s_vec + head, true);
         else {
@@ -291,8 +368,7 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
         load_aop<R>(AZ, stead, R, K, j16);                       // steady Z
         scan(AG, AZ, std::true_type{}, 0, R);                 // xi_ts -> ... -> xi_T
     }
-    __syncthreads();   // xi_T in LDS; every w_t of this replicate is written (workgroup-visible); the G powers are done with
-    stage_powers(3 + kS3Lev);                                 // J^(L 2^k)
+    __syncthreads();   // xi_T in LDS; every w_t of this replicate is written (workgroup-visible)
 
     // ---- terminal -------------------------------------------------------------------------------------------------------
     if (wave == 0) {
@@ -317,17 +393,25 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
     }
     __syncthreads();
 
-    // ---- backward transient: steps ts - 1 .. 0 (wave 0) -----------------------------------------------------------------
-    if (wave == 0) {
-        double v = s_vec[3 * R + i32];                        // smoothed mean at the steady / transient boundary
-        for (int t = ts - 1; t >= 0; --t) {
-            double Jp[R];
-            load_xperm<R>(Jp, tab + (size_t)t * 3 * R * R + R * R, i32);
-            const double wt = wtab[(size_t)t * R + i32];
-            v = matvec_x<R>(Jp, v, wt);
-            if (cg == 0 && t >= 1 && i32 < r) fout[(size_t)(t - 1) * r + i32] = v;
+    // ---- backward transient: v <- J_t v + w_t, t = ts - 1 .. 0; step k = ts - 1 - t on wave k mod NW, whose J_t and w_t were
+    // requested under the backward re-run (preload_bwd); v travels through LDS (s_vec[3 R ..) <-> s_vec[0 ..))
+    {
+        auto v_slot = [&](int k) { return (k & 1) ? 0 : 3 * R; };
+        for (int k = 0; k < ts; ++k) {
+            if (kn == k) {                                    // (wave-uniform)
+                const int t = ts - 1 - k;
+                const double v = matvec_x<R>(Mb, s_vec[v_slot(k) + i32], wtv);
+                if (cg == 0) {
+                    s_vec[v_slot(k + 1) + i32] = v;
+                    if (t >= 1 && i32 < r) fout[(size_t)(t - 1) * r + i32] = v;
+                    if (t == 0 && a.f0s) a.f0s[(size_t)b * R + i32] = v;    // E[f_0 | X] (EM)
+                }
+                kn += NW;
+                preload_bwd(kn);
+            }
+            s3_barrier_lds();
         }
-        if (a.f0s && cg == 0) a.f0s[(size_t)b * R + i32] = v;  // E[f_0 | X] (EM)
+        if (ts == 0 && wave == 0 && cg == 0 && a.f0s) a.f0s[(size_t)b * R + i32] = s_vec[3 * R + i32];
     }
 
     if ((a.abl & 256) && blockIdx.x == 0 && tid == 0) {
