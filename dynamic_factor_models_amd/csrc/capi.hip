@@ -150,6 +150,10 @@ bool g_widen_small_r = true;
 // 1 = where mstep_lam_kernel keeps its per-series accumulators in global memory (Rp > 8 or N > 256; default), 2 = wherever supported.
 int g_mstep_miss_mode = 1;
 
+// rows of the w_t scratch per replicate: T, plus (fast path, Rp >= 16) the chunk-major region of meanscan_mfma_kernel
+static size_t wtab_rows(bool fast, int Rp, int T) {
+    return (size_t)T + ((fast && Rp >= 16) ? (size_t)fast_scan_groups(Rp) * fast_chunk_len(Rp, T) : 0);
+}
 Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = false) {
     Plan p;
     int Rp = pad_r(r);
@@ -195,7 +199,9 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
         if (p.Rc == 0 && Rp == 32 && N > collapse_max_n(32) && collapse_wide2_supported(32, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, 32));
     }
-    p.wtab = take(off, (size_t)B * T * Rp * d);
+    // (fast path, Rp >= 16: the mean scan on the matrix pipe keeps the steady part of w_t in a second, chunk-major region behind the
+    // T natural rows -- scan_mfma32.hip)
+    p.wtab = take(off, (size_t)B * wtab_rows(fast, Rp, T) * Rp * d);
     p.status = take(off, 256);
     p.ncov = take(off, (size_t)B * sizeof(int));
     p.S11 = p.S10 = p.S00 = p.P0s = p.f0s = p.fsm = p.Psm = p.Sxf = p.Sxx = p.Dmiss = p.llbuf = p.active = (size_t)-1;
@@ -409,7 +415,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     fa.tab = at<double>(h, p.f_tab); fa.E = at<int>(h, p.f_E); fa.stead = at<double>(h, p.f_stead);
     fa.xi0 = at<double>(h, p.f_xi0); fa.PT = at<double>(h, p.f_PT); fa.llc = at<double>(h, p.f_llc);
     fa.fill = at<int>(h, p.f_fill); fa.PsInf = at<double>(h, p.f_PsInf);
-    fa.bcol = ca.bcol; fa.ssum = ca.ssum; fa.wtab = at<double>(h, p.wtab);
+    fa.bcol = ca.bcol; fa.ssum = ca.ssum; fa.wtab = at<double>(h, p.wtab); fa.wrep = wtab_rows(true, p.Rp, T) * (size_t)p.Rp;
     // collapse kernel of the balanced path: contraction on the matrix pipe where the shape allows it
     // (collapse_mfma.hip), else the VALU kernel (collapse_dma.hip); DFM_COLLAPSE_VARIANT < 200 forces the latter
     // shapes outside the register tilings (or DFM_COLLAPSE_VARIANT=198): the wide kernel
@@ -420,11 +426,17 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     const int cvariant = use_mfma ? (h->collapse_variant >= 200 ? h->collapse_variant : 200)
                                   : (h->collapse_variant == 199 ? 0 : h->collapse_variant);   // 199: the VALU kernel's default
     const bool use_wide2 = use_wide && !h->wide_old && p.Wwide != (size_t)-1 && collapse_wide2_supported(p.Rp, N);
-    if (use_wide) { fa.scol = ca.scol; fa.ntile = use_wide2 ? collapse_wide2_tiles(T) : collapse_wide_tiles(T); }
+    if (use_wide) {   // sum_t s_t arrives as partials per tile of the collapse kernel that will run
+        fa.scol = ca.scol;
+        fa.ntile = !use_wide2 ? collapse_wide_tiles(T) : collapse_ks_supported(p.Rp, p.r, N, false) ? collapse_ks_tiles(T) : collapse_wide2_tiles(T);
+    }
+    // Rp = 32 on the streaming collapse: b_t rows 8 ceil(r / 8) doubles apart instead of 32 -- the padding components are exact zeros
+    // that the mean scan (its only reader here) substitutes; at BASELINE config 4 (r = 20) a quarter of the 0.39 GB of b_t traffic
+    if (use_wide2 && p.Rp == 32) ca.bst = fa.bst = 8 * ((p.r + 7) / 8);
     double* Wwide = use_wide2 ? at<double>(h, p.Wwide) : nullptr;
     // Gram matrix (+ W for the Rp = 32 collapse) and the streaming collapse of this shape, on stream `st`
     auto run_gram = [&](hipStream_t st) -> hipError_t {
-        if (use_wide2) return launch_wide_prep(ca, Wwide, p.Rp, st);
+        if (use_wide2) return launch_wide_prep(ca, Wwide, p.Rp, st, p.r);
         return gram_supported(p.Rp, N) ? launch_gram(p.Rp, ca, st) : launch_gram_wide(p.Rp, ca, st);
     };
     auto run_collapse = [&](const CollapseArgs& c, hipStream_t st) -> hipError_t {
@@ -531,12 +543,12 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
             CollapseArgs c = ca;
             c.B = b1 - b0;
             c.panel = ca.panel + (size_t)b0 * T * N; c.Lam = ca.Lam + (size_t)b0 * N * p.Rp; c.Rv = ca.Rv + (size_t)b0 * N;
-            c.bcol = ca.bcol + (size_t)b0 * T * p.Rp; c.scol = ca.scol + (size_t)b0 * T; c.ssum = ca.ssum + (size_t)b0 * kSsumSlots;
+            c.bcol = ca.bcol + (size_t)b0 * T * (ca.bst > 0 ? ca.bst : p.Rp); c.scol = ca.scol + (size_t)b0 * T; c.ssum = ca.ssum + (size_t)b0 * kSsumSlots;
             c.Cfull = ca.Cfull + (size_t)b0 * p.Rp * p.Rp; c.ldfull = ca.ldfull + b0;
             return c;
         };
         auto sub_ws = [&](int s_) { return reinterpret_cast<double*>(reinterpret_cast<char*>(Wwide) + (size_t)s_ * slice); };
-        for (int s_ = 0; s_ < Sw; ++s_) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(sub_args(s_), sub_ws(s_), p.Rp, h->stream)); }
+        for (int s_ = 0; s_ < Sw; ++s_) { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(sub_args(s_), sub_ws(s_), p.Rp, h->stream, p.r)); }
         HIP_TRY(h, hipEventRecord(h->ev_fork, h->stream));
         HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
         { ProfScope ps(h, K_COV); HIP_TRY(h, launch_cov(p.Rp, fa, h->stream)); }      // resident before the collapse fills the CUs
@@ -576,9 +588,8 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
         // Rp = 32 (config 4): the fill is 0.86 GB of stores -- beside the collapse they cost it 0.4 ms of its 1.13; beside the
         // latency-bound scan they are free.  So: cov -> [event] ; collapse (side) -> [event] ; fill on the third stream
         // after both, scan on the caller's stream after the collapse, join at the end.
-        // DFM_PFILL_TRICKLE=n (route; experiment): the fill from n persistent workgroups, started behind the covariance kernel --
-        // a trickle of stores under the whole collapse, not a burst beside the scan
-        static const int trickle = [] { const char* v = route_env("DFM_PFILL_TRICKLE"); return v ? atoi(v) : 0; }();
+        // (A trickle of these stores from a few persistent workgroups UNDER the collapse was tried: the collapse lost what the scan
+        // gained -- profiles/r04/ab_pfill_trickle_c4.txt.)
         const bool fill_late = fill && use_wide2;
         if (fill && !fill_late) {         // the data-independent rows of P_smooth, beside the collapse
             ProfScope ps(h, K_PFILL);
@@ -593,8 +604,8 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
             }
             HIP_TRY(h, hipEventRecord(h->ev_sub[0], h->stream));            // cov_kernel's outputs
             HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_sub[0], 0));
-            if (trickle <= 0) HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));        // ... and not before the collapse is done
-            { ProfScope ps(h, K_PFILL, h->post); HIP_TRY(h, launch_pfill(p.Rp, fa, h->post, trickle)); }
+            HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_join, 0));        // ... and not before the collapse is done
+            { ProfScope ps(h, K_PFILL, h->post); HIP_TRY(h, launch_pfill(p.Rp, fa, h->post)); }
             HIP_TRY(h, hipEventRecord(h->ev_post, h->post));
             fa.abl |= 1;
         }

@@ -124,22 +124,30 @@ __global__ __launch_bounds__(kPrepThreads) void wide_prep_kernel(CollapseArgs a,
     const double* __restrict__ L = a.Lam + (size_t)b * N * rd;
     const double* __restrict__ Rv = a.Rv + (size_t)b * N;
     double* W = Wout + (size_t)b * N * R;
-    // stored with the two 16-column halves of ODD series swapped (column f of series c at f ^ 16 (c & 1)): the B operand of
-    // a step reads 4 consecutive series x 16 columns, and two series 256 bytes apart would meet on the same banks
-    for (int e = tid; e < N * R; e += kPrepThreads) {
-        const int c = e / R;
-        const int f = e % R;
-        W[R == 32 ? (e ^ (16 * (c & 1))) : e] = f < rd ? L[(size_t)c * rd + f] / Rv[c] : 0.0;
-    }
+    // 1 / R and log R ONCE per series (a first version divided every element of W by R and took every logarithm twice: 32 fp64
+    // divisions and 2 logarithms per thread in front of a pass whose streaming kernel waits for W)
+    double* rinv = rinv_out + (size_t)b * npad;
+    double ld = 0.0;
     for (int c = tid; c < npad; c += kPrepThreads) {          // (0 past N: padding of the last stage)
-        rinv_out[(size_t)b * npad + c] = c < N ? 1.0 / Rv[c] : 0.0;
-        logr_out[(size_t)b * npad + c] = c < N ? log(Rv[c]) : 0.0;
+        const double rv = c < N ? Rv[c] : 1.0;
+        const double lg = c < N ? log(rv) : 0.0;
+        rinv[c] = c < N ? 1.0 / rv : 0.0;
+        logr_out[(size_t)b * npad + c] = lg;
+        ld += lg;
     }
     if (b == 0 && tid < 8) ctr[tid] = 0;                      // tile queues of the collapse that follows on this stream
-    double ld = 0.0;
-    for (int c = tid; c < N; c += kPrepThreads) ld += log(Rv[c]);
     ld = wave_allsum(ld);
     if (lane == 0) red[wave] = ld;
+    __syncthreads();                                          // (1 / R of this replicate is visible to its workgroup)
+    // W stored with the two 16-column halves of ODD series swapped (column f of series c at f ^ 16 (c & 1)): the B operand of
+    // a step reads 4 consecutive series x 16 columns, and two series 256 bytes apart would meet on the same banks
+    if (Wout != nullptr) {                                    // (collapse_ks_kernel takes lam and 1 / R themselves)
+        for (int e = tid; e < N * R; e += kPrepThreads) {
+            const int c = e / R;
+            const int f = e % R;
+            W[R == 32 ? (e ^ (16 * (c & 1))) : e] = f < rd ? L[(size_t)c * rd + f] * rinv[c] : 0.0;
+        }
+    }
     // tile (it, jt) of C over the series of slice sl: C[16 it + i][16 jt + j] = sum_c Lam[c][16 it + i] Lam[c][16 jt + j] / R_c
     const int tile = wave % NTILE, sl = wave / NTILE;
     const int it = tile / (R / 16), jt = tile % (R / 16);
@@ -156,13 +164,13 @@ __global__ __launch_bounds__(kPrepThreads) void wide_prep_kernel(CollapseArgs a,
             const int cc = c < N ? c : N - 1;
             av[u] = (16 * it + c16 < rd) ? L[(size_t)cc * rd + 16 * it + c16] : 0.0;
             bv[u] = (16 * jt + c16 < rd) ? L[(size_t)cc * rd + 16 * jt + c16] : 0.0;
-            rv[u] = Rv[cc];
+            rv[u] = rinv[cc];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int c = 4 * (s0 + u) + k4;
             const bool ok = c < N && s0 + u < s_hi;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av[u] : 0.0, bv[u] / rv[u], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av[u] : 0.0, bv[u] * rv[u], acc, 0, 0, 0);
         }
     }
 #pragma unroll
@@ -369,13 +377,15 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
     double pacc4[N4 > 0 ? N4 : 1];
     auto flush_pending = [&]() {
         if (pend_b < 0) return;
-        double* out = a.bcol + ((size_t)pend_b * T + pend_t0 + 16 * wave) * rd;   // (rd = R except for the narrow states on R = 16)
+        // row stride of b_t: rd (= R except for the narrow states on R = 16), or -- R = 32, balanced -- CollapseArgs::bst
+        const int bs = (R == 32 && !MISS && a.bst > 0) ? a.bst : rd;
+        double* out = a.bcol + ((size_t)pend_b * T + pend_t0 + 16 * wave) * bs;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {                         // 16x16x4: D[(l / 16) + 4 v][l % 16]
             const int row = k4 + 4 * v;
             if (pend_t0 + 16 * wave + row < T) {
-                if (R == 32 || c16 < rd) out[(size_t)row * rd + c16] = pacc[v];
-                if (NX == 4) out[(size_t)row * R + 16 + c16] = paccb[v];
+                if (R == 32 || c16 < rd) out[(size_t)row * bs + c16] = pacc[v];
+                if (NX == 4 && 16 + c16 < bs) out[(size_t)row * bs + 16 + c16] = paccb[v];
             }
         }
         if (R == 32 && NX < 4) {                              // 4x4x4: block (l / 4) % 4, D[row = l / 16][col = l % 4] -> period 4 blk + l / 16
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
             if (pend_t0 + 16 * wave + row < T) {
 #pragma unroll
                 for (int x = 0; x < 4; ++x)                   // (the padding columns past 16 + 4 NX are zero)
-                    out[(size_t)row * R + 16 + 4 * x + (lane & 3)] = x < N4 ? pacc4[x < N4 ? x : 0] : 0.0;
+                    if (16 + 4 * x < bs) out[(size_t)row * bs + 16 + 4 * x + (lane & 3)] = x < N4 ? pacc4[x < N4 ? x : 0] : 0.0;
             }
         }
         if (!MISS && tid == 0) {
@@ -808,18 +818,20 @@ hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, in
 }
 }  // namespace
 
-hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s) {
+hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s, int r) {
     note_kernel("wide_prep_kernel");
     const W2Ws w = w2_ws(a, ws, Rpad);
+    const bool ks = r > 0 && collapse_ks_supported(Rpad, r, a.N, a.nobs != nullptr);   // no W table for that collapse
     if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad);
-    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, 32);
+    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(kPrepThreads), 0, s, a, ks ? nullptr : w.W, w.rinv, w.logr, w.npad, w.ctr, 32);
     return hipGetLastError();
 }
 
 // r = the caller's factor count (columns r .. Rpad - 1 of Lam are zero padding)
 hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
-    note_kernel("collapse_wide2_kernel");
     const W2Ws w = w2_ws(a, ws, Rpad);
+    if (collapse_ks_supported(Rpad, r, a.N, a.nobs != nullptr)) return launch_collapse_ks(a, w.rinv, w.npad, num_cu, s);
+    note_kernel("collapse_wide2_kernel");
     const int ntile = collapse_wide2_tiles(a.T);
     const size_t lds = (size_t)kW2NBuf * kW2StageB + 32 * sizeof(double) + 64 * 4 * sizeof(unsigned long long);   // stages | redS, itemq | DIAG stamps
     static const int xcd_env = [] { const char* v = diag_env("DFM_WIDE_XCD"); return v ? atoi(v) : -1; }();

@@ -64,6 +64,8 @@ struct CollapseArgs {
     const void* fuse_cov; // collapse_mfma only, HOST pointer read by the launcher (not by the kernel): FastArgs of the pass whose
                           // covariance workgroups + P_smooth fill ride at the front of this launch, or null
     int wpr;              // collapse_mfma only: waves (period segments) per replicate (0 = 4); nseg = wpr <= kSsumSlots
+    int bst;              // collapse_wide2 (Rp = 32, balanced) only: > 0 = doubles between the rows of bcol (a multiple of 8, >= the state
+                          // width: the padding components of b_t are exact zeros nobody needs); 0 = Rp
     int ct_r;             // ct_miss_wide2 only: > 0 = Ct rows are the packed LEADING ct_r x ct_r block (ct_r (ct_r + 1) / 2 doubles; the
                           // padding of the state carries no loadings, its entries equal Cfull's) -- what recursion_tile_kernel reads;
                           // 0 = the full Rp (Rp + 1) / 2 layout of the other recursion kernels
@@ -169,8 +171,13 @@ hipError_t launch_gram_wide(int Rpad, const CollapseArgs& a, hipStream_t s);
 // ldfull (the Gram kernel's outputs); launch_collapse_wide2 then streams the panel (partials of sum_t s_t: scol[b][tile])
 bool collapse_wide2_supported(int Rpad, int N);
 int collapse_wide2_tiles(int T);
+// Rp = 32, 17 <= r <= 20, 256 < N <= 1024 even, balanced: series split over the waves, weights in registers (collapse_ks.hip);
+// launch_collapse_wide2 / launch_wide_prep route to it themselves, callers only need the number of s_t partials per replicate
+bool collapse_ks_supported(int Rpad, int r, int N, bool missing);
+int collapse_ks_tiles(int T);
+hipError_t launch_collapse_ks(const CollapseArgs& a, const double* rinv, int npad, int num_cu, hipStream_t s);
 size_t collapse_wide2_ws_bytes(int B, int N, int Rpad);    // W [B][N][Rp] | 1 / R, log R [B][N padded to 32] | tile queue counters
-hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s);
+hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s, int r = 0);   // r > 0: the caller's factor count (skips the W table when launch_collapse_wide2 will not read it)
 hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s);
 // a.nobs != nullptr selects the variant for panels with missing cells (per-period scol / nobs / ldrow); their C_t:
 bool ct_miss_wide_compact_ok(int N, int ct_r);   // compact C_t rows (CollapseArgs::ct_r) are available for this cross-section
@@ -242,6 +249,8 @@ struct FastArgs {
     int nseg;                   // slots of ssum that were written
     const double* scol; int ntile;   // ntile > 0: sum_t s_t = sum of scol[b][0 .. ntile) instead (collapse_wide)
     double* wtab;               // [B][T][Rp] scratch
+    size_t wrep;                // doubles per replicate of wtab (0: T Rp)
+    int bst;                    // doubles between the rows of bcol (0: Rp) -- CollapseArgs::bst of the collapse that wrote them
     // outputs
     double* f_smooth; double* P_smooth; double* loglik;
     double* f0s;                // [B][Rp] E[f_0 | X] (EM) or null
@@ -266,7 +275,7 @@ hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s);
 bool cov_fuses_gram(int Rpad, int N);   // launch_cov with a.Lam != nullptr is supported for this shape
 hipError_t launch_meanscan(int Rpad, const FastArgs& a, hipStream_t s);
 hipError_t launch_meanscan_mfma(int Rpad, const FastArgs& a, hipStream_t s);   // Rp = 16, 32: the steady scans on the matrix pipe (scan_mfma32.hip)
-hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s, int trickle_wgs = 0);   // the P_smooth fill of meanscan (then run it with abl bit 0)
+hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s);   // the P_smooth fill of meanscan (then run it with abl bit 0)
 // The whole balanced pass in one launch (pass_fused.hip: persistent workgroups, stream / covariance / scan waves) and the
 // one-wave-per-replicate covariance recursion as a drop-in for launch_cov (Rp = 8, Cfull / ldfull from gram_kernel).
 bool pass_fused_supported(int Rpad, int T, int N);
@@ -283,6 +292,7 @@ hipError_t launch_cov_tile(const FastArgs& a, int rstate, hipStream_t s);
 hipError_t launch_cov_grid(int Rpad, const FastArgs& a, hipStream_t s);
 int fast_chunk_len(int Rpad, int T);
 int fast_stead_mats(int Rpad);
+int fast_scan_groups(int Rpad);   // time chunks of the mean scan
 
 // PCA initialisation (pca.hip).  Scratch arrays use the padded factor dimension Rp; outputs the caller's r.
 struct PcaArgs {

@@ -66,34 +66,12 @@ __global__ __launch_bounds__(256) void pfill_kernel(FastArgs a) {
     __syncthreads();
     // gridDim.y slices of the row range: one workgroup per replicate cannot saturate the write bandwidth when a replicate's
     // P_smooth is megabytes (config 4: 3.4 MB each, 256 replicates -- 1.03 ms; 8 slices: the stores of 2048 workgroups)
+    // ... and every WAVE walks its own contiguous quarter of the slice: four waves interleaved 1 KB at a time wrote at 4.1 TB/s,
+    // a wave per contiguous segment writes at 5.5-5.9 (scripts/microbench/storebw.hip, profiles/r04/microbench_storebw.txt)
     const int lo = a.fill[2 * b], hi = a.fill[2 * b + 1];
-    const int ns = (int)gridDim.y, sl = (int)blockIdx.y;
+    const int ns = 4 * (int)gridDim.y, sl = 4 * (int)blockIdx.y + (tid >> 6);
     const long long span = hi > lo ? hi - lo : 0;
-    fill_psmooth_range(a, b, tid, 256, s_ps, lo + (int)(span * sl / ns), lo + (int)(span * (sl + 1) / ns));
-}
-
-// The same rows from a FEW persistent workgroups (gridDim.x of them take the (replicate, slice) items in turn): a trickle of
-// stores beside the streaming collapse of the wide path instead of a burst beside the mean scan behind it -- see
-// enqueue_pass_fast in capi.hip.
-template <int R>
-__global__ __launch_bounds__(256) void pfill_trickle_kernel(FastArgs a, int ns) {
-    __shared__ double s_ps[R * (R + 1) / 2];
-    const int tid = threadIdx.x;
-    const int npr = a.r * (a.r + 1) / 2;
-    for (int item = blockIdx.x; item < a.B * ns; item += gridDim.x) {
-        // slice-major: the first replicates' rows are not all written first (every replicate's scan may start early)
-        const int b = item % a.B, sl = item / a.B;
-        __syncthreads();
-        for (int v = tid; v < npr; v += 256) {
-            int ri = 0;
-            while ((ri + 1) * (ri + 2) / 2 <= v) ++ri;
-            s_ps[v] = a.PsInf[(size_t)b * R * R + ri * R + (v - ri * (ri + 1) / 2)];
-        }
-        __syncthreads();
-        const int lo = a.fill[2 * b], hi = a.fill[2 * b + 1];
-        const long long span = hi > lo ? hi - lo : 0;
-        fill_psmooth_range(a, b, tid, 256, s_ps, lo + (int)(span * sl / ns), lo + (int)(span * (sl + 1) / ns));
-    }
+    fill_psmooth_range(a, b, tid & 63, 64, s_ps, lo + (int)(span * sl / ns), lo + (int)(span * (sl + 1) / ns));
 }
 
 template <int R>
@@ -137,7 +115,7 @@ __global__ __launch_bounds__(scan_threads(R)) void meanscan_kernel(FastArgs a) {
     const int ts = E - 1;
     const int nst = ts < ecap(R) ? ts : ecap(R);              // transient steps staged in LDS
     const double* bcol = a.bcol + (size_t)b * T * R;
-    double* wtab = a.wtab + (size_t)b * T * R;
+    double* wtab = a.wtab + (size_t)b * (a.wrep ? a.wrep : (size_t)T * R);
     const double* tab = a.tab + (size_t)b * T * 3 * R * R;
     const double* stead = a.stead + (size_t)b * NST * R * R;
     double* fout = a.f_smooth + (size_t)b * T * r;
@@ -511,6 +489,7 @@ static hipError_t launch_scan_r(const FastArgs& a, hipStream_t s) {
 }
 
 int fast_stead_mats(int Rpad) { return stead_mats(Rpad); }
+int fast_scan_groups(int Rpad) { return scan_groups(Rpad); }
 
 int fast_chunk_len(int Rpad, int T) {
     const int ng = scan_groups(Rpad);
@@ -532,17 +511,13 @@ hipError_t launch_cov(int Rpad, const FastArgs& a, hipStream_t s) {
         default: return hipErrorInvalidValue;
     }
 }
-hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s, int trickle_wgs) {
+hipError_t launch_pfill(int Rpad, const FastArgs& a, hipStream_t s) {
     if (!a.P_smooth) return hipSuccess;
     // slices per replicate: enough workgroups to fill the chip, each with at least ~64 KB of rows
     const long long bytes = (long long)a.T * (a.r * (a.r + 1) / 2) * 8;
     int ns = (int)((2048 + a.B - 1) / a.B);
     while (ns > 1 && bytes / ns < 65536) --ns;
     if (ns < 1) ns = 1;
-    if (trickle_wgs > 0 && Rpad == 32) {
-        hipLaunchKernelGGL((pfill_trickle_kernel<32>), dim3(trickle_wgs), dim3(256), 0, s, a, ns);
-        return hipGetLastError();
-    }
     const dim3 grid(a.B, ns);
     switch (Rpad) {
         case 2: hipLaunchKernelGGL((pfill_kernel<2>), grid, dim3(256), 0, s, a); break;

@@ -128,8 +128,18 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
     const int T = a.T, r = a.r, L = a.L;
     const int E = a.E[b];
     const int ts = E - 1;
-    const double* bcol = a.bcol + (size_t)b * T * R;
-    double* wtab = a.wtab + (size_t)b * T * R;
+    const int bst = a.bst > 0 ? a.bst : R;                    // doubles between the rows of b_t (the wide collapse drops padding columns)
+    const double* bcol = a.bcol + (size_t)b * T * bst;
+    double* wtab = a.wtab + (size_t)b * (a.wrep ? a.wrep : (size_t)T * R);   // natural rows (the transient steps use them)
+    // steady w_t, CHUNK-MAJOR behind the T natural rows: 16-byte piece pc (= 2 io + h) of step j of wave w's 16 chunks is the
+    // 1 KB [(w L + j) NPc + pc][lane] -- the forward re-run writes whole KBs, every wave its own contiguous run (interleaved
+    // 64-byte pieces wrote at the 4 TB/s of grid-stride stores: scripts/microbench/storebw.hip), and the backward runs read the
+    // same KBs back (their chunks are the forward ones shifted: at most two KBs per instruction, every byte used)
+    constexpr int NPc = R / 8;
+    const int lsh = __builtin_ctz((unsigned)L);
+    const int npc = ((a.rstate > 0 ? a.rstate : R) + 7) >> 3;   // 16-byte pieces per lane and period that carry state components (the rest: padding)
+    double2* wch = reinterpret_cast<double2*>(wtab + (size_t)T * R);
+
     const double* tab = a.tab + (size_t)b * T * 3 * R * R;
     const double* stead = a.stead + (size_t)b * stead_mats(R) * R * R;
     double* fout = a.f_smooth + (size_t)b * T * r;
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
     auto preload_fwd = [&](int t) {
         if (t < ts) {
             load_xperm<R>(Mp, tab + (size_t)t * 3 * R * R + (isG ? 2 * R * R : 0), i32);
-            if (isG) btv = bcol[(size_t)t * R + i32];
+            if (isG) btv = i32 < bst ? bcol[(size_t)t * bst + i32] : 0.0;
         }
     };
     const double xi00 = a.xi0[(size_t)b * R + i32];
@@ -238,10 +248,20 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
         auto load_u = [&](s3_v4 (&U)[NIO], int j) {
             int t = step_t(j);
             t = t < ts ? ts : (t >= T ? T - 1 : t);           // (a row that exists; the step is skipped when invalid)
-            const double2* p = reinterpret_cast<const double2*>((FWD ? bcol : wtab) + (size_t)t * R) + K;
+            const double2* p;
+            int st;                                           // stride between the lane's pieces, in 16-byte units
+            if constexpr (FWD) {
+                p = reinterpret_cast<const double2*>(bcol + (size_t)t * bst) + K;   // components 16 io + 8 h + 2 K (+ 1): piece pc at 4 pc + K
+                st = 4;
+            } else {                                          // w_t where the forward re-run put it: chunk (t - ts) / L, step (t - ts) % L
+                const int d = t - ts, cf = d >> lsh, jf = d & (L - 1);   // (L is a power of two: fast_chunk_len)
+                p = wch + ((size_t)((cf >> 4) * L + jf) * NPc) * 64 + 16 * K + (cf & 15);
+                st = 64;
+            }
 #pragma unroll
-            for (int io = 0; io < NIO; ++io) {                // components 16 io + 2 K (+ 1) and 16 io + 8 + 2 K (+ 1)
-                const double2 x = p[8 * io], y = p[8 * io + 4];
+            for (int io = 0; io < NIO; ++io) {                // (pieces of padding components only -- exact zeros -- are neither stored nor read)
+                const double2 z2 = make_double2(0.0, 0.0);
+                const double2 x = (2 * io < npc) ? p[(2 * io) * st] : z2, y = (2 * io + 1 < npc) ? p[(2 * io + 1) * st] : z2;
                 U[io][0] = x.x; U[io][1] = x.y; U[io][2] = y.x; U[io][3] = y.y;
             }
         };
@@ -264,13 +284,13 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
                             for (int io = 0; io < NIO; ++io) W[io] = s3_v4{0.0, 0.0, 0.0, 0.0};
                             mm_step<R>(AZ, X, W);
                             if (ok) {
-                                double2* q = reinterpret_cast<double2*>(wtab + (size_t)t * R) + K;
+                                double2* q = wch + ((size_t)(wave * L + j) * NPc) * 64 + lane;
 #pragma unroll
                                 for (int io = 0; io < NIO; ++io) {
 #pragma unroll
                                     for (int v = 0; v < 4; ++v) dot = fma(X[io][v], W[io][v], dot);
-                                    q[8 * io] = make_double2(W[io][0], W[io][1]);
-                                    q[8 * io + 4] = make_double2(W[io][2], W[io][3]);
+                                    if (2 * io < npc) q[(2 * io) * 64] = make_double2(W[io][0], W[io][1]);
+                                    if (2 * io + 1 < npc) q[(2 * io + 1) * 64] = make_double2(W[io][2], W[io][3]);
                                 }
                             }
                         }
@@ -441,6 +461,7 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
 namespace {
 template <int R>
 hipError_t launch_scan_mfma_r(const FastArgs& a, hipStream_t s) {
+    if (a.wrep < (size_t)(a.T + S3Geo<R>::NC * a.L) * R) return hipErrorInvalidValue;   // (the chunk-major region of w_t: capi.hip wtab_rows)
     const size_t lds = (size_t)S3Geo<R>::total * sizeof(double);
     static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
