@@ -729,7 +729,7 @@ int em_iteration(dfm_handle* h, const Plan& p, int B, int T, int N, const double
     ma.panel = panel; ma.fsm = fsm; ma.Psm = Psm;
     ma.S11 = at<double>(h, p.S11); ma.S11inv = at<double>(h, p.Sxf);
     ma.Dmiss = mstep_needs_dmiss(Rp, N) ? at<double>(h, p.Dmiss) : nullptr;
-    ma.active = eo.active; ma.Lam_out = LamP; ma.R_out = Rv; ma.lam_stride = Rp;
+    ma.active = eo.active; ma.Lam_out = LamP; ma.R_out = Rv; ma.lam_stride = Rp; ma.min_cells = 1;
     if (p.fast && p.ms_ws != (size_t)-1 && !h->no_mstep_mfma) {   // balanced panel: second panel read on the matrix pipe
         ProfScope ps(h, K_MSTEP_MFMA);
         HIP_TRY(h, launch_mstep_mfma(Rp, ma, p.ms_wpr, at<double>(h, p.ms_ws), h->stream, h->have_deferred_em ? &h->deferred_em : nullptr));
@@ -1089,7 +1089,9 @@ int obs_em_run(dfm_handle* h, int B, int T, int N, int ru, int ro, const double*
                double* f_smooth, double* P_smooth, unsigned flags) {
     if (!h) return DFM_E_NULL;
     if (int rc = check_dims(h, B, T, N, ru)) return rc;
-    if (!mstep_obs_supported(ro, ru)) return fail(h, DFM_E_R_UNSUPPORTED, "observed factors: need r_o >= 1, r_u >= 1 and r_o + r_u <= 8%s");
+    const bool wide_obs = mstep_obs_wide_supported(ro, ru);   // r_o + r_u = 9 .. 32: the ordinary loadings step on augmented moments
+    if (!mstep_obs_supported(ro, ru) && !wide_obs)
+        return fail(h, DFM_E_R_UNSUPPORTED, "observed factors: need r_o >= 1, r_u >= 1 and r_o + r_u <= 32%s");
     if (int rc = check_em_n(h, N, ru, flags)) return rc;
     if (!panel || !G || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
@@ -1097,7 +1099,18 @@ int obs_em_run(dfm_handle* h, int B, int T, int N, int ru, int ro, const double*
     HIP_TRY(h, hipSetDevice(h->device));
     const Plan p = make_plan(B, T, N, ru, flags, true, fast_eligible(h, N, ru, flags) && !h->em_general);
     const size_t yoff = (p.total + 255) & ~(size_t)255;
-    if (int rc = ensure_ws(h, yoff + (size_t)B * T * N * sizeof(double))) return rc;
+    // wide joint regression: z [B][T][Re] | Var z [B][T][NPe] | LamAug [B][N][Re] | S11, S11inv [B][Re][Re] | Dmiss [B][N][NPe]
+    const int Re = wide_obs ? mstep_obs_wide_width(ro, ru) : 0;
+    const size_t NPe = (size_t)Re * (Re + 1) / 2;
+    size_t woff = (yoff + (size_t)B * T * N * sizeof(double) + 255) & ~(size_t)255, wend = woff;
+    auto wtake = [&](size_t bytes) { const size_t o = wend; wend = (wend + bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_z = wide_obs ? wtake((size_t)B * T * Re * sizeof(double)) : 0;
+    const size_t o_v = wide_obs ? wtake((size_t)B * T * NPe * sizeof(double)) : 0;
+    const size_t o_l = wide_obs ? wtake((size_t)B * N * Re * sizeof(double)) : 0;
+    const size_t o_s = wide_obs ? wtake((size_t)B * Re * Re * sizeof(double)) : 0;
+    const size_t o_i = wide_obs ? wtake((size_t)B * Re * Re * sizeof(double)) : 0;
+    const size_t o_d = wide_obs ? wtake((size_t)B * N * NPe * sizeof(double)) : 0;
+    if (int rc = ensure_ws(h, wend)) return rc;
     const int Rp = p.Rp, Rl = p.Rc ? p.Rc : p.Rp;            // state width, loadings width
     const bool padded = (ru != Rp);
     double *LamP = at<double>(h, p.LamP), *y = at<double>(h, yoff);
@@ -1126,7 +1139,22 @@ int obs_em_run(dfm_handle* h, int B, int T, int N, int ru, int ro, const double*
         eo.A_out = AP; eo.Q_out = QP; eo.mu0_out = mu0P; eo.P0_out = P0P;
         eo.active = active; eo.iters = iters; eo.ll_path = loglik_path; eo.k = it; eo.max_iter = max_iter; eo.tol = tol;
         if (int rc = enqueue_pass(h, p, B, T, N, Rl, y, pp, R, fsm, Psm, llbuf, &eo)) return rc;
-        { ProfScope ps(h, K_MSTEP_STATS); HIP_TRY(h, launch_mstep_obs(oa, h->stream)); }
+        if (!wide_obs) {
+            ProfScope ps(h, K_MSTEP_STATS);
+            HIP_TRY(h, launch_mstep_obs(oa, h->stream));
+        } else {
+            double *z = at<double>(h, o_z), *Vz = at<double>(h, o_v), *LamAug = at<double>(h, o_l);
+            { ProfScope ps(h, K_PAD); HIP_TRY(h, launch_obs_augment(oa, Re, z, Vz, LamAug, at<double>(h, o_s), at<double>(h, o_i), h->stream)); }
+            MstepArgs ma;
+            ma.B = B; ma.T = T; ma.N = N; ma.r = Re;
+            ma.panel = panel; ma.fsm = z; ma.Psm = Vz; ma.S11 = at<double>(h, o_s); ma.S11inv = at<double>(h, o_i);
+            ma.Dmiss = at<double>(h, o_d);
+            ma.active = active; ma.Lam_out = LamAug; ma.R_out = R; ma.lam_stride = Re;
+            ma.min_cells = ro + ru + 1;                       // (as mstep_obs_kernel and the oracle: too few cells for the joint regression)
+            HIP_TRY(h, hipMemsetAsync(ma.Dmiss, 0, (size_t)B * N * NPe * sizeof(double), h->stream));
+            { ProfScope ps(h, K_MSTEP_STATS); HIP_TRY(h, launch_mstep_lam(Re, ma, h->stream)); }
+            if (int rc = copy_block(h, (size_t)B * N, 1, Re, 1, ro + ru, LamAug, Lam)) return rc;   // (inactive replicates: their own values back)
+        }
         if (tol > 0.0 && it + 1 < max_iter) {
             act_host.resize(B);
             HIP_TRY(h, hipMemcpyAsync(act_host.data(), active, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1693,7 +1721,7 @@ int dfm_em_obs_batch(dfm_handle* h, int B, int T, int N, int r_u, int r_o, const
                      double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
                      int* iters, double* f_smooth, double* P_smooth, unsigned flags) {
     if (int rc = check_dims(h, B, T, N, r_u)) return rc;
-    if (r_o < 1 || r_o + r_u > 8) return fail(h, DFM_E_R_UNSUPPORTED, "observed factors: need r_o >= 1 and r_o + r_u <= 8%s");
+    if (r_o < 1 || r_o + r_u > 32) return fail(h, DFM_E_R_UNSUPPORTED, "observed factors: need r_o >= 1 and r_o + r_u <= 32%s");
     if (!panel || !G || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");

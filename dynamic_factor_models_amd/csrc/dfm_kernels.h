@@ -131,6 +131,7 @@ struct MstepArgs {
     double* Lam_out;      // [B][N][lam_stride]
     double* R_out;        // [B][N]
     int lam_stride;
+    int min_cells;        // mstep_lam: a series with fewer observed cells keeps its parameters (0 = 1)
 };
 
 // balanced panels at Rp = 16 | 32 (even N): the loadings step as a second streaming pass on the matrix pipe (mstep_wide.hip);
@@ -224,6 +225,13 @@ struct ObsArgs {
 };
 bool mstep_obs_supported(int ro, int ru);
 hipError_t launch_mstep_obs(const ObsArgs& a, hipStream_t s);
+// r_o + r_u in 9 .. 32: the joint regression is the ORDINARY loadings step (launch_mstep_lam at Re = 16 | 32) on augmented
+// moments z = (g, f), Var z = blockdiag(0, P) -- and the identity on the padding, as the padded state of an ordinary pass has it.
+// launch_obs_augment builds z [B][T][Re], Var z packed [B][T][Re (Re + 1) / 2], the padded copy of the loadings [B][N][Re] and
+// sum_t E z z' with its inverse [B][Re][Re] each.
+bool mstep_obs_wide_supported(int ro, int ru);
+int mstep_obs_wide_width(int ro, int ru);                      // Re
+hipError_t launch_obs_augment(const ObsArgs& a, int Re, double* z, double* Vz, double* LamAug, double* S11, double* S11inv, hipStream_t s);
 // y = x - Lam_o g (NaN stays NaN) and LamP [B][N][Rl] = unobserved-factor loadings, zero padded
 hipError_t launch_obs_residual(const ObsArgs& a, double* y, double* LamP, hipStream_t s);
 

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
     for (int j = 0; j < CPL; ++j) {
         const int col = tid + 256 * j;
         if (col >= N) continue;
-        if (ti[j] < 1) continue;      // a series without a single observed cell keeps its parameters (as mmw_finish_kernel, mstep_obs_kernel)
+        if (ti[j] < (a.min_cells > 1 ? a.min_cells : 1)) continue;   // a series without a single observed cell (or fewer than the caller's minimum) keeps its parameters (as mmw_finish_kernel, mstep_obs_kernel)
         double lam[R];
         double quad;   // lam' Sff lam
         if (ti[j] == T) {   // fully observed series: shared inverse

@@ -12,6 +12,7 @@
 //                         a period are the same for every series (wave-uniform addresses: scalar loads), the solve is an
 //                         in-register Cholesky.  A niche path (a handful of observed factors, FAVAR): written for clarity,
 //                         not tuned -- it reads the panel once more per iteration with a stride of N.
+#include "dfm_grid.h"
 #include "dfm_kernels.h"
 
 namespace dfm {
@@ -163,9 +164,85 @@ hipError_t launch_obs_re(const ObsArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---- r_o + r_u = 9 .. 32: augmented moments for the ordinary loadings step (mstep.hip) -----------------------------------
+// z_t = (g_t, f_t, 0 ..),  Var z_t = blockdiag(0, P_t, I): the identity on the padding keeps sum_t E z z' positive definite (T on
+// its diagonal, as the padded state of an ordinary pass) and the padded loadings at exactly zero.
+__global__ __launch_bounds__(256) void obs_augment_kernel(ObsArgs a, int Re, double* __restrict__ z, double* __restrict__ Vz,
+                                                         double* __restrict__ LamAug) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = a.T, N = a.N, ro = a.ro, ru = a.ru, re = a.ro + a.ru, Rl = a.Rl;
+    const int NPe = Re * (Re + 1) / 2;
+    const size_t npk = (size_t)Rl * (Rl + 1) / 2;
+    const size_t nz = (size_t)a.B * T * Re, nv = (size_t)a.B * T * NPe, nl = (size_t)a.B * N * Re;
+    if (tid < nz) {
+        const int c = (int)(tid % Re);
+        const size_t bt = tid / Re;
+        z[tid] = c < ro ? a.G[bt * ro + c] : c < re ? a.fsm[bt * Rl + (c - ro)] : 0.0;
+    }
+    if (tid < nv) {
+        const int v = (int)(tid % NPe);
+        const size_t bt = tid / NPe;
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= v) ++i;
+        const int j = v - i * (i + 1) / 2;                    // j <= i
+        double x = 0.0;
+        if (i >= re) x = (i == j) ? 1.0 : 0.0;
+        else if (j >= ro) x = a.Psm[bt * npk + (size_t)(i - ro) * (i - ro + 1) / 2 + (j - ro)];
+        Vz[tid] = x;
+    }
+    if (tid < nl) {
+        const int c = (int)(tid % Re);
+        const size_t bn = tid / Re;
+        LamAug[tid] = c < re ? a.Lam[bn * re + c] : 0.0;
+    }
+    (void)ru;
+}
+
+// sum_t E z_t z_t' and its inverse: one workgroup of R x R threads per replicate (element per thread, Grid<R>)
+template <int R>
+__global__ __launch_bounds__(R * R) void obs_moments_kernel(int T, const double* __restrict__ z, const double* __restrict__ Vz,
+                                                            double* __restrict__ S11, double* __restrict__ S11inv) {
+    constexpr int RR = R * R, NP = R * (R + 1) / 2, TS = kTileStride<R>, RT = R * TS;
+    __shared__ __attribute__((aligned(16))) double wsm[kGridProw<R> + 2 * (RR / 64) * R + 2 * RT];
+    Grid<R> G;
+    G.prow = wsm;
+    G.red = G.prow + kGridProw<R>;
+    G.tt = G.red + 2 * (RR / 64) * R;
+    const int l = threadIdx.x, i = l / R, j = l % R;
+    G.l = l; G.i = i; G.j = j;
+    const int b = blockIdx.x;
+    const double* zb = z + (size_t)b * T * R;
+    const double* vb = Vz + (size_t)b * T * NP;
+    const int hi = i > j ? i : j, lo = i > j ? j : i;
+    const int pk = hi * (hi + 1) / 2 + lo;
+    double s = 0.0;
+    for (int t = 0; t < T; ++t) s += fma(zb[(size_t)t * R + hi], zb[(size_t)t * R + lo], vb[(size_t)t * NP + pk]);   // (symmetric by construction)
+    S11[(size_t)b * RR + l] = s;
+    double inv = s;
+    (void)G.sweep_inverse(inv);
+    S11inv[(size_t)b * RR + l] = inv;
+}
+
 }  // namespace
 
 bool mstep_obs_supported(int ro, int ru) { return ro >= 1 && ru >= 1 && ro + ru <= 8; }
+bool mstep_obs_wide_supported(int ro, int ru) { return ro >= 1 && ru >= 1 && ro + ru > 8 && ro + ru <= 32; }
+int mstep_obs_wide_width(int ro, int ru) { return ro + ru <= 16 ? 16 : 32; }
+
+hipError_t launch_obs_augment(const ObsArgs& a, int Re, double* z, double* Vz, double* LamAug, double* S11, double* S11inv, hipStream_t s) {
+    note_kernel("obs_augment_kernel");
+    const size_t NPe = (size_t)Re * (Re + 1) / 2;
+    size_t n = (size_t)a.B * a.T * NPe;
+    const size_t nl = (size_t)a.B * a.N * Re;
+    if (nl > n) n = nl;
+    hipLaunchKernelGGL(obs_augment_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, Re, z, Vz, LamAug);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (Re == 16) hipLaunchKernelGGL(obs_moments_kernel<16>, dim3(a.B), dim3(256), 0, s, a.T, z, Vz, S11, S11inv);
+    else if (Re == 32) hipLaunchKernelGGL(obs_moments_kernel<32>, dim3(a.B), dim3(1024), 0, s, a.T, z, Vz, S11, S11inv);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
 
 hipError_t launch_mstep_obs(const ObsArgs& a, hipStream_t s) {
     note_kernel("mstep_obs_kernel");

@@ -275,7 +275,8 @@ int dfm_em_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, con
  * one joint regression per series on (g_t, f_t) over its observed periods; A, Q, mu0, P0 as dfm_em_batch (oracle/obs_oracle.py).
  * G [B][T][r_o] (no NaN), Lam [B][N][r_o + r_u] with the OBSERVED-factor loadings first, A / Q / P0 [B][r_u][r_u], mu0 [B][r_u];
  * f_smooth [B][T][r_u], P_smooth [B][T][r_u(r_u+1)/2] (may be NULL); bookkeeping (loglik_path, iters, tol) as dfm_em_batch.
- * r_o >= 1, r_u >= 1, r_o + r_u <= 8.  A series with fewer than r_o + r_u + 1 observed cells keeps its loadings and variance. */
+ * r_o >= 1, r_u >= 1, r_o + r_u <= 32 (up to 8: a per-series Cholesky in registers; 9 .. 32: the ordinary loadings step on the
+ * moments of z = (g, f)).  A series with fewer than r_o + r_u + 1 observed cells keeps its loadings and variance. */
 int dfm_em_obs_batch_dev(dfm_handle* h, int B, int T, int N, int r_u, int r_o, const double* panel, const double* G, double* Lam,
                          double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
                          int* iters, double* f_smooth, double* P_smooth, unsigned flags);

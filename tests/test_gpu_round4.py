@@ -291,3 +291,38 @@ def test_collapse_ks_route(tmp_path):
         assert np.all(np.isfinite(b)), k
         scale = np.maximum(np.abs(a).max(), 1e-300)
         assert np.abs(a - b).max() <= 1e-10 * scale, (k, np.abs(a - b).max(), scale)
+
+
+# ---- observed factors beyond r_o + r_u = 8: the ordinary loadings step on the moments of z = (g, f) -------
+@pytest.mark.parametrize("N,T,ru,ro,missing", [
+    (60, 150, 6, 4, 0.0),      # width 10 -> 16, state Rp = 8, balanced panel (every series takes the shared inverse)
+    (80, 160, 9, 3, 0.1),      # width 12 -> 16, state Rp = 16, per-series solves
+    (300, 200, 12, 8, 0.05),   # width 20 -> 32, N > 256 (two series per lane)
+    (40, 120, 2, 7, 0.0),      # more observed than latent factors
+])
+def test_em_with_many_observed_factors_matches_the_oracle(ctx, N, T, ru, ro, missing):
+    from oracle import obs_oracle as oo
+    B, iters = 2, 4
+    reps = [oo.synth_obs(300 + b, N, T, ru, ro, missing=missing) for b in range(B)]
+    panel = np.stack([x for x, _, _ in reps]); G = np.stack([g for _, g, _ in reps])
+    st = {k: np.stack([p[k] for _, _, p in reps]) for k in KEYS}
+    new, path, its, f, P = ctx.em_obs_batch_host(panel, G, *[st[k] for k in KEYS], max_iter=iters, tol=0.0)
+    for b in range(B):
+        p, opath, out = oo.em_obs(panel[b], G[b], {k: st[k][b] for k in KEYS}, max_iter=iters, tol=0.0)
+        np.testing.assert_allclose(path[b], opath, rtol=1e-9, err_msg=f"loglik path b={b}")
+        for k in KEYS:
+            assert np.abs(new[k][b] - p[k]).max() <= 1e-8 * max(1.0, np.abs(p[k]).max()), (k, b, np.abs(new[k][b] - p[k]).max())
+        assert np.abs(f[b] - out["f_smooth"]).max() <= 1e-8 * np.abs(out["f_smooth"]).max()
+    # a series with fewer than r_o + r_u + 1 observed cells keeps its parameters (as the narrow kernel and the oracle)
+    if missing > 0.0:
+        x2 = panel.copy()
+        x2[:, ro + ru - 2:, 5] = np.nan
+        new2, *_ = ctx.em_obs_batch_host(x2, G, *[st[k] for k in KEYS], max_iter=2, tol=0.0)
+        assert np.array_equal(new2["Lam"][:, 5], st["Lam"][:, 5]) and np.array_equal(new2["R"][:, 5], st["R"][:, 5])
+        for b in range(B):
+            p, _, _ = oo.em_obs(x2[b], G[b], {k: st[k][b] for k in KEYS}, max_iter=2, tol=0.0)
+            assert np.abs(new2["Lam"][b] - p["Lam"]).max() <= 1e-8 * max(1.0, np.abs(p["Lam"]).max())
+    from dynamic_factor_models_amd import DfmError
+    with pytest.raises(DfmError):                                  # r_o + r_u = 33
+        ctx.em_obs_batch_host(np.zeros((1, 50, 40)), np.zeros((1, 50, 17)), np.zeros((1, 40, 33)), np.ones((1, 40)),
+                              np.zeros((1, 16, 16)), np.eye(16)[None], np.zeros((1, 16)), np.eye(16)[None], max_iter=1)
