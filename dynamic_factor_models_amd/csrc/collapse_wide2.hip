@@ -203,8 +203,11 @@ __global__ __launch_bounds__(kPrepThreads) void wide_prep_kernel(CollapseArgs a,
 template <int R, int NX, int MODE>
 __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs a, const double* __restrict__ Wall,
                                                                    const double* __restrict__ rinvAll, int npad, int* ctr,
-                                                                   int ntile, int xcd_map, int abl_, int rd) {
+                                                                   int ntile, int xcd_map, int abl_, int rd, int lamd_) {
     constexpr bool DIAG = MODE == 1, MISS = MODE == 2;
+    // lamd: the B operands are the LOADINGS themselves (DMA'd straight from CollapseArgs::Lam, the half swap of odd series applied by
+    // the source addresses) and the A operand is x / R -- the product x (1 / R) the s_t term forms anyway; wide_prep then writes no W
+    const bool lamd = !MISS && R == 32 && lamd_ != 0;
     static_assert((R == 32 && NX >= 1 && NX <= 4) || (R == 16 && NX == 0), "R = 32: 1..4 column groups past the first 16; R = 16: none");
     using GEO = W2Geo<R>;
     constexpr int N4 = NX < 4 ? NX : 0;                       // 4x4x4 groups
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
         auto issue_dma = [&](int b, int t0, int ch, int bsel) {
             if (abl & 32) return;                             // (diagnostics: compute only)
             const char* Xb = reinterpret_cast<const char*>(a.panel + (size_t)b * T * N);
-            const char* Wb = reinterpret_cast<const char*>(Wall + (size_t)b * N * R);
+            const char* Wb = lamd ? reinterpret_cast<const char*>(a.Lam + (size_t)b * N * R) : reinterpret_cast<const char*>(Wall + (size_t)b * N * R);
             const char* Rb = reinterpret_cast<const char*>(rinvAll + (size_t)b * npad);
             const unsigned sbase = lds0 + (unsigned)bsel * kW2StageB;
             const int h = lane >> 4;                          // row of the group; its lane u fetches piece (u - h) mod 16
@@ -292,7 +295,9 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
             for (int u = 0; u < GEO::WPieces; ++u) {   // past the end of W -- the last, partial stage -- the lanes re-read its last 16 bytes; those rows only ever meet a zeroed A
                 const unsigned o = (unsigned)ch * GEO::WB + (unsigned)(GEO::WPieces * pw + u) * 1024u + 16u * lane;
                 const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + (unsigned)(GEO::WPieces * pw + u) * 1024u);
-                dma16w(Wb + (o < wbytes ? o : wbytes - 16u), dst);
+                unsigned oo = o < wbytes ? o : wbytes - 16u;
+                if (lamd) oo ^= (oo & 256u) >> 1;           // odd series (256-byte rows): 16-byte unit u <- u ^ 8, i.e. byte offset ^ 128
+                dma16w(Wb + oo, dst);
             }
             if (pw == 0) {                  // 1 / R of the stage's 32 series (the table is padded with zeros to a whole stage)
                 const unsigned dst = __builtin_amdgcn_readfirstlane(sbase + kW2PanelB + kW2WB);
@@ -441,12 +446,14 @@ __global__ __launch_bounds__(kW2Threads) void collapse_wide2_kernel(CollapseArgs
                     nmis += nanv ? 1.0 : 0.0;
                     lmis += nanv ? lr[MISS ? s : 0] : 0.0;
                 }
-                if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[s], acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bv[s], acc0, 0, 0, 0);
-                if (NX == 4) accb = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bvb[NX == 4 ? s : 0], accb, 0, 0, 0);
+                const double ar = a_ * ri[s];                 // x / R
+                const double am = lamd ? ar : a_;             // A operand: x / R against the loadings, x against W = lam / R
+                if (s & 1) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[s], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bv[s], acc0, 0, 0, 0);
+                if (NX == 4) accb = __builtin_amdgcn_mfma_f64_16x16x4f64(am, bvb[NX == 4 ? s : 0], accb, 0, 0, 0);
 #pragma unroll
-                for (int x = 0; x < N4; ++x) acc4[x] = __builtin_amdgcn_mfma_f64_4x4x4f64(a_, b4v[x][s], acc4[x], 0, 0, 0);
-                qs = fma(a_ * ri[s], a_, qs);                 // s_t = sum_i x_it^2 / R_i from the same register
+                for (int x = 0; x < N4; ++x) acc4[x] = __builtin_amdgcn_mfma_f64_4x4x4f64(am, b4v[x][s], acc4[x], 0, 0, 0);
+                qs = fma(ar, a_, qs);                         // s_t = sum_i x_it^2 / R_i from the same register
             }
         }
         stamp(3);
@@ -788,6 +795,13 @@ size_t collapse_wide2_ws_bytes(int B, int N, int Rpad) {
     return ((size_t)B * N * w2_compute_width(Rpad) + 2 * (size_t)B * npad) * sizeof(double) + 64;
 }
 
+// Rp = 32, balanced: the collapse takes the loadings and 1 / R themselves (collapse_wide2_kernel `lamd`), wide_prep writes no W.
+// DFM_WIDE_W=1 (route): the W table as before.
+static bool wide2_lam_direct(int Rpad, bool missing) {
+    static const bool off = [] { const char* v = route_env("DFM_WIDE_W"); return v && atoi(v) != 0; }();
+    return !off && Rpad == 32 && !missing;
+}
+
 namespace {
 struct W2Ws { double* W; double* rinv; double* logr; int* ctr; int npad; };
 W2Ws w2_ws(const CollapseArgs& a, double* ws, int Rpad) {
@@ -800,7 +814,7 @@ W2Ws w2_ws(const CollapseArgs& a, double* ws, int Rpad) {
     return w;
 }
 template <int R, int NX, int MODE>
-hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s, int rd = R) {
+hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s, int rd = R, int lamd = 0) {
     static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_wide2_kernel<R, NX, MODE>),
@@ -808,20 +822,21 @@ hipError_t launch_w2v(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, i
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((collapse_wide2_kernel<R, NX, MODE>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl, rd);
+    hipLaunchKernelGGL((collapse_wide2_kernel<R, NX, MODE>), dim3((unsigned)G), dim3(kW2Threads), lds, s, a, w.W, w.rinv, w.npad, w.ctr, ntile, xcd_map, abl, rd, lamd);
     return hipGetLastError();
 }
 template <int NX>
 hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, int ntile, int xcd_map, int abl, hipStream_t s) {
     if (a.nobs != nullptr) return launch_w2v<32, NX, 2>(a, w, G, lds, ntile, xcd_map, 0, s);   // panel with missing cells
-    return abl ? launch_w2v<32, NX, 1>(a, w, G, lds, ntile, xcd_map, abl, s) : launch_w2v<32, NX, 0>(a, w, G, lds, ntile, xcd_map, 0, s);
+    const int lamd = wide2_lam_direct(32, false) ? 1 : 0;
+    return abl ? launch_w2v<32, NX, 1>(a, w, G, lds, ntile, xcd_map, abl, s, 32, lamd) : launch_w2v<32, NX, 0>(a, w, G, lds, ntile, xcd_map, 0, s, 32, lamd);
 }
 }  // namespace
 
 hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s, int r) {
     note_kernel("wide_prep_kernel");
     const W2Ws w = w2_ws(a, ws, Rpad);
-    const bool ks = r > 0 && collapse_ks_supported(Rpad, r, a.N, a.nobs != nullptr);   // no W table for that collapse
+    const bool ks = (r > 0 && collapse_ks_supported(Rpad, r, a.N, a.nobs != nullptr)) || wide2_lam_direct(Rpad, a.nobs != nullptr);   // no W table for these
     if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad);
     else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(kPrepThreads), 0, s, a, ks ? nullptr : w.W, w.rinv, w.logr, w.npad, w.ctr, 32);
     return hipGetLastError();
