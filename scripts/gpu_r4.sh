@@ -19,6 +19,8 @@ cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv 
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_c4_missing10.csv 2>/dev/null; rm -rf $OUT/stats
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --N 1000 --T 2000 --r 20 --batch-per-gpu 256 --missing 0.1 --mode em --steps 2 --warmup 1 --repeats 2 --no-cpu-baseline --no-secondary > $OUT/bench_c4m_em_under_rocprof.json 2> $OUT/bench_c4m_em_under_rocprof.err)
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_c4_em_missing10.csv 2>/dev/null; rm -rf $OUT/stats
+(cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --N 1000 --T 2000 --r 20 --batch-per-gpu 256 --steps 10 --warmup 2 --repeats 3 --no-cpu-baseline --no-secondary > $OUT/bench_c4_under_rocprof.json 2> $OUT/bench_c4_under_rocprof.err)
+cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_c4.csv 2>/dev/null; rm -rf $OUT/stats
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python $R/bench.py --mode em --steps 20 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary > $OUT/bench_em_under_rocprof.json 2> $OUT/bench_em_under_rocprof.err)
 cp $(find $OUT/stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats_em.csv 2>/dev/null; rm -rf $OUT/stats
 if [ -z "$SKIP_PMC" ]; then
@@ -33,7 +35,12 @@ if [ -z "$SKIP_PMC" ]; then
   (cd /tmp && K=2 B=256 N=1000 T=2000 R=20 MISSING=0.1 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c4m/pmc_write -o p -- python $R/scripts/gpu_trace.py > /dev/null 2> $OUT/c4m/pmc_write.err)
   [ -d $OUT/pmc_calib ] && cp -r $OUT/pmc_calib $OUT/c4m/pmc_calib
   DFM_PMC_WORKLOAD=pass:B256:N1000:T2000:r20:m0.1 python scripts/pmc_summary.py $OUT/c4m > $OUT/pmc_traffic_c4_missing10.json 2>> $OUT/pmc_summary.err
-  rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_calib $OUT/c4m
+  mkdir -p $OUT/c4
+  (cd /tmp && K=4 B=256 N=1000 T=2000 R=20 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/c4/pmc_fetch -o p -- python $R/scripts/gpu_trace.py > /dev/null 2> $OUT/c4/pmc_fetch.err)
+  (cd /tmp && K=4 B=256 N=1000 T=2000 R=20 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/c4/pmc_write -o p -- python $R/scripts/gpu_trace.py > /dev/null 2> $OUT/c4/pmc_write.err)
+  [ -d $OUT/pmc_calib ] && cp -r $OUT/pmc_calib $OUT/c4/pmc_calib
+  DFM_PMC_WORKLOAD=pass:B256:N1000:T2000:r20:m0.0 python scripts/pmc_summary.py $OUT/c4 > $OUT/pmc_traffic_c4.json 2>> $OUT/pmc_summary.err
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_calib $OUT/c4m $OUT/c4
 fi
 tail -6 $OUT/pytest_gpu.log 2>/dev/null; cat $OUT/smoke.log 2>/dev/null
 python - $OUT/bench.json <<'PY'
