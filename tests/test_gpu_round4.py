@@ -326,3 +326,21 @@ def test_em_with_many_observed_factors_matches_the_oracle(ctx, N, T, ru, ro, mis
     with pytest.raises(DfmError):                                  # r_o + r_u = 33
         ctx.em_obs_batch_host(np.zeros((1, 50, 40)), np.zeros((1, 50, 17)), np.zeros((1, 40, 33)), np.ones((1, 40)),
                               np.zeros((1, 16, 16)), np.eye(16)[None], np.zeros((1, 16)), np.eye(16)[None], max_iter=1)
+
+
+# ---- balanced wide states at every padding width: cov_tile_kernel's block pivots (ceil(r / 4) of 8), the mean scan's state pieces
+# (ceil(r / 8) of 4), the unpadded b_t rows of the streaming collapse -- pass and three EM iterations against the oracle ----------
+@pytest.mark.parametrize("N,T,r", [(64, 140, 17), (300, 90, 21), (64, 70, 24), (520, 60, 25), (64, 130, 31), (96, 80, 32), (64, 1, 20), (64, 2, 18)])
+def test_balanced_wide_states_at_every_width(ctx, N, T, r):
+    from test_gpu_ks_pass import _batch, _run_dev
+    Tg = max(T, 8)
+    panel, st = _batch(3, N, Tg, r, 0.0, seed=ko.SEED0 + 31 * r + N)
+    panel = np.ascontiguousarray(panel[:, :T])
+    _compare(_run_dev(ctx, panel, st, may_have_missing=False), _oracle(panel, st), f"balanced N={N} T={T} r={r}")
+    if T >= 60:
+        new, gpath, _, _, _ = ctx.em_batch_host(panel, *[st[k] for k in KEYS], max_iter=3, tol=0.0, may_have_missing=False)
+        for b in range(panel.shape[0]):
+            p, path, _ = ko.em(panel[b], {k: st[k][b] for k in KEYS}, max_iter=3, tol=0.0)
+            np.testing.assert_allclose(gpath[b], path, rtol=1e-9)
+            for k in KEYS:
+                assert np.abs(new[k][b] - p[k]).max() <= 1e-8 * max(1.0, np.abs(p[k]).max()), (k, b, r, np.abs(new[k][b] - p[k]).max())
