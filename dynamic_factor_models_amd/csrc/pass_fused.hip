@@ -89,7 +89,13 @@ constexpr int kPfNst = stead_mats(kPfR);                    // steady Z, J, G + 
 constexpr int kPfNlev = scan_levels(kPfR);
 constexpr int kPfScanWaves = kScanThreads / 64;             // 4
 constexpr int kPfMaxCov = 2;
-constexpr int kPfDeferDefault = 1;                          // P_smooth fills left to the stream waves' tail (replicates per workgroup)
+// (development A/B: -DDFM_PF_DEFER=n.  Round 4, with the non-temporal panel stream: 1 -> 0.2064 ms, 2 -> 0.2044, 3 -> 0.2015, 4 -> 0.1955 at
+//  B = 1024 in one process, all the same at B = 8192 -- profiles/r04/ab_pf_defer.txt.  While the panel streams HBM is the bottleneck and
+//  every byte of fill costs stream time; the scan-only tail of the kernel has the bandwidth to spare.)
+#ifndef DFM_PF_DEFER
+#define DFM_PF_DEFER 4
+#endif
+constexpr int kPfDeferDefault = DFM_PF_DEFER;                          // P_smooth fills left to the stream waves' tail (replicates per workgroup)
 constexpr int kPfMaxWaves = 12;                             // 3 waves per SIMD: 168 VGPRs each
 constexpr int kPfMaxThreads = 64 * kPfMaxWaves;
 constexpr unsigned kPfLdsLimit = 160u * 1024u;
