@@ -1115,14 +1115,18 @@ __global__ __launch_bounds__(kPfMaxThreads) void pass_fused_kernel(CollapseArgs 
         const bool use_reg = fa.L <= kRegL && (fa.abl & 512) == 0;    // DFM_SCAN_ABL bit 9: the round-2 scan (A/B)
         const int prio_mode = (fa.abl & 1024) ? 1 : (fa.abl & 2048) ? 2 : 0;   // bit 10: always 3; bit 11: always 0
 #else
-        constexpr int prio_mode = 0;                              // (the launcher admits L <= kRegL only: pass_fused_supported)
+#ifndef DFM_PF_PRIO_MODE
+#define DFM_PF_PRIO_MODE 0
+#endif
+        constexpr int prio_mode = DFM_PF_PRIO_MODE;               // (development A/B: 1 = always 3, 2 = always 0; the launcher admits L <= kRegL only: pass_fused_supported)
 #endif
         // Priority.  The scan is the pipeline's latency chain only while somebody waits for it: the first replicate of the
         // workgroup (everything behind it waits), or a stream that has run out of b_t buffers.  Otherwise it runs BESIDE a
         // stream that is the bottleneck, and at high priority its bursts delay the stream waves' DMA issue (measured at
         // B = 8192: -4 % with the faster scan at priority 3 throughout).
         auto set_prio = [&](int j) {
-            const bool hot = prio_mode == 1 || (prio_mode == 0 && (j == 0 || ld_flag(flags + kFStreamWaits) != 0));
+            const bool hot = prio_mode == 1 || (prio_mode == 0 && (j == 0 || ld_flag(flags + kFStreamWaits) != 0)) ||
+                             (prio_mode == 3 && ld_flag(flags + kFStreamWaits) != 0) || (prio_mode == 4 && j == 0);
             if (hot) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
         };
