@@ -220,7 +220,6 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         if (fast && mstep_mfma_supported(Rp, N)) {
             int w = (256 * 12) / B;
             w = w < 1 ? 1 : (w > 8 ? 8 : w);
-            if (B >= 512) w = 4;                             // one workgroup of four segment waves per replicate: the finish rides in the launch (mstep_mfma.hip)
             while (w > 1 && T / w < 8) --w;
             p.ms_wpr = w;
             p.ms_ws = take(off, mstep_mfma_workspace(B, N, Rp, w));

@@ -64,56 +64,9 @@ __host__ __device__ inline unsigned ms_slot_bytes(int N) {   // as collapse_mfma
     return sb;
 }
 
-// the loadings step's finish for replicate b by 256 threads (thread = series); smat: 2 R R doubles of LDS
-template <int R>
-__device__ __forceinline__ void ms_finish(const MstepArgs& a, int b, int wpr, const double* part_sxf, const double* part_sxx, double* smat, int tid) {
-    double* s11 = smat;
-    double* s11i = smat + R * R;
-    const int N = a.N;
-    for (int e = tid; e < R * R; e += 256) {
-        s11[e] = a.S11[(size_t)b * R * R + e];
-        s11i[e] = a.S11inv[(size_t)b * R * R + e];
-    }
-    __syncthreads();
-    for (int col = tid; col < N; col += 256) {
-        asm volatile("" ::: "memory");                        // (the 2 R R matrix entries are re-read from LDS per series, not hoisted into 256 registers)
-
-        double sxf[R], sxx = 0.0;
-#pragma unroll
-        for (int k = 0; k < R; ++k) sxf[k] = 0.0;
-        for (int w = 0; w < wpr; ++w) {
-            const double* ps = part_sxf + (((size_t)b * wpr + w) * N + col) * R;
-#pragma unroll
-            for (int k = 0; k < R; ++k) sxf[k] += ps[k];
-            sxx += part_sxx[((size_t)b * wpr + w) * N + col];
-        }
-        double lam[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < R; ++k) s = fma(s11i[i * R + k], sxf[k], s);
-            lam[i] = s;
-        }
-        double quad = 0.0, cross = 0.0;
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < R; ++k) s = fma(s11[i * R + k], lam[k], s);
-            quad = fma(lam[i], s, quad);
-            cross = fma(lam[i], sxf[i], cross);
-        }
-        a.R_out[(size_t)b * N + col] = (sxx - 2.0 * cross + quad) / (double)a.T;
-        double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
-#pragma unroll
-        for (int k = 0; k < R; ++k) lo[k] = lam[k];
-    }
-}
-
 template <int R, int STEPS, int NDR>
 __global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigned SB, int wpr, double* part_sxf, double* part_sxx, EmUpdArgs ua,
-                                                            int nfront_, int dma_nt, int wg_mode) {
+                                                            int nfront_, int dma_nt) {
     using G = MsGeo<R>;
     constexpr int NB = 2, NS = 4 * NB, CS = G::CS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,28 +78,18 @@ __global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigne
     // is its only consumer.  Streaming waves may read `active` before or after its update: a replicate that stops in this
     // iteration then computes sums nobody uses -- except in iteration 0, where the array is still UNINITIALISED until the front
     // waves have written it (every replicate is active then by definition): nfront < 0 says "do not look at it".
-    // wg_mode (bit 0; wpr == 4): ONE workgroup per replicate -- wave 0 runs the transition step of ITS replicate, then the four waves
-    // stream its four segments, meet at a barrier and finish (sum of the partial sums, lam, R: mstep_finish_kernel's work) as 256
-    // threads.  Everything the finish needs was produced inside the workgroup: no launch of its own, no device-scope hand-over (a
-    // counter + fences version across workgroups ran 3 x slower: profiles/r04/ab_mstep_finish_in_launch.txt).  Bit 1: iteration 0.
-    const bool wg = (wg_mode & 1) != 0;
-    const int nfront = wg ? 0 : (nfront_ < 0 ? -nfront_ : nfront_);
-    const bool trust_active = wg ? (wg_mode & 2) == 0 : nfront_ >= 0;
-    if (!wg && (int)blockIdx.x < nfront) {
+    const int nfront = nfront_ < 0 ? -nfront_ : nfront_;
+    const bool trust_active = nfront_ >= 0;
+    if ((int)blockIdx.x < nfront) {
         const int be = (int)blockIdx.x * 4 + wave;
         constexpr int kEmDoubles = (64 / R) * (R * R + 2 * R);
         em_update_wave<R>(ua, be < ua.B ? be : ua.B - 1, be < ua.B, lane, reinterpret_cast<double*>(smem) + wave * kEmDoubles);
         return;
     }
-    const int gw = wg ? (int)blockIdx.x * 4 + wave : ((int)blockIdx.x - nfront) * 4 + wave;
-    if (gw >= a.B * wpr) return;                              // (wg: wpr == 4, never)
+    const int gw = ((int)blockIdx.x - nfront) * 4 + wave;
+    if (gw >= a.B * wpr) return;
     const int b = gw / wpr, segi = gw % wpr;
-    const bool skip = trust_active && a.active && !a.active[b];   // (a converged replicate is not streamed)
-    if (skip && !wg) return;
-    if (wg && wave == 0 && ua.fsm != nullptr) {               // the transition step of this replicate (scratch: this wave's ring, not yet in use)
-        em_update_wave<R>(ua, b, true, lane, reinterpret_cast<double*>(smem));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    if (trust_active && a.active && !a.active[b]) return;
     const int N = a.N, T = a.T;
     const unsigned rowB = (unsigned)N * 8u;
     const int K = lane >> 4, blk = (lane >> 2) & 3, q = lane & 3;
@@ -161,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigne
     }
     const int ta = (segi * tq < T) ? segi * tq : T;
     const int tb = (ta + tq < T) ? ta + tq : T;
-    const int nrows = skip ? 0 : tb - ta;
+    const int nrows = tb - ta;
     const int nblk = (nrows + 3) / 4;
     const char* __restrict__ seg = reinterpret_cast<const char*>(a.panel + ((size_t)b * T + ta) * N);
     const double* __restrict__ fseg = a.fsm + ((size_t)b * T + ta) * R;
@@ -304,19 +247,52 @@ __global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigne
         if (c < N) px[c] = qa[j][0];
         if (c + 1 < N) px[c + 1] = qa[j][1];
     }
-    if (!wg) return;                                          // (mstep_finish_kernel follows)
-    __syncthreads();                                          // the four segments' partial sums, S11 / S11^-1 / active of wave 0: all of this workgroup
-    if (a.active && !a.active[b]) return;
-    ms_finish<R>(a, b, wpr, part_sxf, part_sxx, reinterpret_cast<double*>(smem), (int)threadIdx.x);
 }
 
 // thread = series: add the segments' partial sums, lam_i = S11^-1 Sxf_i, R_i = (Sxx_i - 2 lam_i'Sxf_i + lam_i'S11 lam_i) / T
 template <int R>
 __global__ __launch_bounds__(256, 2) void mstep_finish_kernel(MstepArgs a, int wpr, const double* part_sxf, const double* part_sxx) {
-    __shared__ double smat[2 * R * R];
+    __shared__ double s11[R * R], s11i[R * R];
     const int b = blockIdx.x;
     if (a.active && !a.active[b]) return;
-    ms_finish<R>(a, b, wpr, part_sxf, part_sxx, smat, (int)threadIdx.x);
+    const int N = a.N;
+    for (int e = threadIdx.x; e < R * R; e += 256) {
+        s11[e] = a.S11[(size_t)b * R * R + e];
+        s11i[e] = a.S11inv[(size_t)b * R * R + e];
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < N; col += 256) {
+        double sxf[R], sxx = 0.0;
+#pragma unroll
+        for (int k = 0; k < R; ++k) sxf[k] = 0.0;
+        for (int w = 0; w < wpr; ++w) {
+            const double* ps = part_sxf + (((size_t)b * wpr + w) * N + col) * R;
+#pragma unroll
+            for (int k = 0; k < R; ++k) sxf[k] += ps[k];
+            sxx += part_sxx[((size_t)b * wpr + w) * N + col];
+        }
+        double lam[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) s = fma(s11i[i * R + k], sxf[k], s);
+            lam[i] = s;
+        }
+        double quad = 0.0, cross = 0.0;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < R; ++k) s = fma(s11[i * R + k], lam[k], s);
+            quad = fma(lam[i], s, quad);
+            cross = fma(lam[i], sxf[i], cross);
+        }
+        a.R_out[(size_t)b * N + col] = (sxx - 2.0 * cross + quad) / (double)a.T;
+        double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
+#pragma unroll
+        for (int k = 0; k < R; ++k) lo[k] = lam[k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,19 +313,9 @@ static hipError_t launch_ms_one(const MstepArgs& a, int wpr, double* pf, double*
     }
     EmUpdArgs u0;
     memset(&u0, 0, sizeof(u0));
-    const int dnt = stream_nt_hint((size_t)a.B * a.T * a.N * sizeof(double)) ? 1 : 0;
-    static const bool wg_off = [] { const char* v = route_env("DFM_MSTEP_FINISH"); return v && atoi(v) != 0; }();   // =1: the finish as its own launch
-    // Measured (profiles/r04/ab_mstep_layouts.txt, EM iteration at C2): B = 1024: front waves + segment waves + finish launch 0.395 ms (0.41-0.43
-    // with three segments per replicate, the round-3 choice), one workgroup per replicate 0.408; B = 8192: 3.10 against 2.99 -- the launch of
-    // the finish and the front waves' head start pay while a CU holds a few replicates, the self-contained workgroup once it holds many.
-    if (wpr == 4 && !wg_off && a.B >= 4096) {                 // one workgroup per replicate: transition step, stream, finish (see the kernel)
-        hipLaunchKernelGGL((mstep_mfma_kernel<R, STEPS, NDR>), dim3(a.B), dim3(256), lds, s, a, SB, wpr, pf, px, ua ? *ua : u0, 0, dnt,
-                           1 | ((ua && ua->k == 0) ? 2 : 0));
-        return hipGetLastError();
-    }
     const int nfront = ua ? (a.B + 3) / 4 : 0;                // transition M-step waves in front of the streaming workgroups
     hipLaunchKernelGGL((mstep_mfma_kernel<R, STEPS, NDR>), dim3((a.B * wpr + 3) / 4 + nfront), dim3(256), lds, s, a, SB, wpr, pf, px, ua ? *ua : u0,
-                       (ua && ua->k == 0) ? -nfront : nfront, dnt, 0);
+                       (ua && ua->k == 0) ? -nfront : nfront, stream_nt_hint((size_t)a.B * a.T * a.N * sizeof(double)) ? 1 : 0);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((mstep_finish_kernel<R>), dim3(a.B), dim3(256), 0, s, a, wpr, (const double*)pf, (const double*)px);
