@@ -344,3 +344,31 @@ def test_balanced_wide_states_at_every_width(ctx, N, T, r):
             np.testing.assert_allclose(gpath[b], path, rtol=1e-9)
             for k in KEYS:
                 assert np.abs(new[k][b] - p[k]).max() <= 1e-8 * max(1.0, np.abs(p[k]).max()), (k, b, r, np.abs(new[k][b] - p[k]).max())
+
+
+# ---- BASELINE config 4 at the BENCHMARKED batch (256 replicates, one workgroup of every persistent kernel per CU): scattered
+# replicates with their own parameters against the oracle -- the pass (cov_tile + collapse_wide2 + meanscan_mfma + pfill) and two EM
+# iterations (+ em_update_grid + mstep_wide) ---------------------------------------------------------------------------------------
+def test_config4_at_the_benchmarked_batch_against_the_oracle(ctx):
+    import torch
+    B, N, T, r = 256, 1000, 2000, 20
+    panel, par = ctx.synth_panels(404, 0, B, T, N, r)
+    f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(ll).all())
+    ix = torch.tensor([0, 1, 37, 128, 255], device=panel.device)
+    x = _take(panel, ix)
+    st = dict(zip(KEYS, [_take(p, ix) for p in par]))
+    _compare((_take(f, ix), _take(P, ix), _take(ll, ix)), _oracle(x, st), "config 4 at B = 256")
+    q = [p.clone() for p in par]
+    path, its, _, _ = ctx.em_batch(panel, *q, max_iter=2, tol=0.0, want_smooth=False, may_have_missing=False)
+    torch.cuda.synchronize()
+    new = dict(zip(KEYS, [_take(p, ix) for p in q]))
+    gp = _take(path, ix)
+    for k in range(2):                                             # (two replicates: the NumPy EM at this size takes seconds each)
+        p, opath, _ = ko.em(x[k], {kk: st[kk][k] for kk in KEYS}, max_iter=2, tol=0.0)
+        np.testing.assert_allclose(gp[k], opath, rtol=1e-9)
+        for kk in KEYS:
+            assert np.abs(new[kk][k] - p[kk]).max() <= 1e-8 * max(1.0, np.abs(p[kk]).max()), (kk, k, np.abs(new[kk][k] - p[kk]).max())
+    del panel, f, P
+    torch.cuda.empty_cache()
