@@ -21,11 +21,14 @@ namespace dfm {
 // Solve the SPD system S x = rhs (S packed lower, row-major) by Cholesky.  R <= 8: fully unrolled
 // (compile-time indices, everything in registers).  Larger R: plain loops over a private array
 // (only series with missing cells take this path).
+// Returns false when a pivot is not positive (S not positive definite to working precision: the caller keeps the series'
+// parameters, as mstep_obs_kernel and mmw_finish_kernel do); x is then unspecified.
 template <int R>
-__device__ __forceinline__ void chol_solve_packed(const double (&S)[R * (R + 1) / 2], const double (&rhs)[R],
+__device__ __forceinline__ bool chol_solve_packed(const double (&S)[R * (R + 1) / 2], const double (&rhs)[R],
                                                   double (&x)[R]) {
     double L[R * (R + 1) / 2];
     double y[R];
+    bool ok = true;
     if constexpr (R <= 8) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -34,7 +37,7 @@ __device__ __forceinline__ void chol_solve_packed(const double (&S)[R * (R + 1) 
                 double s = S[i * (i + 1) / 2 + j];
 #pragma unroll
                 for (int k = 0; k < j; ++k) s = fma(-L[i * (i + 1) / 2 + k], L[j * (j + 1) / 2 + k], s);
-                if (j == i) L[i * (i + 1) / 2 + j] = sqrt(s);
+                if (j == i) { ok = ok && (s > 0.0); L[i * (i + 1) / 2 + j] = sqrt(s > 0.0 ? s : 1.0); }
                 else L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
             }
         }
@@ -60,7 +63,7 @@ __device__ __forceinline__ void chol_solve_packed(const double (&S)[R * (R + 1) 
                 double s = S[i * (i + 1) / 2 + j];
 #pragma unroll 1
                 for (int k = 0; k < j; ++k) s = fma(-L[i * (i + 1) / 2 + k], L[j * (j + 1) / 2 + k], s);
-                if (j == i) L[i * (i + 1) / 2 + j] = sqrt(s);
+                if (j == i) { ok = ok && (s > 0.0); L[i * (i + 1) / 2 + j] = sqrt(s > 0.0 ? s : 1.0); }
                 else L[i * (i + 1) / 2 + j] = s / L[j * (j + 1) / 2 + j];
             }
         }
@@ -79,6 +82,7 @@ __device__ __forceinline__ void chol_solve_packed(const double (&S)[R * (R + 1) 
             x[i] = s / L[i * (i + 1) / 2 + i];
         }
     }
+    return ok;
 }
 
 template <int R, int CPL, bool REGD>
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
                     else d = dmg[(size_t)col * NP + v];
                     Sff[v] = 0.5 * (S11[i * R + jj] + S11[jj * R + i]) - d;
                 }
-            chol_solve_packed<R>(Sff, sxf[j], lam);
+            if (!chol_solve_packed<R>(Sff, sxf[j], lam)) continue;   // not positive definite: the series keeps its parameters
             quad = 0.0;
 #pragma unroll
             for (int i = 0; i < R; ++i) {
