@@ -250,8 +250,10 @@ __global__ __launch_bounds__(256, 2) void mstep_mfma_kernel(MstepArgs a, unsigne
 }
 
 // thread = series: add the segments' partial sums, lam_i = S11^-1 Sxf_i, R_i = (Sxx_i - 2 lam_i'Sxf_i + lam_i'S11 lam_i) / T
+// (8 waves per SIMD = 64 VGPRs: all 1024 workgroups of a C2 batch are resident at once -- at 2 per SIMD the kernel ran as two rounds of a
+// latency chain, 29 us for a few loads and 150 flops per series)
 template <int R>
-__global__ __launch_bounds__(256, 2) void mstep_finish_kernel(MstepArgs a, int wpr, const double* part_sxf, const double* part_sxx) {
+__global__ __launch_bounds__(256, 8) void mstep_finish_kernel(MstepArgs a, int wpr, const double* part_sxf, const double* part_sxx) {
     __shared__ double s11[R * R], s11i[R * R];
     const int b = blockIdx.x;
     if (a.active && !a.active[b]) return;
@@ -262,6 +264,7 @@ __global__ __launch_bounds__(256, 2) void mstep_finish_kernel(MstepArgs a, int w
     }
     __syncthreads();
     for (int col = threadIdx.x; col < N; col += 256) {
+        asm volatile("" ::: "memory");                        // (the 2 R R matrix entries are re-read from LDS per series, not hoisted into 256 registers)
         double sxf[R], sxx = 0.0;
 #pragma unroll
         for (int k = 0; k < R; ++k) sxf[k] = 0.0;
