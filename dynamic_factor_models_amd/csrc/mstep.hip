@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
     // wave-uniform, R + NP doubles a period) are in flight while group g is processed: rows into registers, moments
     // through a double-buffered LDS tile that all four waves read back as broadcasts -- a period no longer waits for
     // its own (scalar) loads.
-    constexpr int UN = (R <= 8) ? 8 : 4;
+#ifndef DFM_MSTEP_UN8
+#define DFM_MSTEP_UN8 8
+#endif
+    constexpr int UN = (R <= 8) ? DFM_MSTEP_UN8 : 4;          // (development A/B: -DDFM_MSTEP_UN8=n; 16 and 24 periods ahead are SLOWER -- 0.574 / 0.598 / 0.945 ms: the kernel is bound by its masked moment updates, not by bytes in flight)
     constexpr int PER = R + NP;                               // moments per period
     constexpr int NLD = (UN * PER + 255) / 256;               // loads per thread and group
     __shared__ double mom[2][UN * PER];
