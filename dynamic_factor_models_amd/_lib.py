@@ -54,6 +54,7 @@ SYMBOLS = {
     "dfm_set_stream": (c_int, [c_vp, c_vp]),
     "dfm_synchronize": (c_int, [c_vp]),
     "dfm_check_status": (c_int, [c_vp]),
+    "dfm_chunk_fallbacks": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "dfm_last_error": (ctypes.c_char_p, [c_vp]),
     "dfm_version": (ctypes.c_char_p, []),
     "dfm_profile_enable": (c_int, [c_vp, c_int]),

@@ -56,6 +56,7 @@ struct dfm_handle {
     bool cov_wave = false;                 // DFM_COV_WAVE=1: one-wave-per-replicate covariance recursion on the separate-launch path
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    const int* ck_fail_dev = nullptr; int ck_fail_n = 0;   // chunk_fail of the last launch on recursion_chunk_kernel (dfm_chunk_fallbacks)
     // EM on the fast path at Rp <= 8: the transition M-step is not launched behind the E-step but handed to the loadings step's
     // streaming launch (mstep_mfma.hip runs it as extra workgroups): em_iteration sets defer_em, enqueue_pass_fast parks the
     // arguments here
@@ -124,6 +125,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t LamP, AP, QP, P0P, mu0P;                // padded parameters (only used when r != Rp)
     size_t bcol, scol, ldrow, nobs, Ct, Cfull, ldfull;
     size_t ZJ, wtab, status, ncov;
+    size_t ck_scr = (size_t)-1, ck_obs = (size_t)-1, ck_cst = (size_t)-1, ck_term = (size_t)-1, ck_fail = (size_t)-1;   // recursion_chunk.hip (Rp = 8, general path)
     size_t S11, S10, S00, P0s, f0s, fsm, Psm, Sxf, Sxx, Dmiss, llbuf, active;
     // balanced fast path (fastpath.hip); (size_t)-1 when the plan is for the general path
     size_t f_tab, f_E, f_stead, f_xi0, f_PT, f_llc, f_fill, f_PsInf, f_ssum;
@@ -202,6 +204,13 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
     // (fast path, Rp >= 16: the mean scan on the matrix pipe keeps the steady part of w_t in a second, chunk-major region behind the
     // T natural rows -- scan_mfma32.hip)
     p.wtab = take(off, (size_t)B * wtab_rows(fast, Rp, T) * Rp * d);
+    if (!fast && !p.cov && Rp == 8) {
+        p.ck_scr = take(off, recursion_chunk_scratch_bytes(B, T));
+        p.ck_obs = take(off, recursion_chunk_obs_bytes(B, T));
+        p.ck_cst = take(off, (size_t)B * 320 * d);
+        p.ck_term = take(off, (size_t)B * 96 * d);
+        p.ck_fail = take(off, (size_t)B * sizeof(int));
+    }
     p.status = take(off, 256);
     p.ncov = take(off, (size_t)B * sizeof(int));
     p.S11 = p.S10 = p.S00 = p.P0s = p.f0s = p.fsm = p.Psm = p.Sxf = p.Sxx = p.Dmiss = p.llbuf = p.active = (size_t)-1;
@@ -664,6 +673,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
     ra.ZJtab = at<double>(h, p.ZJ); ra.wtab = at<double>(h, p.wtab); ra.eidx = nullptr;
+    ra.chunk_scr = at<double>(h, p.ck_scr); ra.chunk_obs = at<double>(h, p.ck_obs); ra.chunk_cst = at<double>(h, p.ck_cst); ra.chunk_term = at<double>(h, p.ck_term); ra.chunk_fail = at<int>(h, p.ck_fail);
     ra.f_smooth = f_smooth; ra.P_smooth = P_smooth; ra.loglik = loglik;
     ra.ncov = at<int>(h, p.ncov);
     if (em) {
@@ -689,6 +699,8 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
             { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_ct_miss_wide(ca, W, p.r, h->stream)); }
         } else { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(Rcol, ca, h->stream)); }
     }
+    h->ck_fail_dev = nullptr; h->ck_fail_n = 0;
+    if (ra.wave && recursion_chunk_supported(p.Rp, ra)) { h->ck_fail_dev = ra.chunk_fail; h->ck_fail_n = B; }
     { ProfScope ps(h, K_RECURSION); HIP_TRY(h, launch_recursion(p.Rp, ra, h->stream)); }
     return 0;
 }
@@ -1311,6 +1323,21 @@ int dfm_synchronize(dfm_handle* h) {
 }
 
 int dfm_check_status(dfm_handle* h) { return dfm_synchronize(h); }
+
+int dfm_chunk_fallbacks(dfm_handle* h, int* n_failed, int* n_total) {
+    if (!h) return DFM_E_NULL;
+    if (!n_failed || !n_total) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
+    *n_failed = 0; *n_total = 0;
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (!h->ck_fail_dev || h->ck_fail_n <= 0) return 0;
+    std::vector<int> host((size_t)h->ck_fail_n);
+    HIP_TRY(h, hipMemcpy(host.data(), h->ck_fail_dev, host.size() * sizeof(int), hipMemcpyDeviceToHost));
+    int nf = 0;
+    for (int v : host) nf += v != 0;
+    *n_failed = nf; *n_total = h->ck_fail_n;
+    return 0;
+}
 
 int dfm_profile_enable(dfm_handle* h, int on) {
     if (!h) return DFM_E_NULL;

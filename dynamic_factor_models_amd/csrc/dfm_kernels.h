@@ -112,7 +112,27 @@ struct RecursionArgs {
     int ct_r;             // > 0: Ct holds the packed leading ct_r x ct_r block per period (see CollapseArgs::ct_r; recursion_tile only)
     int rstate;           // the model's state width before padding (0: unknown) -- recursion_tile.hip executes ceil(rstate / 4) of
                           // the 8 block pivots / k-steps of a 32-wide state and keeps the mean vectors in (padding) column 31
+    // time-chunked recursion (recursion_chunk.hip; Rp = 8, information form): a replicate's T periods as 64 chunks of chunk_L, one per
+    // lane of a wave, each lane warmed up over chunk_W periods; scratch owned by the handle's workspace
+    double* chunk_scr;    // [B][chunk_L][22][64][2]  -Z_t (36 packed) and w_t (8) of every period, chunk-major (lane = chunk)
+    double* chunk_cst;    // [B][320]  per-replicate constants (K, K', Q^-1 + Phi, Phi, Om_0 + Phi, xi_0, log-det and quadratic constants)
+    double* chunk_term;   // [B][96]   P_T|T (36), f_T|T (8), P_0|T (36), f_0|T (8)
+    double* chunk_obs;    // [B][chunk_L][23][64][2]  C_t (36 packed), b_t (8), s_t, n_t log 2 pi + log det R_t of every period, chunk-major
+    int chunk_obs_ready;  // 1: the collapse kernel wrote chunk_obs itself (else launch_recursion_chunk transposes the per-period rows)
+    int* chunk_fail;      // [B]       1: a chunk boundary did not agree to chunk_tol -- the replicate belongs to the sequential kernel
+    const int* only_if;   // [B] or null: the sequential kernels (recursion_wave / recursion_pair) run replicate b only if only_if[b] != 0
+    int chunk_L, chunk_W;
+    double chunk_tol;
 };
+
+// Rp = 8, information form, plain factor model (no companion state): the time-chunked recursion
+bool recursion_chunk_supported(int Rpad, const RecursionArgs& a);
+size_t recursion_chunk_scratch_bytes(int B, int T);          // chunk_scr
+size_t recursion_chunk_obs_bytes(int B, int T);              // chunk_obs
+int recursion_chunk_len(int T);                              // chunk_L for a sample of T periods
+hipError_t launch_recursion_chunk(const RecursionArgs& a, hipStream_t s);
+bool recursion_wave8_fits(int T);
+hipError_t launch_recursion_wave8_fallback(const RecursionArgs& a, hipStream_t s);
 
 // Rp = 32, 17 <= rstate <= 31, information form, plain factor model: four waves per replicate, matrices as MFMA accumulator
 // tiles, 4 x 4 block-pivot sweep inverse (recursion_tile.hip)

@@ -632,6 +632,17 @@ static hipError_t launch_rec(const RecursionArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s) {
+    // Rp = 8, information form: the time-chunked recursion, then the sequential kernel for the replicates whose chunk boundaries
+    // did not agree (normally none: the launch then costs its blocks' early exit)
+    if (a.wave && recursion_chunk_supported(Rpad, a)) {
+        hipError_t e = launch_recursion_chunk(a, s);
+        if (e != hipSuccess) return e;
+        RecursionArgs f = a;
+        f.only_if = a.chunk_fail;
+        e = launch_recursion_wave8_fallback(f, s);
+        note_kernel("recursion_chunk_kernel");
+        return e;
+    }
     if (a.wave && recursion_tile_supported(Rpad, a)) return launch_recursion_tile(a, s);
     if (a.wave && recursion_wave_supported(Rpad, a)) return launch_recursion_wave(a, s, Rpad);
     if (a.cov) {

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(R * R, (R == 16 ? DFM_WG16_WAVES : 1)) void recursi
     unsigned long long t_fwd_end = 0, t_bwd_start = 0;
 #endif
     const int b = blockIdx.x;
+    if (a.only_if && a.only_if[b] == 0) return;              // (block-uniform) the replicate was done by recursion_chunk_kernel
     const bool diag = (i == j);
 
     const int Rc = a.Rc > 0 ? a.Rc : R;                      // width of the collapsed observations (state padded beyond it)
@@ -526,6 +527,13 @@ static hipError_t launch_wave_cov(const RecursionArgs& a, hipStream_t s) {
 template <int R>
 static hipError_t launch_wave(const RecursionArgs& a, hipStream_t s) {
     return a.cov ? launch_wave_cov<R, true>(a, s) : launch_wave_cov<R, false>(a, s);
+}
+
+// the sequential kernel for the replicates recursion_chunk_kernel handed back (a.only_if): one wave per replicate at any batch size
+bool recursion_wave8_fits(int T) { return wave_lds_bytes<8>(T) <= 60 * 1024; }
+hipError_t launch_recursion_wave8_fallback(const RecursionArgs& a, hipStream_t s) {
+    note_kernel("recursion_wave_kernel");
+    return launch_wave<8>(a, s);
 }
 
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad) {

@@ -174,6 +174,13 @@ class DfmContext:
             out[name] = g.value
         return out
 
+    def chunk_fallbacks(self):
+        """dfm_chunk_fallbacks: (failed, total) replicates of the last pass that ran on the time-chunked recursion (total = 0:
+        it did not); `failed` of them were redone by the sequential kernel."""
+        nf = ctypes.c_int(); nt = ctypes.c_int()
+        _check(self._h, self._lib.dfm_chunk_fallbacks(self._h, ctypes.byref(nf), ctypes.byref(nt)))
+        return nf.value, nt.value
+
     def profile_enable(self, on: bool = True):
         self._sync_stream()
         _check(self._h, self._lib.dfm_profile_enable(self._h, 1 if on else 0))

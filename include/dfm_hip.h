@@ -91,6 +91,12 @@ int dfm_profile_read(dfm_handle* h, int kernel_index, char* name_out, int name_c
  * events.  *gbs = GB/s, *ms_per_launch may be NULL. */
 int dfm_hbm_probe(dfm_handle* h, size_t bytes, int mode, int iters, double* gbs, double* ms_per_launch);
 
+/* dfm_chunk_fallbacks: diagnostics of the last pass / EM iteration with missing cells at r <= 8 that ran on the time-chunked
+ * recursion (csrc/recursion_chunk.hip; no reference counterpart).  *n_total = replicates of that launch (0: the last call did not
+ * use it), *n_failed = replicates whose chunk boundaries did not agree to the tolerance and were redone by the sequential kernel.
+ * Synchronises the handle's stream. */
+int dfm_chunk_fallbacks(dfm_handle* h, int* n_failed, int* n_total);
+
 /* Bytes of device workspace the handle will hold for a pass / EM call on a (B,T,N,r) problem with these flags (for
  * capacity planning; the larger of the sequential and -- for balanced panels -- the time-parallel plan).  The VAR(p),
  * AR-idiosyncratic, PCA and synthetic-panel entry points add their own scratch on top (a quasi-differenced panel copy,
