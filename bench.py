@@ -271,6 +271,7 @@ def kernel_bytes_table(B, N, T, r):
     seq = B * (b_in - panel_b + b_out)
     return {"collapse_mfma_kernel": B * panel_b, "collapse_dma_kernel": B * panel_b, "collapse_wide_kernel": B * panel_b,
             "collapse_wide2_kernel": B * panel_b, "collapse_kernel": B * panel_b, "collapse_miss_kernel": B * panel_b,
+            "recursion_chunk_kernel": seq,
             "pass_fused_kernel": B * (b_in + b_out),
             "recursion_kernel": seq, "recursion_wave_kernel": seq, "recursion_pair_kernel": seq, "recursion_tile_kernel": seq,
             "meanscan_kernel": B * (b_in - panel_b + 8 * (T * r + 1)), "meanscan_mfma_kernel": B * (b_in - panel_b + 8 * (T * r + 1)),

@@ -664,6 +664,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ca.bcol = at<double>(h, p.bcol); ca.scol = at<double>(h, p.scol); ca.nobs = at<int>(h, p.nobs);
     ca.ldrow = at<double>(h, p.ldrow); ca.Ct = at<double>(h, p.Ct); ca.Cfull = at<double>(h, p.Cfull);
     ca.ldfull = at<double>(h, p.ldfull); ca.status = h->status_dev;
+    ca.obs_chunk = nullptr;
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
@@ -691,6 +692,14 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ra.ct_r = ca.ct_r;
     {
         const int Rcol = p.Rc ? p.Rc : p.Rp;
+        // the time-chunked recursion reads one table row per period (C_t, b_t, s_t, n_t log 2 pi + log det R_t): at Rp = 8 with loadings as
+        // wide as the state collapse_miss_kernel writes it directly
+        const bool table = ra.wave && !h->collapse_miss_old && p.Rc == 0 && recursion_chunk_supported(p.Rp, ra);
+        if (table && collapse_miss_supported(Rcol, N)) {
+            ca.obs_chunk = ra.chunk_obs;
+            ra.chunk_obs_ready = 1;
+            ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream));
+        } else
         if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream)); }
         else if (p.Wwide != (size_t)-1 && N > collapse_max_n(Rcol)) {   // Rp = 32 beyond the register tiling (config 4 with missing cells)
             double* W = at<double>(h, p.Wwide);

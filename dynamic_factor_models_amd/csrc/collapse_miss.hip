@@ -128,6 +128,10 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
     const bool tail_clamp = (STEPS - 1) * CS + 4 * g + K >= N;
     const unsigned last_off = tail_clamp ? (unsigned)q * SB + (unsigned)(N - 1) * 8u : lane_off + (unsigned)(STEPS - 1) * (CS * 8u);
     const char* seg = reinterpret_cast<const char*>(a.panel + ((size_t)b * T + ta) * N);
+    // table mode (a.obs_chunk: the observation table of recursion_chunk.hip instead of bcol .. ldrow): one 368-byte row per period,
+    // doubles 0..35 C_t (packed; EVERY period), 36..43 b_t, 44 s_t, 45 n_t log 2 pi + log det R_t
+    const bool obs = a.obs_chunk != nullptr;
+    auto obs_row = [&](int t) { return a.obs_chunk + ((size_t)b * T + t) * 46; };
 
     auto issue_block = [&](int k, int bslot) {                   // 4 rows x NDR DMAs, always (rows past the segment: its last row)
 #pragma unroll
@@ -248,8 +252,10 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
         {
             const double hi = xor_lane<1>(D);
             const int t = ta + r0 + K;
-            if (g == 0 && (q & 1) == 0 && t < tb)
-                *reinterpret_cast<double2*>(&a.bcol[((size_t)b * T + t) * R + 4 * h + q]) = make_double2(D, hi);
+            if (g == 0 && (q & 1) == 0 && t < tb) {
+                if (obs) *reinterpret_cast<double2*>(obs_row(t) + 36 + 4 * h + q) = make_double2(D, hi);
+                else *reinterpret_cast<double2*>(&a.bcol[((size_t)b * T + t) * R + 4 * h + q]) = make_double2(D, hi);
+            }
         }
         // s_t and the missing cells' sum of log R of the 4 periods from the duplicate-free second read of the rows: 8 values,
         // one transpose-reduce
@@ -276,16 +282,22 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
         bool canon;
         const int ridx = reduce_index<8>(lane, canon);
         int nmiss_row[4] = {0, 0, 0, 0};
-        if (anynan != 0ull && !(abl & 1)) {                      // (wave-uniform) some period of the block has a missing cell
+        if ((anynan != 0ull || obs) && !(abl & 1)) {             // (wave-uniform) some period of the block has a missing cell
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int t = ta + r0 + rr;
                 const unsigned long long rowany = __ballot(nanbits[rr] != 0u);
-                if (rowany == 0ull || t >= tb) continue;         // (wave-uniform)
-                if (a.Ct == nullptr) {                           // caller promised a balanced panel: flag it, keep valid memory
-                    if (lane == 0) atomicOr(a.status, 1);
+                if (t >= tb) continue;                           // (wave-uniform)
+                if (rowany == 0ull) {                            // a complete period: the table takes the replicate's full Gram matrix
+                    if (obs && g == 0) {
+                        double* ct = obs_row(t);
+                        if (q <= K) ct[i0 * (i0 + 1) / 2 + f0] = CF0;
+                        if (h == 0) ct[i1 * (i1 + 1) / 2 + q] = CF1;
+                    }
                     continue;
                 }
+                if (a.Ct == nullptr && lane == 0) atomicOr(a.status, 1);   // caller promised a balanced panel: flag it
+                if (a.Ct == nullptr && !obs) continue;           // (no table, no C_t array: keep valid memory)
                 // index list of the missing series of the period (ballot compaction), or of the observed ones when fewer
                 unsigned long long mb[NQ][2];
                 int nmiss = 0;
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
                 list_gram(nst, E0, E1);
                 wave_lds_sync();
                 if (g == 0) {
-                    double* ct = a.Ct + ((size_t)b * T + t) * NP;
+                    double* ct = obs ? obs_row(t) : a.Ct + ((size_t)b * T + t) * NP;
                     if (q <= K) ct[i0 * (i0 + 1) / 2 + f0] = comp ? CF0 - E0 : E0;
                     if (h == 0) ct[i1 * (i1 + 1) / 2 + q] = comp ? CF1 - E1 : E1;
                 }
@@ -330,7 +342,11 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
             const int t = ta + r0 + rr;
             int nm = nmiss_row[0];
             nm = rr == 1 ? nmiss_row[1] : nm; nm = rr == 2 ? nmiss_row[2] : nm; nm = rr == 3 ? nmiss_row[3] : nm;
-            if (canon && t < tb) {
+            if (canon && t < tb && obs) {                        // doubles 44, 45 of the table row: s_t, n_t log 2 pi + sum of log R over the observed
+                double* sl = obs_row(t) + 44;
+                if (ridx < 4) sl[0] = red[0];
+                else sl[1] = (double)(N - nm) * 1.8378770664093454835606594728112 + (ldfull - red[0]);
+            } else if (canon && t < tb) {
                 if (ridx < 4) {
                     a.scol[(size_t)b * T + t] = red[0];
                     a.nobs[(size_t)b * T + t] = N - nm;

@@ -637,6 +637,10 @@ hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s) {
     if (a.wave && recursion_chunk_supported(Rpad, a)) {
         hipError_t e = launch_recursion_chunk(a, s);
         if (e != hipSuccess) return e;
+        if (a.chunk_obs_ready) {
+            e = launch_chunk_unbridge(a, s);
+            if (e != hipSuccess) return e;
+        }
         RecursionArgs f = a;
         f.only_if = a.chunk_fail;
         e = launch_recursion_wave8_fallback(f, s);

@@ -29,7 +29,7 @@
 #include "dfm_chunk_core.h"
 
 // development ablations (scripts/dbg/r05/abl_chunk.sh builds one library per value; results are WRONG for any value but 0):
-// 1 no output stores, 2 no row fetches (one scalar for every constant), 4 no LDS-DMA, 8 no table stores
+// 1 no output stores, 2 no row fetches (one scalar for every constant), 4 no LDS-DMA, 8 no table stores, 16 print shader-clock vs wall ticks
 #ifndef DFM_CK_ABL
 #define DFM_CK_ABL 0
 #endif
@@ -153,13 +153,40 @@ __device__ __forceinline__ void dma_rows(const double2* base, unsigned voff, uns
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// the stage as the core's accessors see it: double index k of the period's row sits in row k / 2, component k % 2
+// the observation stage: the DMA below copies 64 table rows of 368 bytes back to back -- lane j's period is row j: doubles 0..35 C_t,
+// 36..43 b_t, 44 s_t, 45 n_t log 2 pi + log det R_t
 struct StageObs {
-    const double* st;   // stage + 2 * lane
+    const double* st;   // stage + 46 * lane
     __device__ __forceinline__ void ready() const { wait_dma(); }
-    __device__ __forceinline__ double c(int p) const { return st[(p >> 1) * 128 + (p & 1)]; }
-    __device__ __forceinline__ double b(int i) const { return st[((chunk::NP + i) >> 1) * 128 + (i & 1)]; }
+    __device__ __forceinline__ double c(int p) const { return st[p]; }
+    __device__ __forceinline__ double b(int i) const { return st[chunk::NP + i]; }
 };
+// 64 rows of the observation table (one 368-byte row per period, [b][t][46]) -> stage, by 23 LDS-DMAs of 16 bytes per lane: piece
+// e = 64 i + lane of DMA i belongs to row e / 23, 16-byte piece e % 23.  Row j of the
+// stage is the period of lane clamp(j + sh, 0, smax) at this step's slot (base: the replicate's row `slot`; LB = L * 368 bytes from
+// one lane's period to the next lane's).  2.8 rows per DMA: ~10 cache lines per instruction where a per-lane gather would touch 64.
+__device__ __forceinline__ void dma_obs(const double* base, int lane, int sh, int smax, unsigned LB, unsigned lds_dst) {
+#if DFM_CK_ABL & 4
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < kObsRows; ++i) {
+        const unsigned e = 64u * i + (unsigned)lane, row = e / kObsRows, piece = e - row * kObsRows;   // (constant divisor: a multiply-high)
+        int src = (int)row + sh;
+        src = src < 0 ? 0 : (src > smax ? smax : src);
+        const unsigned voff = (unsigned)src * LB + 16u * piece;
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(base), "s"(lds_dst + 1024u * i)
+            : "memory");
+    }
+}
 struct StageZw {
     const double* st;
     __device__ __forceinline__ void ready() const { wait_dma(); }
@@ -210,20 +237,18 @@ __global__ __launch_bounds__(64) void chunk_prep_kernel(RecursionArgs a) {
     }
 }
 
-// ---- the collapse kernels' per-period rows ([b][t][..]; C_t only where a cell is missing) into the chunk-major table the pass reads:
-// obs[b][slot][row][lane] (double2), period t = L lane + slot; rows 0..17 C_t (8 x 8 packed, zero beyond the RC x RC block), 18..21 b_t,
-// 22 = (s_t, n_t log 2 pi + sum of log R over the observed cells).  One block per (replicate, slot): the 64 lanes' stores are contiguous.
-// (collapse_miss_kernel writes the table itself: CollapseArgs::obs_chunk; this is the bridge for the other collapse kernels.)
+// ---- the collapse kernels' per-period arrays (bcol, scol, nobs, ldrow; C_t only where a cell is missing, else the replicate's Cfull) as
+// rows of the observation table the pass reads: obs[b][t][46] = C_t (8 x 8 packed, zero beyond the RC x RC block), b_t, s_t,
+// n_t log 2 pi + sum of log R over the observed cells.  (collapse_miss_kernel writes the rows itself: CollapseArgs::obs_chunk; this is
+// the bridge for the other collapse kernels.)
 template <int RC>
 __global__ __launch_bounds__(64) void chunk_bridge_kernel(RecursionArgs a) {
     using namespace chunk;
     constexpr int NPC = RC * (RC + 1) / 2;
-    const int lane = threadIdx.x;
-    const int L = a.chunk_L, T = a.T;
-    const int b = blockIdx.x / L, slot = blockIdx.x - b * L;
-    const int t = L * lane + slot;
-    if (t >= T) return;
-    const size_t bt = (size_t)b * T + t;
+    const int T = a.T;
+    const size_t bt = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (bt >= (size_t)a.B * T) return;
+    const int b = (int)(bt / T);
     const int n = a.nobs[bt];
     const bool full = n == a.N || a.Ct == nullptr;
     double v[2 * kObsRows];
@@ -238,9 +263,45 @@ __global__ __launch_bounds__(64) void chunk_bridge_kernel(RecursionArgs a) {
     for (int i = 0; i < RC; ++i) v[NP + i] = a.bcol[bt * RC + i];
     v[NP + R] = a.scol[bt];
     v[NP + R + 1] = (double)n * kLog2PiC + (n == a.N ? a.ldfull[b] : a.ldrow[bt]);
-    double2* dst = reinterpret_cast<double2*>(a.chunk_obs) + ((size_t)b * L + slot) * kObsRows * 64 + lane;
+    double2* dst = reinterpret_cast<double2*>(a.chunk_obs + bt * (2 * kObsRows));
 #pragma unroll
-    for (int k = 0; k < kObsRows; ++k) dst[k * 64] = make_double2(v[2 * k], v[2 * k + 1]);
+    for (int k = 0; k < kObsRows; ++k) dst[k] = make_double2(v[2 * k], v[2 * k + 1]);
+}
+
+// ---- ... and back, for the replicates the pass hands to the sequential kernel when the collapse wrote the table only
+// (collapse_miss_kernel's table mode): bcol, scol, C_t of every period; nobs = 0 and ldrow = n_t log 2 pi + sum log R make the sequential kernels'
+// "n log 2 pi + sum of log R" come out right without n_t (they read C_t / ldrow of every period whose nobs differs from N).
+// Without a C_t array (the caller promised a balanced panel) the periods are all alike: nobs = N, Cfull and ldfull from period 0.
+__global__ __launch_bounds__(64) void chunk_unbridge_kernel(RecursionArgs a, double* bcol, double* scol, int* nobs, double* ldrow, double* Ct,
+                                                          double* Cfull, double* ldfull) {
+    using namespace chunk;
+    const int T = a.T;
+    const size_t bt = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (bt >= (size_t)a.B * T) return;
+    const int b = (int)(bt / T), t = (int)(bt - (size_t)b * T);
+    if (a.chunk_fail[b] == 0) return;
+    const double2* src = reinterpret_cast<const double2*>(a.chunk_obs + bt * (2 * kObsRows));
+    double v[2 * kObsRows];
+#pragma unroll
+    for (int k = 0; k < kObsRows; ++k) { const double2 u = src[k]; v[2 * k] = u.x; v[2 * k + 1] = u.y; }
+#pragma unroll
+    for (int i = 0; i < R; ++i) bcol[bt * R + i] = v[NP + i];
+    scol[bt] = v[NP + R];
+    if (Ct) {
+        nobs[bt] = a.N > 0 ? 0 : 1;
+        ldrow[bt] = v[NP + R + 1];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) Ct[bt * NP + k] = v[k];
+    } else {
+        nobs[bt] = a.N;
+        if (t == 0) {
+            ldfull[b] = v[NP + R + 1] - (double)a.N * kLog2PiC;
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+#pragma unroll
+                for (int j = 0; j < R; ++j) Cfull[(size_t)b * R * R + i * R + j] = v[pidx(i, j)];
+        }
+    }
 }
 
 // ---- the pass ---------------------------------------------------------------------------------------------------------------
@@ -257,16 +318,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const cdp cst = as_const(a.chunk_cst + (size_t)b * kCstStride);
     const RowSrc krow{cst + kOffK}, ktrow{cst + kOffKT}, qrow{cst + kOffQPhi};
     const double tol = a.chunk_tol;
-    const double2* obs = reinterpret_cast<const double2*>(a.chunk_obs) + (size_t)b * L * kObsRows * 64;
+    const double* obs = a.chunk_obs + (size_t)b * T * (2 * kObsRows);
     double2* scr = reinterpret_cast<double2*>(a.chunk_scr) + (size_t)b * L * kScrRows * 64;
     double* term = a.chunk_term + (size_t)b * kTermStride;
     const int r = a.r;
     const int rl = a.rl > 0 ? a.rl : R;
     const int npr = r * (r + 1) / 2;
 
-    // LDS: the stage (23 rows of 64 double2), then (EM) the accumulators [64 + 36][kAccSlots] and two 8 x 8 tiles of the epilogue
+    // LDS: the stage (64 x 368 bytes), then (EM) the accumulators [64 + 36][kAccSlots]
+    // and two 8 x 8 tiles of the epilogue
     double* stage = csm;
-    const double* stl = stage + 2 * lane;
+    const double* stl = stage + 2 * lane;                          // (the backward table's stage: rows of 64 double2)
+    const double* sto = stage + 2 * kObsRows * lane;               // (the observation stage: lane's own 46 doubles)
     const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)(reinterpret_cast<char*>(stage)));
     double* acc10 = csm + 2 * 64 * kObsRows;
     double* acc11 = acc10 + 64 * kAccSlots;
@@ -274,13 +337,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int e = lane; e < 100 * kAccSlots; e += 64) acc10[e] = 0.0;
         wave_lds_sync();
     }
+    const unsigned LB = (unsigned)L * (2 * kObsRows * 8);
 
-    // the observation row of period c0 + d (d may be negative: the lanes below) -> stage
+    // the observation rows of the periods c0 + d of all lanes (d may be negative: the lanes below) -> stage
     auto issue_obs = [&](int d) {
         const int sh = floor_div(d, L), slot = d - sh * L;
-        int src = lane + sh;
-        src = src < 0 ? 0 : (src > 63 ? 63 : src);
-        dma_rows<kObsRows>(obs + (size_t)slot * kObsRows * 64, (unsigned)src * 16u, stage_lds);
+        int smax = (T - 1 - slot) / L;
+        smax = smax > 63 ? 63 : smax;
+        dma_obs(obs + (size_t)slot * (2 * kObsRows), lane, sh, smax, LB, stage_lds);
     };
     auto store_row = [&](int trow, const double (&P)[NP], const double (&f)[R]) {
 #if DFM_CK_ABL & 1
@@ -309,11 +373,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     };
 
+#if DFM_CK_ABL & 16
+    const long long ck0 = clock64(), wk0 = wall_clock64();
+#endif
     // =================================================== forward ===========================================================
     double m[NP], xi[R];
     {   // guess at the start of the window: a step "with J = 0" on the data of the period before it
         issue_obs(-W - 1);
-        const StageObs ob{stl};
+        const StageObs ob{sto};
         ob.ready();
         const cdp qf = launder(cst + kOffQPhi);
 #pragma unroll
@@ -345,7 +412,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         if (u == W) hs = state_hash(m, xi);
         const bool counted = u >= W && t < T;
         double det, xw;
-        fwd_step(m, xi, StageObs{stl}, det, xw, krow, qrow, RcpDev{}, [&](const double (&zn)[NP], const double (&w)[R]) {
+        fwd_step(m, xi, StageObs{sto}, det, xw, krow, qrow, RcpDev{}, [&](const double (&zn)[NP], const double (&w)[R]) {
             if (counted && !((DFM_CK_ABL & 8) && tol >= 0.0)) {
                 double2* dst = scr + (size_t)(u - W) * kScrRows * 64 + lane;
 #pragma unroll
@@ -355,7 +422,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
         });
         {
-            const double st_s = stl[(kObsRows - 1) * 128], st_l = stl[(kObsRows - 1) * 128 + 1];
+            const double st_s = sto[NP + R], st_l = sto[NP + R + 1];
             lp.mul(counted ? det : 1.0);
             sxw += counted ? xw : 0.0;
             ssum += counted ? st_s : 0.0;
@@ -466,6 +533,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const Hash hq = hash_from_lane(heb, lane < 63 ? lane + 1 : 63);
         ok = ok && (L * (lane + 1) >= T || hash_close(hsb, hq, tol));
     }
+#if DFM_CK_ABL & 16
+    if (lane == 0 && (b == 0 || b == 777)) printf("CKCLK b=%d shader cycles %lld wall ticks %lld\n", b, clock64() - ck0, wall_clock64() - wk0);
+#endif
     const bool good = __all(ok) != 0 && ll == ll;                  // (a NaN log-likelihood also goes to the sequential kernel)
     if (lane == 0) a.chunk_fail[b] = good ? 0 : 1;
     if (!good) return;
@@ -574,7 +644,7 @@ bool chunk_enabled() {
     return on;
 }
 size_t chunk_lds_bytes(bool em) {
-    return (size_t)2 * 64 * kObsRows * sizeof(double) + (em ? (size_t)(100 * kAccSlots + 2 * 8 * kTileStride<8>) * sizeof(double) : 0);
+    return (size_t)(2 * 64 * kObsRows) * sizeof(double) + (em ? (size_t)(100 * kAccSlots + 2 * 8 * kTileStride<8>) * sizeof(double) : 0);
 }
 }  // namespace
 
@@ -586,7 +656,7 @@ size_t recursion_chunk_scratch_bytes(int B, int T) {
     return (size_t)B * recursion_chunk_len(T) * kScrRows * 64 * sizeof(double2);
 }
 size_t recursion_chunk_obs_bytes(int B, int T) {
-    return (size_t)B * recursion_chunk_len(T) * kObsRows * 64 * sizeof(double2);
+    return (size_t)B * T * kObsRows * sizeof(double2) + 4096;      // (+ slack: the last DMA of the last replicate reads whole 16-byte pieces)
 }
 
 // Plain factor model at Rp = 8 in information form (no companion state: the EM epilogue here has no shift rows), collapsed
@@ -624,7 +694,7 @@ hipError_t launch_recursion_chunk(const RecursionArgs& a0, hipStream_t s) {
     if (e != hipSuccess) return e;
     if (!a.chunk_obs_ready) {
         const int Rc = a.Rc > 0 ? a.Rc : 8;
-        const dim3 grid((unsigned)a.B * a.chunk_L);
+        const dim3 grid((unsigned)(((size_t)a.B * a.T + 63) / 64));
         if (Rc == 8) hipLaunchKernelGGL(chunk_bridge_kernel<8>, grid, dim3(64), 0, s, a);
         else if (Rc == 4) hipLaunchKernelGGL(chunk_bridge_kernel<4>, grid, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(chunk_bridge_kernel<2>, grid, dim3(64), 0, s, a);
@@ -632,6 +702,16 @@ hipError_t launch_recursion_chunk(const RecursionArgs& a0, hipStream_t s) {
         if (e != hipSuccess) return e;
     }
     return a.S11 != nullptr ? launch_chunk_em<true>(a, s) : launch_chunk_em<false>(a, s);
+}
+
+// the per-period rows of the replicates with chunk_fail set, for the sequential kernel (the table came from collapse_gemm_kernel)
+hipError_t launch_chunk_unbridge(const RecursionArgs& a0, hipStream_t s) {
+    RecursionArgs a = a0;
+    a.chunk_L = recursion_chunk_len(a.T);
+    hipLaunchKernelGGL(chunk_unbridge_kernel, dim3((unsigned)(((size_t)a.B * a.T + 63) / 64)), dim3(64), 0, s, a, const_cast<double*>(a.bcol),
+                       const_cast<double*>(a.scol), const_cast<int*>(a.nobs), const_cast<double*>(a.ldrow), const_cast<double*>(a.Ct),
+                       const_cast<double*>(a.Cfull), const_cast<double*>(a.ldfull));
+    return hipGetLastError();
 }
 
 }  // namespace dfm
