@@ -36,6 +36,7 @@ struct dfm_handle {
     // 2 % of the headline's step.  Device-pointer callers that never check see nothing; dfm_synchronize / dfm_check_status and
     // every host-pointer entry report (and clear) whatever was raised since the last check.
     int* status_dev = nullptr;
+    int discarded_status = 0;              // status bits of earlier, unchecked device-pointer calls that a host-pointer entry cleared (status_epoch)
     bool no_rec_wave = false;              // DFM_NO_RECURSION_WAVE=1: lane-group recursion_kernel also at Rp = 8 (A/B)
     int pair_bmax = -1;                    // Rp = 8: batch limit of the covariance-wave + mean-wave pair (recursion_pair.hip); -1 = one replicate per SIMD,
                                            // DFM_PAIR_BMAX=n; DFM_NO_PAIR=1 = 0 (never)
@@ -64,6 +65,7 @@ struct dfm_handle {
     dfm::EmUpdArgs deferred_em;
     void* odd = nullptr;                   // panel / loadings / R with one all-missing series appended (odd N beyond the tilings, odd_pad)
     size_t odd_bytes = 0;
+    const double* odd_panel_src = nullptr; int odd_panel_dims[3] = {0, 0, 0};   // the panel whose padded copy h->odd holds (odd_pad keep_panel)
     std::string prof_file;                 // DFM_PF_PROF_FILE with DFM_SCAN_ABL=256: phase stamps of the fused pass
     char err[512] = {0};
     // optional per-kernel timing (bench.py roofline leg): event pairs on the launch stream
@@ -357,11 +359,15 @@ __global__ void copy_series_rows_kernel(size_t nb, int Ns, int Nd, int w, double
     dst[tid] = n < Ns ? src[(b * Ns + n) * w + k] : fill;
 }
 struct OddPad { double *panel, *Lam, *R; };
-int odd_pad(dfm_handle* h, int B, int T, int N, int r, const double* panel, const double* Lam, const double* R, OddPad* out) {
+// keep_panel: the call continues an EM run on the same panel (dfm_em_iterate_batch_dev with k > 0: one call per iteration from the
+// multi-GPU drivers) -- the padded copy made at k = 0 is still in h->odd, only the loadings and variances are copied again
+int odd_pad(dfm_handle* h, int B, int T, int N, int r, const double* panel, const double* Lam, const double* R, OddPad* out,
+            bool keep_panel = false) {
     const size_t n_panel = (size_t)B * T * (N + 1), n_lam = (size_t)B * (N + 1) * r, n_R = (size_t)B * (N + 1);
     const size_t bytes = (n_panel + n_lam + n_R) * sizeof(double) + 768;
     if (bytes > h->odd_bytes) {
         if (h->odd) { HIP_TRY(h, hipDeviceSynchronize()); HIP_TRY(h, hipFree(h->odd)); h->odd = nullptr; h->odd_bytes = 0; }
+        h->odd_panel_src = nullptr;
         HIP_TRY(h, hipMalloc(&h->odd, bytes));
         h->odd_bytes = bytes;
     }
@@ -370,7 +376,9 @@ int odd_pad(dfm_handle* h, int B, int T, int N, int r, const double* panel, cons
     out->Lam = out->panel + al(n_panel);
     out->R = out->Lam + al(n_lam);
     auto grid = [](size_t n) { return dim3((unsigned)((n + 255) / 256)); };
-    hipLaunchKernelGGL(pad_last_col_kernel, grid(n_panel), dim3(256), 0, h->stream, (size_t)B * T, N, panel, out->panel);
+    const bool same = keep_panel && h->odd_panel_src == panel && h->odd_panel_dims[0] == B && h->odd_panel_dims[1] == T && h->odd_panel_dims[2] == N;
+    if (!same) hipLaunchKernelGGL(pad_last_col_kernel, grid(n_panel), dim3(256), 0, h->stream, (size_t)B * T, N, panel, out->panel);
+    h->odd_panel_src = panel; h->odd_panel_dims[0] = B; h->odd_panel_dims[1] = T; h->odd_panel_dims[2] = N;
     hipLaunchKernelGGL(copy_series_rows_kernel, grid(n_lam), dim3(256), 0, h->stream, (size_t)B, N, N + 1, r, 0.0, Lam, out->Lam);
     hipLaunchKernelGGL(copy_series_rows_kernel, grid(n_R), dim3(256), 0, h->stream, (size_t)B, N, N + 1, 1, 1.0, R, out->R);
     HIP_TRY(h, hipGetLastError());
@@ -791,9 +799,10 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
     HIP_TRY(h, hipSetDevice(h->device));
     if (needs_odd_pad(fast_eligible(h, N, r, flags) && !h->em_general, N, r)) {   // odd N beyond the tilings: one all-missing series appended
         OddPad o;
-        if (int rc = odd_pad(h, B, T, N, r, panel, Lam, R, &o)) return rc;
+        if (int rc = odd_pad(h, B, T, N, r, panel, Lam, R, &o, k_first > 0)) return rc;
+        // (the appended series is missing in EVERY period: the padded problem has missing cells whatever the caller said about N)
         if (int rc = em_run(h, B, T, N + 1, r, o.panel, o.Lam, o.R, A, Q, mu0, P0, max_iter, tol, loglik_path, iters, loglik_single,
-                            f_smooth, P_smooth, flags, k_first, k_count, active_ext)) return rc;
+                            f_smooth, P_smooth, flags | DFM_F_MAY_HAVE_MISSING, k_first, k_count, active_ext)) return rc;
         const size_t n_lam = (size_t)B * N * r, n_R = (size_t)B * N;
         hipLaunchKernelGGL(copy_series_rows_kernel, dim3((unsigned)((n_lam + 255) / 256)), dim3(256), 0, h->stream, (size_t)B, N + 1, N, r, 0.0, o.Lam, Lam);
         hipLaunchKernelGGL(copy_series_rows_kernel, dim3((unsigned)((n_R + 255) / 256)), dim3(256), 0, h->stream, (size_t)B, N + 1, N, 1, 0.0, o.R, R);
@@ -1114,6 +1123,8 @@ int obs_em_run(dfm_handle* h, int B, int T, int N, int ru, int ro, const double*
     if (!mstep_obs_supported(ro, ru) && !wide_obs)
         return fail(h, DFM_E_R_UNSUPPORTED, "observed factors: need r_o >= 1, r_u >= 1 and r_o + r_u <= 32%s");
     if (int rc = check_em_n(h, N, ru, flags)) return rc;
+    if (wide_obs && N > 1024)   // (the joint regression at r_o + r_u > 8 runs on mstep_lam_kernel: lane = series, N <= 1024)
+        return fail(h, DFM_E_DIMS, "observed factors with r_o + r_u > 8: N <= 1024%s");
     if (!panel || !G || !Lam || !R || !A || !Q || !mu0 || !P0 || !loglik_path || !iters)
         return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
@@ -1309,8 +1320,8 @@ static int status_check(dfm_handle* h);
 // A host-pointer entry point opens a new status epoch: whatever earlier, unchecked *_dev calls left in the sticky word is
 // read and cleared here, so that the check at the END of the call reports this call's own kernels only (a stale NaN / PCA /
 // time-out bit used to fail the next unrelated host call, and silently triggered api.estimate's singular-Q retry).  The
-// discarded bits stay visible in dfm_last_error until the next error; device-pointer callers that care call dfm_check_status
-// after their own calls.  These entries copy whole panels across PCIe -- one 4-byte read more is free.
+// discarded bits are kept in the handle (discarded_status) but NOT written to dfm_last_error -- a caller that reads the string after
+// a successful call must not find an error text there; device-pointer callers that care call dfm_check_status after their own calls.  These entries copy whole panels across PCIe -- one 4-byte read more is free.
 static int status_epoch(dfm_handle* h) {
     if (!h->status_dev) return 0;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1319,7 +1330,7 @@ static int status_epoch(dfm_handle* h) {
     HIP_TRY(h, hipMemcpy(&st, h->status_dev, sizeof(int), hipMemcpyDeviceToHost));
     if (st) {
         HIP_TRY(h, hipMemset(h->status_dev, 0, sizeof(int)));
-        snprintf(h->err, sizeof(h->err), "note: status bits 0x%x of an earlier unchecked device-pointer call were discarded", st);
+        h->discarded_status |= st;                               // (not into h->err: this call has not failed)
     }
     return 0;
 }
@@ -1410,7 +1421,9 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     if (needs_odd_pad(fast_eligible(h, N, r, flags), N, r)) {  // odd N beyond the tilings: one all-missing series appended
         OddPad o;
         if (int rc = odd_pad(h, B, T, N, r, panel, Lam, R, &o)) return rc;
-        return dfm_ks_pass_batch_dev(h, B, T, N + 1, r, o.panel, o.Lam, o.R, A, Q, mu0, P0, f_smooth, P_smooth, loglik, flags);
+        // (the appended series is missing in EVERY period: the padded problem has missing cells whatever the caller said about N)
+        return dfm_ks_pass_batch_dev(h, B, T, N + 1, r, o.panel, o.Lam, o.R, A, Q, mu0, P0, f_smooth, P_smooth, loglik,
+                                     flags | DFM_F_MAY_HAVE_MISSING);
     }
     const Plan p = make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags));
     if (int rc = ensure_ws(h, p.total)) return rc;

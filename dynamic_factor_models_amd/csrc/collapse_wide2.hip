@@ -583,7 +583,9 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide_kernel(CollapseArgs a
             for (int q = 0; q < kCtQ; ++q) E[q] = fma(Ws[ii * R + (oj[q] ^ sw)], Ls[ii * R + ok[q]], E[q]);
         }
     }
-    if (mine) {
+    if (mine && a.Ct == nullptr) {                            // the caller promised a balanced panel: flag it, keep valid memory
+        if (lane == 0) atomicOr(a.status, 1);
+    } else if (mine) {
         const int t = t0 + wave;
 #pragma unroll
         for (int q = 0; q < kCtQ; ++q) {
@@ -774,8 +776,12 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs 
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        double* Co = a.Ct + ((size_t)b * T + (t0 + tw0 + pp)) * NPo;          // (NPo is even: rows are 16-byte aligned)
-        for (int v = 2 * lane; v < NPo; v += 128) *reinterpret_cast<double2*>(Co + v) = *reinterpret_cast<const double2*>(Cs + v);
+        if (a.Ct == nullptr) {                                // the caller promised a balanced panel: flag it, keep valid memory
+            if (lane == 0) atomicOr(a.status, 1);
+        } else {
+            double* Co = a.Ct + ((size_t)b * T + (t0 + tw0 + pp)) * NPo;      // (NPo is even: rows are 16-byte aligned)
+            for (int v = 2 * lane; v < NPo; v += 128) *reinterpret_cast<double2*>(Co + v) = *reinterpret_cast<const double2*>(Cs + v);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the row is read before the next period overwrites it)
         __builtin_amdgcn_wave_barrier();
     }

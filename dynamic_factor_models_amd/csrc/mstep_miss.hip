@@ -341,7 +341,9 @@ __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const doub
 #undef LL
     const int col = s0 + tid;
     const double nobs_i = cnt[(size_t)b * N + col];
-    if (!ok || nobs_i < (double)(r + 1)) return;
+    // a series without a single observed cell keeps its parameters; so does one with fewer cells than the caller's minimum (the
+    // observed-factor joint regression asks for r_o + r_u + 1; the plain EM for 1: sum E[f f'] includes P_t and is positive definite)
+    if (!ok || nobs_i < (double)(a.min_cells > 1 ? a.min_cells : 1)) return;
     a.R_out[(size_t)b * N + col] = (sxx[(size_t)b * N + col] - yy) / nobs_i;
     double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
     for (int k = 0; k < Rp; ++k) lo[k] = k < r ? y[(size_t)k * ns] : 0.0;

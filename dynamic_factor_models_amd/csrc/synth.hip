@@ -93,9 +93,9 @@ __global__ __launch_bounds__(kSynThreads) void synth_params_kernel(SynthArgs a) 
 
 // x_ti = lam_i' f_t + sqrt(R_i) eps_ti for the tile's periods and the thread's two columns (two cells per counter: cell c and
 // c + 1 share counter c / 2 when c is even)
-__global__ __launch_bounds__(kSynThreads) void synth_cells_kernel(SynthArgs a, int ntile) {
+__global__ __launch_bounds__(kSynThreads) void synth_cells_kernel(SynthArgs a, int ntile, int zoff) {
     __shared__ double Fs[kSynTile * 32];
-    const int b = blockIdx.z, tile = blockIdx.y;
+    const int b = (int)blockIdx.z + zoff, tile = blockIdx.y;
     const int tid = threadIdx.x;
     const int N = a.N, T = a.T, r = a.r;
     const uint64_t key = a.seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(a.first_replicate + b + 1));
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(kSynThreads) void synth_cells_kernel(SynthArgs a, i
 
 // standardise the tile's rows of the thread's two columns (mean, population s.d.), punch the missing cells; tile 0 also rescales
 // the parameters to the standardised panel
-__global__ __launch_bounds__(kSynThreads) void synth_standardize_kernel(SynthArgs a, int ntile) {
-    const int b = blockIdx.z, tile = blockIdx.y;
+__global__ __launch_bounds__(kSynThreads) void synth_standardize_kernel(SynthArgs a, int ntile, int zoff) {
+    const int b = (int)blockIdx.z + zoff, tile = blockIdx.y;
     const int tid = threadIdx.x;
     const int N = a.N, T = a.T, r = a.r;
     const int i0 = 2 * ((int)blockIdx.x * kSynThreads + tid);
@@ -197,10 +197,22 @@ hipError_t launch_synth(const SynthArgs& a, hipStream_t s) {
     const int ntile = synth_tiles(a.T);
     const int npair = (a.N + 1) / 2;
     hipLaunchKernelGGL(synth_params_kernel, dim3(a.B), dim3(kSynThreads), 0, s, a);
-    const dim3 grid((npair + kSynThreads - 1) / kSynThreads, ntile, a.B);
-    hipLaunchKernelGGL(synth_cells_kernel, grid, dim3(kSynThreads), 0, s, a, ntile);
-    hipLaunchKernelGGL(synth_standardize_kernel, grid, dim3(kSynThreads), 0, s, a, ntile);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // the batch rides on gridDim.z (<= 65535): larger batches in slices, each launch checked
+    for (int z0 = 0; z0 < a.B; z0 += 65535) {
+        const int nz = a.B - z0 < 65535 ? a.B - z0 : 65535;
+        const dim3 grid((npair + kSynThreads - 1) / kSynThreads, ntile, nz);
+        hipLaunchKernelGGL(synth_cells_kernel, grid, dim3(kSynThreads), 0, s, a, ntile, z0);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    for (int z0 = 0; z0 < a.B; z0 += 65535) {
+        const int nz = a.B - z0 < 65535 ? a.B - z0 : 65535;
+        const dim3 grid((npair + kSynThreads - 1) / kSynThreads, ntile, nz);
+        hipLaunchKernelGGL(synth_standardize_kernel, grid, dim3(kSynThreads), 0, s, a, ntile, z0);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace dfm

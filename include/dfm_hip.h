@@ -70,7 +70,7 @@ int dfm_set_stream(dfm_handle* h, void* stream);
  * of every pass).  The "_dev" entry points only enqueue, so this is where a device-pointer caller learns that a call went
  * wrong; the host-pointer entry points make the same check themselves -- and open a new EPOCH when they start: they read and
  * clear the word at entry, so what they report at the end is their own kernels' (a bit left by an earlier unchecked "_dev" call
- * is discarded there, with a note in dfm_last_error).  dfm_check_status is the same call under the name a reader looks for. */
+ * is discarded there; dfm_last_error is left alone -- the call has not failed).  dfm_check_status is the same call under the name a reader looks for. */
 int dfm_synchronize(dfm_handle* h);
 int dfm_check_status(dfm_handle* h);
 const char* dfm_last_error(const dfm_handle* h);
@@ -282,7 +282,7 @@ int dfm_em_ar_batch(dfm_handle* h, int B, int T, int N, int r, int p, int q, con
  * G [B][T][r_o] (no NaN), Lam [B][N][r_o + r_u] with the OBSERVED-factor loadings first, A / Q / P0 [B][r_u][r_u], mu0 [B][r_u];
  * f_smooth [B][T][r_u], P_smooth [B][T][r_u(r_u+1)/2] (may be NULL); bookkeeping (loglik_path, iters, tol) as dfm_em_batch.
  * r_o >= 1, r_u >= 1, r_o + r_u <= 32 (up to 8: a per-series Cholesky in registers; 9 .. 32: the ordinary loadings step on the
- * moments of z = (g, f)).  A series with fewer than r_o + r_u + 1 observed cells keeps its loadings and variance. */
+ * moments of z = (g, f), N <= 1024).  A series with fewer than r_o + r_u + 1 observed cells keeps its loadings and variance. */
 int dfm_em_obs_batch_dev(dfm_handle* h, int B, int T, int N, int r_u, int r_o, const double* panel, const double* G, double* Lam,
                          double* R, double* A, double* Q, double* mu0, double* P0, int max_iter, double tol, double* loglik_path,
                          int* iters, double* f_smooth, double* P_smooth, unsigned flags);

@@ -372,3 +372,46 @@ def test_config4_at_the_benchmarked_batch_against_the_oracle(ctx):
             assert np.abs(new[kk][k] - p[kk]).max() <= 1e-8 * max(1.0, np.abs(p[kk]).max()), (kk, k, np.abs(new[kk][k] - p[kk]).max())
     del panel, f, P
     torch.cuda.empty_cache()
+
+
+def test_balanced_odd_n_beyond_the_tiling_on_the_general_path(ctx):
+    """A BALANCED odd-N panel with singular_q=True takes the general path without the may-have-missing flag; the library appends
+    an all-missing series, so the padded problem has a missing cell in every period -- it must carry the flag itself (the C_t
+    array used to be absent there: a GPU fault instead of the DFM_E_DIMS of round 3)."""
+    import torch
+    B, N, T, r = 2, 301, 40, 20
+    reps = [ko.synth_replicate(b, N, T, r, seed=ko.SEED0 + 5, missing=0.0) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    st = {k: np.stack([p[k] for _, p in reps]) for k in KEYS}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_batch(t(panel), *[t(st[k]) for k in KEYS], may_have_missing=False, singular_q=True)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    _compare((f.cpu().numpy(), P.cpu().numpy(), ll.cpu().numpy()), _oracle(panel, st), "balanced odd N, covariance form")
+
+
+def test_a_sparse_series_is_updated_on_the_wide_loadings_route(ctx):
+    """Plain EM on the matrix-pipe loadings step (Rp > 8: mmw_finish_kernel): a series with FEWER observed cells than r + 1 is
+    still updated, as in the oracle (sum E[f f'] includes P_t: positive definite with one observed cell) and in mstep_lam_kernel --
+    the r + 1 rule belongs to the observed-factor joint regression only."""
+    import torch
+    B, N, T, r = 2, 300, 40, 20
+    reps = [ko.synth_replicate(b, N, T, r, seed=78, missing=0.05) for b in range(B)]
+    panel = np.stack([x for x, _ in reps])
+    panel[:, 3:, 7] = np.nan                                     # series 7: three observed cells (< r + 1)
+    panel[:, :3, 7] = np.nan_to_num(panel[:, :3, 7])
+    st = {k: np.stack([p[k] for _, p in reps]) for k in KEYS}
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    par = [t(st[k]) for k in KEYS]
+    path, its, _, _ = ctx.em_batch(t(panel), *par, max_iter=1, tol=0.0, want_smooth=False, may_have_missing=True)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    for b in range(B):
+        p, opath, _ = ko.em(panel[b], {k: st[k][b] for k in KEYS}, max_iter=1, tol=0.0)
+        np.testing.assert_allclose(path[b].cpu().numpy(), opath, rtol=1e-9)
+        Lam = par[0][b].cpu().numpy(); R = par[1][b].cpu().numpy()
+        assert np.abs(Lam - p["Lam"]).max() <= 1e-8 * max(1.0, np.abs(p["Lam"]).max())
+        assert np.abs(R - p["R"]).max() <= 1e-8 * max(1.0, np.abs(p["R"]).max())
+        assert not np.array_equal(Lam[7], st["Lam"][b][7])
