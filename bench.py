@@ -603,13 +603,18 @@ def config1_config5_lines(torch, ctx, dev, cpu_seconds=2.0):
     nd = 256
     signs = np.where(g.random((nd, y.shape[0])) < 0.5, -1.0, 1.0)
     t0 = time.perf_counter(); done = 0
+    irf_o = None
     while time.perf_counter() - t0 < cpu_seconds:
-        bo.var_bootstrap_irf(y, 4, H, signs); done += nd
+        irf_o = bo.var_bootstrap_irf(y, 4, H, signs)[0]; done += nd
     cpu_s = (time.perf_counter() - t0) / done
+    # the same draws (the oracle's signs) on the GPU: responses equal to the oracle's to 1e-9 of their scale
+    irf_g = ctx.var_bootstrap_irf_host(y, v.betahat, resid, 4, H, nd, signs=signs)
+    irf_g = irf_g[0] if isinstance(irf_g, tuple) else irf_g
+    boot_ok = bool(np.abs(np.asarray(irf_g) - irf_o).max() <= 1e-9 * np.abs(irf_o).max())
     out["c5_boot"] = dict(workload="BASELINE configs[4] on one GPU: 10000 wild-bootstrap draws x VAR(4) of the 4 Stock-Watson factors (T=222) -> "
                                    "IRFs to 12 horizons -> 5/16/50/84/95 % bands",
                           value=Bd / gpu_s, unit="bootstrap draws/s", ms_per_step=1e3 * gpu_s, draws=Bd, dominant="var_boot_kernel", whole_step=None,
-                          bands_finite=bool(torch.isfinite(bands).all()),
+                          bands_finite=bool(torch.isfinite(bands).all()), matches_oracle=boot_ok,
                           note="latency-bound (218 dependent periods per draw, 17 x 17 normal equations); draw + re-estimation + Cholesky + IRF + bands",
                           cpu_baseline=dict(value=1.0 / cpu_s, unit="bootstrap draws/s", cores=1, kind="port",
                                             sample=f"{done} draws of oracle/boot_oracle.py (NumPy) in {cpu_s * done:.1f} s"),
