@@ -84,8 +84,9 @@ def source_hash():
 def measured_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes (scripts/gpu_profile.sh -> profiles/rNN/
     pmc_traffic*.json), ONLY when that file was produced by exactly this source tree on this workload; else None."""
-    for rnd in ("r04", "r03", "r02"):
-        for name in ("pmc_traffic.json", "pmc_traffic_c4.json"):      # headline workload; BASELINE config 4
+    for rnd in ("r05", "r04", "r03", "r02"):
+        for name in ("pmc_traffic.json", "pmc_traffic_c4.json", "pmc_traffic_missing10.json", "pmc_traffic_missing10_b8192.json",
+                     "pmc_traffic_c4_missing10.json"):                 # headline; BASELINE config 4; the missing-cell lines
             try:
                 with open(os.path.join(ROOT, "profiles", rnd, name)) as fh:
                     d = json.load(fh)
@@ -622,6 +623,77 @@ def config1_config5_lines(torch, ctx, dev, cpu_seconds=2.0):
     return out
 
 
+def f3_lines(torch, ctx, dev, cpu_seconds=2.0):
+    """SURVEY 8 f3, driver-visible: one EM iteration of the model with VAR(p) factor dynamics (companion state
+    r p = 16; dfm_functions.ipynb:477-492) and of the model with AR(q) idiosyncratic terms on top (state 20), both at the
+    Stock-Watson window's shape (139 series x 222 periods, r = 4, p = q = 4: what `estimate!` hands over, :405-412), 10 % of the
+    cells missing, 1024 replicates per call -- beside the oracle (NumPy, one thread), first replicate's likelihood path compared.
+    Companion states run the covariance-form sequential recursion (recursion_wave_kernel<16 | 32, COV>): latency-bound, no
+    roofline claim."""
+    import numpy as np
+    from oracle import ar_oracle as aro
+    from oracle import varp_oracle as vo
+    out = {}
+    Bv, Nv, Tv, rv, pv, qv, miss, nit = 1024, 139, 222, 4, 4, 4, 0.1, 5
+    tile = lambda a: torch.from_numpy(np.ascontiguousarray(np.tile(a, (Bv // 16,) + (1,) * (a.ndim - 1)))).to(dev)
+    # ---- VAR(p)
+    t_line = time.perf_counter()
+    KV = ("Lam", "R", "Avar", "Q", "mu0", "P0")
+    xs, qs = [], []
+    for b in range(16):
+        x = vo.synth_varp(b, Nv, Tv, rv, pv, missing=miss)
+        xs.append(x); qs.append(vo.varp_init(np.nan_to_num(x), rv, pv)[0])
+    xv = tile(np.stack(xs))
+    d0 = {k: tile(np.stack([q[k] for q in qs])) for k in KV}
+    dd = {k: v.clone() for k, v in d0.items()}
+    ctx.em_varp_batch(xv, *[dd[k] for k in KV], max_iter=2, tol=0.0, may_have_missing=True)
+    dd = {k: v.clone() for k, v in d0.items()}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    path, its, _, _ = ctx.em_varp_batch(xv, *[dd[k] for k in KV], max_iter=nit, tol=0.0, may_have_missing=True)
+    torch.cuda.synchronize(); s_it = (time.perf_counter() - t0) / nit
+    _, opath, _ = vo.em_varp(xs[0], dict(qs[0]), pv, max_iter=nit, tol=0.0)
+    ok = bool(np.allclose(path[0].cpu().numpy(), opath, rtol=1e-8) and np.allclose(path[16].cpu().numpy(), opath, rtol=1e-8))
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < cpu_seconds:
+        vo.em_step_varp(xs[0], p=pv, **dict(qs[0])); n += 1
+    cpu_s = (time.perf_counter() - t0) / n
+    out["varp_em"] = dict(workload=f"VAR({pv}) factor dynamics, r={rv} (companion state {rv * pv}), N={Nv} T={Tv} (Stock-Watson :All window shape), "
+                                   f"{miss:.0%} missing, batch {Bv}: one EM iteration (dfm_em_varp_batch)",
+                          value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv, whole_step=None,
+                          dominant="recursion_wave_kernel", matches_oracle=ok,
+                          note="covariance-form sequential recursion on a 16-wide companion state: one 256-thread workgroup per replicate, latency-bound",
+                          cpu_baseline=dict(value=1.0 / cpu_s, unit="EM iterations/s", cores=1, kind="port",
+                                            sample=f"{n} iterations of oracle/varp_oracle.py em_step_varp (NumPy) in {cpu_seconds:.0f} s"),
+                          seconds=round(time.perf_counter() - t_line, 2))
+    # ---- AR(q) idiosyncratic terms
+    t_line = time.perf_counter()
+    KA = ("Lam", "sig2", "rho", "Avar", "Q", "mu0", "P0")
+    xs, sts = zip(*[aro.synth_ar(b, Nv, Tv, rv, pv, qv, missing=miss) for b in range(16)])
+    xa = tile(np.stack(xs))
+    a0 = {k: tile(np.stack([st[k] for st in sts])) for k in KA}
+    aa = {k: v.clone() for k, v in a0.items()}
+    ctx.em_ar_batch(xa, *[aa[k] for k in KA], max_iter=2)
+    aa = {k: v.clone() for k, v in a0.items()}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    path, its, _, _ = ctx.em_ar_batch(xa, *[aa[k] for k in KA], max_iter=nit)
+    torch.cuda.synchronize(); s_it = (time.perf_counter() - t0) / nit
+    _, opath, _ = aro.em_ar(xs[0], {k: sts[0][k] for k in KA}, max_iter=nit)
+    ok = bool(np.allclose(path[0].cpu().numpy(), opath, rtol=1e-7) and np.allclose(path[16].cpu().numpy(), opath, rtol=1e-7))
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < cpu_seconds:
+        aro.em_step_ar(xs[0], **{k: sts[0][k] for k in KA}); n += 1
+    cpu_s = (time.perf_counter() - t0) / n
+    out["ar_em"] = dict(workload=f"AR({qv}) idiosyncratic terms + VAR({pv}) factors, r={rv} (state {rv * (qv + 1)}), N={Nv} T={Tv}, {miss:.0%} missing, "
+                                 f"batch {Bv}: one ECM iteration (dfm_em_ar_batch)",
+                        value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv, whole_step=None,
+                        dominant="recursion_wave_kernel", matches_oracle=ok,
+                        note="quasi-differenced observation equation, 20-wide state padded to 32: one 1024-thread workgroup per replicate, latency-bound",
+                        cpu_baseline=dict(value=1.0 / cpu_s, unit="EM iterations/s", cores=1, kind="port",
+                                          sample=f"{n} iterations of oracle/ar_oracle.py em_step_ar (NumPy) in {cpu_seconds:.0f} s"),
+                        seconds=round(time.perf_counter() - t_line, 2))
+    return out
+
+
 def secondary_plan(world: int, default_line: bool, no_secondary: bool):
     """Which secondary lines a run times (pure: tested on CPU).  One GPU, default invocation: the other lines of the path.
     N > 1 GPUs, default invocation (what the driver's SCALE run launches): BASELINE configs[2]'s per-GPU shard (8192 replicates
@@ -629,7 +701,7 @@ def secondary_plan(world: int, default_line: bool, no_secondary: bool):
     if not default_line or no_secondary:
         return []
     if world == 1:
-        return [k for k, *_ in SECONDARY] + ["c1_als", "c5_boot"]
+        return [k for k, *_ in SECONDARY] + ["c1_als", "c5_boot", "varp_em", "ar_em"]
     return ["c3", "em", "pass_gather_every_step"]
 
 
@@ -829,8 +901,8 @@ def main():
     for key in plan:
         t0 = time.perf_counter()
         try:
-            if key in ("c1_als", "c5_boot"):
-                continue                                          # (both measured by one call below)
+            if key in ("c1_als", "c5_boot", "varp_em", "ar_em"):
+                continue                                          # (measured by the calls below)
             if world == 1:
                 cfg, k, w = next((c, kk, ww) for kk_, c, kk, ww in SECONDARY if kk_ == key)
                 gather = "block"
@@ -862,6 +934,11 @@ def main():
             sec.update(config1_config5_lines(torch, ctx, dev))
         except Exception as e:  # noqa: BLE001
             sec["c1_als"] = dict(error=f"{type(e).__name__}: {e}")
+    if "varp_em" in plan and rank == 0:
+        try:
+            sec.update(f3_lines(torch, ctx, dev))
+        except Exception as e:  # noqa: BLE001
+            sec["varp_em"] = dict(error=f"{type(e).__name__}: {e}")
     if plan and rank == 0:
         out["secondary"] = sec
     if rank == 0:
