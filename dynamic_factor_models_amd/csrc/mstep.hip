@@ -166,6 +166,20 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
         }
         __syncthreads();
         if (g + 1 < ngroups) issue(g + 1);
+        // E_t = f_t f_t' + P_t once per period, in place of P_t in the tile: it is the same for every series (every lane of every
+        // wave used to recompute the 36 products for each of its missing cells -- half of the masked update's instructions)
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int e = tid + 256 * q - UN * R;
+            if (e >= 0 && e < UN * NP) {
+                const int u = e / NP, v = e - u * NP;
+                int i = 0;
+                while ((i + 1) * (i + 2) / 2 <= v) ++i;
+                const int jj = v - i * (i + 1) / 2;
+                mb[UN * R + e] = fma(mb[u * R + i], mb[u * R + jj], mb[UN * R + e]);
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = t0 + u;
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
 #pragma unroll
                             for (int jj = 0; jj <= i; ++jj) {
                                 const int v = i * (i + 1) / 2 + jj;
-                                const double ef = fma(f[i], f[jj], pv[v]);
+                                const double ef = pv[v];             // E_t (see above)
                                 if constexpr (REGD) dm[j][v] += ef;
                                 else dmg[(size_t)col * NP + v] += ef;
                             }
