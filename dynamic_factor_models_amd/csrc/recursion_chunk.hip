@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64) void chunk_unbridge_kernel(RecursionArgs a, dou
     for (int i = 0; i < R; ++i) bcol[bt * R + i] = v[NP + i];
     scol[bt] = v[NP + R];
     if (Ct) {
-        nobs[bt] = a.N > 0 ? 0 : 1;
+        nobs[bt] = 0;                                          // (never equal to N >= 1: the period reads its own C_t / ldrow; adds 0 to the n-sum)
         ldrow[bt] = v[NP + R + 1];
 #pragma unroll
         for (int k = 0; k < NP; ++k) Ct[bt * NP + k] = v[k];
