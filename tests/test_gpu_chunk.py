@@ -127,3 +127,56 @@ def test_em_on_the_chunked_recursion_matches_oracle(ctx, B, N, T, r, missing, it
             assert np.abs(got - p[k]).max() <= 1e-8 * max(1.0, np.abs(p[k]).max()), (k, b, np.abs(got - p[k]).max())
         assert np.abs(f[b] - out["f_smooth"]).max() <= 1e-8 * np.abs(out["f_smooth"]).max()
         assert np.abs(P[b] - ko.pack_sym(out["P_smooth"])).max() <= 1e-8 * np.abs(out["P_smooth"]).max()
+
+
+@pytest.mark.parametrize("B,N,T,r,missing,blank", [
+    (3, 200, 24, 8, 0.1, ()),             # the shortest sample the chunked kernel takes (L = 4, W = 8: two windows)
+    (3, 200, 25, 8, 0.1, ()),
+    (2, 300, 100, 8, 0.1, ()),            # N > 224: collapse_kernel's per-period arrays + the bridge, loadings as wide as the state
+    (3, 200, 120, 8, 0.1, (0, 57, 58, 119)),   # periods without a single observed cell, first and last among them
+    (1, 200, 500, 8, 0.1, ()),            # one replicate
+])
+def test_chunked_pass_edge_shapes(ctx, B, N, T, r, missing, blank):
+    panel, st = _batch(B, N, T, r, missing, first=40)
+    for t in blank:
+        panel[:, t, :] = np.nan
+    ref = co.ks_pass_batch(panel, *[st[k] for k in KEYS])
+    got = _pass(ctx, panel, st)
+    nf, nt = ctx.chunk_fallbacks()
+    assert nt == B, "the pass did not run on recursion_chunk_kernel"
+    _compare(got, ref, f"B={B} N={N} T={T} r={r} blank={blank}")
+
+
+def test_em_with_replicates_on_both_kernels(ctx):
+    """EM on a batch in which every other replicate fails the boundary check: the EM bookkeeping (log-likelihood path, iteration
+    counts, the transition M-step) is done by recursion_chunk_kernel for some replicates and by the sequential kernel for the
+    others, iteration after iteration."""
+    import torch
+    B, T, r, iters = 6, 200, 8, 3
+    panels, starts = [], []
+    for b in range(B):
+        N = 12 if b % 2 == 0 else 200
+        x, p = ko.synth_replicate(b, N, T, r, missing=0.15)
+        xx = np.full((T, 200), np.nan); xx[:, :N] = x
+        Lam = 0.01 * np.random.default_rng(b).standard_normal((200, r)); Lam[:N] = p["Lam"]
+        R = np.ones(200); R[:N] = p["R"]
+        panels.append(xx); starts.append(dict(p, Lam=Lam, R=R))
+    panel = np.stack(panels)
+    st = {k: np.stack([s[k] for s in starts]) for k in KEYS}
+    dev = {k: _dev(ctx, st[k]) for k in KEYS}
+    path, its, f, P = ctx.em_batch(_dev(ctx, panel), *[dev[k] for k in KEYS], max_iter=iters, tol=0.0)
+    torch.cuda.synchronize()
+    nf, nt = ctx.chunk_fallbacks()
+    assert nt == B and 0 < nf < B, (nf, nt)
+    path = path.cpu().numpy(); f = f.cpu().numpy()
+    assert np.all(its.cpu().numpy() == iters)
+    for b in range(B):
+        keep = ~np.isnan(panel[b]).all(axis=0)                   # (series without any observed cell keep their parameters: drop them for the oracle)
+        sub = {k: (st[k][b][keep] if k in ("Lam", "R") else st[k][b]) for k in KEYS}
+        p, opath, out = ko.em(panel[b][:, keep], sub, max_iter=iters, tol=0.0)
+        np.testing.assert_allclose(path[b], opath, rtol=1e-8, err_msg=f"loglik path b={b}")
+        for k in ("A", "Q", "mu0", "P0"):
+            got = dev[k][b].cpu().numpy()
+            assert np.abs(got - p[k]).max() <= 1e-7 * max(1.0, np.abs(p[k]).max()), (k, b, np.abs(got - p[k]).max())
+        assert np.abs(dev["Lam"][b].cpu().numpy()[keep] - p["Lam"]).max() <= 1e-7 * max(1.0, np.abs(p["Lam"]).max())
+        assert np.abs(f[b] - out["f_smooth"]).max() <= 1e-7 * np.abs(out["f_smooth"]).max()
