@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
             const int e = tid + 256 * q;
             if (e < UN * PER) mb[e] = mn[q];
         }
-        __syncthreads();
+        // (workgroup barriers that order LDS traffic only: __syncthreads() also drains the vector-memory counter, i.e. it would
+        // wait for the rows of the next group that are requested in between)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (g + 1 < ngroups) issue(g + 1);
         // E_t = f_t f_t' + P_t once per period, in place of P_t in the tile: it is the same for every series (every lane of every
         // wave used to recompute the 36 products for each of its missing cells -- half of the masked update's instructions)
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
                 mb[UN * R + e] = fma(mb[u * R + i], mb[u * R + jj], mb[UN * R + e]);
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = t0 + u;
@@ -187,6 +189,14 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
             double f[R];
 #pragma unroll
             for (int k = 0; k < R; ++k) f[k] = mb[u * R + k];
+            // E_t: REGD (accumulators in registers, R <= 8) reads the period's 36 entries in ONE batch in front of the update and
+            // adds them by a multiply-add with the lane's 0 / 1 mask: no divergent region, no wait per LDS read
+            double ef[REGD ? NP : 1];
+            if constexpr (REGD) {
+                const double* pv = mb + UN * R + u * NP;
+#pragma unroll
+                for (int v = 0; v < NP; ++v) ef[v] = pv[v];
+            }
             bool miss_any = false;
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
@@ -202,7 +212,16 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) sxf[j][k] = fma(xz, f[k], sxf[j][k]);
             }
-            if (__any(miss_any)) {   // wave-uniform: somebody in this wave lacks period t
+            if constexpr (REGD) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    const int col = tid + 256 * j;
+                    const double x = xv[u][j];
+                    const double mk = (col < N && x != x) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int v = 0; v < NP; ++v) dm[j][v] = fma(mk, ef[v], dm[j][v]);
+                }
+            } else if (__any(miss_any)) {   // wave-uniform: somebody in this wave lacks period t
                 const double* pv = mb + UN * R + u * NP;
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
@@ -210,14 +229,7 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
                     const double x = xv[u][j];
                     if (col < N && x != x) {
 #pragma unroll
-                        for (int i = 0; i < R; ++i)
-#pragma unroll
-                            for (int jj = 0; jj <= i; ++jj) {
-                                const int v = i * (i + 1) / 2 + jj;
-                                const double ef = pv[v];             // E_t (see above)
-                                if constexpr (REGD) dm[j][v] += ef;
-                                else dmg[(size_t)col * NP + v] += ef;
-                            }
+                        for (int v = 0; v < NP; ++v) dmg[(size_t)col * NP + v] += pv[v];   // E_t (see above)
                     }
                 }
             }
