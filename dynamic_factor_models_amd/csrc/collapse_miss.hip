@@ -86,7 +86,9 @@ __device__ __forceinline__ double wave_allsum_x(double v) {
     return v;
 }
 
-template <int STEPS, int NDR>
+// TAB: table mode (a.obs_chunk: one row per period for recursion_chunk.hip) as its own instantiation -- the kernel is bound by what
+// it issues, and the per-period arrays' stores and tests are not compiled into it
+template <int STEPS, int NDR, bool TAB>
 __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, unsigned SB, int abl) {
     constexpr int R = 8, NP = 36;
     constexpr int NB = 2, NS = 4 * NB;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
     const char* seg = reinterpret_cast<const char*>(a.panel + ((size_t)b * T + ta) * N);
     // table mode (a.obs_chunk: the observation table of recursion_chunk.hip instead of bcol .. ldrow): one 368-byte row per period,
     // doubles 0..35 C_t (packed; EVERY period), 36..43 b_t, 44 s_t, 45 n_t log 2 pi + log det R_t
-    const bool obs = a.obs_chunk != nullptr;
+    constexpr bool obs = TAB;
     auto obs_row = [&](int t) { return a.obs_chunk + ((size_t)b * T + t) * 46; };
 
     auto issue_block = [&](int k, int bslot) {                   // 4 rows x NDR DMAs, always (rows past the segment: its last row)
@@ -369,21 +371,25 @@ static size_t cm_lds_bytes(int N) {
     return (size_t)4 * 8 * SB + ((size_t)(N + 1) * 8 + (N + 2)) * sizeof(double) + (size_t)4 * (N8 + 8) * sizeof(int);
 }
 
-template <int STEPS, int NDR>
-static hipError_t launch_cm_one(const CollapseArgs& a, int num_cu, hipStream_t s) {
-    (void)num_cu;
+template <int STEPS, int NDR, bool TAB>
+static hipError_t launch_cm_tab(const CollapseArgs& a, hipStream_t s) {
     const unsigned SB = miss_slot_bytes(a.N);
     const size_t lds = cm_lds_bytes(a.N);
     static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_miss_kernel<STEPS, NDR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_miss_kernel<STEPS, NDR, TAB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
     static const int abl = [] { const char* v = diag_env("DFM_CM_ABL"); return v ? atoi(v) : 0; }();   // diagnostics: bit 0 skips C_t
-    hipLaunchKernelGGL((collapse_miss_kernel<STEPS, NDR>), dim3(a.B), dim3(256), lds, s, a, SB, abl);
+    hipLaunchKernelGGL((collapse_miss_kernel<STEPS, NDR, TAB>), dim3(a.B), dim3(256), lds, s, a, SB, abl);
     return hipGetLastError();
+}
+template <int STEPS, int NDR>
+static hipError_t launch_cm_one(const CollapseArgs& a, int num_cu, hipStream_t s) {
+    (void)num_cu;
+    return a.obs_chunk ? launch_cm_tab<STEPS, NDR, true>(a, s) : launch_cm_tab<STEPS, NDR, false>(a, s);
 }
 
 template <int S>
