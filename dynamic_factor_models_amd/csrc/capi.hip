@@ -38,6 +38,8 @@ struct dfm_handle {
     int* status_dev = nullptr;
     int discarded_status = 0;              // status bits of earlier, unchecked device-pointer calls that a host-pointer entry cleared (status_epoch)
     bool no_rec_wave = false;              // DFM_NO_RECURSION_WAVE=1: lane-group recursion_kernel also at Rp = 8 (A/B)
+    bool no_chunk = false; int chunk_w = 0; double chunk_tol = 0.0;   // DFM_NO_CHUNK=1 (route): panels with missing cells at Rp = 8 on the sequential kernels;
+                                           // DFM_CHUNK_W=n, DFM_CHUNK_TOL=x (route): warm-up periods / boundary tolerance of recursion_chunk.hip (0 = its defaults: 8, 1e-10)
     int pair_bmax = -1;                    // Rp = 8: batch limit of the covariance-wave + mean-wave pair (recursion_pair.hip); -1 = one replicate per SIMD,
                                            // DFM_PAIR_BMAX=n; DFM_NO_PAIR=1 = 0 (never)
     bool no_pfill = false;                 // DFM_NO_PFILL=1: P_smooth fill inside meanscan (diagnostics)
@@ -682,7 +684,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
     ra.ZJtab = at<double>(h, p.ZJ); ra.wtab = at<double>(h, p.wtab); ra.eidx = nullptr;
-    ra.chunk_scr = at<double>(h, p.ck_scr); ra.chunk_obs = at<double>(h, p.ck_obs); ra.chunk_cst = at<double>(h, p.ck_cst); ra.chunk_term = at<double>(h, p.ck_term); ra.chunk_fail = at<int>(h, p.ck_fail);
+    ra.chunk_scr = h->no_chunk ? nullptr : at<double>(h, p.ck_scr); ra.chunk_W = h->chunk_w; ra.chunk_tol = h->chunk_tol; ra.chunk_obs = at<double>(h, p.ck_obs); ra.chunk_cst = at<double>(h, p.ck_cst); ra.chunk_term = at<double>(h, p.ck_term); ra.chunk_fail = at<int>(h, p.ck_fail);
     ra.f_smooth = f_smooth; ra.P_smooth = P_smooth; ra.loglik = loglik;
     ra.ncov = at<int>(h, p.ncov);
     if (em) {
@@ -1272,6 +1274,9 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = diag_env("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
     if (const char* v = diag_env("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
     if (const char* v = diag_env("DFM_COLLAPSE_MISS_OLD")) h->collapse_miss_old = atoi(v) != 0;
+    if (const char* v = route_env("DFM_NO_CHUNK")) h->no_chunk = atoi(v) != 0;
+    if (const char* v = route_env("DFM_CHUNK_W")) h->chunk_w = atoi(v) > 0 ? atoi(v) : 0;
+    if (const char* v = route_env("DFM_CHUNK_TOL")) h->chunk_tol = atof(v) > 0.0 ? atof(v) : 0.0;
     if (const char* v = diag_env("DFM_WIDE_OLD")) h->wide_old = atoi(v) != 0;
     if (const char* v = route_env("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;

@@ -631,18 +631,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
 // ------------------------------------------------------------------------------------------------------------------------------
 namespace {
-int chunk_warm() {
-    static const int w = [] { const char* v = route_env("DFM_CHUNK_W"); const int x = v ? atoi(v) : 8; return x < 1 ? 1 : (x > 64 ? 64 : x); }();
-    return w;
-}
-double chunk_tolerance() {
-    static const double t = [] { const char* v = route_env("DFM_CHUNK_TOL"); return v ? atof(v) : 1e-10; }();
-    return t;
-}
-bool chunk_enabled() {
-    static const bool on = [] { const char* v = route_env("DFM_NO_CHUNK"); return !(v && atoi(v) != 0); }();
-    return on;
-}
+// (the route switches DFM_NO_CHUNK, DFM_CHUNK_W, DFM_CHUNK_TOL belong to the HANDLE -- capi.hip reads them at dfm_create and hands them
+// over in RecursionArgs::chunk_W / chunk_tol, or leaves chunk_scr null -- so that one process can hold contexts on either kernel)
+constexpr int kChunkWarmDefault = 8;
+constexpr double kChunkTolDefault = 1e-10;
+int chunk_warm(const RecursionArgs& a) { return a.chunk_W > 0 ? (a.chunk_W > 64 ? 64 : a.chunk_W) : kChunkWarmDefault; }
 size_t chunk_lds_bytes(bool em) {
     return (size_t)(2 * 64 * kObsRows) * sizeof(double) + (em ? (size_t)(100 * kAccSlots + 2 * 8 * kTileStride<8>) * sizeof(double) : 0);
 }
@@ -662,7 +655,7 @@ size_t recursion_chunk_obs_bytes(int B, int T) {
 // Plain factor model at Rp = 8 in information form (no companion state: the EM epilogue here has no shift rows), collapsed
 // observations 2, 4 or 8 wide; a sample long enough for two lanes.  The sequential kernel must be able to take a replicate back.
 bool recursion_chunk_supported(int Rpad, const RecursionArgs& a) {
-    if (!chunk_enabled() || Rpad != 8 || a.cov || a.kdim != 0 || a.kb != 0 || a.ka != 0 || a.ct_r != 0) return false;
+    if (Rpad != 8 || a.cov || a.kdim != 0 || a.kb != 0 || a.ka != 0 || a.ct_r != 0) return false;
     if (!a.chunk_scr || !a.chunk_cst || !a.chunk_term || !a.chunk_fail || !a.chunk_obs) return false;
     if (a.rl != 0 && a.Rc == 0) return false;
     const int Rc = a.Rc > 0 ? a.Rc : 8;
@@ -670,7 +663,7 @@ bool recursion_chunk_supported(int Rpad, const RecursionArgs& a) {
     if (a.rl != 0 && a.rl != Rc) return false;
     if (!recursion_wave8_fits(a.T)) return false;
     const int L = recursion_chunk_len(a.T);
-    return a.T >= 2 * (L + chunk_warm());
+    return a.T >= 2 * (L + chunk_warm(a));
 }
 
 template <bool EM>
@@ -687,8 +680,8 @@ hipError_t launch_recursion_chunk(const RecursionArgs& a0, hipStream_t s) {
     note_kernel("recursion_chunk_kernel");
     RecursionArgs a = a0;
     a.chunk_L = recursion_chunk_len(a.T);
-    a.chunk_W = chunk_warm();
-    a.chunk_tol = chunk_tolerance();
+    a.chunk_W = chunk_warm(a0);
+    a.chunk_tol = a0.chunk_tol > 0.0 ? a0.chunk_tol : kChunkTolDefault;
     hipLaunchKernelGGL(chunk_prep_kernel, dim3(a.B), dim3(64), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

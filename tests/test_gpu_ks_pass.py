@@ -237,12 +237,15 @@ def test_balanced_kernel_choices_agree(env):
         c.close()
 
 
-@pytest.mark.parametrize("env", [dict(), dict(DFM_NO_PAIR=1), dict(DFM_PAIR_BMAX=3)])
+@pytest.mark.parametrize("env", [dict(), dict(DFM_NO_CHUNK=1), dict(DFM_NO_CHUNK=1, DFM_NO_PAIR=1), dict(DFM_NO_CHUNK=1, DFM_PAIR_BMAX=3),
+                                 dict(DFM_CHUNK_W=12), dict(DFM_CHUNK_W=2), dict(DFM_CHUNK_TOL=1e-30)])
 def test_sequential_kernel_choices_agree(env):
-    """Panels with missing cells at Rp = 8: the covariance-wave + mean-wave pair (recursion_pair.hip, the default up to
-    one replicate per SIMD) and the one-wave-per-replicate kernel are the same function of the inputs -- dense chunks
-    (every period with a missing cell), mixed chunks, fully observed stretches that reach the steady state, r = 3
-    padded to the 8-wide state, T not a multiple of the chunk."""
+    """Panels with missing cells at Rp = 8: the time-chunked recursion (recursion_chunk.hip, the default since round 5; W = 12: a
+    longer warm-up; W = 2 or a tolerance nothing meets: every replicate fails its boundary check and is redone by the sequential
+    kernel behind it), the covariance-wave + mean-wave pair (recursion_pair.hip, DFM_NO_CHUNK=1: the default of rounds 3-4 up to one
+    replicate per SIMD) and the one-wave-per-replicate kernel are the same function of the inputs -- dense chunks (every period
+    with a missing cell), mixed chunks, fully observed stretches that reach the steady state, r = 3 padded to the 8-wide state, T not
+    a multiple of the chunk."""
     c = _ctx_with_env(**env)
     try:
         for (B, N, T, r, miss) in [(5, 200, 500, 8, 0.1), (4, 64, 203, 8, 0.01), (6, 30, 41, 3, 0.3), (3, 120, 257, 5, 0.0005),
