@@ -645,12 +645,13 @@ def f3_lines(torch, ctx, dev, cpu_seconds=2.0):
         xs.append(x); qs.append(vo.varp_init(np.nan_to_num(x), rv, pv)[0])
     xv = tile(np.stack(xs))
     d0 = {k: tile(np.stack([q[k] for q in qs])) for k in KV}
-    dd = {k: v.clone() for k, v in d0.items()}
-    ctx.em_varp_batch(xv, *[dd[k] for k in KV], max_iter=2, tol=0.0, may_have_missing=True)
-    dd = {k: v.clone() for k, v in d0.items()}
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    path, its, _, _ = ctx.em_varp_batch(xv, *[dd[k] for k in KV], max_iter=nit, tol=0.0, may_have_missing=True)
-    torch.cuda.synchronize(); s_it = (time.perf_counter() - t0) / nit
+    s_it = None
+    for rep in range(4):                                          # (the first call warms the clocks up after the CPU legs before it: best of the other three)
+        dd = {k: v.clone() for k, v in d0.items()}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        path, its, _, _ = ctx.em_varp_batch(xv, *[dd[k] for k in KV], max_iter=nit, tol=0.0, may_have_missing=True)
+        torch.cuda.synchronize(); el = (time.perf_counter() - t0) / nit
+        if rep > 0: s_it = el if s_it is None else min(s_it, el)
     _, opath, _ = vo.em_varp(xs[0], dict(qs[0]), pv, max_iter=nit, tol=0.0)
     ok = bool(np.allclose(path[0].cpu().numpy(), opath, rtol=1e-8) and np.allclose(path[16].cpu().numpy(), opath, rtol=1e-8))
     t0 = time.perf_counter(); n = 0
@@ -671,12 +672,13 @@ def f3_lines(torch, ctx, dev, cpu_seconds=2.0):
     xs, sts = zip(*[aro.synth_ar(b, Nv, Tv, rv, pv, qv, missing=miss) for b in range(16)])
     xa = tile(np.stack(xs))
     a0 = {k: tile(np.stack([st[k] for st in sts])) for k in KA}
-    aa = {k: v.clone() for k, v in a0.items()}
-    ctx.em_ar_batch(xa, *[aa[k] for k in KA], max_iter=2)
-    aa = {k: v.clone() for k, v in a0.items()}
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    path, its, _, _ = ctx.em_ar_batch(xa, *[aa[k] for k in KA], max_iter=nit)
-    torch.cuda.synchronize(); s_it = (time.perf_counter() - t0) / nit
+    s_it = None
+    for rep in range(3):
+        aa = {k: v.clone() for k, v in a0.items()}
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        path, its, _, _ = ctx.em_ar_batch(xa, *[aa[k] for k in KA], max_iter=nit)
+        torch.cuda.synchronize(); el = (time.perf_counter() - t0) / nit
+        if rep > 0: s_it = el if s_it is None else min(s_it, el)
     _, opath, _ = aro.em_ar(xs[0], {k: sts[0][k] for k in KA}, max_iter=nit)
     ok = bool(np.allclose(path[0].cpu().numpy(), opath, rtol=1e-7) and np.allclose(path[16].cpu().numpy(), opath, rtol=1e-7))
     t0 = time.perf_counter(); n = 0
