@@ -38,6 +38,7 @@ struct dfm_handle {
     int* status_dev = nullptr;
     int discarded_status = 0;              // status bits of earlier, unchecked device-pointer calls that a host-pointer entry cleared (status_epoch)
     bool no_rec_wave = false;              // DFM_NO_RECURSION_WAVE=1: lane-group recursion_kernel also at Rp = 8 (A/B)
+    int tile_nc = 0, tile_w = 0;   // DFM_TILE_NC (route): chunks per replicate on recursion_tile_kernel (0 = automatic, 1 = the sequential kernel), DFM_TILE_W: warm-up periods
     bool no_chunk = false; int chunk_w = 0; double chunk_tol = 0.0;   // DFM_NO_CHUNK=1 (route): panels with missing cells at Rp = 8 on the sequential kernels;
                                            // DFM_CHUNK_W=n, DFM_CHUNK_TOL=x (route): warm-up periods / boundary tolerance of recursion_chunk.hip (0 = its defaults: 8, 1e-10)
     int pair_bmax = -1;                    // Rp = 8: batch limit of the covariance-wave + mean-wave pair (recursion_pair.hip); -1 = one replicate per SIMD,
@@ -130,6 +131,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t bcol, scol, ldrow, nobs, Ct, Cfull, ldfull;
     size_t ZJ, wtab, status, ncov;
     size_t ck_scr = (size_t)-1, ck_obs = (size_t)-1, ck_cst = (size_t)-1, ck_term = (size_t)-1, ck_fail = (size_t)-1;   // recursion_chunk.hip (Rp = 8, general path)
+    size_t tk_scr = (size_t)-1, tk_bytes = 0;   // recursion_tile.hip (Rp = 32, general path): the chunks' scratch (ck_fail is shared)
     size_t S11, S10, S00, P0s, f0s, fsm, Psm, Sxf, Sxx, Dmiss, llbuf, active;
     // balanced fast path (fastpath.hip); (size_t)-1 when the plan is for the general path
     size_t f_tab, f_E, f_stead, f_xi0, f_PT, f_llc, f_fill, f_PsInf, f_ssum;
@@ -213,6 +215,11 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.ck_obs = take(off, recursion_chunk_obs_bytes(B, T));
         p.ck_cst = take(off, (size_t)B * 320 * d);
         p.ck_term = take(off, (size_t)B * 96 * d);
+        p.ck_fail = take(off, (size_t)B * sizeof(int));
+    }
+    if (!fast && !p.cov && Rp == 32 && p.Rc == 0) {
+        p.tk_bytes = recursion_tile_scratch_bytes(B, T);
+        p.tk_scr = take(off, p.tk_bytes);
         p.ck_fail = take(off, (size_t)B * sizeof(int));
     }
     p.status = take(off, 256);
@@ -685,6 +692,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
     ra.ZJtab = at<double>(h, p.ZJ); ra.wtab = at<double>(h, p.wtab); ra.eidx = nullptr;
     ra.chunk_scr = h->no_chunk ? nullptr : at<double>(h, p.ck_scr); ra.chunk_W = h->chunk_w; ra.chunk_tol = h->chunk_tol; ra.chunk_obs = at<double>(h, p.ck_obs); ra.chunk_cst = at<double>(h, p.ck_cst); ra.chunk_term = at<double>(h, p.ck_term); ra.chunk_fail = at<int>(h, p.ck_fail);
+    ra.tile_scr = at<double>(h, p.tk_scr); ra.tile_scr_bytes = p.tk_bytes; ra.tile_nc = h->tile_nc; ra.tile_w = h->tile_w; ra.num_cu = h->num_cu;
     ra.f_smooth = f_smooth; ra.P_smooth = P_smooth; ra.loglik = loglik;
     ra.ncov = at<int>(h, p.ncov);
     if (em) {
@@ -720,6 +728,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     }
     h->ck_fail_dev = nullptr; h->ck_fail_n = 0;
     if (ra.wave && recursion_chunk_supported(p.Rp, ra)) { h->ck_fail_dev = ra.chunk_fail; h->ck_fail_n = B; }
+    else if (ra.wave && recursion_tile_supported(p.Rp, ra) && recursion_tile_chunks(ra, nullptr, nullptr) > 1) { h->ck_fail_dev = ra.chunk_fail; h->ck_fail_n = B; }
     { ProfScope ps(h, K_RECURSION); HIP_TRY(h, launch_recursion(p.Rp, ra, h->stream)); }
     return 0;
 }
@@ -1277,6 +1286,8 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = route_env("DFM_NO_CHUNK")) h->no_chunk = atoi(v) != 0;
     if (const char* v = route_env("DFM_CHUNK_W")) h->chunk_w = atoi(v) > 0 ? atoi(v) : 0;
     if (const char* v = route_env("DFM_CHUNK_TOL")) h->chunk_tol = atof(v) > 0.0 ? atof(v) : 0.0;
+    if (const char* v = route_env("DFM_TILE_NC")) h->tile_nc = atoi(v) > 0 ? atoi(v) : 0;
+    if (const char* v = route_env("DFM_TILE_W")) h->tile_w = atoi(v) > 0 ? atoi(v) : 0;
     if (const char* v = diag_env("DFM_WIDE_OLD")) h->wide_old = atoi(v) != 0;
     if (const char* v = route_env("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;

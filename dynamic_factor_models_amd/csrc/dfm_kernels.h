@@ -125,6 +125,13 @@ struct RecursionArgs {
     const int* only_if;   // [B] or null: the sequential kernels (recursion_wave / recursion_pair) run replicate b only if only_if[b] != 0
     int chunk_L, chunk_W;
     double chunk_tol;
+    // time-chunked recursion_tile (Rp = 32, information form): tile_nc chunks of tile_lc periods per replicate, one workgroup each,
+    // warmed up over tile_w periods; boundaries checked to chunk_tol, chunk_fail / only_if as above
+    double* tile_scr;     // [B][tile_nc][...]  private tables of the warm-up periods, boundary states, parts of the sums (recursion_tile.hip)
+    size_t tile_scr_bytes;
+    int tile_nc;          // in: 0 = automatic, 1 = never, n = that many; the launcher fills in the count it uses
+    int tile_lc, tile_w;
+    int num_cu;
 };
 
 // Rp = 8, information form, plain factor model (no companion state): the time-chunked recursion
@@ -141,6 +148,8 @@ hipError_t launch_recursion_wave8_fallback(const RecursionArgs& a, hipStream_t s
 // tiles, 4 x 4 block-pivot sweep inverse (recursion_tile.hip)
 bool recursion_tile_supported(int Rpad, const RecursionArgs& a);
 hipError_t launch_recursion_tile(const RecursionArgs& a, hipStream_t s);
+int recursion_tile_chunks(const RecursionArgs& a, int* lc_out, int* w_out);   // chunks per replicate the launch will use (1: sequential)
+size_t recursion_tile_scratch_bytes(int B, int T);            // tile_scr
 
 struct MstepArgs {
     int B, T, N, r;

@@ -178,7 +178,58 @@ __device__ __forceinline__ double rt_sweep_inverse(RtCtx& x, v4d& m, int npiv) {
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a) {
+// ------------------------------------------------------------------------------------------------------------------
+// Time chunks (round 5).  One workgroup per replicate leaves the machine idle twice over: B = 256 replicates put one wave on each
+// SIMD, and that wave is a chain of dependent MFMAs, LDS exchanges and 4-wave barriers (B = 512 takes 13.3 ms where B = 256 takes
+// 10.8: a second workgroup per CU runs in the first one's bubbles).  CH = true cuts a replicate's T periods into tile_nc chunks of
+// tile_lc periods, one workgroup each -- the scheme of recursion_chunk.hip at workgroup granularity:
+//   * forward: chunk c > 0 starts tile_w periods early from a guess (Om_f = Q^-1 + C, xi = 0) -- the filter forgets its start at
+//     the rate of its closed loop -- and every chunk but the last runs tile_w periods PAST its end (exact: a continuation), into a
+//     private table, so that
+//   * backward: it can start tile_w periods late from a guess (P = Z, f = w of the last extra period) and arrive at its own end
+//     with the smoothed moments, forgotten likewise;
+//   * nothing is assumed: the state each chunk ENTERS its own periods with (forward at its first period, backward at its last)
+//     is compared with the exact one its neighbour LEAVES there (tile_chunk_finish_kernel, chunk_tol relative to the largest
+//     entry); a replicate with one boundary off is run again by the sequential instantiation (only_if = chunk_fail), which
+//     overwrites everything the chunks wrote;
+//   * per-chunk parts of the log-likelihood and of the EM sums meet in tile_chunk_finish_kernel, which also keeps the EM
+//     bookkeeping and the three sums over f_smooth (they span the chunks).
+// Scratch per (replicate, chunk): the private table [tile_w][2][32][32] + [tile_w][32], four boundary states, the parts.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kTkBst = kRt * kRt + kRt;            // a boundary state: matrix (register-pair layout) + vector
+constexpr int kTkPart = 16;                        // log-likelihood part of a chunk (one double used)
+constexpr int kTkWmax = 32, kTkNCmax = 16;
+__host__ __device__ inline size_t tk_slot_doubles(int W) {
+    return (size_t)W * (2 * kRt * kRt + kRt) + 4 * kTkBst + kTkPart + 3 * kRt * kRt;
+}
+
+// sum_t f_t f_t', sum_t f_t f_t-1', sum_t f_t-1 f_t-1' (periods 1 .. T; f_0 in f0sh) as products over time: k = 4 periods per
+// MFMA, operands straight from f_smooth (agent-scope loads: in the sequential kernel this CU wrote the rows itself)
+__device__ __forceinline__ void tile_gsums(const double* F, const double* f0sh, int T, int r, int I, int J, int q, int c,
+                                           v4d& G11, v4d& G10, v4d& G00) {
+    const int ci = 16 * I + c, cj = 16 * J + c;                  // this lane's column of F as A operand (I) and as B operand (J)
+    const bool oki = ci < r, okj = cj < r;
+    const double f0i = f0sh[ci], f0j = f0sh[cj];
+    for (int k0 = 0; k0 < T; k0 += 4) {
+        const int t = k0 + q;                                    // F row t = period t + 1; "previous" = row t - 1, or f_0
+        const bool in = t < T;
+        const double fi = (in && oki) ? __hip_atomic_load(F + (size_t)t * r + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        const double fj = (in && okj) ? __hip_atomic_load(F + (size_t)t * r + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        double pi = 0.0, pj = 0.0;
+        if (in) {
+            pi = t == 0 ? f0i : (oki ? __hip_atomic_load(F + (size_t)(t - 1) * r + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
+            pj = t == 0 ? f0j : (okj ? __hip_atomic_load(F + (size_t)(t - 1) * r + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
+        }
+        G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, fj, G11, 0, 0, 0);
+        G10 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, pj, G10, 0, 0, 0);
+        G00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, pj, G00, 0, 0, 0);
+    }
+}
+}  // namespace
+
+template <bool CH>
+__global__ __launch_bounds__(256, CH ? 2 : 1) void recursion_tile_kernel(RecursionArgs a) {
     constexpr int R = kRt, RR = R * R;
     __shared__ __attribute__((aligned(16))) double sm[kRtLds];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -186,8 +237,17 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     RtCtx x;
     x.sm = sm; x.lane = lane; x.w = w; x.I = w >> 1; x.J = w & 1; x.q = lane >> 4; x.c = lane & 15; x.pp = 0;
     const int I = x.I, J = x.J, q = x.q, c = x.c;
-    const int b = blockIdx.x;
+    const int NC = CH ? a.tile_nc : 1;
+    const int b = CH ? (int)blockIdx.x % a.B : (int)blockIdx.x;
+    const int ck = CH ? (int)blockIdx.x / a.B : 0;            // this workgroup's chunk
+    if (!CH && a.only_if != nullptr && a.only_if[b] == 0) return;   // (the sequential run of the replicates a chunk boundary rejected)
     const int T = a.T, N = a.N, r = a.r;                      // r: width of the OUTPUT layout (the caller's r, or 32 inside EM)
+    const bool first = !CH || ck == 0, lastc = !CH || ck == NC - 1;
+    const int Wk = CH ? a.tile_w : 0;
+    const int s0 = CH ? ck * a.tile_lc : 0;                    // own periods s0 .. e0 - 1 (steps; the last chunk adds the terminal step T)
+    const int e0 = lastc ? T : s0 + a.tile_lc;
+    const int tb = first ? 0 : s0 - Wk;                        // forward steps tb .. te - 1 (tb, s0 even: register sets go by parity)
+    const int te = lastc ? T + 1 : e0 + Wk;
     const int rs = a.rstate;                                   // the model's state width, 17 .. 31
     const int npiv = (rs + 3) >> 2, nks = npiv;
     const int col = 16 * J + c;
@@ -217,6 +277,23 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     const double ldfull = a.ldfull[b];
     double* ZJ = a.ZJtab + (size_t)b * (T + 1) * 2 * RR;       // per period: Z (4 tiles), J' (4 tiles), register-pair layout
     double* wtab = a.wtab + (size_t)b * T * R;
+    // chunk scratch: the table of the extra forward steps e0 .. e0 + Wk - 1, boundary states, parts
+    double* const slot = CH ? a.tile_scr + ((size_t)b * NC + ck) * tk_slot_doubles(Wk) : nullptr;
+    double* const xZJ = slot;
+    double* const xw = CH ? slot + (size_t)Wk * 2 * RR : nullptr;
+    double* const bst = CH ? xw + (size_t)Wk * R : nullptr;
+    double* const part = CH ? bst + 4 * kTkBst : nullptr;
+    double* const sums = CH ? part + kTkPart : nullptr;
+    auto tab_ent = [&](int t) -> double* { return (CH && t >= e0) ? xZJ + (size_t)(t - e0) * 2 * RR : ZJ + (size_t)t * 2 * RR; };
+    auto w_ent = [&](int t) -> double* { return (CH && t >= e0) ? xw + (size_t)(t - e0) * R : wtab + (size_t)t * R; };
+    auto put_state = [&](int k, const v4d& M, const double (&vec)[4]) {   // boundary state k: 0 / 1 forward entry / exit, 2 / 3 backward
+        double* d = bst + (size_t)k * kTkBst;
+        st_tile_g(d, w, lane, M);
+        if (c31) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) d[RR + rowv[v]] = vec[v];
+        }
+    };
     // C_t rows: the packed leading ct_r x ct_r block (ct_miss_wide2_kernel writes that for this kernel: the padding beyond it carries
     // no loadings, its entries are Cfull's), or the full packed 32 x 32 layout of the other collapse kernels (ct_r = 0)
     const int ctr = a.ct_r > 0 ? a.ct_r : R;
@@ -275,6 +352,11 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
 #pragma unroll
         for (int v = 0; v < 4; ++v) { xi[v] = x0[v]; qacc = fma(mu0v[v], x0[v], qacc); }
     }
+    if (CH && !first) {                                        // (uniform) a later chunk: the guess its warm-up periods forget
+        qacc = 0.0;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { xi[v] = 0.0; Omf[v] = Qi[v] + Cf[v]; }
+    }
     rt_barrier();                                           // (every wave has read Xk before the next patch)
     put_c31(Xk, xi);
 
@@ -300,15 +382,19 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     v4d Ps = zero4;
     double fs[4] = {0.0, 0.0, 0.0, 0.0};
     double detOmT = 1.0;
-    const int nchf = (T + 1 + kRtCh - 1) / kRtCh;              // T + 1 steps
-    load_fwd(0, 0);
-    load_fwd(1, 1);
-    for (int ch = 0; ch < nchf; ++ch) {
+    load_fwd(0, tb);
+    load_fwd(1, tb + 1);
+    for (int ch = tb / kRtCh; ch * kRtCh < te; ++ch) {
 #pragma unroll
         for (int s = 0; s < kRtCh; ++s) {
             const int t = ch * kRtCh + s;
-            if (t <= T) {                                        // (uniform)
+            if (t < te) {                                        // (uniform)
                 const bool last = (t == T);
+                const bool own = !CH || (t >= s0 && t < e0);     // (uniform) a period of this chunk: it counts, its table entry is THE entry
+                if (CH) {
+                    if (!first && t == s0) put_state(0, Omf, xi);   // what the warm-up arrived at ...
+                    if (!lastc && t == e0) put_state(1, Omf, xi);   // ... is checked against the exact state the chunk before leaves
+                }
                 v4d Z;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) Z[v] = last ? Omf[v] : Omf[v] + Phi[v];
@@ -328,16 +414,19 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) { fs[v] = Jaug[v]; qacc = fma(-xi[v], Jaug[v], qacc); }   // f_T = P_T xi_T (column 31)
                 } else {
-                    detprod.mul(dM);
+                    if (own) detprod.mul(dM);
                     const v4d ZX0 = ld_tile(bufA, tX0, lane), ZX1 = ld_tile(bufA, tX1, lane);
                     const v4d Jt = mm_tn(KtY0, KtY1, ZX0, ZX1, nks, zero4);    // J' = K Z
                     st_tile(bufB, w, lane, Jaug);
-                    double* ent = ZJ + (size_t)t * 2 * RR;
-                    st_tile_g(ent, w, lane, Z);
-                    st_tile_g(ent + RR, w, lane, Jt);
-                    if (c31) {
+                    if (!CH || t >= s0) {                        // (uniform; warm-up periods leave no entry)
+                        double* ent = tab_ent(t);
+                        st_tile_g(ent, w, lane, Z);
+                        st_tile_g(ent + RR, w, lane, Jt);
+                        if (c31) {
+                            double* we = w_ent(t);
 #pragma unroll
-                        for (int v = 0; v < 4; ++v) wtab[(size_t)t * R + rowv[v]] = Jaug[v];
+                            for (int v = 0; v < 4; ++v) we[rowv[v]] = Jaug[v];
+                        }
                     }
                     RT_TOCK(p_p1);
                     RT_TICK(p_p2);
@@ -353,14 +442,16 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                     if (c31) {
 #pragma unroll
                         for (int v = 0; v < 4; ++v) {
-                            qacc = fma(-xi[v], Jaug[v], qacc);   // xi_t'w_t
+                            if (own) qacc = fma(-xi[v], Jaug[v], qacc);   // xi_t'w_t
                             xi[v] = prod[v] + cb[s][v];          // xi_t+1 = K w_t + b_t
                         }
                     }
                     put_c31(Xk, xi);                             // (read again after the next barrier at the earliest)
-                    ssum += cs[s];
-                    nsum += (double)cn[s];
-                    ldsum += full ? ldfull : cl[s];
+                    if (own) {
+                        ssum += cs[s];
+                        nsum += (double)cn[s];
+                        ldsum += full ? ldfull : cl[s];
+                    }
                     load_fwd(s, t + 2);                          // (this set's operands are consumed)
                     RT_TOCK(p_p2);
                 }
@@ -377,19 +468,27 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
             double qd = 0.0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) qd += sm[kRtRed + k];
-            const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) + detprod.log_value();
-            const double ll = -0.5 * (nsum * kLog2PiT + ldsum + LD + ssum + qd);
-            a.loglik[b] = ll;
-            if (a.ncov) a.ncov[b] = T;
-            if (a.active) {                                      // EM bookkeeping, as recursion_kernel
-                const bool was = a.k == 0 ? true : (a.active[b] != 0);
-                bool go = was;
-                if (was && a.k >= 1 && a.tol > 0.0) {
-                    const double llp = a.ll_path[(size_t)b * a.max_iter + a.k - 1];
-                    go = !((ll - llp) / (0.5 * (fabs(ll) + fabs(llp))) < a.tol);
+            if (CH) {
+                // this chunk's part of  n log 2 pi + sum log det R_t + log dets + sum s_t + quadratic terms  (tile_chunk_finish_kernel adds them up)
+                double LD = detprod.log_value();
+                if (first) LD += log(detP0) + (double)T * log(detQ);
+                if (lastc) LD += log(detOmT);
+                part[0] = nsum * kLog2PiT + ldsum + LD + ssum + qd;
+            } else {
+                const double LD = log(detOmT) + log(detP0) + (double)T * log(detQ) + detprod.log_value();
+                const double ll = -0.5 * (nsum * kLog2PiT + ldsum + LD + ssum + qd);
+                a.loglik[b] = ll;
+                if (a.ncov) a.ncov[b] = T;
+                if (a.active) {                                  // EM bookkeeping, as recursion_kernel
+                    const bool was = a.k == 0 ? true : (a.active[b] != 0);
+                    bool go = was;
+                    if (was && a.k >= 1 && a.tol > 0.0) {
+                        const double llp = a.ll_path[(size_t)b * a.max_iter + a.k - 1];
+                        go = !((ll - llp) / (0.5 * (fabs(ll) + fabs(llp))) < a.tol);
+                    }
+                    if (was) { a.ll_path[(size_t)b * a.max_iter + a.k] = ll; a.iters[b] = a.k + 1; }
+                    a.active[b] = go ? 1 : 0;
                 }
-                if (was) { a.ll_path[(size_t)b * a.max_iter + a.k] = ll; a.iters[b] = a.k + 1; }
-                a.active[b] = go ? 1 : 0;
             }
         }
     }
@@ -415,37 +514,45 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                 if (poff[v] >= 0) pr[poff[v]] = P[v];
         }
     };
-    emit(T - 1, Ps, fs);
+    __threadfence();
+    __syncthreads();                                           // (table and w_t stores of the forward sweep are visible: one CU, one L1)
+    if (CH && !lastc) {                                        // (uniform) the guess the backward warm-up forgets: (Z, w) of the last extra period
+        Ps = ld_tile_g(xZJ + (size_t)(Wk - 1) * 2 * RR, w, lane);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) fs[v] = xw[(size_t)(Wk - 1) * R + rowv[v]];
+    } else {
+        emit(T - 1, Ps, fs);
+    }
     const bool em = a.S11 != nullptr;
     const v4d PT = Ps;
-    v4d SP = Ps, SU = zero4;                                   // sum_t P_t (periods 1 .. T), sum of the lag-one covariances
+    v4d SP = lastc ? Ps : zero4, SU = zero4;                   // sum_t P_t (periods 1 .. T), sum of the lag-one covariances: this chunk's part
     // (Z, J') of step t and w_t in register set t & 1, re-loaded for step t - 2 behind their last use: the B operands of the
     // first product early in the step, Z / the A operands / w_t behind the second
     v4d zc[kRtCh], jx0[kRtCh], jx1[kRtCh], jy0[kRtCh], jy1[kRtCh];
     double wc[kRtCh][4];
     auto load_bwd_x = [&](int s, int t) {
-        t = t > 0 ? t : 0;
-        const double* ent = ZJ + (size_t)t * 2 * RR + RR;
+        t = t > s0 ? t : s0;
+        const double* ent = tab_ent(t) + RR;
         jx0[s] = ld_tile_g(ent, tX0, lane); jx1[s] = ld_tile_g(ent, tX1, lane);
     };
     auto load_bwd_y = [&](int s, int t) {
-        t = t > 0 ? t : 0;
-        const double* ent = ZJ + (size_t)t * 2 * RR;
+        t = t > s0 ? t : s0;
+        const double* ent = tab_ent(t);
         zc[s] = ld_tile_g(ent, w, lane);
         jy0[s] = ld_tile_g(ent + RR, tY0, lane); jy1[s] = ld_tile_g(ent + RR, tY1, lane);
+        const double* we = w_ent(t);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) wc[s][v] = wtab[(size_t)t * R + rowv[v]];
+        for (int v = 0; v < 4; ++v) wc[s][v] = we[rowv[v]];
     };
-    const int nchb = (T + kRtCh - 1) / kRtCh;
-    __threadfence();
-    __syncthreads();                                           // (table and w_t stores of the forward sweep are visible: one CU, one L1)
-    load_bwd_x((T - 1) & 1, T - 1); load_bwd_y((T - 1) & 1, T - 1);
-    load_bwd_x((T - 2) & 1, T - 2); load_bwd_y((T - 2) & 1, T - 2);   // (T = 1: step 0 again, unused)
-    for (int ch = nchb - 1; ch >= 0; --ch) {
+    const int tl = lastc ? T - 1 : e0 + Wk - 1;                // backward steps tl .. s0
+    load_bwd_x(tl & 1, tl); load_bwd_y(tl & 1, tl);
+    load_bwd_x((tl - 1) & 1, tl - 1); load_bwd_y((tl - 1) & 1, tl - 1);   // (one step only: that step again, unused)
+    for (int ch = tl / kRtCh; ch * kRtCh >= s0; --ch) {
 #pragma unroll
         for (int s = kRtCh - 1; s >= 0; --s) {
             const int t = ch * kRtCh + s;                        // step t: from period t + 1 to period t (t = 0: the initial state)
-            if (t < T) {                                         // (uniform)
+            if (t <= tl && t >= s0) {                            // (uniform)
+                const bool own = !CH || t < e0;
                 st_tile(bufA, w, lane, Ps);
                 rt_barrier();                                 // E3
                 const v4d PY0 = ld_tile(bufA, tY0, lane), PY1 = ld_tile(bufA, tY1, lane);
@@ -469,14 +576,16 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
                 }
                 Ps = Pn;
                 load_bwd_y(s, t - 2);
-                if (em) {
+                if (em && own) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) { SU[v] += U[v]; if (t > 0) SP[v] += Pn[v]; }
                 }
-                if (t > 0) emit(t - 1, Ps, fs);
+                if (own && t > 0) emit(t - 1, Ps, fs);
+                if (CH && !lastc && t == e0) put_state(2, Ps, fs);   // what the backward warm-up arrived at (period e0) ...
             }
         }
     }
+    if (CH && !first) put_state(3, Ps, fs);                    // ... is checked against the exact moments the chunk behind leaves (its period s0)
 #ifdef DFM_TILE_PROF
     if (b == 5 && tid == 0)
         printf("TILEPROF T=%d (10 ns ticks): total %lld  forward %lld (inverse %lld, Z exchange + 2 products %lld, J exchange + product + update %lld)  backward %lld\n",
@@ -484,8 +593,21 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
 #endif
     if (!em) return;
 
+    if (CH) {                                                  // this chunk's parts of the sums; the rest is tile_chunk_finish_kernel's
+        st_tile_g(sums, w, lane, SP);
+        st_tile_g(sums + RR, w, lane, SU);
+        if (lastc) st_tile_g(sums + 2 * RR, w, lane, PT);
+        if (first) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a.P0s[(size_t)b * RR + rowv[v] * R + col] = Ps[v];
+            if (c31) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a.f0s[(size_t)b * R + rowv[v]] = fs[v];
+            }
+        }
+        return;
+    }
     // ---------------- EM sums: S11 = sum E[f_t f_t'], S10 = sum E[f_t f_t-1'], S00 (periods 1 .. T; f_0 = fs, P_0 = Ps) ----
-    // sum_t f_t f_t' etc. as products over time: k = 4 periods per MFMA, operands straight from f_smooth (this CU wrote it)
     if (c31) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) sm[kRtRed + rowv[v]] = fs[v];               // f_0 (32 doubles)
@@ -493,26 +615,7 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     __threadfence();                                           // (f_smooth rows written by the column-31 lanes are read by every wave)
     __syncthreads();
     v4d G11 = zero4, G10 = zero4, G00 = zero4;
-    {
-        const double* F = a.f_smooth + (size_t)b * T * r;
-        const int ci = 16 * I + c, cj = 16 * J + c;              // this lane's column of F as A operand (I) and as B operand (J)
-        const bool oki = ci < r, okj = cj < r;
-        const double f0i = sm[kRtRed + ci], f0j = sm[kRtRed + cj];
-        for (int k0 = 0; k0 < T; k0 += 4) {
-            const int t = k0 + q;                                // F row t = period t + 1; "previous" = row t - 1, or f_0
-            const bool in = t < T;
-            const double fi = (in && oki) ? __hip_atomic_load(F + (size_t)t * r + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-            const double fj = (in && okj) ? __hip_atomic_load(F + (size_t)t * r + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-            double pi = 0.0, pj = 0.0;
-            if (in) {
-                pi = t == 0 ? f0i : (oki ? __hip_atomic_load(F + (size_t)(t - 1) * r + ci, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
-                pj = t == 0 ? f0j : (okj ? __hip_atomic_load(F + (size_t)(t - 1) * r + cj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
-            }
-            G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, fj, G11, 0, 0, 0);
-            G10 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi, pj, G10, 0, 0, 0);
-            G00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pi, pj, G00, 0, 0, 0);
-        }
-    }
+    tile_gsums(a.f_smooth + (size_t)b * T * r, sm + kRtRed, T, r, I, J, q, c, G11, G10, G00);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const size_t o = (size_t)b * RR + rowv[v] * R + col;
@@ -524,6 +627,96 @@ __global__ __launch_bounds__(256, 1) void recursion_tile_kernel(RecursionArgs a)
     if (c31) {
 #pragma unroll
         for (int v = 0; v < 4; ++v) a.f0s[(size_t)b * R + rowv[v]] = fs[v];
+    }
+}
+
+// The meeting point of a replicate's chunks: boundary checks (chunk_fail), the log-likelihood and the EM bookkeeping, the EM sums.
+__global__ __launch_bounds__(256) void tile_chunk_finish_kernel(RecursionArgs a, double tol) {
+    constexpr int R = kRt, RR = R * R;
+    __shared__ double red[4][4];
+    __shared__ double f0sh[R];
+    __shared__ int failS;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int I = w >> 1, J = w & 1, q = lane >> 4, c = lane & 15;
+    const int b = blockIdx.x, NC = a.tile_nc, Wk = a.tile_w, T = a.T, r = a.r;
+    const size_t sd = tk_slot_doubles(Wk);
+    const double* base = a.tile_scr + (size_t)b * NC * sd;
+    auto bst = [&](int ck, int k) { return base + (size_t)ck * sd + (size_t)Wk * (2 * RR + R) + (size_t)k * kTkBst; };
+    if (tid == 0) failS = 0;
+    __syncthreads();
+    for (int ck = 1; ck < NC; ++ck) {
+#pragma unroll 1
+        for (int dir = 0; dir < 2; ++dir) {
+            // forward: the entry state of chunk ck against the exit state of chunk ck - 1; backward: the entry state of chunk ck - 1
+            // against the exit state of chunk ck
+            const double* got = dir == 0 ? bst(ck, 0) : bst(ck - 1, 2);
+            const double* ref = dir == 0 ? bst(ck - 1, 1) : bst(ck, 3);
+            double dm = 0.0, rm = 0.0, dv = 0.0, rv = 0.0;
+            bool bad = false;
+            for (int i = tid; i < kTkBst; i += 256) {
+                const double g = got[i], e = ref[i], d = fabs(g - e);
+                bad = bad || !(d == d);
+                if (i < RR) { dm = fmax(dm, d); rm = fmax(rm, fabs(e)); } else { dv = fmax(dv, d); rv = fmax(rv, fabs(e)); }
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                dm = fmax(dm, __shfl_xor(dm, o, 64)); rm = fmax(rm, __shfl_xor(rm, o, 64));
+                dv = fmax(dv, __shfl_xor(dv, o, 64)); rv = fmax(rv, __shfl_xor(rv, o, 64));
+            }
+            if (bad) atomicOr(&failS, 1);
+            __syncthreads();                                     // (the last round's reads of red are done)
+            if (lane == 0) { red[w][0] = dm; red[w][1] = rm; red[w][2] = dv; red[w][3] = rv; }
+            __syncthreads();
+            if (tid == 0) {
+                double m[4];
+                for (int k = 0; k < 4; ++k) m[k] = fmax(fmax(red[0][k], red[1][k]), fmax(red[2][k], red[3][k]));
+                // (the mean vector against the larger of its own scale and 1: a state near zero is not a disagreement)
+                if (!(m[0] <= tol * m[1]) || !(m[2] <= tol * fmax(m[3], 1.0))) failS = 1;
+            }
+        }
+    }
+    __syncthreads();
+    const bool fail = failS != 0;
+    if (tid == 0) a.chunk_fail[b] = fail ? 1 : 0;
+    if (fail) return;                                          // (uniform) the sequential kernel runs this replicate again
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int ck = 0; ck < NC; ++ck) tot += (bst(ck, 0) + 4 * kTkBst)[0];
+        const double ll = -0.5 * tot;
+        a.loglik[b] = ll;
+        if (a.ncov) a.ncov[b] = T;
+        if (a.active) {                                          // EM bookkeeping, as recursion_kernel
+            const bool was = a.k == 0 ? true : (a.active[b] != 0);
+            bool go = was;
+            if (was && a.k >= 1 && a.tol > 0.0) {
+                const double llp = a.ll_path[(size_t)b * a.max_iter + a.k - 1];
+                go = !((ll - llp) / (0.5 * (fabs(ll) + fabs(llp))) < a.tol);
+            }
+            if (was) { a.ll_path[(size_t)b * a.max_iter + a.k] = ll; a.iters[b] = a.k + 1; }
+            a.active[b] = go ? 1 : 0;
+        }
+    }
+    if (a.S11 == nullptr) return;
+    // EM sums: the chunks' parts of sum P_t and sum U_t, plus the three products over f_smooth
+    if (tid < R) f0sh[tid] = a.f0s[(size_t)b * R + tid];
+    __syncthreads();
+    v4d SP, SU, G11, G10, G00;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { SP[v] = 0.0; SU[v] = 0.0; G11[v] = 0.0; G10[v] = 0.0; G00[v] = 0.0; }
+    for (int ck = 0; ck < NC; ++ck) {
+        const double* sums = bst(ck, 0) + 4 * kTkBst + kTkPart;
+        const v4d p = ld_tile_g(sums, w, lane), u = ld_tile_g(sums + RR, w, lane);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { SP[v] += p[v]; SU[v] += u[v]; }
+    }
+    const v4d PT = ld_tile_g(bst(NC - 1, 0) + 4 * kTkBst + kTkPart + 2 * RR, w, lane);
+    tile_gsums(a.f_smooth + (size_t)b * T * r, f0sh, T, r, I, J, q, c, G11, G10, G00);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const size_t o = (size_t)b * RR + (16 * I + q + 4 * v) * R + 16 * J + c;
+        a.S11[o] = SP[v] + G11[v];
+        a.S10[o] = SU[v] + G10[v];
+        a.S00[o] = (SP[v] - PT[v] + a.P0s[o]) + G00[v];
     }
 }
 
@@ -847,10 +1040,56 @@ bool recursion_tile_supported(int Rpad, const RecursionArgs& a) {
     return true;
 }
 
+// Chunks per replicate for this launch (1: the sequential kernel), their length and warm-up.  tile_nc: 0 = as many as give every
+// CU two workgroups, 1 = never, n = that many (development / tests); chunks are at least 4 warm-ups long and of even length.
+int recursion_tile_chunks(const RecursionArgs& a, int* lc_out, int* w_out) {
+    int W = a.tile_w > 0 ? a.tile_w : 16;
+    W = (W + 1) & ~1;
+    if (W > kTkWmax) W = kTkWmax;
+    if (w_out) *w_out = W;
+    if (lc_out) *lc_out = a.T;
+    if (a.tile_scr == nullptr || a.chunk_fail == nullptr || a.tile_nc == 1 || a.B < 1) return 1;
+    const int cu = a.num_cu > 0 ? a.num_cu : 256;
+    int want = a.tile_nc > 1 ? a.tile_nc : (2 * cu) / a.B;
+    if (want > kTkNCmax) want = kTkNCmax;
+    for (; want > 1; --want) {
+        const int lc = 2 * ((a.T + 2 * want - 1) / (2 * want));
+        const int lastlen = a.T - (want - 1) * lc;
+        if (lc < 4 * W || lastlen < W + 2) continue;
+        if ((size_t)a.B * want * tk_slot_doubles(W) * sizeof(double) > a.tile_scr_bytes) continue;
+        if (lc_out) *lc_out = lc;
+        return want;
+    }
+    return 1;
+}
+// workspace for the chunks of a batch (sized for the automatic choice on a device of up to 512 CUs and for forced counts on small batches)
+size_t recursion_tile_scratch_bytes(int B, int T) {
+    (void)T;
+    const size_t slots = (size_t)B * kTkNCmax < 1024 ? (size_t)B * kTkNCmax : ((size_t)B > 1024 ? (size_t)B : 1024);
+    return slots * tk_slot_doubles(kTkWmax) * sizeof(double);
+}
+
 hipError_t launch_recursion_tile(const RecursionArgs& a, hipStream_t s) {
     note_kernel("recursion_tile_kernel");
-    hipLaunchKernelGGL(recursion_tile_kernel, dim3(a.B), dim3(256), 0, s, a);
-    hipError_t e = hipGetLastError();
+    int lc = a.T, W = 16;
+    const int nc = recursion_tile_chunks(a, &lc, &W);
+    hipError_t e;
+    if (nc > 1) {
+        RecursionArgs c = a;
+        c.tile_nc = nc; c.tile_lc = lc; c.tile_w = W;
+        hipLaunchKernelGGL(recursion_tile_kernel<true>, dim3((unsigned)(a.B * nc)), dim3(256), 0, s, c);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(tile_chunk_finish_kernel, dim3(a.B), dim3(256), 0, s, c, a.chunk_tol > 0.0 ? a.chunk_tol : 1e-10);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        RecursionArgs f = a;                                    // replicates with a boundary off (normally none: the blocks exit)
+        f.only_if = a.chunk_fail;
+        hipLaunchKernelGGL(recursion_tile_kernel<false>, dim3(a.B), dim3(256), 0, s, f);
+    } else {
+        RecursionArgs f = a;
+        f.only_if = nullptr;
+        hipLaunchKernelGGL(recursion_tile_kernel<false>, dim3(a.B), dim3(256), 0, s, f);
+    }
+    e = hipGetLastError();
     if (e != hipSuccess || !a.S11) return e;
     hipLaunchKernelGGL(tile_mstep_kernel, dim3(a.B), dim3(1024), 0, s, a);
     return hipGetLastError();
