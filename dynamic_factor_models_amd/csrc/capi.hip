@@ -131,6 +131,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t bcol, scol, ldrow, nobs, Ct, Cfull, ldfull;
     size_t ZJ, wtab, status, ncov;
     size_t ck_scr = (size_t)-1, ck_obs = (size_t)-1, ck_cst = (size_t)-1, ck_term = (size_t)-1, ck_fail = (size_t)-1;   // recursion_chunk.hip (Rp = 8, general path)
+    size_t Vwide = (size_t)-1;
     size_t tk_scr = (size_t)-1, tk_bytes = 0;   // recursion_tile.hip (Rp = 32, general path): the chunks' scratch (ck_fail is shared)
     size_t S11, S10, S00, P0s, f0s, fsm, Psm, Sxf, Sxx, Dmiss, llbuf, active;
     // balanced fast path (fastpath.hip); (size_t)-1 when the plan is for the general path
@@ -205,7 +206,10 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         if (collapse_wide2_supported(Rp, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, Rp) + 8 * collapse_wide2_ws_bytes(1, N, Rp));
     } else {
         p.ZJ = take(off, (size_t)B * (T + 1) * 2 * rr * d);
-        if (p.Rc == 0 && Rp == 32 && N > collapse_max_n(32) && collapse_wide2_supported(32, N)) p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, 32));
+        if (p.Rc == 0 && Rp == 32 && N > collapse_max_n(32) && collapse_wide2_supported(32, N)) {
+            p.Wwide = take(off, collapse_wide2_ws_bytes(B, N, 32));
+            p.Vwide = take(off, (size_t)B * N * 32 * d);      // lam / sqrt(R): the C_t kernel's table
+        }
     }
     // (fast path, Rp >= 16: the mean scan on the matrix pipe keeps the steady part of w_t in a second, chunk-major region behind the
     // T natural rows -- scan_mfma32.hip)
@@ -721,9 +725,10 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
         if (!h->collapse_miss_old && collapse_miss_supported(Rcol, N)) { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream)); }
         else if (p.Wwide != (size_t)-1 && N > collapse_max_n(Rcol)) {   // Rp = 32 beyond the register tiling (config 4 with missing cells)
             double* W = at<double>(h, p.Wwide);
-            { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(ca, W, 32, h->stream)); }
+            double* V = at<double>(h, p.Vwide);
+            { ProfScope ps(h, K_GRAM); HIP_TRY(h, launch_wide_prep(ca, W, 32, h->stream, 0, V)); }
             { ProfScope ps(h, K_COLLAPSE_WIDE); HIP_TRY(h, launch_collapse_wide2(ca, W, 32, p.r, h->num_cu, h->stream)); }
-            { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_ct_miss_wide(ca, W, p.r, h->stream)); }
+            { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_ct_miss_wide(ca, W, p.r, h->stream, V)); }
         } else { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse(Rcol, ca, h->stream)); }
     }
     h->ck_fail_dev = nullptr; h->ck_fail_n = 0;

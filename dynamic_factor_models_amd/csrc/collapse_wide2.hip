@@ -43,6 +43,13 @@ using lds_cvd_ptr_w = const volatile __attribute__((address_space(3))) double*;
 // one ds_read_b64 (never merged into ds_read2_b64, never moved relative to other volatile accesses) of LDS byte address a
 __device__ __forceinline__ double lds_read64(unsigned a) { return *(lds_cvd_ptr_w)(size_t)a; }
 typedef double w2_v4 __attribute__((ext_vector_type(4)));
+typedef double w2_v2 __attribute__((ext_vector_type(2)));
+typedef unsigned w2_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned w2_u2 __attribute__((ext_vector_type(2)));
+using lds_cv2_ptr_w = const __attribute__((address_space(3))) w2_v2*;
+using lds_cu4_ptr_w = const __attribute__((address_space(3))) w2_u4*;
+using lds_cu2_ptr_w = const __attribute__((address_space(3))) w2_u2*;
+using lds_cu1_ptr_w = const __attribute__((address_space(3))) unsigned*;
 
 __device__ __forceinline__ void dma16w(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
@@ -115,7 +122,7 @@ constexpr int kW2Ring = 8;        // published items (ring)
 // beyond the row ring of the MFMA collapse: W is padded with zero columns, the collapse computes 16 and stores rd.
 constexpr int kPrepThreads = 1024;
 template <int R>
-__global__ __launch_bounds__(kPrepThreads) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, double* logr_out, int npad, int* ctr, int rd) {
+__global__ __launch_bounds__(kPrepThreads) void wide_prep_kernel(CollapseArgs a, double* Wout, double* rinv_out, double* logr_out, int npad, int* ctr, int rd, double* Vout) {
     constexpr int NW = kPrepThreads / 64, NTILE = (R / 16) * (R / 16), NSL = NW / NTILE;
     __shared__ double red[NW];
     __shared__ double part[NW * 4 * 64];                      // [wave][v][lane]
@@ -146,6 +153,14 @@ __global__ __launch_bounds__(kPrepThreads) void wide_prep_kernel(CollapseArgs a,
             const int c = e / R;
             const int f = e % R;
             W[R == 32 ? (e ^ (16 * (c & 1))) : e] = f < rd ? L[(size_t)c * rd + f] * rinv[c] : 0.0;
+        }
+    }
+    // V = lam / sqrt(R), plain [N][R] rows (ct_miss_dma_kernel: the deficit of a period is the sum of v_i v_i' over its missing series)
+    if (Vout != nullptr) {
+        double* V = Vout + (size_t)b * N * R;
+        for (int e = tid; e < N * R; e += kPrepThreads) {
+            const int c = e / R, f = e % R;
+            V[e] = f < rd ? L[(size_t)c * rd + f] * sqrt(rinv[c]) : 0.0;
         }
     }
     // tile (it, jt) of C over the series of slice sl: C[16 it + i][16 jt + j] = sum_c Lam[c][16 it + i] Lam[c][16 jt + j] / R_c
@@ -788,6 +803,215 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs 
     (void)NPfull;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// ct_miss_slice_kernel (round 5).  Three per-period designs were measured at config 4 (256 x 2000 periods, 100 of 1000 series
+// missing per period; profiles/r05/ab_ct_miss.txt) before this one:
+//   the staged kernel above (every series through LDS per tile of 32 periods, 16-wave barriers)                      4.3 ms
+//   one wave per period, rows of W / lam gathered from L2 into registers (4 x 4 blocks, four series per iteration)    3.3 ms
+//   the same with the rows moved by LDS-DMA, 4 | 6 | 8 instructions in flight                                   3.16 | 3.25 | 3.94 ms
+// The counters of the gather version: FETCH_SIZE = the panel once (the rows hit in L2), 135 M L2 requests (17 GB), 1.6 G L1
+// accesses; its phases by s_memrealtime: 9 us for the panel row, 10-12 us for 17 gathers, whatever the number in flight -- a
+// period fetches 200 cache lines of rows beside the 64 of its panel row, and the CUs take ~20 GB/s of lines each, the rate the
+// streaming collapse runs at as well.  So the rows must not travel per period at all:
+//   * V = lam / sqrt(R) (wide_prep_kernel): the deficit of a period is sum v_i v_i' over its missing series;
+//   * V is cut into SLICES of series that fit the LDS of a CU beside the waves' buffers (r = 20: 500 series = 80 KB); one launch
+//     per slice, one persistent workgroup of 16 waves per (replicate, time chunk) that copies its slice into LDS ONCE and then
+//     walks its periods -- wave w the periods w, w + 16, ... -- without another workgroup-level step;
+//   * per period a wave reads its part of the panel row (the next period's is in flight meanwhile), compacts the missing series
+//     of the slice into a list (ballot + prefix count) and takes the rows from LDS, nothing through the L1;
+//   * every lane owns a different BH x BW block of the r x r matrix and the wave takes ONE series at a time (SPT of them per trip:
+//     one broadcast read of their indices, 2 SPT row reads issued together): nothing to add up across lanes at the end;
+//   * the first slice writes C_t = C - E_0 for every period with a missing cell ANYWHERE (n_t < N from the collapse), the later
+//     ones subtract their E_s from the stored row (asked for in front of the arithmetic).  Launches run back to back on the
+//     stream: the order of the subtractions is fixed.
+// 1.87 ms for the two launches of config 4.  Without the panel read and the output it is 2.0 of 2.2 ms (an earlier state): the
+// time is inside the CU -- LDS reads (1 KB per ds_read_b128, 2 per series) and the waves' dependent trips, four waves per SIMD.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kCsWaves = 16;
+// BH x BW: the block a lane owns -- 2 x 2 up to r = 20 (55 lanes), 2 x 4 up to r = 28 (56), 4 x 4 beyond (36).
+template <int BH, int BW>
+__global__ __launch_bounds__(64 * kCsWaves) void ct_miss_slice_kernel(CollapseArgs a, const double* __restrict__ Vall, int r, int s0, int ns, int first, int TC) {
+    constexpr int R = kW2R;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, T = a.T;
+    const int ctr = a.ct_r > 0 ? a.ct_r : R;                  // rows / columns of the packed output block
+    const int NPo = ctr * (ctr + 1) / 2, NPe = (NPo + 1) & ~1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = (int)blockIdx.x / TC, tc = (int)blockIdx.x % TC;
+    const int Tc = (T + TC - 1) / TC;
+    const int t_lo = tc * Tc, t_hi = t_lo + Tc < T ? t_lo + Tc : T;
+    const int rb = ((r + BW - 1) / BW) * BW, recB = 8 * rb;   // a row of the slice in LDS: the leading columns of V (BH divides BW)
+    // LDS: the slice + one row of zeros | packed C (first slice only) | per wave: the packed deficit row | per wave: the list
+    constexpr int SPT = BH * BW == 4 ? 8 : (BH * BW == 8 ? 4 : 2);   // series per trip (registers: SPT (BH + BW) operands)
+    const int nspad = ((ns + 63) / 64) * 64;
+    const int lcap = nspad + 8;                               // (+ the padding of the last trip)
+    char* Vs = smem;
+    double* Cfp = reinterpret_cast<double*>(smem + (size_t)(ns + 1) * recB);
+    double* Cs = Cfp + NPe + (size_t)wave * NPe;
+    unsigned short* list = reinterpret_cast<unsigned short*>(Cfp + (size_t)(1 + kCsWaves) * NPe) + (size_t)wave * lcap;
+    const unsigned list0 = (unsigned)(size_t)(lds_char_ptr_w)(reinterpret_cast<char*>(list));
+    {
+        const int pr = rb / 2;                                // 16-byte pieces per row
+        const double* Vb = Vall + ((size_t)b * N + s0) * R;
+        for (int g = tid; g < (ns + 1) * pr; g += 64 * kCsWaves) {
+            const int i = g / pr, pc = g % pr;
+            *reinterpret_cast<double2*>(Vs + (size_t)i * recB + 16 * pc) =
+                i < ns ? *reinterpret_cast<const double2*>(Vb + (size_t)i * R + 2 * pc) : make_double2(0.0, 0.0);
+        }
+        const double* Cf = a.Cfull + (size_t)b * R * R;
+        for (int v = tid; v < NPe; v += 64 * kCsWaves) {
+            int q = 0;
+            while ((q + 1) * (q + 2) / 2 <= v) ++q;
+            Cfp[v] = v < NPo ? Cf[q * R + (v - q * (q + 1) / 2)] : 0.0;
+        }
+        for (int v = lane; v < NPe; v += 64) Cs[v] = 0.0;     // (entries outside the blocks stay zero: no loadings there)
+    }
+    __syncthreads();                                          // the only workgroup-level step
+    // this lane's block: rows BH ba .., columns BW bc .. (the blocks that meet the lower triangle, row by row)
+    int ba = 0, bc = 0;
+    bool act = false;
+    {
+        int cnt = 0;
+        const int nra = (r + BH - 1) / BH;
+        for (int aa = 0; aa < nra && !act; ++aa)
+            for (int cc = 0; BW * cc <= BH * aa + BH - 1 && BW * cc < r; ++cc) {
+                if (cnt == lane) { ba = aa; bc = cc; act = true; break; }
+                ++cnt;
+            }
+    }
+    const unsigned offr = 8u * BH * ba, offc = 8u * BW * bc;
+    const unsigned vs0 = (unsigned)(size_t)(lds_char_ptr_w)(Vs);
+    const double* __restrict__ X = a.panel + (size_t)b * T * N + s0;
+    const int* __restrict__ nobs = a.nobs + (size_t)b * T;
+    constexpr int XU = 8;                                     // panel loads in flight per lane (512 series per batch)
+    double xn[XU];
+    auto load_row = [&](int t, int k0) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int i = k0 + 64 * u + lane;
+            xn[u] = (t < t_hi && i < ns) ? X[(size_t)t * N + i] : 0.0;
+        }
+    };
+    load_row(t_lo + wave, 0);
+    const bool even = (NPo & 1) == 0;
+    for (int t = t_lo + wave; t < t_hi; t += kCsWaves) {
+        // asked for in front of the arithmetic, used behind it: n_t, and the stored row a later slice subtracts from (two 16-byte
+        // pieces per lane cover 256 entries; wider rows take the rest in the loop at the end)
+        const int nob = nobs[t];
+        double* Co = a.Ct ? a.Ct + ((size_t)b * T + t) * NPo : nullptr;
+        double2 cpre[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int v = 2 * lane + 128 * k;
+            cpre[k] = (!first && even && Co != nullptr && v < NPo) ? *reinterpret_cast<const double2*>(Co + v) : make_double2(0.0, 0.0);
+        }
+        double E[BH][BW];
+#pragma unroll
+        for (int x = 0; x < BH; ++x)
+#pragma unroll
+            for (int y = 0; y < BW; ++y) E[x][y] = 0.0;
+        // ---- the period's missing series of this slice: a list in the wave's LDS (ballot + prefix count), padded with the row of zeros
+        int n = 0;
+        for (int k0 = 0; k0 < nspad; k0 += 64 * XU) {
+            double xv[XU];
+#pragma unroll
+            for (int u = 0; u < XU; ++u) xv[u] = xn[u];
+            if (k0 + 64 * XU < nspad) load_row(t, k0 + 64 * XU);   // (slices wider than a batch: the next batch of this row)
+            else load_row(t + kCsWaves, 0);                   // the next period's first batch: in flight under this period's arithmetic
+#pragma unroll
+            for (int u = 0; u < XU; ++u) {
+                const bool m = xv[u] != xv[u];
+                const unsigned long long bal = __ballot(m);
+                if (m) list[n + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u))] = (unsigned short)(k0 + 64 * u + lane);
+                n += __popcll(bal);
+            }
+        }
+        if (lane < SPT) list[n + lane] = (unsigned short)ns;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // ---- SPT series per trip, the same for every lane: their indices in one broadcast read, their rows in 2 SPT reads issued
+        // together (the empty statements pin that order: left alone, the compiler re-uses one register set and waits per series)
+        for (int e0 = 0; e0 < n; e0 += SPT) {
+            unsigned idx[SPT];
+            if (SPT == 8) {
+                const w2_u4 L = *(lds_cu4_ptr_w)(size_t)(list0 + 2u * (unsigned)e0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { idx[2 * k] = L[k] & 0xffffu; idx[2 * k + 1] = L[k] >> 16; }
+            } else if (SPT == 4) {
+                const w2_u2 L = *(lds_cu2_ptr_w)(size_t)(list0 + 2u * (unsigned)e0);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) { idx[2 * k] = L[k] & 0xffffu; idx[2 * k + 1] = L[k] >> 16; }
+            } else {
+                const unsigned L = *(lds_cu1_ptr_w)(size_t)(list0 + 2u * (unsigned)e0);
+                idx[0] = L & 0xffffu; idx[SPT - 1] = L >> 16;
+            }
+            double vr[SPT][BH], vc[SPT][BW];
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) {
+                const unsigned ra = idx[k] * (unsigned)recB + vs0;
+#pragma unroll
+                for (int x = 0; x < BH; x += 2) {
+                    const w2_v2 d = *(lds_cv2_ptr_w)(size_t)(ra + offr + 8u * x);
+                    vr[k][x] = d[0]; vr[k][x + 1] = d[1];
+                }
+#pragma unroll
+                for (int y = 0; y < BW; y += 2) {
+                    const w2_v2 d = *(lds_cv2_ptr_w)(size_t)(ra + offc + 8u * y);
+                    vc[k][y] = d[0]; vc[k][y + 1] = d[1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < SPT; ++k) {
+#pragma unroll
+                for (int x = 0; x < BH; ++x) asm volatile("" : "+v"(vr[k][x]) : : "memory");
+#pragma unroll
+                for (int y = 0; y < BW; ++y) asm volatile("" : "+v"(vc[k][y]) : : "memory");
+#pragma unroll
+                for (int x = 0; x < BH; ++x)
+#pragma unroll
+                    for (int y = 0; y < BW; ++y) E[x][y] = fma(vr[k][x], vc[k][y], E[x][y]);
+            }
+        }
+        const bool anymiss = nob != N;                        // (uniform) a cell of this period is missing somewhere in the row
+        if (first ? !anymiss : n == 0) continue;              // a complete period keeps Cfull; a later slice with nothing to subtract
+        if (a.Ct == nullptr) {                                // the caller promised a balanced panel: flag it, keep valid memory
+            if (lane == 0) atomicOr(a.status, 1);
+            continue;
+        }
+        // ---- the packed deficit row, then C_t = C - E (first slice) or C_t -= E
+#pragma unroll
+        for (int x = 0; x < BH; ++x)
+#pragma unroll
+            for (int y = 0; y < BW; ++y) {
+                const int q = BH * ba + x, kk = BW * bc + y;
+                if (act && kk <= q && q < ctr) Cs[q * (q + 1) / 2 + kk] = E[x][y];
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (even) {                                           // (rows are 16-byte aligned)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int v = 2 * lane + 128 * k;
+                if (v < NPo) {
+                    const double2 e = *reinterpret_cast<const double2*>(Cs + v);
+                    const double2 c = first ? *reinterpret_cast<const double2*>(Cfp + v) : cpre[k];
+                    *reinterpret_cast<double2*>(Co + v) = make_double2(c.x - e.x, c.y - e.y);
+                }
+            }
+            for (int v = 2 * lane + 256; v < NPo; v += 128) {
+                const double2 e = *reinterpret_cast<const double2*>(Cs + v);
+                const double2 c = first ? *reinterpret_cast<const double2*>(Cfp + v) : *reinterpret_cast<const double2*>(Co + v);
+                *reinterpret_cast<double2*>(Co + v) = make_double2(c.x - e.x, c.y - e.y);
+            }
+        } else {
+            for (int v = lane; v < NPo; v += 64) Co[v] = (first ? Cfp[v] : Co[v]) - Cs[v];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the row is read before the next period overwrites it)
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 int collapse_wide2_tiles(int T) { return (T + kW2Rows - 1) / kW2Rows; }
 // Rp = 16 | 32 with an even N; narrower states (computed 16 wide) only where the row ring of the MFMA collapse ends (8 N > 4 KB)
 bool collapse_wide2_supported(int Rpad, int N) {
@@ -839,12 +1063,12 @@ hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, in
 }
 }  // namespace
 
-hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s, int r) {
+hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s, int r, double* V) {
     note_kernel("wide_prep_kernel");
     const W2Ws w = w2_ws(a, ws, Rpad);
     const bool ks = (r > 0 && collapse_ks_supported(Rpad, r, a.N, a.nobs != nullptr)) || wide2_lam_direct(Rpad, a.nobs != nullptr);   // no W table for these
-    if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad);
-    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(kPrepThreads), 0, s, a, ks ? nullptr : w.W, w.rinv, w.logr, w.npad, w.ctr, 32);
+    if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad, (double*)nullptr);
+    else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(kPrepThreads), 0, s, a, ks ? nullptr : w.W, w.rinv, w.logr, w.npad, w.ctr, 32, V);
     return hipGetLastError();
 }
 
@@ -886,12 +1110,55 @@ bool ct_miss_wide_compact_ok(int N, int ct_r) {
            + (size_t)kCtP * (ct_r * (ct_r + 1) / 2) * sizeof(double) <= 160 * 1024;
 }
 
-hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s) {
+hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s, const double* V) {
     static const int skip = [] { const char* v = diag_env("DFM_CT_SKIP"); return v ? atoi(v) : 0; }();   // diagnostics (wrong results)
     if (skip) return hipSuccess;
     const W2Ws w = w2_ws(a, ws, kW2R);
     const int ntile16 = (a.T + kCtP - 1) / kCtP;
     static const int old = [] { const char* v = diag_env("DFM_CT_OLD"); return v ? atoi(v) : 0; }();     // A/B: the round-2 kernel
+    static const int staged = [] { const char* v = diag_env("DFM_CT_STAGED"); return v ? atoi(v) : 0; }();   // A/B: the round-4 kernel
+    static const int noslice = [] { const char* v = diag_env("DFM_CT_NOSLICE"); return v ? atoi(v) : 0; }();   // A/B: the per-period gather kernels
+    if (!old && !staged && !noslice && V != nullptr && a.nobs != nullptr) {
+        // slices of V that leave room for the waves' rows: as few as fit 150 KB, of equal size, a multiple of 4 series
+        const int rr = r > 0 && r <= kW2R ? r : kW2R;
+        const int shape = rr <= 20 ? 0 : (rr <= 28 ? 1 : 2);  // 2 x 2 | 2 x 4 | 4 x 4 blocks per lane
+        const int bw = shape == 0 ? 2 : 4;
+        const int recB = 8 * (((rr + bw - 1) / bw) * bw);
+        const int ctr = a.ct_r > 0 ? a.ct_r : kW2R;
+        const size_t NPe = (size_t)(((ctr * (ctr + 1) / 2) + 1) & ~1);
+        auto lds_for = [&](int ns) {                              // the slice + a row of zeros | C | per wave: deficit row, list
+            return (size_t)(ns + 1) * recB + (1 + (size_t)kCsWaves) * NPe * sizeof(double) + (size_t)kCsWaves * ((size_t)((ns + 63) / 64) * 64 + 8) * sizeof(unsigned short);
+        };
+        int nsl = 1;
+        while (nsl < a.N && lds_for((a.N + nsl - 1) / nsl + 3) > 150 * 1024) ++nsl;
+        const int per = ((a.N + nsl - 1) / nsl + 3) & ~3;
+        if (lds_for(per) <= 150 * 1024) {
+            note_kernel("ct_miss_slice_kernel");
+            static LdsOptIn attr_cs;
+            if (!attr_cs) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_slice_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_slice_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ct_miss_slice_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return e;
+                attr_cs = true;
+            }
+            // time chunks: one workgroup per CU where the batch leaves CUs idle (each copies its slice once: chunks of >= 64 periods)
+            int TC = a.B >= 256 ? 1 : 256 / a.B;
+            if (TC > a.T / 64) TC = a.T / 64;
+            if (TC < 1) TC = 1;
+            for (int s0 = 0, k = 0; s0 < a.N; s0 += per, ++k) {
+                const int ns = s0 + per <= a.N ? per : a.N - s0;
+                const dim3 grid((unsigned)(a.B * TC)), blk(64 * kCsWaves);
+                const int fst = k == 0 ? 1 : 0;
+                if (shape == 0) hipLaunchKernelGGL((ct_miss_slice_kernel<2, 2>), grid, blk, lds_for(ns), s, a, V, rr, s0, ns, fst, TC);
+                else if (shape == 1) hipLaunchKernelGGL((ct_miss_slice_kernel<2, 4>), grid, blk, lds_for(ns), s, a, V, rr, s0, ns, fst, TC);
+                else hipLaunchKernelGGL((ct_miss_slice_kernel<4, 4>), grid, blk, lds_for(ns), s, a, V, rr, s0, ns, fst, TC);
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) return e;
+            }
+            return hipSuccess;
+        }
+    }
     if (!old) {
         note_kernel("ct_miss_wide2_kernel");
         static const int ppw_env = [] { const char* v = diag_env("DFM_CT_PPW"); return v ? atoi(v) : 0; }();   // A/B: 1 = the round-3 tiling

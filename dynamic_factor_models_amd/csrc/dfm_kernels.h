@@ -210,11 +210,13 @@ bool collapse_ks_supported(int Rpad, int r, int N, bool missing);
 int collapse_ks_tiles(int T);
 hipError_t launch_collapse_ks(const CollapseArgs& a, const double* rinv, int npad, int num_cu, hipStream_t s);
 size_t collapse_wide2_ws_bytes(int B, int N, int Rpad);    // W [B][N][Rp] | 1 / R, log R [B][N padded to 32] | tile queue counters
-hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s, int r = 0);   // r > 0: the caller's factor count (skips the W table when launch_collapse_wide2 will not read it)
+// r > 0: the caller's factor count (skips the W table when launch_collapse_wide2 will not read it); V: [B][N][32] lam / sqrt(R) for
+// launch_ct_miss_wide, or null
+hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s, int r = 0, double* V = nullptr);
 hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s);
 // a.nobs != nullptr selects the variant for panels with missing cells (per-period scol / nobs / ldrow); their C_t:
 bool ct_miss_wide_compact_ok(int N, int ct_r);   // compact C_t rows (CollapseArgs::ct_r) are available for this cross-section
-hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s);   // r: the caller's factor count
+hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStream_t s, const double* V = nullptr);   // r: the caller's factor count; V: launch_wide_prep's
 bool gram_supported(int Rpad, int N);       // launch_gram's register tilings
 hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s);
 hipError_t launch_mstep_lam(int Rpad, const MstepArgs& a, hipStream_t s);
