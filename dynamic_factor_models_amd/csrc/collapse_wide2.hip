@@ -824,8 +824,10 @@ __global__ __launch_bounds__(kCtThreads) void ct_miss_wide2_kernel(CollapseArgs 
 //   * the first slice writes C_t = C - E_0 for every period with a missing cell ANYWHERE (n_t < N from the collapse), the later
 //     ones subtract their E_s from the stored row (asked for in front of the arithmetic).  Launches run back to back on the
 //     stream: the order of the subtractions is fixed.
-// 1.87 ms for the two launches of config 4.  Without the panel read and the output it is 2.0 of 2.2 ms (an earlier state): the
-// time is inside the CU -- LDS reads (1 KB per ds_read_b128, 2 per series) and the waves' dependent trips, four waves per SIMD.
+//   * periods are handed out by a counter in LDS (the SIMD issues its oldest wave first: dealt round-robin, the youngest of its
+//     four waves took 7.4 us per period where the oldest took 4.6, and the workgroup waited for it).
+// 1.73 ms for the two launches of config 4.  Without the panel read and the output an earlier state took 2.0 of 2.2 ms: the time
+// is inside the CU -- the waves' dependent trips (list, index read, row reads, multiply-adds) at four waves per SIMD.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kCsWaves = 16;
 // BH x BW: the block a lane owns -- 2 x 2 up to r = 20 (55 lanes), 2 x 4 up to r = 28 (56), 4 x 4 beyond (36).
@@ -850,6 +852,7 @@ __global__ __launch_bounds__(64 * kCsWaves) void ct_miss_slice_kernel(CollapseAr
     double* Cfp = reinterpret_cast<double*>(smem + (size_t)(ns + 1) * recB);
     double* Cs = Cfp + NPe + (size_t)wave * NPe;
     unsigned short* list = reinterpret_cast<unsigned short*>(Cfp + (size_t)(1 + kCsWaves) * NPe) + (size_t)wave * lcap;
+    int* next_t = reinterpret_cast<int*>(reinterpret_cast<unsigned short*>(Cfp + (size_t)(1 + kCsWaves) * NPe) + (size_t)kCsWaves * lcap);   // (lcap is a multiple of 8: aligned)
     const unsigned list0 = (unsigned)(size_t)(lds_char_ptr_w)(reinterpret_cast<char*>(list));
     {
         const int pr = rb / 2;                                // 16-byte pieces per row
@@ -866,6 +869,7 @@ __global__ __launch_bounds__(64 * kCsWaves) void ct_miss_slice_kernel(CollapseAr
             Cfp[v] = v < NPo ? Cf[q * R + (v - q * (q + 1) / 2)] : 0.0;
         }
         for (int v = lane; v < NPe; v += 64) Cs[v] = 0.0;     // (entries outside the blocks stay zero: no loadings there)
+        if (tid == 0) *next_t = t_lo + kCsWaves;              // (the first kCsWaves periods are the waves' own)
     }
     __syncthreads();                                          // the only workgroup-level step
     // this lane's block: rows BH ba .., columns BW bc .. (the blocks that meet the lower triangle, row by row)
@@ -880,7 +884,13 @@ __global__ __launch_bounds__(64 * kCsWaves) void ct_miss_slice_kernel(CollapseAr
                 ++cnt;
             }
     }
+#if defined(DFM_CS_ABL) && DFM_CS_ABL == 1
+    const unsigned offr = 16u * (lane & 7), offc = 16u * ((lane >> 3) & 7);     // development (wrong results): fewer lanes per address
+#elif defined(DFM_CS_ABL) && DFM_CS_ABL == 2
+    const unsigned offr = 0u, offc = 16u;                                       // development (wrong results): every lane the same two addresses
+#else
     const unsigned offr = 8u * BH * ba, offc = 8u * BW * bc;
+#endif
     const unsigned vs0 = (unsigned)(size_t)(lds_char_ptr_w)(Vs);
     const double* __restrict__ X = a.panel + (size_t)b * T * N + s0;
     const int* __restrict__ nobs = a.nobs + (size_t)b * T;
@@ -895,7 +905,10 @@ __global__ __launch_bounds__(64 * kCsWaves) void ct_miss_slice_kernel(CollapseAr
     };
     load_row(t_lo + wave, 0);
     const bool even = (NPo & 1) == 0;
-    for (int t = t_lo + wave; t < t_hi; t += kCsWaves) {
+    // Periods are handed out by a counter in LDS, not dealt round-robin: the SIMD issues its oldest wave first, the youngest of its
+    // four took 7.4 us per period where the oldest took 4.6, and with equal shares the workgroup waited for the slow ones
+    // (0.92 ms per launch where the mean rate gives 0.73).
+    for (int t = t_lo + wave, tn = 0; t < t_hi; t = tn) {
         // asked for in front of the arithmetic, used behind it: n_t, and the stored row a later slice subtracts from (two 16-byte
         // pieces per lane cover 256 entries; wider rows take the rest in the loop at the end)
         const int nob = nobs[t];
@@ -918,7 +931,12 @@ __global__ __launch_bounds__(64 * kCsWaves) void ct_miss_slice_kernel(CollapseAr
 #pragma unroll
             for (int u = 0; u < XU; ++u) xv[u] = xn[u];
             if (k0 + 64 * XU < nspad) load_row(t, k0 + 64 * XU);   // (slices wider than a batch: the next batch of this row)
-            else load_row(t + kCsWaves, 0);                   // the next period's first batch: in flight under this period's arithmetic
+            else {                                            // the next period's first batch: in flight under this period's arithmetic
+                int got = 0;
+                if (lane == 0) got = atomicAdd(next_t, 1);
+                tn = __builtin_amdgcn_readfirstlane(got);
+                load_row(tn, 0);
+            }
 #pragma unroll
             for (int u = 0; u < XU; ++u) {
                 const bool m = xv[u] != xv[u];
@@ -1127,7 +1145,7 @@ hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStre
         const int ctr = a.ct_r > 0 ? a.ct_r : kW2R;
         const size_t NPe = (size_t)(((ctr * (ctr + 1) / 2) + 1) & ~1);
         auto lds_for = [&](int ns) {                              // the slice + a row of zeros | C | per wave: deficit row, list
-            return (size_t)(ns + 1) * recB + (1 + (size_t)kCsWaves) * NPe * sizeof(double) + (size_t)kCsWaves * ((size_t)((ns + 63) / 64) * 64 + 8) * sizeof(unsigned short);
+            return (size_t)(ns + 1) * recB + (1 + (size_t)kCsWaves) * NPe * sizeof(double) + (size_t)kCsWaves * ((size_t)((ns + 63) / 64) * 64 + 8) * sizeof(unsigned short) + 16;
         };
         int nsl = 1;
         while (nsl < a.N && lds_for((a.N + nsl - 1) / nsl + 3) > 150 * 1024) ++nsl;
