@@ -281,7 +281,8 @@ def kernel_bytes_table(B, N, T, r):
             "mstep_lam_kernel": B * 8 * (N * T + T * (r + npack)),
             "gram_kernel": B * 8 * (N * r + N), "wide_prep_kernel": B * 8 * (N * r + N), "cov_kernel": B * 8 * (3 * r * r + r),
             "cov_grid_kernel": B * 8 * (3 * r * r + r), "cov_tile_kernel": B * 8 * (3 * r * r + r), "collapse_ks_kernel": B * panel_b,
-            "ct_miss_wide_kernel": B * 8 * T * npack, "ct_miss_wide2_kernel": B * 8 * T * npack}
+            "ct_miss_wide_kernel": B * 8 * T * npack, "ct_miss_wide2_kernel": B * 8 * T * npack,
+            "ct_miss_slice_kernel": B * 8 * (N * T + T * npack)}      # (the panel once over its launches + the C_t rows)
 
 
 def gram_flops(kernel, B, N, T):
@@ -480,6 +481,11 @@ class Workload:
                          "panel with missing cells: collapse_miss_kernel streams the panel once and writes one table row per period; "
                          "recursion_chunk_kernel runs the T periods as 64 time chunks (one per lane, 16 + 16 steps each at T = 500)"
                          if dom in ("recursion_chunk_kernel", "collapse_miss_kernel") else
+                         "wide state with missing cells: collapse_wide2_kernel streams the panel once, ct_miss_slice_kernel forms C_t of the periods "
+                         "with missing cells from slices of lam / sqrt(R) resident in LDS, recursion_tile_kernel runs each replicate as time chunks "
+                         "(one workgroup each, warmed up over 16 periods, boundaries checked) of dependent 32 x 32 inversions on the matrix pipe -- "
+                         "latency-bound, not HBM-bound"
+                         if dom == "recursion_tile_kernel" else
                          "sequential path (panel with missing cells): the collapse streams the panel once, the recursion kernel is "
                          "a chain of T dependent r x r inversions per replicate -- latency-bound, not HBM-bound"
                          if dom.startswith("recursion") else "dominant kernel of this mode by HIP-event time"),

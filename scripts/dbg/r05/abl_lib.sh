@@ -7,7 +7,7 @@ f=$1; macro=$2; shift 2
 mkdir -p $L/abl
 base=$(basename $f .hip)
 for v in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -D$macro=$v -c dynamic_factor_models_amd/csrc/$f -o $L/abl/${base}_$v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w $ABL_FLAGS -D$macro=$v -c dynamic_factor_models_amd/csrc/$f -o $L/abl/${base}_$v.o
   objs=$(ls $L/*.o | grep -vF "/$base.o")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $L/abl/libdfm_${base}_$v.so $objs $L/abl/${base}_$v.o -ldl -lpthread
 done
