@@ -518,6 +518,8 @@ SECONDARY = [   # (key, dict(B, N, T, r, missing, mode), steps, warmup) -- three
     ("c4_em", dict(B=256, N=1000, T=2000, r=20, missing=0.0, mode="em"), 3, 1),
     ("c4_missing10", dict(B=256, N=1000, T=2000, r=20, missing=0.1, mode="pass"), 2, 1),
     ("c4_em_missing10", dict(B=256, N=1000, T=2000, r=20, missing=0.1, mode="em"), 2, 1),
+    # a batch that leaves most CUs idle under one workgroup per replicate: recursion_tile_kernel cuts each replicate into 16 time chunks
+    ("c4_missing10_b32", dict(B=32, N=1000, T=2000, r=20, missing=0.1, mode="pass"), 3, 1),
 ]
 
 

@@ -175,7 +175,7 @@ class DfmContext:
         return out
 
     def chunk_fallbacks(self):
-        """dfm_chunk_fallbacks: (failed, total) replicates of the last pass that ran on the time-chunked recursion (total = 0:
+        """dfm_chunk_fallbacks: (failed, total) replicates of the last pass that ran on a time-chunked recursion (total = 0:
         it did not); `failed` of them were redone by the sequential kernel."""
         nf = ctypes.c_int(); nt = ctypes.c_int()
         _check(self._h, self._lib.dfm_chunk_fallbacks(self._h, ctypes.byref(nf), ctypes.byref(nt)))

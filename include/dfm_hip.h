@@ -91,9 +91,10 @@ int dfm_profile_read(dfm_handle* h, int kernel_index, char* name_out, int name_c
  * events.  *gbs = GB/s, *ms_per_launch may be NULL. */
 int dfm_hbm_probe(dfm_handle* h, size_t bytes, int mode, int iters, double* gbs, double* ms_per_launch);
 
-/* dfm_chunk_fallbacks: diagnostics of the last pass / EM iteration with missing cells at r <= 8 that ran on the time-chunked
- * recursion (csrc/recursion_chunk.hip; no reference counterpart).  *n_total = replicates of that launch (0: the last call did not
- * use it), *n_failed = replicates whose chunk boundaries did not agree to the tolerance and were redone by the sequential kernel.
+/* dfm_chunk_fallbacks: diagnostics of the last pass / EM iteration with missing cells that ran on a time-chunked recursion
+ * (r <= 8: csrc/recursion_chunk.hip, one chunk per lane; 17 <= r <= 31: the chunks of recursion_tile_kernel, one workgroup each,
+ * csrc/recursion_tile.hip; no reference counterpart).  *n_total = replicates of that launch (0: the last call did not use one),
+ * *n_failed = replicates whose chunk boundaries did not agree to the tolerance and were redone by the sequential kernel.
  * Synchronises the handle's stream. */
 int dfm_chunk_fallbacks(dfm_handle* h, int* n_failed, int* n_total);
 
