@@ -1062,10 +1062,12 @@ int recursion_tile_chunks(const RecursionArgs& a, int* lc_out, int* w_out) {
     }
     return 1;
 }
-// workspace for the chunks of a batch (sized for the automatic choice on a device of up to 512 CUs and for forced counts on small batches)
+// workspace for the chunks of a batch: sized for the automatic choice on a device of up to 512 CUs (two workgroups each) and for forced
+// counts on small batches; nothing for batches that fill such a device with one workgroup per replicate (they run sequentially)
 size_t recursion_tile_scratch_bytes(int B, int T) {
     (void)T;
-    const size_t slots = (size_t)B * kTkNCmax < 1024 ? (size_t)B * kTkNCmax : ((size_t)B > 1024 ? (size_t)B : 1024);
+    if (B > 512) return 0;
+    const size_t slots = (size_t)B * kTkNCmax < 1024 ? (size_t)B * kTkNCmax : 1024;
     return slots * tk_slot_doubles(kTkWmax) * sizeof(double);
 }
 
