@@ -126,3 +126,24 @@ def test_em_on_chunks(env):
                 assert np.abs(got - p[k]).max() <= 1e-8 * max(1.0, np.abs(p[k]).max()), (env, k, b, np.abs(got - p[k]).max())
     finally:
         c.close()
+
+
+def test_config4_small_batch_sixteen_chunks_per_replicate():
+    """The shape `secondary.c4_missing10_b32` times (N = 1000, T = 2000, r = 20, 10 % missing, 32 replicates: 16 chunks of 126 periods
+    per replicate, time chunks of 250 periods for the C_t kernel): scattered replicates against the C oracle, no boundary rejected."""
+    import torch
+    from dynamic_factor_models_amd import DfmContext
+    B, N, T, r = 32, 1000, 2000, 20
+    c = DfmContext()
+    try:
+        panel, par = c.synth_panels(31, 0, B, T, N, r, missing_prob=0.1)
+        f, P, ll = c.ks_pass_batch(panel, *par, may_have_missing=True)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(ll).all())
+        assert c.chunk_fallbacks() == (0, B)
+        ix = torch.tensor([0, 13, 31], device=panel.device)
+        take = lambda t: t.index_select(0, ix).cpu().numpy()
+        st = dict(zip(KEYS, [take(p) for p in par]))
+        _compare((take(f), take(P), take(ll)), _oracle(take(panel), st), "config 4's shape, 32 replicates")
+    finally:
+        c.close()
