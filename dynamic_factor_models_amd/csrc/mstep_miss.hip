@@ -281,8 +281,9 @@ __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const doub
     if (a.active && !a.active[b]) return;
     const int tid = threadIdx.x;
     const int N = a.N, npr = r * (r + 1) / 2;
-    double* S = reinterpret_cast<double*>(smem);              // [npr + r][ns]: packed Sff, then the right-hand side
-    double* s11 = S + (size_t)(npr + r) * ns;                 // [npr] packed, symmetrised
+    const int nsi = ns + 1;                                    // (odd column stride: the transposing stores below spread over the banks)
+    double* S = reinterpret_cast<double*>(smem);              // [npr + r][ns + 1]: packed Sff, then the right-hand side
+    double* s11 = S + (size_t)(npr + r) * nsi;                // [npr] packed, symmetrised
     for (int v = tid; v < npr; v += 256) {
         int i = 0;
         while ((i + 1) * (i + 2) / 2 <= v) ++i;
@@ -298,55 +299,83 @@ __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const doub
     for (int e = tid; e < ne; e += 256) {
         const int row = e / tt16, c = e % tt16;
         const double v = src[e];
-        if (c < npr) S[(size_t)c * ns + row] = s11[c] - v;
-        else if (c >= ntm16 && c - ntm16 < r) S[(size_t)(npr + c - ntm16) * ns + row] = v;
+        if (c < npr) S[(size_t)c * nsi + row] = s11[c] - v;
+        else if (c >= ntm16 && c - ntm16 < r) S[(size_t)(npr + c - ntm16) * nsi + row] = v;
     }
     __syncthreads();
-    if (tid >= nrow) return;
-    double* L = S + tid;
-    double* y = S + (size_t)npr * ns + tid;
-#define LL(i, j) L[(size_t)((i) * ((i) + 1) / 2 + (j)) * ns]
+    // Cholesky and the two substitutions per series, in the series' LDS column, by ALL threads of the block: thread (si = tid % ns,
+    // w = tid / ns) works on the rows i = w (mod 256 / ns) of series si in the right-looking (outer-product) form -- the updates of a
+    // step are independent, three barriers per column.  (One thread per series walking the row-by-row form was ONE chain of dependent
+    // LDS round trips with one wave per CU busy: 1.94 ms per config-4 EM iteration, a third of the dense product's time.)
+    const int si = tid % ns, w = tid / ns, nw = 256 / ns;
+    const int sic = si < nrow ? si : 0;                        // (series past N of a partial block: a valid column, never stored)
+    double* L = S + sic;
+    double* y = S + (size_t)npr * nsi + sic;
+#define LL(i, j) L[((i) * ((i) + 1) / 2 + (j)) * nsi]
     // a series with fewer than r + 1 observed cells, or whose normal matrix is not positive definite, keeps its parameters
     // (mstep_obs_kernel's rule; an all-missing series -- e.g. the one capi.hip appends to an odd N -- has S = 0, cnt = 0)
     bool ok = true;
-    for (int i = 0; i < r; ++i) {
-        for (int j = 0; j <= i; ++j) {
-            double s0_ = LL(i, j), s1_ = 0.0, s2_ = 0.0, s3_ = 0.0;   // four partial sums: the LDS reads of a row pair overlap
-            int k = 0;
-            for (; k + 3 < j; k += 4) {
-                s0_ = fma(-LL(i, k), LL(j, k), s0_);
-                s1_ = fma(-LL(i, k + 1), LL(j, k + 1), s1_);
-                s2_ = fma(-LL(i, k + 2), LL(j, k + 2), s2_);
-                s3_ = fma(-LL(i, k + 3), LL(j, k + 3), s3_);
+    for (int j = 0; j < r; ++j) {
+        const double d = LL(j, j);                             // (every worker of the series reads it before worker 0 overwrites it)
+        ok = ok && (d > 0.0);
+        const double ljj = sqrt(d > 0.0 ? d : 1.0);
+        const double inv = 1.0 / ljj;
+        __syncthreads();
+        if (w == 0) LL(j, j) = ljj;
+        for (int i = j + 1 + w; i < r; i += nw) LL(i, j) *= inv;   // column j below the diagonal
+        __syncthreads();
+        for (int i = j + 1 + w; i < r; i += nw) {                // trailing update: S[i][k] -= L[i][j] L[k][j], j < k <= i
+            const double lij = LL(i, j);
+            double* row = &LL(i, j + 1);
+            const double* colj = &LL(j + 1, j);
+            int kj = (j + 1) * (j + 2) / 2 + j;                  // packed index of (k, j), advancing by k + 1
+            (void)colj;
+            for (int k = j + 1; k <= i; k += 4) {                // four independent elements at a time
+                double av[4], bv[4];
+                int kk = kj;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = k + u <= i;
+                    av[u] = row[(in ? k + u - (j + 1) : 0) * nsi];
+                    bv[u] = L[(in ? kk : kj) * nsi];
+                    kk += k + u + 1;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(av[u]), "+v"(bv[u]) : : "memory");
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k + u <= i) row[(k + u - (j + 1)) * nsi] = fma(-lij, bv[u], av[u]);
+                kj = kk;
             }
-            for (; k < j; ++k) s0_ = fma(-LL(i, k), LL(j, k), s0_);
-            const double s = (s0_ + s1_) + (s2_ + s3_);
-            if (j == i) ok = ok && (s > 0.0);
-            LL(i, j) = (j == i) ? sqrt(s > 0.0 ? s : 1.0) : s / LL(j, j);
         }
+        __syncthreads();                                       // (the next column's diagonal element is complete)
     }
     double yy = 0.0;
-    for (int i = 0; i < r; ++i) {                             // L y = Sxf
-        double s = y[(size_t)i * ns];
-        for (int k = 0; k < i; ++k) s = fma(-LL(i, k), y[(size_t)k * ns], s);
-        s /= LL(i, i);
-        y[(size_t)i * ns] = s;
-        yy = fma(s, s, yy);                                   // lam' Sff lam = lam' Sxf = y'y
+    for (int j = 0; j < r; ++j) {                             // L y = Sxf, column by column
+        const double yj = y[j * nsi] / LL(j, j);
+        yy = fma(yj, yj, yy);                                 // lam' Sff lam = lam' Sxf = y'y
+        __syncthreads();
+        if (w == 0) y[j * nsi] = yj;
+        for (int i = j + 1 + w; i < r; i += nw) y[i * nsi] = fma(-LL(i, j), yj, y[i * nsi]);
+        __syncthreads();
     }
-    for (int i = r - 1; i >= 0; --i) {                        // L' lam = y
-        double s = y[(size_t)i * ns];
-        for (int k = i + 1; k < r; ++k) s = fma(-LL(k, i), y[(size_t)k * ns], s);
-        y[(size_t)i * ns] = s / LL(i, i);
+    for (int j = r - 1; j >= 0; --j) {                        // L' lam = y, column by column from the last
+        const double xj = y[j * nsi] / LL(j, j);
+        __syncthreads();
+        if (w == 0) y[j * nsi] = xj;
+        for (int i = w; i < j; i += nw) y[i * nsi] = fma(-LL(j, i), xj, y[i * nsi]);
+        __syncthreads();
     }
 #undef LL
-    const int col = s0 + tid;
+    if (w != 0 || si >= nrow) return;
+    const int col = s0 + si;
     const double nobs_i = cnt[(size_t)b * N + col];
     // a series without a single observed cell keeps its parameters; so does one with fewer cells than the caller's minimum (the
     // observed-factor joint regression asks for r_o + r_u + 1; the plain EM for 1: sum E[f f'] includes P_t and is positive definite)
     if (!ok || nobs_i < (double)(a.min_cells > 1 ? a.min_cells : 1)) return;
     a.R_out[(size_t)b * N + col] = (sxx[(size_t)b * N + col] - yy) / nobs_i;
     double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
-    for (int k = 0; k < Rp; ++k) lo[k] = k < r ? y[(size_t)k * ns] : 0.0;
+    for (int k = 0; k < Rp; ++k) lo[k] = k < r ? y[k * nsi] : 0.0;
 }
 
 // Rp = 8 | 16 | 32 (r <= Rp the caller's factor count), even N (16-byte aligned series pairs)
@@ -424,8 +453,10 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     else e = launch_mm_slots<8, 3>(a, V, OUT, sxx, cnt, g, G, s);
     if (e != hipSuccess) return e;
     const int npr = r * (r + 1) / 2;
-    const int nthr = ((size_t)(npr + r) * 64 + npr) * sizeof(double) <= 150 * 1024 ? 64 : 32;   // series per block: their packed matrices fit LDS
-    const size_t lds = ((size_t)(npr + r) * nthr + npr) * sizeof(double);
+    // series per block: 64 where two blocks' packed matrices share a CU's LDS, else 32 (r = 20: 60 KB per block; one block per CU with
+    // 64 series was 1.5 ms of a config-4 iteration's loadings step against 1.0 ms)
+    const int nthr = ((size_t)(npr + r) * 65 + npr) * sizeof(double) <= 72 * 1024 ? 64 : 32;
+    const size_t lds = ((size_t)(npr + r) * (nthr + 1) + npr) * sizeof(double);
     static LdsOptIn fin_done;
     if (!fin_done) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmw_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
