@@ -955,6 +955,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist is not None and dist.is_initialized():      # (also the forced 1-rank group of DFM_BENCH_FORCE_DIST=1)
         dist.destroy_process_group()
     ctx.close()
 
