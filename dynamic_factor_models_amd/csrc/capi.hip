@@ -259,6 +259,9 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
 }
 
 int ensure_ws(dfm_handle* h, size_t bytes) {
+    // every entry point sizes the workspace before it uses it: whatever chunk_fail flags the last pass left in the block are about to
+    // be overwritten or freed -- dfm_chunk_fallbacks must not read them (enqueue_pass sets the pointer again behind its launch)
+    h->ck_fail_dev = nullptr; h->ck_fail_n = 0;
     if (bytes <= h->ws_bytes) return 0;
     if (h->ws) {
         // every stream this handle has launched on (the caller may have swapped streams with dfm_set_stream, and the

@@ -279,33 +279,37 @@ struct NoAcc {
     DFM_CK void s11(int, double) const {}
 };
 
-// Two weighted sums of a lane's state (packed matrix + vector) and their scales: what neighbouring lanes compare at a chunk
-// boundary instead of the 44 values themselves.  Weights in [1, 2): a fixed, irrational-step sequence.
-struct Hash {
-    double h1, h2, am, hx, ax;
+// The chunk boundary check: the state a lane holds after its warm-up against the state its neighbour holds at the end of its own
+// chunk, ELEMENT BY ELEMENT -- the largest |a - b| over the 36 packed matrix entries against tol x the largest |entry| of either
+// matrix, and the same for the 8-vector (matrix and vector separately: their scales differ).  A bound, not a projection: every
+// entry of the state a chunk starts from is within tol x scale of the sequential recursion's.  (Until round 5 the lanes compared
+// two weighted sums of the entries: an error orthogonal to the weight vectors passed.)  NaN-safe: anything not provably close
+// fails -- `nn` carries a NaN from any entry (fmax would drop it).
+struct Gap {
+    double dm, sm, dx, sx, nn;
 };
-DFM_CK Hash state_hash(const double (&m)[NP], const double (&x)[R]) {
-    Hash h{0.0, 0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const double g1 = 1.0 + (double)((k * 40503u + 12345u) & 0xFFFFu) / 65536.0;
-        const double g2 = 1.0 + (double)((k * 30011u + 54321u) & 0xFFFFu) / 65536.0;
-        h.h1 = fma(g1, m[k], h.h1);
-        h.h2 = fma(g2, m[k], h.h2);
-        h.am += fabs(m[k]);
-    }
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const double g = 1.0 + (double)((i * 50021u + 777u) & 0xFFFFu) / 65536.0;
-        h.hx = fma(g, x[i], h.hx);
-        h.ax += fabs(x[i]);
-    }
-    return h;
+DFM_CK void gap_mat(Gap& g, double a, double b) {
+    const double d = fabs(a - b);
+    g.dm = d > g.dm ? d : g.dm;
+    const double s = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+    g.sm = s > g.sm ? s : g.sm;
+    g.nn += d;
 }
-// NaN-safe: anything not provably close fails
-DFM_CK bool hash_close(const Hash& a, const Hash& b, double tol) {
-    const double sm = tol * (a.am + b.am), sx = tol * (a.ax + b.ax);
-    return fabs(a.h1 - b.h1) <= sm && fabs(a.h2 - b.h2) <= sm && fabs(a.hx - b.hx) <= sx;
+DFM_CK void gap_vec(Gap& g, double a, double b) {
+    const double d = fabs(a - b);
+    g.dx = d > g.dx ? d : g.dx;
+    const double s = fabs(a) > fabs(b) ? fabs(a) : fabs(b);
+    g.sx = s > g.sx ? s : g.sx;
+    g.nn += d;
+}
+DFM_CK bool gap_close(const Gap& g, double tol) { return g.dm <= tol * g.sm && g.dx <= tol * g.sx && g.nn == g.nn && g.nn <= 1.7e308; }
+DFM_CK Gap state_gap(const double (&m)[NP], const double (&x)[R], const double (&m2)[NP], const double (&x2)[R]) {
+    Gap g{0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NP; ++k) gap_mat(g, m[k], m2[k]);
+#pragma unroll
+    for (int i = 0; i < R; ++i) gap_vec(g, x[i], x2[i]);
+    return g;
 }
 
 }  // namespace chunk

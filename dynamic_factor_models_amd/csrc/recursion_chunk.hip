@@ -7,12 +7,14 @@
 // Why it is allowed: the filter forgets.  Om_f,t depends on Om_f,t-W through a product of W contractions (with N series loading
 // on r factors, (I + C P)^-1 is O(r / N) per period), so a lane that starts W periods before its chunk from a GUESS (forward:
 // Om_p = Q^-1, xi = b; backward: P = 0, f = 0) holds the exact state to rounding when its chunk begins.  That is CHECKED, not assumed:
-// the state a lane holds after its warm-up is compared (two weighted sums + scales, dfm_chunk_core.h state_hash) with the state
-// its neighbour holds at the end of its own chunk -- forward and backward -- and a replicate with one boundary off by more than
-// chunk_tol (relative) raises chunk_fail[b]: launch_recursion then runs it on the sequential kernel (RecursionArgs::only_if).
-// By induction over the chunks (lane 0 starts from the exact initial state, the top lane from the exact terminal state) every
-// counted period is within chunk_tol of the sequential recursion; on the C2 shape with 10 % missing cells the boundaries agree to
-// 1e-13 with W = 8 (tests/test_chunk_core_cpu.py has the lane-level NumPy model of this file against the oracle).
+// the state a lane holds after its warm-up is compared ELEMENT BY ELEMENT (dfm_chunk_core.h state_gap / gap_close: largest difference
+// against chunk_tol x the largest entry, matrix and vector separately) with the state its neighbour holds at the end of its own
+// chunk -- forward and backward -- and a replicate with one boundary off raises chunk_fail[b]: launch_recursion then runs it on
+// the sequential kernel (RecursionArgs::only_if).  The warm-up states wait for the comparison in two extra slots of the smoother
+// table (44 doubles per lane, lane-contiguous like the table's rows; the neighbour reads them back after its last step).
+// Lane 0 starts from the exact initial state, the top lane from the exact terminal state, so every chunk starts within chunk_tol
+// (relative, max-norm) of the state the sequential recursion holds there; on the C2 shape with 10 % missing cells the boundaries
+// agree to 1e-13 with W = 8 (tests/test_chunk_core_cpu.py has the lane-level NumPy model of this file against the oracle).
 //
 // Cost: L + W steps per lane instead of T per replicate -- 16 forward + 16 backward steps at T = 500 where recursion_pair_kernel
 // runs 500 + 500 on a chain of cross-lane exchanges, each step ~1400 / ~1900 full-rate fp64 instructions on all 64 lanes
@@ -93,11 +95,32 @@ __device__ __forceinline__ double wave_sum64(double v) {
     v += xor_lane<32>(v);
     return v;
 }
-__device__ __forceinline__ chunk::Hash hash_from_lane(const chunk::Hash& h, int src) {
-    chunk::Hash o;
-    o.h1 = __shfl(h.h1, src, 64); o.h2 = __shfl(h.h2, src, 64); o.am = __shfl(h.am, src, 64);
-    o.hx = __shfl(h.hx, src, 64); o.ax = __shfl(h.ax, src, 64);
-    return o;
+// a lane's state after its warm-up -> one slot of the smoother table (rows of 64 double2, lane = chunk: 22 coalesced stores), and
+// the comparison of lane `src`'s stored state with the caller's own (the stores are visible: a wave_mem_fence() lies between)
+__device__ __forceinline__ void save_state(double2* slot, int lane, const double (&m)[chunk::NP], const double (&x)[chunk::R]) {
+    double2* dst = slot + lane;
+#pragma unroll
+    for (int k = 0; k < chunk::NP / 2; ++k) dst[k * 64] = make_double2(m[2 * k], m[2 * k + 1]);
+#pragma unroll
+    for (int k = 0; k < chunk::R / 2; ++k) dst[(chunk::NP / 2 + k) * 64] = make_double2(x[2 * k], x[2 * k + 1]);
+}
+__device__ __forceinline__ bool saved_state_close(const double2* slot, int src, const double (&m)[chunk::NP], const double (&x)[chunk::R],
+                                                  double tol) {
+    const double2* p = slot + src;
+    chunk::Gap g{0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < chunk::NP / 2; ++k) {
+        const double2 v = p[k * 64];
+        chunk::gap_mat(g, m[2 * k], v.x);
+        chunk::gap_mat(g, m[2 * k + 1], v.y);
+    }
+#pragma unroll
+    for (int k = 0; k < chunk::R / 2; ++k) {
+        const double2 v = p[(chunk::NP / 2 + k) * 64];
+        chunk::gap_vec(g, x[2 * k], v.x);
+        chunk::gap_vec(g, x[2 * k + 1], v.y);
+    }
+    return chunk::gap_close(g, tol);
 }
 
 // EM accumulators in LDS: statistic q, slot = lane & (kAccSlots - 1)
@@ -150,6 +173,11 @@ __device__ __forceinline__ void dma_rows(const double2* base, unsigned voff, uns
             : "memory", "scc");
     }
 }
+// What the wave stores to global memory (the smoother table, the warm-up states, the terminal states) is read back by the SAME wave --
+// by other lanes, through the same CU's write-through L1.  The stores have to be complete and ordered before the loads, nothing more:
+// a workgroup-scope fence (s_waitcnt).  __threadfence() is agent scope: buffer_wbl2 + buffer_inv -- the XCD's L2 writes back every dirty
+// line it holds (all the outputs the batch has just stored) once per fence and replicate.
+__device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
@@ -319,7 +347,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const RowSrc krow{cst + kOffK}, ktrow{cst + kOffKT}, qrow{cst + kOffQPhi};
     const double tol = a.chunk_tol;
     const double* obs = a.chunk_obs + (size_t)b * T * (2 * kObsRows);
-    double2* scr = reinterpret_cast<double2*>(a.chunk_scr) + (size_t)b * L * kScrRows * 64;
+    double2* scr = reinterpret_cast<double2*>(a.chunk_scr) + (size_t)b * (L + 2) * kScrRows * 64;
+    double2* sav_f = scr + (size_t)L * kScrRows * 64;            // the states after the warm-ups (forward, backward): slots L, L + 1
+    double2* sav_b = sav_f + kScrRows * 64;
     double* term = a.chunk_term + (size_t)b * kTermStride;
     const int r = a.r;
     const int rl = a.rl > 0 ? a.rl : R;
@@ -395,7 +425,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     LogProd lp;
     double sxw = 0.0, ssum = 0.0, ldnsum = 0.0;
     double ldT = 0.0, xfT = 0.0;
-    Hash hs{0.0, 0.0, 0.0, 0.0, 0.0};
     const int ucap = W + (T - 1) % L;
     for (int u = 0; u < NS; ++u) {
         const int t = c0 - W + u;
@@ -409,7 +438,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 for (int i = 0; i < R; ++i) xi[i] = m0[kOffXi0 - kOffM0 + i];
             }
         }
-        if (u == W) hs = state_hash(m, xi);
+        if (u == W) save_state(sav_f, lane, m, xi);
         const bool counted = u >= W && t < T;
         double det, xw;
         fwd_step(m, xi, StageObs{sto}, det, xw, krow, qrow, RcpDev{}, [&](const double (&zn)[NP], const double (&w)[R]) {
@@ -461,12 +490,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
         }
     }
-    const Hash he = state_hash(m, xi);
-    bool ok;
-    {
-        const Hash hp = hash_from_lane(he, lane > 0 ? lane - 1 : 0);
-        ok = (lane == 0 || lane > jtop) || hash_close(hs, hp, tol);
-    }
     // log-likelihood (oracle/info_form.py): the lanes' counted periods add up
     double ll;
     {
@@ -477,7 +500,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const double qd = cst[kOffQ0] - xfTt - sx;
         ll = -0.5 * (ls + LD + ss + qd);
     }
-    __threadfence();                                               // the table and the terminal state are read back below
+    wave_mem_fence();                                               // the table, the warm-up states and the terminal state are read back below
+    // boundary check, forward: the state lane + 1 started its chunk from against the state this lane leaves its own chunk with
+    bool ok = lane + 1 > jtop || saved_state_close(sav_f, lane < 63 ? lane + 1 : 63, m, xi, tol);
 
     // =================================================== backward ==========================================================
     double P[NP], f[R];
@@ -492,7 +517,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     };
     wait_lds_reads();
     issue_zw(NS - 1);
-    Hash hsb{0.0, 0.0, 0.0, 0.0, 0.0};
     for (int u = 0; u < NS; ++u) {
         const int d = NS - 1 - u;
         const int t = c0 + d;                                      // the step that takes state t + 1 to state t
@@ -508,7 +532,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
             }
         }
-        if (u == W) hsb = state_hash(P, f);
+        if (u == W) save_state(sav_b, lane, P, f);
         const bool counted = u >= W && t < T;
         if constexpr (EM) {
             LdsAcc acc{acc10, acc11, lane & (kAccSlots - 1), counted, counted && t >= 1};
@@ -528,11 +552,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
         }
     }
-    {
-        const Hash heb = state_hash(P, f);
-        const Hash hq = hash_from_lane(heb, lane < 63 ? lane + 1 : 63);
-        ok = ok && (L * (lane + 1) >= T || hash_close(hsb, hq, tol));
-    }
+    wave_mem_fence();
+    // ... backward: the state lane - 1 started its chunk from (period L * lane) against the state this lane arrives there with
+    ok = ok && (lane == 0 || L * lane >= T || saved_state_close(sav_b, lane > 0 ? lane - 1 : 0, P, f, tol));
 #if DFM_CK_ABL & 16
     if (lane == 0 && (b == 0 || b == 777)) printf("CKCLK b=%d shader cycles %lld wall ticks %lld\n", b, clock64() - ck0, wall_clock64() - wk0);
 #endif
@@ -566,7 +588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 a.active[b] = go ? 1 : 0;
             }
         }
-        __threadfence();                                           // state 0 (term[44..]) and the LDS accumulators
+        wave_mem_fence();                                           // state 0 (term[44..]) and the LDS accumulators
         wave_lds_sync();
         const int i = lane >> 3, j = lane & 7;
         Grid<R> G;
@@ -646,7 +668,7 @@ int recursion_chunk_len(int T) {
     return L < 4 ? 4 : L;
 }
 size_t recursion_chunk_scratch_bytes(int B, int T) {
-    return (size_t)B * recursion_chunk_len(T) * kScrRows * 64 * sizeof(double2);
+    return (size_t)B * (recursion_chunk_len(T) + 2) * kScrRows * 64 * sizeof(double2);     // (+ 2 slots: the states after the warm-ups)
 }
 size_t recursion_chunk_obs_bytes(int B, int T) {
     return (size_t)B * T * kObsRows * sizeof(double2) + 4096;      // (+ slack: the last DMA of the last replicate reads whole 16-byte pieces)
@@ -682,6 +704,9 @@ hipError_t launch_recursion_chunk(const RecursionArgs& a0, hipStream_t s) {
     a.chunk_L = recursion_chunk_len(a.T);
     a.chunk_W = chunk_warm(a0);
     a.chunk_tol = a0.chunk_tol > 0.0 ? a0.chunk_tol : kChunkTolDefault;
+    // EM: the stop rule (ll_k - ll_k-1) / avg < tol is evaluated on this kernel's log-likelihood, which equals the sequential
+    // recursion's to ~chunk_tol only -- keep the boundary tolerance two decades under the caller's so that chunk noise cannot decide it
+    if (a0.S11 != nullptr && a0.tol > 0.0 && 1e-2 * a0.tol < a.chunk_tol) a.chunk_tol = 1e-2 * a0.tol;
     hipLaunchKernelGGL(chunk_prep_kernel, dim3(a.B), dim3(64), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256, CH ? 2 : 1) void recursion_tile_kernel(Recursi
                 if (poff[v] >= 0) pr[poff[v]] = P[v];
         }
     };
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (one workgroup = one CU = one write-through L1: no agent-scope L2 write-back)
     __syncthreads();                                           // (table and w_t stores of the forward sweep are visible: one CU, one L1)
     if (CH && !lastc) {                                        // (uniform) the guess the backward warm-up forgets: (Z, w) of the last extra period
         Ps = ld_tile_g(xZJ + (size_t)(Wk - 1) * 2 * RR, w, lane);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256, CH ? 2 : 1) void recursion_tile_kernel(Recursi
 #pragma unroll
         for (int v = 0; v < 4; ++v) sm[kRtRed + rowv[v]] = fs[v];               // f_0 (32 doubles)
     }
-    __threadfence();                                           // (f_smooth rows written by the column-31 lanes are read by every wave)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (one workgroup = one CU = one write-through L1: no agent-scope L2 write-back)                                           // (f_smooth rows written by the column-31 lanes are read by every wave)
     __syncthreads();
     v4d G11 = zero4, G10 = zero4, G00 = zero4;
     tile_gsums(a.f_smooth + (size_t)b * T * r, sm + kRtRed, T, r, I, J, q, c, G11, G10, G00);
@@ -1081,7 +1081,9 @@ hipError_t launch_recursion_tile(const RecursionArgs& a, hipStream_t s) {
         c.tile_nc = nc; c.tile_lc = lc; c.tile_w = W;
         hipLaunchKernelGGL(recursion_tile_kernel<true>, dim3((unsigned)(a.B * nc)), dim3(256), 0, s, c);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(tile_chunk_finish_kernel, dim3(a.B), dim3(256), 0, s, c, a.chunk_tol > 0.0 ? a.chunk_tol : 1e-10);
+        double ctol = a.chunk_tol > 0.0 ? a.chunk_tol : 1e-10;
+        if (a.S11 != nullptr && a.tol > 0.0 && 1e-2 * a.tol < ctol) ctol = 1e-2 * a.tol;   // (EM stop rule: see launch_recursion_chunk)
+        hipLaunchKernelGGL(tile_chunk_finish_kernel, dim3(a.B), dim3(256), 0, s, c, ctol);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         RecursionArgs f = a;                                    // replicates with a boundary off (normally none: the blocks exit)
         f.only_if = a.chunk_fail;

@@ -90,3 +90,68 @@ def test_the_chunk_model_reproduces_the_oracle_pass_or_says_it_did_not(N, T, r, 
         np.testing.assert_allclose(f, out["f_smooth"], rtol=1e-9, atol=1e-11)
         np.testing.assert_allclose(P, out["P_smooth"], rtol=1e-9, atol=1e-12)
         np.testing.assert_allclose(info["f0"], out["f0_smooth"], atol=1e-11)
+
+
+# ---- the boundary check itself (dfm_chunk_core.h state_gap / gap_close) ---------------------------------------------------------------
+def _old_weights():
+    """The weight vectors of the check this one replaces (round 5: two weighted sums of the packed matrix, one of the vector)."""
+    k = np.arange(36, dtype=np.uint64)
+    g1 = 1.0 + ((k * 40503 + 12345) & 0xFFFF) / 65536.0
+    g2 = 1.0 + ((k * 30011 + 54321) & 0xFFFF) / 65536.0
+    i = np.arange(8, dtype=np.uint64)
+    g = 1.0 + ((i * 50021 + 777) & 0xFFFF) / 65536.0
+    return g1, g2, g
+
+
+def _gap_verdicts(tmp_path, records):
+    exe = str(tmp_path / "chunk_gap_host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host", "chunk_gap_host.cpp")], check=True)
+    blob = struct.pack("i", len(records))
+    for tol, m, x, m2, x2 in records:
+        blob += struct.pack("d", tol) + np.concatenate([m, x, m2, x2]).astype(np.float64).tobytes()
+    res = subprocess.run([exe], input=blob, capture_output=True, check=True)
+    return [int(v) for v in res.stdout.split()]
+
+
+def test_the_boundary_check_is_a_bound_not_a_projection(tmp_path):
+    rng = np.random.default_rng(7)
+    A = rng.standard_normal((8, 8)); S = A @ A.T + 8 * np.eye(8)
+    m = S[np.tril_indices(8)]
+    x = rng.standard_normal(8)
+    g1, g2, g = _old_weights()
+    # an error of 1e-3 (relative) in the null space of BOTH matrix weight vectors, and one orthogonal to the vector's weights:
+    # the weighted sums of round 5 are unchanged to rounding, every entry is off
+    _, _, vt = np.linalg.svd(np.vstack([g1, g2]))
+    em = vt[-1] * 1e-3 * np.abs(m).max() / np.abs(vt[-1]).max()
+    ex = rng.standard_normal(8); ex -= g * (g @ ex) / (g @ g); ex *= 1e-3 * np.abs(x).max() / np.abs(ex).max()
+    assert abs(g1 @ em) < 1e-12 * np.abs(m).sum() and abs(g2 @ em) < 1e-12 * np.abs(m).sum() and abs(g @ ex) < 1e-12 * np.abs(x).sum()
+    tiny_m = 1e-12 * np.abs(m).max() * rng.uniform(-1, 1, 36)
+    tiny_x = 1e-12 * np.abs(x).max() * rng.uniform(-1, 1, 8)
+    nan_m = m.copy(); nan_m[17] = np.nan
+    one = m.copy(); one[30] += 3e-10 * np.abs(m).max()                       # ONE entry off by three tolerances
+    recs = [(1e-10, m, x, m, x),                                             # identical
+            (1e-10, m, x, m + tiny_m, x + tiny_x),                           # inside the tolerance, every entry
+            (1e-10, m, x, m + em, x),                                        # orthogonal to the old matrix weights
+            (1e-10, m, x, m, x + ex),                                        # orthogonal to the old vector weights
+            (1e-10, m, x, one, x),
+            (1e-10, m, x, nan_m, x),                                         # NaN never passes
+            (1e-10, nan_m, x, nan_m, x),
+            (1e-10, m, x, m, x + np.inf),
+            (1e-2, m, x, m + em, x + ex)]                                    # ... and a tolerance above the error accepts it
+    assert _gap_verdicts(tmp_path, recs) == [1, 1, 0, 0, 0, 0, 0, 0, 1]
+
+
+@pytest.mark.parametrize("W,N,miss", [(8, 32, 0.2), (8, 48, 0.0), (8, 48, 0.4), (8, 64, 0.2), (8, 96, 0.6), (4, 64, 0.0), (4, 96, 0.4), (2, 32, 0.6)])
+def test_the_boundary_residual_bounds_the_error_of_the_result(W, N, miss):
+    """The intermediate forgetting regime (boundary states off by 1e-10 ... 1e-2): the largest element-wise boundary residual of a
+    replicate is an upper bound on the error of its smoothed moments -- so a replicate the kernel keeps at tolerance tol is within
+    tol (tests/test_gpu_chunk.py runs the same sweep through the kernel)."""
+    T, r = 200, 8
+    for b in range(3):
+        x, p = ko.synth_replicate(100 + b, N, T, r, missing=miss)
+        out = ko.kfs_pass(x, p["Lam"], p["R"], p["A"], p["Q"], p["mu0"], p["P0"])
+        f, P, ll, info = ce.chunk_pass(x, p["Lam"], p["R"], p["A"], p["Q"], p["mu0"], p["P0"], W=W, tol=1e-10)
+        res = max(info["res_f"].max(), info["res_b"].max())
+        err = max(np.abs(f - out["f_smooth"]).max() / np.abs(out["f_smooth"]).max(),
+                  np.abs(P - out["P_smooth"]).max() / np.abs(out["P_smooth"]).max(), abs(ll - out["loglik"]) / abs(out["loglik"]))
+        assert 1e-12 < res and err <= res, (res, err)

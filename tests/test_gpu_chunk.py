@@ -180,3 +180,86 @@ def test_em_with_replicates_on_both_kernels(ctx):
             assert np.abs(got - p[k]).max() <= 1e-7 * max(1.0, np.abs(p[k]).max()), (k, b, np.abs(got - p[k]).max())
         assert np.abs(dev["Lam"][b].cpu().numpy()[keep] - p["Lam"]).max() <= 1e-7 * max(1.0, np.abs(p["Lam"]).max())
         assert np.abs(f[b] - out["f_smooth"]).max() <= 1e-7 * np.abs(out["f_smooth"]).max()
+
+
+# ---- the boundary check as a BOUND: a sweep over forgetting rates (round 6) ------------------------------------------------------------
+def _ctx_with_env(**env):
+    import os
+    from dynamic_factor_models_amd import DfmContext
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return DfmContext()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _rel_errors(got, ref):
+    """Per replicate: the largest relative deviation (max-norm) of the log-likelihood, f_smooth and P_smooth from the oracle."""
+    f, P, ll = got
+    fo, Po, llo = ref
+    ax = tuple(range(1, f.ndim))
+    e = np.abs(ll - llo) / np.abs(llo)
+    e = np.maximum(e, np.abs(f - fo).max(axis=ax) / np.abs(fo).max(axis=ax))
+    return np.maximum(e, np.abs(P - Po).max(axis=ax) / np.abs(Po).max(axis=ax))
+
+
+SWEEP_N = (10, 12, 16, 24, 32, 48, 64, 96, 160)          # r + 2 ... 4 r at r = 8 (slow forgetting) and on into the regime that forgets
+SWEEP_MISS = (0.0, 0.2, 0.4, 0.6)
+
+
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_forgetting_rate_sweep_every_replicate_is_exact_or_was_redone(W):
+    """r = 8, T = 200 (L = 4), N from r + 2 up, 0 ... 60 % missing cells, warm-ups of 2 / 4 / 8 periods: the states at the chunk
+    boundaries differ by anything between 1e-1 and 1e-12 (scripts/dbg/chunk_emul.py prints them).  Whatever the rate, EVERY replicate
+    must come out within 1e-9 of the oracle -- because its boundaries passed the element-wise check at 1e-10, or because the
+    sequential kernel redid it (dfm_chunk_fallbacks counts those).  Both classes must occur."""
+    c = _ctx_with_env(DFM_CHUNK_W=W)
+    B, T, r = 4, 200, 8
+    tot_f = tot = 0
+    try:
+        for N in SWEEP_N:
+            for miss in SWEEP_MISS:
+                panel, st = _batch(B, N, T, r, miss, first=100)
+                ref = co.ks_pass_batch(panel, *[st[k] for k in KEYS])
+                got = _pass(c, panel, st, may_have_missing=True)
+                nf, nt = c.chunk_fallbacks()
+                assert nt == B
+                err = _rel_errors(got, ref)
+                assert err.max() <= RTOL, f"W={W} N={N} miss={miss}: {err} ({nf} of {nt} redone)"
+                if N <= 24:
+                    assert nf == B, f"W={W} N={N} miss={miss}: {nf} of {nt} (a filter that cannot have forgotten passed its check)"
+                tot_f += nf; tot += nt
+    finally:
+        c.close()
+    assert tot_f > 0
+    if W == 8:
+        assert tot_f < tot
+
+
+@pytest.mark.parametrize("tol", [1e-4, 1e-6, 1e-8])
+def test_a_boundary_within_tol_means_a_result_within_tol(tol):
+    """The intermediate regime: with the boundary tolerance LOOSENED to `tol` the kernel keeps replicates whose chunks start from
+    states that far off.  The check is a bound: every replicate it keeps is within `tol` of the oracle (an error at a chunk's start
+    only contracts along the chunk), and the ones it hands to the sequential kernel are exact.  The sweep must contain kept
+    replicates whose error is far above the production tolerance -- otherwise it did not reach the regime."""
+    c = _ctx_with_env(DFM_CHUNK_TOL=tol)
+    B, T, r = 4, 200, 8
+    worst, kept = 0.0, 0
+    try:
+        for N in (32, 40, 48, 64, 96):
+            for miss in SWEEP_MISS:
+                panel, st = _batch(B, N, T, r, miss, first=100)
+                ref = co.ks_pass_batch(panel, *[st[k] for k in KEYS])
+                got = _pass(c, panel, st, may_have_missing=True)
+                nf, nt = c.chunk_fallbacks()
+                err = _rel_errors(got, ref)
+                assert err.max() <= tol, f"tol={tol} N={N} miss={miss}: {err} ({nf} of {nt} redone)"
+                worst = max(worst, err.max()); kept += nt - nf
+    finally:
+        c.close()
+    assert kept > 0 and worst > 1e-3 * tol, (kept, worst)
