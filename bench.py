@@ -84,7 +84,7 @@ def source_hash():
 def measured_traffic(kernel, workload_key):
     """HBM bytes per launch of `kernel` from the rocprofv3 --pmc passes (scripts/gpu_profile.sh -> profiles/rNN/
     pmc_traffic*.json), ONLY when that file was produced by exactly this source tree on this workload; else None."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         for name in ("pmc_traffic.json", "pmc_traffic_c4.json", "pmc_traffic_missing10.json", "pmc_traffic_missing10_b8192.json",
                      "pmc_traffic_c4_missing10.json"):                 # headline; BASELINE config 4; the missing-cell lines
             try:
@@ -283,6 +283,13 @@ def kernel_bytes_table(B, N, T, r):
             "cov_grid_kernel": B * 8 * (3 * r * r + r), "cov_tile_kernel": B * 8 * (3 * r * r + r), "collapse_ks_kernel": B * panel_b,
             "ct_miss_wide_kernel": B * 8 * T * npack, "ct_miss_wide2_kernel": B * 8 * T * npack,
             "ct_miss_slice_kernel": B * 8 * (N * T + T * npack)}      # (the panel once over its launches + the C_t rows)
+
+
+def em_iteration_bytes(N, T, r, k, q=0):
+    """Compulsory bytes of ONE EM iteration of one replicate with a k-wide state (k = r p: VAR(p) factor dynamics in companion form;
+    q > 0: AR(q) idiosyncratic terms on top): the panel twice (E-step, loadings step), the parameters in and out, the log-likelihood."""
+    par = N * r + N + N * q + r * k + r * r + k + k * k
+    return 8 * (2 * N * T + 2 * par + 1)
 
 
 def gram_flops(kernel, B, N, T):
@@ -573,11 +580,13 @@ def config1_config5_lines(torch, ctx, dev, cpu_seconds=2.0):
         n += 1
     cpu_s = (time.perf_counter() - t0) / n
     ok = abs(float(ssr[0]) - o["ssr"]) < 1e-8 * o["ssr"] and abs(float(ssr[-1]) - o["ssr"]) < 1e-8 * o["ssr"]
+    als_bytes = 8 * T * N + B * 8 * (2 * T * 4 + N * 4 + 2)        # the shared panel once; per run: start factors in, factors + loadings + ssr + iters out
     out["c1_als"] = dict(workload="BASELINE configs[0]: Stock-Watson real panel (222 x 58, 12 700 observed cells), r=4, PCA start + 10 ALS sweeps "
                                   "(estimate_factor!(m, 10)), 4096 runs per dfm_als_batch_dev call",
                          value=B / gpu_s, unit="ALS runs/s", ms_per_step=1e3 * gpu_s, batch=B, sweeps_per_s=10 * B / gpu_s, dominant="als_kernel",
-                         whole_step=None, matches_oracle_ssr=bool(ok),
-                         note="latency-bound (222 + 58 small dependent solves per sweep and run); the 103-KB panel is L2-resident",
+                         whole_step=als_bytes / gpu_s / 1e9 / HBM_PEAK_GBS, compulsory_bytes=als_bytes, matches_oracle_ssr=bool(ok),
+                         note="latency-bound (222 + 58 small dependent solves per sweep and run); the 103-KB panel is L2-resident: whole_step "
+                              "(compulsory bytes / time / HBM peak) says how far from any memory bound this small-matrix work is, not a roofline claim",
                          cpu_baseline=dict(value=1.0 / cpu_s, unit="ALS runs/s", cores=1, kind="port",
                                            sample=f"{n} runs of oracle/als_oracle.py (NumPy normal equations) in {cpu_seconds:.0f} s"),
                          seconds=round(time.perf_counter() - t_line, 2))
@@ -620,9 +629,11 @@ def config1_config5_lines(torch, ctx, dev, cpu_seconds=2.0):
     irf_g = ctx.var_bootstrap_irf_host(y, v.betahat, resid, 4, H, nd, signs=signs)
     irf_g = irf_g[0] if isinstance(irf_g, tuple) else irf_g
     boot_ok = bool(np.abs(np.asarray(irf_g) - irf_o).max() <= 1e-9 * np.abs(irf_o).max())
+    boot_bytes = 8 * (2 * y.size + v.betahat.size) + Bd * 8 * 4 * H * 4 + 5 * 8 * 4 * H * 4   # shared inputs once; per draw its IRFs out; the bands
     out["c5_boot"] = dict(workload="BASELINE configs[4] on one GPU: 10000 wild-bootstrap draws x VAR(4) of the 4 Stock-Watson factors (T=222) -> "
                                    "IRFs to 12 horizons -> 5/16/50/84/95 % bands",
-                          value=Bd / gpu_s, unit="bootstrap draws/s", ms_per_step=1e3 * gpu_s, draws=Bd, dominant="var_boot_kernel", whole_step=None,
+                          value=Bd / gpu_s, unit="bootstrap draws/s", ms_per_step=1e3 * gpu_s, draws=Bd, dominant="var_boot_kernel",
+                          whole_step=boot_bytes / gpu_s / 1e9 / HBM_PEAK_GBS, compulsory_bytes=boot_bytes,
                           bands_finite=bool(torch.isfinite(bands).all()), matches_oracle=boot_ok,
                           note="latency-bound (218 dependent periods per draw, 17 x 17 normal equations); draw + re-estimation + Cholesky + IRF + bands",
                           cpu_baseline=dict(value=1.0 / cpu_s, unit="bootstrap draws/s", cores=1, kind="port",
@@ -668,7 +679,9 @@ def f3_lines(torch, ctx, dev, cpu_seconds=2.0):
     cpu_s = (time.perf_counter() - t0) / n
     out["varp_em"] = dict(workload=f"VAR({pv}) factor dynamics, r={rv} (companion state {rv * pv}), N={Nv} T={Tv} (Stock-Watson :All window shape), "
                                    f"{miss:.0%} missing, batch {Bv}: one EM iteration (dfm_em_varp_batch)",
-                          value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv, whole_step=None,
+                          value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv,
+                          whole_step=Bv * em_iteration_bytes(Nv, Tv, rv, rv * pv) / s_it / 1e9 / HBM_PEAK_GBS,
+                          compulsory_bytes=Bv * em_iteration_bytes(Nv, Tv, rv, rv * pv),
                           dominant="recursion_wave_kernel", matches_oracle=ok,
                           note="covariance-form sequential recursion on a 16-wide companion state: one 256-thread workgroup per replicate, latency-bound",
                           cpu_baseline=dict(value=1.0 / cpu_s, unit="EM iterations/s", cores=1, kind="port",
@@ -695,12 +708,83 @@ def f3_lines(torch, ctx, dev, cpu_seconds=2.0):
     cpu_s = (time.perf_counter() - t0) / n
     out["ar_em"] = dict(workload=f"AR({qv}) idiosyncratic terms + VAR({pv}) factors, r={rv} (state {rv * (qv + 1)}), N={Nv} T={Tv}, {miss:.0%} missing, "
                                  f"batch {Bv}: one ECM iteration (dfm_em_ar_batch)",
-                        value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv, whole_step=None,
+                        value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv,
+                        whole_step=Bv * em_iteration_bytes(Nv, Tv, rv, rv * (qv + 1), qv) / s_it / 1e9 / HBM_PEAK_GBS,
+                        compulsory_bytes=Bv * em_iteration_bytes(Nv, Tv, rv, rv * (qv + 1), qv),
                         dominant="recursion_wave_kernel", matches_oracle=ok,
                         note="quasi-differenced observation equation, 20-wide state padded to 32: one 1024-thread workgroup per replicate, latency-bound",
                         cpu_baseline=dict(value=1.0 / cpu_s, unit="EM iterations/s", cores=1, kind="port",
                                           sample=f"{n} iterations of oracle/ar_oracle.py em_step_ar (NumPy) in {cpu_seconds:.0f} s"),
                         seconds=round(time.perf_counter() - t_line, 2))
+    return out
+
+
+def c1_em_lines(torch, ctx, dev, cpu_seconds=2.0):
+    """BASELINE configs[0] in its PARAMETRIC form, driver-visible: the Stock-Watson panel's :All window (222 periods x
+    the included series with >= 20 observations, its own ragged missing pattern), r = 4, factor VAR(p) with p = 1 and with the model's
+    own n_factorlag = 4 (dfm_functions.ipynb:120-146; companion state 16, :477-492).  The point estimate (PCA start + 10 EM
+    iterations through api.estimate(m, Parametric())) is untimed set-up; from it 1024 parametric-bootstrap panels are drawn with the
+    window's missing pattern (what `estimate!(m, Parametric(); nrep)` does) and the timed unit is the batch's 10 EM iterations from
+    the point estimate, panels and parameters resident in HBM.  Beside it the oracle's EM (NumPy, one thread) on replicate 0, whose
+    log-likelihood path is compared."""
+    import numpy as np
+    from dynamic_factor_models_amd import api
+    from oracle import kalman_oracle as ko
+    from oracle import varp_oracle as vo
+    out = {}
+    d = np.load(os.path.join(ROOT, "tests", "golden", "sw_panel.npz"))
+    r, init, last, Bc, nit = 4, 3, 224, 1024, 10
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for lags in (1, 4):
+        t_line = time.perf_counter()
+        m = api.DFMModel(d["bpdata"], d["inclcode"], 20, 40, init, last, 0, r, 1e-8, 4, 4)
+        api.estimate(m, api.Parametric(), max_em_iter=nit, tol_em=0.0, factor_lags=lags, ctx=ctx)
+        q = m.em_params
+        z, _ = api.standardize_data(d["bpdata"][init - 1:last][:, d["inclcode"] == 1])
+        z = z[:, (~np.isnan(z)).sum(axis=0) >= 20]
+        T, N = z.shape
+        k = r * lags
+        Avar = q["A"]                                               # ([A_1 .. A_p], r x r p; the r x r transition at p = 1)
+        rng = np.random.default_rng(20160415 + lags)
+        LQ, LS, sq = api._psd_sqrt(q["Q"]), api._psd_sqrt(q["P0"]), np.sqrt(q["R"])
+        st = q["mu0"][None] + rng.standard_normal((Bc, k)) @ LS.T                   # companion state [f_t .. f_t-p+1]
+        panels = np.empty((Bc, T, N))
+        for t in range(T):
+            f = st @ Avar.T + rng.standard_normal((Bc, r)) @ LQ.T
+            st = np.concatenate([f, st[:, :k - r]], axis=1)
+            panels[:, t] = f @ q["Lam"].T + sq * rng.standard_normal((Bc, N))
+        panels[:, np.isnan(z)] = np.nan
+        keys = ("Lam", "R", "Avar" if lags > 1 else "A", "Q", "mu0", "P0")
+        host = {kk: np.repeat(q["A" if kk == "Avar" else kk][None], Bc, axis=0) for kk in keys}
+        x = up(panels)
+        d0 = {kk: up(v) for kk, v in host.items()}
+        run = ctx.em_varp_batch if lags > 1 else ctx.em_batch
+        s_job, path = None, None
+        for rep_ in range(4):                                         # (first call: clocks after the CPU set-up; best of the other three)
+            dd = {kk: v.clone() for kk, v in d0.items()}
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            path, its, _, _ = run(x, *[dd[kk] for kk in keys], max_iter=nit, tol=0.0, may_have_missing=True)
+            torch.cuda.synchronize(); el = time.perf_counter() - t0
+            if rep_ > 0: s_job = el if s_job is None else min(s_job, el)
+        start = {kk: host[kk][0] for kk in keys}
+        t0 = time.perf_counter(); n = 0; opath = None
+        while n == 0 or time.perf_counter() - t0 < cpu_seconds:
+            opath = (vo.em_varp(panels[0], dict(start), lags, nit)[1] if lags > 1 else ko.em(panels[0], dict(start), max_iter=nit, tol=0.0)[1])
+            n += 1
+        cpu_s = (time.perf_counter() - t0) / n
+        got = path[0].cpu().numpy()
+        err = float(np.max(np.abs(got - opath) / np.abs(opath)))
+        nb = Bc * em_iteration_bytes(N, T, r, k) * nit
+        out["c1_em" if lags == 1 else "c1_em_p4"] = dict(
+            workload=f"BASELINE configs[0], parametric form: Stock-Watson :All window ({T} x {N}, {np.isnan(z).mean():.1%} of the cells missing, ragged), "
+                     f"r={r}, factor VAR({lags}), {Bc} parametric-bootstrap replicates x {nit} EM iterations from the point estimate",
+            value=Bc / s_job, unit="replicate estimations/s", ms_per_step=1e3 * s_job, batch=Bc, em_iterations=nit,
+            whole_step=nb / s_job / 1e9 / HBM_PEAK_GBS, compulsory_bytes=nb,
+            dominant="recursion_chunk_kernel" if lags == 1 else "recursion_wave_kernel",
+            matches_oracle=bool(err <= 1e-8), loglik_path_max_rel_err=err,
+            cpu_baseline=dict(value=1.0 / cpu_s, unit="replicate estimations/s", cores=1, kind="port",
+                              sample=f"{n} x {nit} EM iterations of oracle/{'varp_oracle.py em_varp' if lags > 1 else 'kalman_oracle.py em'} (NumPy) on replicate 0"),
+            seconds=round(time.perf_counter() - t_line, 2))
     return out
 
 
@@ -711,7 +795,7 @@ def secondary_plan(world: int, default_line: bool, no_secondary: bool):
     if not default_line or no_secondary:
         return []
     if world == 1:
-        return [k for k, *_ in SECONDARY] + ["c1_als", "c5_boot", "varp_em", "ar_em"]
+        return [k for k, *_ in SECONDARY] + ["c1_als", "c5_boot", "varp_em", "ar_em", "c1_em", "c1_em_p4"]
     return ["c3", "em", "pass_gather_every_step"]
 
 
@@ -720,6 +804,36 @@ MULTI_SECONDARY = {   # key -> (cfg, steps, warmup, gather)
     "em": (dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="em"), 10, 3, "block"),
     "pass_gather_every_step": (dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="pass"), 20, 3, "step"),
 }
+
+
+HBM_BYTES_PER_GPU = 288 * 10**9
+
+
+def resident_bytes(cfg, lib=None):
+    """HBM bytes ONE GPU holds for a line's batch (pure: tested on CPU for every line a default run times, incl. the N-GPU plan):
+    panels + parameters + outputs, x the number of distinct resident batches of a cache-cold line, + the library's workspace
+    (dfm_workspace_bytes: the larger of the plans the entry points may take for the shape)."""
+    B, N, T, r = cfg["B"], cfg["N"], cfg["T"], cfg["r"]
+    b_in, b_out = algorithmic_bytes(N, T, r)
+    if lib is None:
+        from dynamic_factor_models_amd import _lib
+        lib = _lib.load()
+    flags = 1 if cfg.get("missing", 0.0) > 0 else 0                # DFM_F_MAY_HAVE_MISSING
+    ws = int(lib.dfm_workspace_bytes(B, T, N, r, flags))
+    copies = max(1, int(cfg.get("cold", 0)))
+    em = 2 if cfg.get("mode") == "em" else 1                      # (EM lines keep the start parameters beside the working copy)
+    return copies * B * (b_in * em + b_out) + ws
+
+
+def check_distinct_devices(rank_devices, world):
+    """A multi-rank line must run on `world` DISTINCT GPUs: N ranks on one device would print an N-GPU line measured on one.  Returns the
+    number of distinct devices; raises SystemExit when ranks share one (DFM_BENCH_ALLOW_SHARED_DEVICE=1: the forced 1-GPU groups of the
+    development runs)."""
+    ids = {(d or {}).get("pci_bus_id") or (d or {}).get("uuid") or f"rank{i}" for i, d in enumerate(rank_devices)}
+    if len(ids) < world and os.environ.get("DFM_BENCH_ALLOW_SHARED_DEVICE") != "1":
+        raise SystemExit(f"bench.py: {world} ranks on {len(ids)} distinct device(s) {sorted(ids)} -- every rank needs its own GPU "
+                         "(LOCAL_RANK -> device); refusing to print a multi-GPU line")
+    return len(ids)
 
 
 def workload_name(N, T, r, B):
@@ -841,6 +955,7 @@ def main():
         mine = dict(rank=rank, local_device=local_rank, name=pr_.name, pci_bus_id=getattr(pr_, "pci_bus_id", None), uuid=str(getattr(pr_, "uuid", "")))
         rank_devices = [None] * world
         dist.all_gather_object(rank_devices, mine)
+        check_distinct_devices(rank_devices, world)
 
     from dynamic_factor_models_amd import DfmContext, shard
     ctx = DfmContext(local_rank)
@@ -911,7 +1026,7 @@ def main():
     for key in plan:
         t0 = time.perf_counter()
         try:
-            if key in ("c1_als", "c5_boot", "varp_em", "ar_em"):
+            if key in ("c1_als", "c5_boot", "varp_em", "ar_em", "c1_em", "c1_em_p4"):
                 continue                                          # (measured by the calls below)
             if world == 1:
                 cfg, k, w = next((c, kk, ww) for kk_, c, kk, ww in SECONDARY if kk_ == key)
@@ -949,8 +1064,27 @@ def main():
             sec.update(f3_lines(torch, ctx, dev))
         except Exception as e:  # noqa: BLE001
             sec["varp_em"] = dict(error=f"{type(e).__name__}: {e}")
+    if "c1_em" in plan and rank == 0:
+        try:
+            sec.update(c1_em_lines(torch, ctx, dev))
+        except Exception as e:  # noqa: BLE001
+            sec["c1_em"] = dict(error=f"{type(e).__name__}: {e}")
     if plan and rank == 0:
         out["secondary"] = sec
+        # driver-visible scalars: the cache-cold figure of the headline's kernel INSIDE the roofline object (the driver's record keeps
+        # the scalars of `roofline`; `secondary` is cut off by its stored tail), and one compact [ms per step, fraction of the HBM peak]
+        # pair per secondary line at the very END of the line
+        cold = sec.get("pass_cold") or {}
+        if cold.get("whole_step") is not None:
+            out["roofline"]["cold_frac"] = cold["whole_step"]
+            out["roofline"]["cold_ms_per_step"] = cold["ms_per_step"]
+        for key_, tag in (("c4", "frac_c4"), ("c4_em", "frac_c4_em"), ("missing10", "frac_missing10"), ("missing10_b8192", "frac_missing10_b8192"),
+                          ("em", "frac_em"), ("c4_missing10", "frac_c4_missing10")):
+            if (sec.get(key_) or {}).get("whole_step") is not None:
+                out["roofline"][tag] = sec[key_]["whole_step"]
+        out["secondary_summary"] = {k_: [None if v.get("ms_per_step") is None else round(v["ms_per_step"], 4),
+                                         None if v.get("whole_step") is None else round(v["whole_step"], 4)] if "error" not in v else "error"
+                                    for k_, v in sec.items()}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

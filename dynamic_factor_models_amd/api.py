@@ -650,15 +650,28 @@ def estimate_factor_numbers(m: DFMModel, nfacs, *, ctx=None, with_aw: bool = Fal
 
 def impulse_response(varm: VARModel, shock_ids, T: int) -> np.ndarray:
     """`impulse_response(varm, shock_ids, T)` -- dfm_functions.ipynb:793-816: irf[:, t, k] = Q M^t G[:, shock_k]
-    (point estimate; host arithmetic on the 16 x 16 companion, as in the reference)."""
-    shock_ids = [int(s) for s in np.atleast_1d(shock_ids)]
-    out = np.empty((varm.Q.shape[0], T, len(shock_ids)))
-    for k, s in enumerate(shock_ids):
+    (point estimate; host arithmetic on the 16 x 16 companion, as in the reference).  The reference's three methods:
+      * a vector of shock ids  -> [ny, T, len(shock_ids)]                                   (:793-799)
+      * ONE shock id (a number) -> the [ny, T] matrix of that shock                         (:817-821: the reference's method
+        passes an undefined `x` and six arguments to the five-argument `compute_irf_single_shock!` and cannot run; this is
+        what it evidently means -- the same recursion written into a matrix; julia/dfm_hip.jl repairs it the same way)
+      * "all" (the reference's `:all`) -> every column of G                                 (:822-825)
+    Shock ids are 0-based here (1-based in Julia)."""
+    if isinstance(shock_ids, str):
+        if shock_ids != "all":
+            raise ValueError("shock_ids: a shock index, a sequence of them, or 'all'")
+        shock_ids = range(varm.G.shape[1])
+    scalar = np.isscalar(shock_ids)
+    ids = [int(s) for s in np.atleast_1d(shock_ids)]
+    out = np.empty((varm.Q.shape[0], T, len(ids)))
+    for k, s in enumerate(ids):
+        if not 0 <= s < varm.G.shape[1]:
+            raise IndexError(f"shock id {s} out of range (G has {varm.G.shape[1]} columns)")
         x = varm.G[:, s].copy()
         for t in range(T):
             out[:, t, k] = varm.Q @ x
             x = varm.M @ x
-    return out
+    return out[:, :, 0] if scalar else out
 
 
 def bootstrap_irf_bands(varm: VARModel, H: int, ndraws: int = 10000, quantiles=(0.05, 0.16, 0.5, 0.84, 0.95),

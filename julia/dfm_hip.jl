@@ -603,6 +603,20 @@ function estimate_factor_hip!(m::DFMModel, max_iter::Integer = 100000000, comput
     return nothing
 end
 
+# `impulse_response(varm, shock_id::Real, T)` (dfm_functions.ipynb:817-821) repaired.  The reference's method cannot run: it passes an
+# undefined `x` and SIX arguments to the five-argument `compute_irf_single_shock!(irfs, varm, i, shock_id, T)` (:801-810).  What it
+# means is evident from the vector method (:793-799): the same recursion -- irf[:, t] = Q M^(t-1) G[:, shock_id] -- written into a
+# ny x T matrix (`irfs[:, t, 1]` addresses a Matrix: a trailing index 1 is legal).  Defining it here REPLACES the broken method once
+# the notebook's functions are loaded (same signature); the vector and `:all` methods (:793-799, :822-825) are the reference's own.
+# Mirror: dynamic_factor_models_amd/api.py impulse_response (scalar shock id).
+function impulse_response(varm::VARModel, shock_id::Real, T::Integer)
+    isinteger(shock_id) && 1 <= shock_id <= size(varm.G, 2) ||
+        throw(ArgumentError("shock_id must be an integer in 1:$(size(varm.G, 2))"))
+    irfs = Matrix{Float64}(undef, size(varm.Q, 1), T)
+    compute_irf_single_shock!(irfs, varm, 1, Int(shock_id), T)
+    return irfs
+end
+
 # Wild-bootstrap bands of `impulse_response(varm, shock_ids, T)` (dfm_functions.ipynb:793-816) for an estimated VARModel.
 function bootstrap_irf_bands(varm::VARModel, H::Integer; ndraws::Integer = 10000, seed::Integer = 20160415,
                              device::Integer = 0, handle = nothing)

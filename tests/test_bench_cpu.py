@@ -112,3 +112,34 @@ def test_gram_flops_are_the_executed_ones():
     exw, _ = bench.gram_flops("gram_xx_wide_kernel", 256, 1000, 2000)
     assert exw == 2.0 * 2000 * 128 * 128 * 36 * 256              # 8 blocks of 128 series: 36 pairs
     assert bench.gram_flops("gram_xx_kernel", 1, 10, 10)[0] == 2000.0
+
+
+def test_every_default_line_fits_the_hbm_of_one_gpu():
+    """the batches a default run keeps resident -- one GPU's secondary lines and the N-GPU plan (BASELINE
+    configs[2]: 8192 replicates per GPU) -- with the library's own workspace (dfm_workspace_bytes) stay inside 288 GB per GPU."""
+    import pytest
+    cfgs = [dict(B=1024, N=200, T=500, r=8, missing=0.0, mode="pass")] + [c for _, c, _, _ in bench.SECONDARY]
+    cfgs += [c for c, _, _, _ in bench.MULTI_SECONDARY.values()]
+    assert {k for k in bench.secondary_plan(8, True, False)} == set(bench.MULTI_SECONDARY)
+    worst = 0
+    for cfg in cfgs:
+        need = bench.resident_bytes(cfg)
+        assert 0 < need < 0.5 * bench.HBM_BYTES_PER_GPU, (cfg, need)           # (half: torch's allocator and RCCL need room too)
+        worst = max(worst, need)
+    assert worst > 10 * 10**9                                                   # (the 8192-replicate shards are tens of GB: the check is not vacuous)
+    big = dict(B=400000, N=200, T=500, r=8, missing=0.0, mode="pass")           # 40 x configs[2]'s shard does NOT fit
+    assert bench.resident_bytes(big) > bench.HBM_BYTES_PER_GPU
+    with pytest.raises(SystemExit):
+        bench.check_distinct_devices([dict(pci_bus_id="0000:05:00.0"), dict(pci_bus_id="0000:05:00.0")], 2)
+    assert bench.check_distinct_devices([dict(pci_bus_id="0000:05:00.0"), dict(pci_bus_id="0000:06:00.0")], 2) == 2
+    os.environ["DFM_BENCH_ALLOW_SHARED_DEVICE"] = "1"
+    try:
+        assert bench.check_distinct_devices([dict(pci_bus_id="a"), dict(pci_bus_id="a")], 2) == 1
+    finally:
+        del os.environ["DFM_BENCH_ALLOW_SHARED_DEVICE"]
+
+
+def test_em_iteration_bytes():
+    """Compulsory bytes of an EM iteration with a k-wide companion state: the panel twice, the parameters in and out."""
+    assert bench.em_iteration_bytes(139, 222, 4, 16) == 8 * (2 * 139 * 222 + 2 * (139 * 4 + 139 + 4 * 16 + 16 + 16 + 256) + 1)
+    assert bench.em_iteration_bytes(139, 222, 4, 20, 4) - bench.em_iteration_bytes(139, 222, 4, 20) == 8 * 2 * 139 * 4

@@ -138,3 +138,25 @@ def test_parametric_argument_checks_run_before_any_device_work():
     m8 = api.DFMModel(np.random.default_rng(2).standard_normal((60, 12)), np.ones(12), 5, 5, 1, 60, 0, 8, 1e-8, 4, 4)
     with pytest.raises(ValueError, match="must not exceed 32"):
         api.smooth_factors_ar_idio(m8)                                # 8 * max(4, 5) = 40
+
+
+def test_impulse_response_methods_mirror_the_reference():
+    """dfm_functions.ipynb:793-825: a vector of shocks -> [ny, T, k]; ONE shock -> the [ny, T] matrix (the reference's method is
+    broken, :817-821; repaired here and in julia/dfm_hip.jl); 'all' -> every column of G."""
+    rng = np.random.default_rng(3)
+    v = api._var_model(rng.standard_normal((30, 3)), nlag=2)
+    v.M = 0.3 * rng.standard_normal((6, 6)); v.Q = rng.standard_normal((3, 6)); v.G = rng.standard_normal((6, 3))
+    full = api.impulse_response(v, [0, 1, 2], 7)
+    assert full.shape == (3, 7, 3)
+    for s in range(3):
+        ref = np.stack([v.Q @ np.linalg.matrix_power(v.M, t) @ v.G[:, s] for t in range(7)], axis=1)
+        np.testing.assert_allclose(full[:, :, s], ref, rtol=1e-12, atol=1e-14)
+        one = api.impulse_response(v, s, 7)
+        assert one.shape == (3, 7) and np.array_equal(one, full[:, :, s])
+        assert np.array_equal(api.impulse_response(v, np.int64(s), 7), one)
+    assert np.array_equal(api.impulse_response(v, "all", 7), full)
+    assert np.array_equal(api.impulse_response(v, [2], 7)[:, :, 0], full[:, :, 2])
+    with pytest.raises(IndexError):
+        api.impulse_response(v, 3, 7)
+    with pytest.raises(ValueError):
+        api.impulse_response(v, "some", 7)

@@ -88,6 +88,9 @@ def test_estimate_parametric_with_the_models_factor_lags():
     np.testing.assert_allclose(var.seps, m.em_params["Q"], rtol=1e-12)
 
 
+C1_TOL = 1e-10      # attained on MI355X (round 6, printed below): log-likelihood path 3.4e-15, smoothed factors 2.3e-14 (VAR(1)) / 3.5e-14 (VAR(4))
+
+
 @pytest.mark.parametrize("lags", [1, 4])
 def test_config1_stock_watson_panel_pca_plus_10_em_iterations(lags):
     """BASELINE configs[0]: the Stock-Watson panel, r = 4, PCA start + 10 EM iterations through estimate(m, Parametric())
@@ -125,9 +128,11 @@ def test_config1_stock_watson_panel_pca_plus_10_em_iterations(lags):
         qe, pathe, out = vo.em_varp(z, start, lags, 10)
         fo = out["f_smooth"][:, :r]
     assert m.em_iters == 10 and np.all(np.diff(pathe) > 0)
-    np.testing.assert_allclose(path, pathe, rtol=1e-6)                     # north_star: 1e-6 relative
     f = m.factor[init - 1:last]
-    assert np.abs(f - fo).max() <= 1e-6 * np.abs(fo).max()
+    err_path = float(np.max(np.abs(path - pathe) / np.abs(pathe)))
+    err_f = float(np.abs(f - fo).max() / np.abs(fo).max())
+    print(f"config 1, factor VAR({lags}): attained loglik-path error {err_path:.2e}, factor error {err_f:.2e}")
+    assert err_path <= C1_TOL and err_f <= C1_TOL, (err_path, err_f)      # (north_star asks 1e-6 relative)
 
 
 def test_estimate_parametric_with_bootstrap_replicates_and_short_series():

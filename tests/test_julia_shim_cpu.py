@@ -137,3 +137,17 @@ def test_the_shim_never_drops_loading_constraints():
     est = est[:est.index("\nend\n")]
     assert "nt_min_factor_estimation" in est                                  # the `enough` filter of api.estimate
     assert "lam_constr_f === nothing" in est and "nrep" in est and "ngpu" in est
+
+
+def test_the_shim_repairs_the_scalar_shock_impulse_response():
+    """dfm_functions.ipynb:817-821 calls the five-argument compute_irf_single_shock! with six arguments and an undefined `x`; the shim's
+    replacement must call it with (irfs, varm, 1, shock_id, T) on a ny x T matrix."""
+    body = src_of("function impulse_response(varm::VARModel, shock_id::Real, T::Integer)")
+    assert "Matrix{Float64}(undef, size(varm.Q, 1), T)" in body
+    assert "compute_irf_single_shock!(irfs, varm, 1, Int(shock_id), T)" in body
+
+
+def src_of(signature):
+    src = open(os.path.join(ROOT, "julia", "dfm_hip.jl")).read()
+    start = src.index(signature)
+    return src[start:src.index("\nend\n", start)]
