@@ -130,6 +130,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t LamP, AP, QP, P0P, mu0P;                // padded parameters (only used when r != Rp)
     size_t bcol, scol, ldrow, nobs, Ct, Cfull, ldfull;
     size_t ZJ, wtab, status, ncov;
+    size_t ck_rows = (size_t)-1;                  // collapse_miss_kernel's rows + NaN masks (ct_build_kernel's input)
     size_t ck_scr = (size_t)-1, ck_obs = (size_t)-1, ck_cst = (size_t)-1, ck_term = (size_t)-1, ck_fail = (size_t)-1;   // recursion_chunk.hip (Rp = 8, general path)
     size_t Vwide = (size_t)-1;
     size_t tk_scr = (size_t)-1, tk_bytes = 0;   // recursion_tile.hip (Rp = 32, general path): the chunks' scratch (ck_fail is shared)
@@ -217,6 +218,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
     if (!fast && !p.cov && Rp == 8) {
         p.ck_scr = take(off, recursion_chunk_scratch_bytes(B, T));
         p.ck_obs = take(off, recursion_chunk_obs_bytes(B, T));
+        if (p.Rc == 0 && collapse_miss_supported(8, N)) p.ck_rows = take(off, recursion_chunk_rows_bytes(B, T));
         p.ck_cst = take(off, (size_t)B * 320 * d);
         p.ck_term = take(off, (size_t)B * 96 * d);
         p.ck_fail = take(off, (size_t)B * sizeof(int));
@@ -683,12 +685,13 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
                  const EmOpts* em) {
     if (p.fast) return enqueue_pass_fast(h, p, B, T, N, out_r, panel, pp, Rv, f_smooth, P_smooth, loglik, em);
     CollapseArgs ca;
+    memset(&ca, 0, sizeof(ca));
     ca.B = B; ca.T = T; ca.N = N;
     ca.panel = panel; ca.Lam = pp.Lam; ca.Rv = Rv;
     ca.bcol = at<double>(h, p.bcol); ca.scol = at<double>(h, p.scol); ca.nobs = at<int>(h, p.nobs);
     ca.ldrow = at<double>(h, p.ldrow); ca.Ct = at<double>(h, p.Ct); ca.Cfull = at<double>(h, p.Cfull);
     ca.ldfull = at<double>(h, p.ldfull); ca.status = h->status_dev;
-    ca.obs_chunk = nullptr;
+    ca.obs_chunk = nullptr; ca.obs_table = nullptr; ca.obs_L = 0;
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
@@ -720,8 +723,9 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
         // the time-chunked recursion reads one table row per period (C_t, b_t, s_t, n_t log 2 pi + log det R_t): at Rp = 8 with loadings as
         // wide as the state collapse_miss_kernel writes it directly
         const bool table = ra.wave && !h->collapse_miss_old && p.Rc == 0 && recursion_chunk_supported(p.Rp, ra);
-        if (table && collapse_miss_supported(Rcol, N)) {
-            ca.obs_chunk = ra.chunk_obs;
+        if (table && p.ck_rows != (size_t)-1 && collapse_miss_supported(Rcol, N)) {
+            ca.obs_chunk = at<double>(h, p.ck_rows);
+            ca.obs_table = ra.chunk_obs; ca.obs_L = recursion_chunk_len(T);
             ra.chunk_obs_ready = 1;
             ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream));
         } else

@@ -20,12 +20,19 @@
 //   * n_t from the ballots, s_t and ld_t = ldfull - sum over the missing cells of log R by ONE 8-value transpose-reduce per
 //     row block (wave_allsum through ds_bpermute cost 0.11 ms).
 // Periods without a missing cell skip all of it (wave-uniform branch): the kernel then runs at the balanced collapse's rate.
+// TABLE MODE (round 6; the route of the time-chunked recursion, recursion_chunk.hip): no C_t here at all.  The per-period list work
+// above cost as much as the stream (0.39 ms against 0.226 at the C2 shape, three rewrites in round 5 did not move it: two LDS round
+// trips and a gathered contraction per period on the whole wave).  The kernel writes one 112-byte row per period -- b_t, s_t,
+// n_t log 2 pi + sum log R, and the period's NaN bit mask as four ballots -- and, when its four waves have streamed their segments, the
+// workgroup forms C_t of the replicate's periods with one LANE per period from the masks, straight into the pass's chunk-major
+// observation table (dfm_ctbuild.h: the table's stores go out while the CU's other workgroup streams its panel).
 // One workgroup per replicate, one wave per period segment; 2 workgroups per CU (rings 53 KB + tables 14 KB + lists).
 // The reference's analogue is the per-period complete-case regression of x_t on Lambda (dfm_functions.ipynb:271-286 called
 // from :364), which also forms the normal equations Lambda_t' Lambda_t and Lambda_t' x_t over the observed series.
 #include <stdlib.h>
 #include <string.h>
 
+#include "dfm_ctbuild.h"
 #include "dfm_gram.h"
 #include "dfm_grid.h"
 #include "dfm_kernels.h"
@@ -130,10 +137,10 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
     const bool tail_clamp = (STEPS - 1) * CS + 4 * g + K >= N;
     const unsigned last_off = tail_clamp ? (unsigned)q * SB + (unsigned)(N - 1) * 8u : lane_off + (unsigned)(STEPS - 1) * (CS * 8u);
     const char* seg = reinterpret_cast<const char*>(a.panel + ((size_t)b * T + ta) * N);
-    // table mode (a.obs_chunk: the observation table of recursion_chunk.hip instead of bcol .. ldrow): one 368-byte row per period,
-    // doubles 0..35 C_t (packed; EVERY period), 36..43 b_t, 44 s_t, 45 n_t log 2 pi + log det R_t
+    // table mode (a.obs_chunk = RecursionArgs::chunk_rows instead of bcol .. ldrow / C_t): one 112-byte row per period,
+    // doubles 0..7 b_t, 8 s_t, 9 n_t log 2 pi + log det R_t, 10..13 the NaN mask: bit l of word 2 jq + e = series 2 l + 128 jq + e is missing
     constexpr bool obs = TAB;
-    auto obs_row = [&](int t) { return a.obs_chunk + ((size_t)b * T + t) * 46; };
+    auto obs_row = [&](int t) { return a.obs_chunk + ((size_t)b * T + t) * 14; };
 
     auto issue_block = [&](int k, int bslot) {                   // 4 rows x NDR DMAs, always (rows past the segment: its last row)
 #pragma unroll
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
         }
         if (lane == 0) a.ldfull[b] = ldfull;
     }
-    if (nrows <= 0) return;
+    if (nrows <= 0 && !TAB) return;                              // (table mode: every wave meets the barrier in front of the tail)
     unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));   // lanes below this one
 
     // ---- the stream ------------------------------------------------------------------------------------------------
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
             const double hi = xor_lane<1>(D);
             const int t = ta + r0 + K;
             if (g == 0 && (q & 1) == 0 && t < tb) {
-                if (obs) *reinterpret_cast<double2*>(obs_row(t) + 36 + 4 * h + q) = make_double2(D, hi);
+                if (obs) *reinterpret_cast<double2*>(obs_row(t) + 4 * h + q) = make_double2(D, hi);
                 else *reinterpret_cast<double2*>(&a.bcol[((size_t)b * T + t) * R + 4 * h + q]) = make_double2(D, hi);
             }
         }
@@ -284,22 +291,40 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
         bool canon;
         const int ridx = reduce_index<8>(lane, canon);
         int nmiss_row[4] = {0, 0, 0, 0};
-        if ((anynan != 0ull || obs) && !(abl & 1)) {             // (wave-uniform) some period of the block has a missing cell
+        if constexpr (TAB) {
+            // the masks of the block's four periods: 2 NQ ballots each, ballot (rr, w = 2 jq + e) into lane 4 rr + w of (mlo, mhi);
+            // lanes 0..15 store one 64-bit word each (words of a short cross-section stay 0)
+            int mlo = 0, mhi = 0;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                int nm = 0;
+#pragma unroll
+                for (int jq = 0; jq < NQ; ++jq)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const unsigned long long bal = __ballot(((nanbits[rr] >> (2 * jq + e)) & 1u) != 0u);
+                        nm += __popcll(bal);
+                        if (2 * jq + e < 4) {
+                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mlo) : "s"((unsigned)bal), "i"(4 * rr + 2 * jq + e));
+                            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mhi) : "s"((unsigned)(bal >> 32)), "i"(4 * rr + 2 * jq + e));
+                        }
+                    }
+                nmiss_row[rr] = nm;
+            }
+            if (anynan != 0ull && a.Ct == nullptr && lane == 0) atomicOr(a.status, 1);   // caller promised a balanced panel: flag it
+            const int tm = ta + r0 + (lane >> 2);
+            if (lane < 16 && tm < tb)
+                *reinterpret_cast<uint2*>(obs_row(tm) + 10 + (lane & 3)) = make_uint2((unsigned)mlo, (unsigned)mhi);
+        } else
+        if (anynan != 0ull && !(abl & 1)) {                      // (wave-uniform) some period of the block has a missing cell
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int t = ta + r0 + rr;
                 const unsigned long long rowany = __ballot(nanbits[rr] != 0u);
                 if (t >= tb) continue;                           // (wave-uniform)
-                if (rowany == 0ull) {                            // a complete period: the table takes the replicate's full Gram matrix
-                    if (obs && g == 0) {
-                        double* ct = obs_row(t);
-                        if (q <= K) ct[i0 * (i0 + 1) / 2 + f0] = CF0;
-                        if (h == 0) ct[i1 * (i1 + 1) / 2 + q] = CF1;
-                    }
-                    continue;
-                }
+                if (rowany == 0ull) continue;                    // a complete period
                 if (a.Ct == nullptr && lane == 0) atomicOr(a.status, 1);   // caller promised a balanced panel: flag it
-                if (a.Ct == nullptr && !obs) continue;           // (no table, no C_t array: keep valid memory)
+                if (a.Ct == nullptr) continue;                   // (no C_t array: keep valid memory)
                 // index list of the missing series of the period (ballot compaction), or of the observed ones when fewer
                 unsigned long long mb[NQ][2];
                 int nmiss = 0;
@@ -332,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
                 list_gram(nst, E0, E1);
                 wave_lds_sync();
                 if (g == 0) {
-                    double* ct = obs ? obs_row(t) : a.Ct + ((size_t)b * T + t) * NP;
+                    double* ct = a.Ct + ((size_t)b * T + t) * NP;
                     if (q <= K) ct[i0 * (i0 + 1) / 2 + f0] = comp ? CF0 - E0 : E0;
                     if (h == 0) ct[i1 * (i1 + 1) / 2 + q] = comp ? CF1 - E1 : E1;
                 }
@@ -344,8 +369,8 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
             const int t = ta + r0 + rr;
             int nm = nmiss_row[0];
             nm = rr == 1 ? nmiss_row[1] : nm; nm = rr == 2 ? nmiss_row[2] : nm; nm = rr == 3 ? nmiss_row[3] : nm;
-            if (canon && t < tb && obs) {                        // doubles 44, 45 of the table row: s_t, n_t log 2 pi + sum of log R over the observed
-                double* sl = obs_row(t) + 44;
+            if (canon && t < tb && obs) {                        // doubles 8, 9 of the row: s_t, n_t log 2 pi + sum of log R over the observed
+                double* sl = obs_row(t) + 8;
                 if (ridx < 4) sl[0] = red[0];
                 else sl[1] = (double)(N - nm) * 1.8378770664093454835606594728112 + (ldfull - red[0]);
             } else if (canon && t < tb) {
@@ -358,6 +383,28 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
             }
         }
         bslot = (bslot + 1 == NB) ? 0 : bslot + 1;
+    }
+    if constexpr (TAB) {
+        // ---- the tail: C_t of the replicate's periods -> the observation table (dfm_ctbuild.h).  The rows are this workgroup's own
+        // stores (same CU, write-through L1): complete and visible behind the barrier.  The rings are dead: v = lam / sqrt(R) and the
+        // packed full Gram matrix take their place.
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __syncthreads();
+        double* Cf = reinterpret_cast<double*>(smem);
+        double* V = Cf + kCtbLdsDoubles;
+        for (int e = threadIdx.x; e < N * R; e += 256) {
+            const int c = e >> 3;
+            V[c * kCtbStride + (e & 7)] = Wt[e] * sqrt(Rt[c]);       // (lam / R) sqrt(R)
+        }
+        if (threadIdx.x < NP) {
+            int i = 0;
+            while ((i + 1) * (i + 2) / 2 <= (int)threadIdx.x) ++i;
+            Cf[threadIdx.x] = a.Cfull[(size_t)b * R * R + i * R + ((int)threadIdx.x - i * (i + 1) / 2)];
+        }
+        __syncthreads();
+        const int L = a.obs_L;
+        ct_build_replicate(reinterpret_cast<const unsigned long long*>(a.obs_chunk) + (size_t)b * T * 14,
+                           reinterpret_cast<double2*>(a.obs_table) + (size_t)b * L * kObsRows * 64, Cf, V, T, N, L, wave, WPR, lane);
     }
 }
 

@@ -69,8 +69,10 @@ struct CollapseArgs {
     int ct_r;             // ct_miss_wide2 only: > 0 = Ct rows are the packed LEADING ct_r x ct_r block (ct_r (ct_r + 1) / 2 doubles; the
                           // padding of the state carries no loadings, its entries equal Cfull's) -- what recursion_tile_kernel reads;
                           // 0 = the full Rp (Rp + 1) / 2 layout of the other recursion kernels
-    double* obs_chunk;    // collapse_miss only: the observation table of recursion_chunk.hip (RecursionArgs::chunk_obs: one 368-byte row per
-                          // period), written INSTEAD of bcol .. ldrow
+    double* obs_chunk;    // collapse_miss only (table mode): RecursionArgs::chunk_rows -- one 112-byte row per period: b_t (8), s_t,
+                          // n_t log 2 pi + sum log R, the period's NaN bit mask (4 x 64 bits) -- written INSTEAD of bcol .. ldrow and C_t
+    double* obs_table;    // ... and RecursionArgs::chunk_obs, the pass's observation table [B][obs_L][23][64] double2 (chunk-major, period
+    int obs_L;            // t = obs_L lane + slot), which the workgroup fills from those rows when its stream is done (dfm_ctbuild.h)
 };
 
 struct RecursionArgs {
@@ -119,8 +121,10 @@ struct RecursionArgs {
     double* chunk_scr;    // [B][chunk_L][22][64][2]  -Z_t (36 packed) and w_t (8) of every period, chunk-major (lane = chunk)
     double* chunk_cst;    // [B][320]  per-replicate constants (K, K', Q^-1 + Phi, Phi, Om_0 + Phi, xi_0, log-det and quadratic constants)
     double* chunk_term;   // [B][96]   P_T|T (36), f_T|T (8), P_0|T (36), f_0|T (8)
-    double* chunk_obs;    // [B][T][46]  one row per period: C_t (36 packed), b_t (8), s_t, n_t log 2 pi + log det R_t
-    int chunk_obs_ready;  // 1: the collapse kernel wrote chunk_obs itself (else launch_recursion_chunk gathers the per-period arrays)
+    double* chunk_obs;    // [B][chunk_L][23][64][2]  the observation table, chunk-major (period t = chunk_L lane + slot): C_t (36 packed), b_t (8),
+                          // s_t, n_t log 2 pi + log det R_t of EVERY slot of all 64 lanes (benign rows beyond the sample)
+    int chunk_obs_ready;  // 1: collapse_miss_kernel wrote the table itself (its table mode); 0: launch_recursion_chunk gathers the collapse
+                          // kernels' per-period arrays
     int* chunk_fail;      // [B]       1: a chunk boundary did not agree to chunk_tol -- the replicate belongs to the sequential kernel
     const int* only_if;   // [B] or null: the sequential kernels (recursion_wave / recursion_pair) run replicate b only if only_if[b] != 0
     int chunk_L, chunk_W;
@@ -138,6 +142,7 @@ struct RecursionArgs {
 bool recursion_chunk_supported(int Rpad, const RecursionArgs& a);
 size_t recursion_chunk_scratch_bytes(int B, int T);          // chunk_scr
 size_t recursion_chunk_obs_bytes(int B, int T);              // chunk_obs
+size_t recursion_chunk_rows_bytes(int B, int T);             // chunk_rows
 int recursion_chunk_len(int T);                              // chunk_L for a sample of T periods
 hipError_t launch_recursion_chunk(const RecursionArgs& a, hipStream_t s);
 hipError_t launch_chunk_unbridge(const RecursionArgs& a, hipStream_t s);

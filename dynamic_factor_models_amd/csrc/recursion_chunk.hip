@@ -29,6 +29,7 @@
 #include "dfm_smallmat.h"
 #include "dfm_grid.h"
 #include "dfm_chunk_core.h"
+#include "dfm_ctbuild.h"
 
 // development ablations (scripts/dbg/r05/abl_chunk.sh builds one library per value; results are WRONG for any value but 0):
 // 1 no output stores, 2 no row fetches (one scalar for every constant), 4 no LDS-DMA, 8 no table stores, 16 print shader-clock vs wall ticks
@@ -46,7 +47,6 @@ constexpr int kOffK = 0, kOffKT = 64, kOffQPhi = 128, kOffPhi = 192, kOffM0 = 25
 constexpr int kTermStride = 96;     // P_T (36) f_T (8) P_0 (36) f_0 (8)
 constexpr int kScrRows = 22;        // double2 rows per period: 18 of -Z, 4 of w
 constexpr int kAccSlots = 16;       // LDS accumulator slots per statistic (four lanes per slot)
-constexpr int kObsRows = 23;        // double2 rows per period of the observation table: 18 of C_t, 4 of b_t, (s_t, n_t log 2 pi + log det R_t)
 
 using cdp = const double __attribute__((address_space(4)))*;
 
@@ -181,40 +181,15 @@ __device__ __forceinline__ void wave_mem_fence() { __builtin_amdgcn_fence(__ATOM
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// the observation stage: the DMA below copies 64 table rows of 368 bytes back to back -- lane j's period is row j: doubles 0..35 C_t,
+// the observation stage: 23 rows of 64 double2 (lane = chunk), as the table has them: doubles 0..35 of a lane's period C_t (packed),
 // 36..43 b_t, 44 s_t, 45 n_t log 2 pi + log det R_t
 struct StageObs {
-    const double* st;   // stage + 46 * lane
+    const double* st;   // stage + 2 * lane
     __device__ __forceinline__ void ready() const { wait_dma(); }
-    __device__ __forceinline__ double c(int p) const { return st[p]; }
-    __device__ __forceinline__ double b(int i) const { return st[chunk::NP + i]; }
+    __device__ __forceinline__ double at(int e) const { return st[(e >> 1) * 128 + (e & 1)]; }
+    __device__ __forceinline__ double c(int p) const { return at(p); }
+    __device__ __forceinline__ double b(int i) const { return at(chunk::NP + i); }
 };
-// 64 rows of the observation table (one 368-byte row per period, [b][t][46]) -> stage, by 23 LDS-DMAs of 16 bytes per lane: piece
-// e = 64 i + lane of DMA i belongs to row e / 23, 16-byte piece e % 23.  Row j of the
-// stage is the period of lane clamp(j + sh, 0, smax) at this step's slot (base: the replicate's row `slot`; LB = L * 368 bytes from
-// one lane's period to the next lane's).  2.8 rows per DMA: ~10 cache lines per instruction where a per-lane gather would touch 64.
-__device__ __forceinline__ void dma_obs(const double* base, int lane, int sh, int smax, unsigned LB, unsigned lds_dst) {
-#if DFM_CK_ABL & 4
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < kObsRows; ++i) {
-        const unsigned e = 64u * i + (unsigned)lane, row = e / kObsRows, piece = e - row * kObsRows;   // (constant divisor: a multiply-high)
-        int src = (int)row + sh;
-        src = src < 0 ? 0 : (src > smax ? smax : src);
-        const unsigned voff = (unsigned)src * LB + 16u * piece;
-        unsigned keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(base), "s"(lds_dst + 1024u * i)
-            : "memory");
-    }
-}
 struct StageZw {
     const double* st;
     __device__ __forceinline__ void ready() const { wait_dma(); }
@@ -265,19 +240,23 @@ __global__ __launch_bounds__(64) void chunk_prep_kernel(RecursionArgs a) {
     }
 }
 
-// ---- the collapse kernels' per-period arrays (bcol, scol, nobs, ldrow; C_t only where a cell is missing, else the replicate's Cfull) as
-// rows of the observation table the pass reads: obs[b][t][46] = C_t (8 x 8 packed, zero beyond the RC x RC block), b_t, s_t,
-// n_t log 2 pi + sum of log R over the observed cells.  (collapse_miss_kernel writes the rows itself: CollapseArgs::obs_chunk; this is
-// the bridge for the other collapse kernels.)
+// ---- the observation table: obs[b][slot][23][lane] double2, period t = L lane + slot -- doubles 0..35 C_t (8 x 8 packed, zero beyond
+// the RC x RC block), 36..43 b_t, 44 s_t, 45 n_t log 2 pi + sum of log R over the observed cells.  Chunk-major like the smoother table:
+// the pass's LDS-DMA of a step is 23 contiguous KBs, and the kernels below store whole KBs.  EVERY slot of all 64 lanes is written:
+// beyond the sample a benign row (the replicate's full Gram matrix, zeros) -- lanes step through such periods uncounted.
+//
+// From the collapse kernels' per-period arrays (bcol, scol, nobs, ldrow; C_t only where a cell is missing, else the replicate's
+// Cfull): collapse_kernel's shapes (N > 224, collapsed observations 2 / 4 wide).  One wave per (replicate, slot), lane = chunk.
 template <int RC>
 __global__ __launch_bounds__(64) void chunk_bridge_kernel(RecursionArgs a) {
     using namespace chunk;
     constexpr int NPC = RC * (RC + 1) / 2;
-    const int T = a.T;
-    const size_t bt = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (bt >= (size_t)a.B * T) return;
-    const int b = (int)(bt / T);
-    const int n = a.nobs[bt];
+    const int T = a.T, L = a.chunk_L;
+    const int b = blockIdx.x / L, slot = blockIdx.x - b * L, lane = threadIdx.x;
+    const int t = L * lane + slot;
+    const bool in = t < T;
+    const size_t bt = (size_t)b * T + (in ? t : 0);
+    const int n = in ? a.nobs[bt] : a.N;
     const bool full = n == a.N || a.Ct == nullptr;
     double v[2 * kObsRows];
 #pragma unroll
@@ -287,31 +266,34 @@ __global__ __launch_bounds__(64) void chunk_bridge_kernel(RecursionArgs a) {
 #pragma unroll
         for (int j = 0; j <= i; ++j)
             v[pidx(i, j)] = full ? a.Cfull[(size_t)b * RC * RC + i * RC + j] : a.Ct[bt * NPC + pidx(i, j)];
+    if (in) {
 #pragma unroll
-    for (int i = 0; i < RC; ++i) v[NP + i] = a.bcol[bt * RC + i];
-    v[NP + R] = a.scol[bt];
-    v[NP + R + 1] = (double)n * kLog2PiC + (n == a.N ? a.ldfull[b] : a.ldrow[bt]);
-    double2* dst = reinterpret_cast<double2*>(a.chunk_obs + bt * (2 * kObsRows));
+        for (int i = 0; i < RC; ++i) v[NP + i] = a.bcol[bt * RC + i];
+        v[NP + R] = a.scol[bt];
+        v[NP + R + 1] = (double)n * kLog2PiC + (n == a.N ? a.ldfull[b] : a.ldrow[bt]);
+    }
+    double2* dst = reinterpret_cast<double2*>(a.chunk_obs) + ((size_t)b * L + slot) * kObsRows * 64 + lane;
 #pragma unroll
-    for (int k = 0; k < kObsRows; ++k) dst[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    for (int k = 0; k < kObsRows; ++k) dst[k * 64] = make_double2(v[2 * k], v[2 * k + 1]);
 }
 
-// ---- ... and back, for the replicates the pass hands to the sequential kernel when the collapse wrote the table only
+// ---- ... and back, for the replicates the pass hands to the sequential kernel when the collapse wrote rows and masks only
 // (collapse_miss_kernel's table mode): bcol, scol, C_t of every period; nobs = 0 and ldrow = n_t log 2 pi + sum log R make the sequential kernels'
 // "n log 2 pi + sum of log R" come out right without n_t (they read C_t / ldrow of every period whose nobs differs from N).
 // Without a C_t array (the caller promised a balanced panel) the periods are all alike: nobs = N, Cfull and ldfull from period 0.
 __global__ __launch_bounds__(64) void chunk_unbridge_kernel(RecursionArgs a, double* bcol, double* scol, int* nobs, double* ldrow, double* Ct,
                                                           double* Cfull, double* ldfull) {
     using namespace chunk;
-    const int T = a.T;
-    const size_t bt = (size_t)blockIdx.x * 64 + threadIdx.x;
-    if (bt >= (size_t)a.B * T) return;
-    const int b = (int)(bt / T), t = (int)(bt - (size_t)b * T);
+    const int T = a.T, L = a.chunk_L;
+    const int b = blockIdx.x / L, slot = blockIdx.x - b * L, lane = threadIdx.x;
     if (a.chunk_fail[b] == 0) return;
-    const double2* src = reinterpret_cast<const double2*>(a.chunk_obs + bt * (2 * kObsRows));
+    const int t = L * lane + slot;
+    if (t >= T) return;
+    const size_t bt = (size_t)b * T + t;
+    const double2* src = reinterpret_cast<const double2*>(a.chunk_obs) + ((size_t)b * L + slot) * kObsRows * 64 + lane;
     double v[2 * kObsRows];
 #pragma unroll
-    for (int k = 0; k < kObsRows; ++k) { const double2 u = src[k]; v[2 * k] = u.x; v[2 * k + 1] = u.y; }
+    for (int k = 0; k < kObsRows; ++k) { const double2 u = src[k * 64]; v[2 * k] = u.x; v[2 * k + 1] = u.y; }
 #pragma unroll
     for (int i = 0; i < R; ++i) bcol[bt * R + i] = v[NP + i];
     scol[bt] = v[NP + R];
@@ -346,7 +328,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const cdp cst = as_const(a.chunk_cst + (size_t)b * kCstStride);
     const RowSrc krow{cst + kOffK}, ktrow{cst + kOffKT}, qrow{cst + kOffQPhi};
     const double tol = a.chunk_tol;
-    const double* obs = a.chunk_obs + (size_t)b * T * (2 * kObsRows);
+    const double2* obs = reinterpret_cast<const double2*>(a.chunk_obs) + (size_t)b * L * kObsRows * 64;   // [slot][23][lane]
     double2* scr = reinterpret_cast<double2*>(a.chunk_scr) + (size_t)b * (L + 2) * kScrRows * 64;
     double2* sav_f = scr + (size_t)L * kScrRows * 64;            // the states after the warm-ups (forward, backward): slots L, L + 1
     double2* sav_b = sav_f + kScrRows * 64;
@@ -358,8 +340,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // LDS: the stage (64 x 368 bytes), then (EM) the accumulators [64 + 36][kAccSlots]
     // and two 8 x 8 tiles of the epilogue
     double* stage = csm;
-    const double* stl = stage + 2 * lane;                          // (the backward table's stage: rows of 64 double2)
-    const double* sto = stage + 2 * kObsRows * lane;               // (the observation stage: lane's own 46 doubles)
+    const double* stl = stage + 2 * lane;                          // (both tables' stage: rows of 64 double2, lane = chunk)
+    const double* sto = stl;
     const unsigned stage_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_cptr)(reinterpret_cast<char*>(stage)));
     double* acc10 = csm + 2 * 64 * kObsRows;
     double* acc11 = acc10 + 64 * kAccSlots;
@@ -367,14 +349,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int e = lane; e < 100 * kAccSlots; e += 64) acc10[e] = 0.0;
         wave_lds_sync();
     }
-    const unsigned LB = (unsigned)L * (2 * kObsRows * 8);
 
-    // the observation rows of the periods c0 + d of all lanes (d may be negative: the lanes below) -> stage
+    // the observation rows of the periods c0 + d of all lanes (d may be negative: slot d mod L of the lanes below; ct_build / the bridge
+    // fill the table for every slot of all 64 lanes -- benign rows beyond the sample) -> stage
     auto issue_obs = [&](int d) {
         const int sh = floor_div(d, L), slot = d - sh * L;
-        int smax = (T - 1 - slot) / L;
-        smax = smax > 63 ? 63 : smax;
-        dma_obs(obs + (size_t)slot * (2 * kObsRows), lane, sh, smax, LB, stage_lds);
+        int src = lane + sh;
+        src = src < 0 ? 0 : (src > 63 ? 63 : src);
+        dma_rows<kObsRows>(obs + (size_t)slot * kObsRows * 64, (unsigned)src * 16u, stage_lds);
     };
     auto store_row = [&](int trow, const double (&P)[NP], const double (&f)[R]) {
 #if DFM_CK_ABL & 1
@@ -451,7 +433,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }
         });
         {
-            const double st_s = sto[NP + R], st_l = sto[NP + R + 1];
+            const double st_s = StageObs{sto}.at(NP + R), st_l = StageObs{sto}.at(NP + R + 1);
             lp.mul(counted ? det : 1.0);
             sxw += counted ? xw : 0.0;
             ssum += counted ? st_s : 0.0;
@@ -671,14 +653,16 @@ size_t recursion_chunk_scratch_bytes(int B, int T) {
     return (size_t)B * (recursion_chunk_len(T) + 2) * kScrRows * 64 * sizeof(double2);     // (+ 2 slots: the states after the warm-ups)
 }
 size_t recursion_chunk_obs_bytes(int B, int T) {
-    return (size_t)B * T * kObsRows * sizeof(double2) + 4096;      // (+ slack: the last DMA of the last replicate reads whole 16-byte pieces)
+    return (size_t)B * recursion_chunk_len(T) * kObsRows * 64 * sizeof(double2);   // [B][L][23][64] double2: every slot of all 64 lanes
 }
+size_t recursion_chunk_rows_bytes(int B, int T) { return (size_t)B * T * 14 * sizeof(double); }   // collapse_miss_kernel's 112-byte rows
 
 // Plain factor model at Rp = 8 in information form (no companion state: the EM epilogue here has no shift rows), collapsed
 // observations 2, 4 or 8 wide; a sample long enough for two lanes.  The sequential kernel must be able to take a replicate back.
 bool recursion_chunk_supported(int Rpad, const RecursionArgs& a) {
     if (Rpad != 8 || a.cov || a.kdim != 0 || a.kb != 0 || a.ka != 0 || a.ct_r != 0) return false;
     if (!a.chunk_scr || !a.chunk_cst || !a.chunk_term || !a.chunk_fail || !a.chunk_obs) return false;
+    if ((size_t)a.B * recursion_chunk_len(a.T) > 0x7fffffffu) return false;   // (grid of the bridge kernels)
     if (a.rl != 0 && a.Rc == 0) return false;
     const int Rc = a.Rc > 0 ? a.Rc : 8;
     if (Rc != 2 && Rc != 4 && Rc != 8) return false;
@@ -710,9 +694,9 @@ hipError_t launch_recursion_chunk(const RecursionArgs& a0, hipStream_t s) {
     hipLaunchKernelGGL(chunk_prep_kernel, dim3(a.B), dim3(64), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (!a.chunk_obs_ready) {
+    if (!a.chunk_obs_ready) {                                       // (else collapse_miss_kernel wrote the table itself: dfm_ctbuild.h)
         const int Rc = a.Rc > 0 ? a.Rc : 8;
-        const dim3 grid((unsigned)(((size_t)a.B * a.T + 63) / 64));
+        const dim3 grid((unsigned)a.B * (unsigned)a.chunk_L);
         if (Rc == 8) hipLaunchKernelGGL(chunk_bridge_kernel<8>, grid, dim3(64), 0, s, a);
         else if (Rc == 4) hipLaunchKernelGGL(chunk_bridge_kernel<4>, grid, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(chunk_bridge_kernel<2>, grid, dim3(64), 0, s, a);
@@ -726,7 +710,7 @@ hipError_t launch_recursion_chunk(const RecursionArgs& a0, hipStream_t s) {
 hipError_t launch_chunk_unbridge(const RecursionArgs& a0, hipStream_t s) {
     RecursionArgs a = a0;
     a.chunk_L = recursion_chunk_len(a.T);
-    hipLaunchKernelGGL(chunk_unbridge_kernel, dim3((unsigned)(((size_t)a.B * a.T + 63) / 64)), dim3(64), 0, s, a, const_cast<double*>(a.bcol),
+    hipLaunchKernelGGL(chunk_unbridge_kernel, dim3((unsigned)a.B * (unsigned)a.chunk_L), dim3(64), 0, s, a, const_cast<double*>(a.bcol),
                        const_cast<double*>(a.scol), const_cast<int*>(a.nobs), const_cast<double*>(a.ldrow), const_cast<double*>(a.Ct),
                        const_cast<double*>(a.Cfull), const_cast<double*>(a.ldfull));
     return hipGetLastError();
