@@ -280,7 +280,7 @@ def kernel_bytes_table(B, N, T, r):
             "mstep_mfma_kernel": B * 8 * (N * T + T * r), "mstep_wide_kernel": B * 8 * (N * T + T * r),
             "mstep_lam_kernel": B * 8 * (N * T + T * (r + npack)),
             "gram_kernel": B * 8 * (N * r + N), "wide_prep_kernel": B * 8 * (N * r + N), "cov_kernel": B * 8 * (3 * r * r + r),
-            "cov_grid_kernel": B * 8 * (3 * r * r + r), "cov_tile_kernel": B * 8 * (3 * r * r + r), "collapse_ks_kernel": B * panel_b,
+            "cov_grid_kernel": B * 8 * (3 * r * r + r), "cov_tile_kernel": B * 8 * (3 * r * r + r),
             "ct_miss_wide_kernel": B * 8 * T * npack, "ct_miss_wide2_kernel": B * 8 * T * npack,
             "ct_miss_slice_kernel": B * 8 * (N * T + T * npack)}      # (the panel once over its launches + the C_t rows)
 

@@ -463,7 +463,7 @@ int enqueue_pass_fast(dfm_handle* h, const Plan& p, int B, int T, int N, int out
     const bool use_wide2 = use_wide && !h->wide_old && p.Wwide != (size_t)-1 && collapse_wide2_supported(p.Rp, N);
     if (use_wide) {   // sum_t s_t arrives as partials per tile of the collapse kernel that will run
         fa.scol = ca.scol;
-        fa.ntile = !use_wide2 ? collapse_wide_tiles(T) : collapse_ks_supported(p.Rp, p.r, N, false) ? collapse_ks_tiles(T) : collapse_wide2_tiles(T);
+        fa.ntile = !use_wide2 ? collapse_wide_tiles(T) : collapse_wide2_tiles(T);
     }
     // Rp = 32 on the streaming collapse: b_t rows 8 ceil(r / 8) doubles apart instead of 32 -- the padding components are exact zeros
     // that the mean scan (its only reader here) substitutes; at BASELINE config 4 (r = 20) a quarter of the 0.39 GB of b_t traffic
@@ -1271,27 +1271,27 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
         return (int)e;
     }
     if (const char* v = route_env("DFM_FORCE_GENERAL")) h->force_general = atoi(v) != 0;
-    if (const char* v = route_env("DFM_COLLAPSE_VARIANT")) h->collapse_variant = atoi(v);
-    if (const char* v = route_env("DFM_COLLAPSE_WPR")) { h->collapse_wpr = atoi(v); if (h->collapse_wpr < 0 || h->collapse_wpr > kSsumSlots) h->collapse_wpr = 0; }
+    if (const char* v = diag_env("DFM_COLLAPSE_VARIANT")) h->collapse_variant = atoi(v);
+    if (const char* v = diag_env("DFM_COLLAPSE_WPR")) { h->collapse_wpr = atoi(v); if (h->collapse_wpr < 0 || h->collapse_wpr > kSsumSlots) h->collapse_wpr = 0; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
     if (const char* v = route_env("DFM_NUM_CU")) { if (atoi(v) > 0) h->num_cu = atoi(v); }   // diagnostics: persistent grids sized for fewer CUs
     if (const char* v = diag_env("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
-    if (const char* v = route_env("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
-    if (const char* v = route_env("DFM_PAIR_BMAX")) h->pair_bmax = atoi(v) > 0 ? atoi(v) : 0;
+    if (const char* v = diag_env("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_PAIR_BMAX")) h->pair_bmax = atoi(v) > 0 ? atoi(v) : 0;
     if (const char* v = route_env("DFM_NO_PAIR")) { if (atoi(v) != 0) h->pair_bmax = 0; }
     g_widen_small_r = !h->no_rec_wave;      // process-wide: follows the most recently created handle
     if (const char* v = diag_env("DFM_NO_PFILL")) h->no_pfill = atoi(v) != 0;
     if (const char* v = diag_env("DFM_FUSED_GRAM")) h->fused_gram = atoi(v) != 0;
-    if (const char* v = route_env("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_NO_FUSE_COV")) h->no_fuse_cov = atoi(v) != 0;
     if (const char* v = diag_env("DFM_NO_MSTEP_MFMA")) h->no_mstep_mfma = atoi(v) != 0;
-    if (const char* v = route_env("DFM_NO_DEFER_EM")) h->no_defer_em = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_NO_DEFER_EM")) h->no_defer_em = atoi(v) != 0;
     if (const char* v = diag_env("DFM_EM_GENERAL")) h->em_general = atoi(v) != 0;
     if (const char* v = diag_env("DFM_FUSE_GRAM")) h->fuse_gram = atoi(v) != 0;
     if (const char* v = diag_env("DFM_SUBBATCH")) h->subbatch = atoi(v);
     if (const char* v = diag_env("DFM_SCAN_ABL")) h->scan_abl = atoi(v);
     if (const char* v = route_env("DFM_MSTEP_MISS")) g_mstep_miss_mode = atoi(v);
     if (const char* v = route_env("DFM_PASS_FUSED")) h->pass_fused = atoi(v);
-    if (const char* v = route_env("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
+    if (const char* v = diag_env("DFM_PASS_NSW")) h->pass_nsw = atoi(v);
     if (const char* v = diag_env("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
     if (const char* v = diag_env("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
     if (const char* v = diag_env("DFM_COLLAPSE_MISS_OLD")) h->collapse_miss_old = atoi(v) != 0;
@@ -1301,7 +1301,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = route_env("DFM_TILE_NC")) h->tile_nc = atoi(v) > 0 ? atoi(v) : 0;
     if (const char* v = route_env("DFM_TILE_W")) h->tile_w = atoi(v) > 0 ? atoi(v) : 0;
     if (const char* v = diag_env("DFM_WIDE_OLD")) h->wide_old = atoi(v) != 0;
-    if (const char* v = route_env("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_COV_WAVE")) h->cov_wave = atoi(v) != 0;
     *out = h;
     return 0;
 }

@@ -519,17 +519,25 @@ static hipError_t launch_mfma_one(const CollapseArgs& a, hipStream_t s) {
         }
     }
     if (a.fuse_cov) return hipErrorInvalidValue;
-    static LdsOptIn attr_done;
-    if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_done = true;
+#ifndef DFM_DIAG
+    // production: widths whose covariance workgroups ride in this launch (R = 4 | 8) always arrive with them (capi.hip: the two-launch
+    // pass); the stand-alone instantiation is reached only through switches of the diagnostics build and is not compiled here
+    if constexpr (ABL == 0 && mfma_can_fuse(R)) return hipErrorInvalidValue;
+    else
+#endif
+    {
+        static LdsOptIn attr_done;
+        if (!attr_done && lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        FastArgs none;
+        memset(&none, 0, sizeof(none));
+        hipLaunchKernelGGL((collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>), dim3(nstream), dim3(256), lds, s, a, SB, none, 0);
+        return hipGetLastError();
     }
-    FastArgs none;
-    memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL((collapse_mfma_kernel<R, STEPS, NB, NDR, ABL>), dim3(nstream), dim3(256), lds, s, a, SB, none, 0);
-    return hipGetLastError();
 }
 
 template <int R, int STEPS, int NB, int NDR>

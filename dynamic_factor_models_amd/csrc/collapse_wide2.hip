@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kPrepThreads) void wide_prep_kernel(CollapseArgs a,
     __syncthreads();                                          // (1 / R of this replicate is visible to its workgroup)
     // W stored with the two 16-column halves of ODD series swapped (column f of series c at f ^ 16 (c & 1)): the B operand of
     // a step reads 4 consecutive series x 16 columns, and two series 256 bytes apart would meet on the same banks
-    if (Wout != nullptr) {                                    // (collapse_ks_kernel takes lam and 1 / R themselves)
+    if (Wout != nullptr) {                                    // (null: the balanced Rp = 32 collapse takes lam and 1 / R themselves)
         for (int e = tid; e < N * R; e += kPrepThreads) {
             const int c = e / R;
             const int f = e % R;
@@ -1044,9 +1044,9 @@ size_t collapse_wide2_ws_bytes(int B, int N, int Rpad) {
 }
 
 // Rp = 32, balanced: the collapse takes the loadings and 1 / R themselves (collapse_wide2_kernel `lamd`), wide_prep writes no W.
-// DFM_WIDE_W=1 (route): the W table as before.
+// DFM_WIDE_W=1 (diagnostics build): the W table as before.
 static bool wide2_lam_direct(int Rpad, bool missing) {
-    static const bool off = [] { const char* v = route_env("DFM_WIDE_W"); return v && atoi(v) != 0; }();
+    static const bool off = [] { const char* v = diag_env("DFM_WIDE_W"); return v && atoi(v) != 0; }();
     return !off && Rpad == 32 && !missing;
 }
 
@@ -1084,7 +1084,8 @@ hipError_t launch_w2(const CollapseArgs& a, const W2Ws& w, int G, size_t lds, in
 hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStream_t s, int r, double* V) {
     note_kernel("wide_prep_kernel");
     const W2Ws w = w2_ws(a, ws, Rpad);
-    const bool ks = (r > 0 && collapse_ks_supported(Rpad, r, a.N, a.nobs != nullptr)) || wide2_lam_direct(Rpad, a.nobs != nullptr);   // no W table for these
+    (void)r;
+    const bool ks = wide2_lam_direct(Rpad, a.nobs != nullptr);   // no W table for these
     if (Rpad <= 16) hipLaunchKernelGGL(wide_prep_kernel<16>, dim3(a.B), dim3(kPrepThreads), 0, s, a, w.W, w.rinv, w.logr, w.npad, w.ctr, Rpad, (double*)nullptr);
     else hipLaunchKernelGGL(wide_prep_kernel<32>, dim3(a.B), dim3(kPrepThreads), 0, s, a, ks ? nullptr : w.W, w.rinv, w.logr, w.npad, w.ctr, 32, V);
     return hipGetLastError();
@@ -1093,7 +1094,7 @@ hipError_t launch_wide_prep(const CollapseArgs& a, double* ws, int Rpad, hipStre
 // r = the caller's factor count (columns r .. Rpad - 1 of Lam are zero padding)
 hipError_t launch_collapse_wide2(const CollapseArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
     const W2Ws w = w2_ws(a, ws, Rpad);
-    if (collapse_ks_supported(Rpad, r, a.N, a.nobs != nullptr)) return launch_collapse_ks(a, w.rinv, w.npad, num_cu, s);
+    (void)r;
     note_kernel("collapse_wide2_kernel");
     const int ntile = collapse_wide2_tiles(a.T);
     const size_t lds = (size_t)kW2NBuf * kW2StageB + 32 * sizeof(double) + 64 * 4 * sizeof(unsigned long long);   // stages | redS, itemq | DIAG stamps

@@ -17,7 +17,10 @@ extern thread_local const char* t_launched_kernel;
 // Environment switches of the library, in two classes.
 //   route_env: selects among PRODUCTION kernels that compute the same result to rounding (the one-launch pass or the two-launch
 //              pass, one wave or a lane group per replicate, ...): what the test-suite uses to cover every fallback, and tuning
-//              knobs that cannot change a result (DFM_NUM_CU).  Listed in DESIGN.md section 11.
+//              knobs (DFM_NUM_CU).  Ten names since round 6: DFM_FORCE_GENERAL, DFM_PASS_FUSED, DFM_NO_CHUNK, DFM_NO_PAIR,
+//              DFM_MSTEP_MISS, DFM_TILE_NC, DFM_NUM_CU -- which kernel runs, never what it computes -- and DFM_CHUNK_W, DFM_TILE_W,
+//              DFM_CHUNK_TOL, which set the warm-up and the boundary tolerance of the time-chunked recursions (a replicate that misses the
+//              tolerance is redone sequentially: accuracy knobs).
 //   diag_env:  ablations (some produce WRONG results on purpose: stream-only, compute-only, skipped stages), phase stamps, the
 //              *_OLD kernels kept for A/B.  Read only by a library built with -DDFM_DIAG (`python -m
 //              dynamic_factor_models_amd.build --diag`); the default libdfmhip.so ignores them.
@@ -30,9 +33,9 @@ inline const char* diag_env(const char*) { return nullptr; }
 
 // Non-temporal hint on a kernel's ONE-PASS panel stream (pass_fused.hip dma16f, mstep_mfma.hip): on for batches whose panels are
 // <= 2 GiB, where part of the pass's working set survives in the 256-MB Infinity Cache between launches (measured gains up to
-// B = 4096 at the C2 shape, a loss at 8192).  DFM_DMA_NT=0 | 1 (route switch: same results either way) overrides.
+// B = 4096 at the C2 shape, a loss at 8192).  DFM_DMA_NT=0 | 1 (diagnostics build) overrides.
 inline bool stream_nt_hint(size_t panel_bytes) {
-    static const int force = [] { const char* v = route_env("DFM_DMA_NT"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
+    static const int force = [] { const char* v = diag_env("DFM_DMA_NT"); return v ? (atoi(v) != 0 ? 1 : 0) : -1; }();
     if (force >= 0) return force != 0;
     return panel_bytes <= ((size_t)2 << 30);
 }
@@ -209,11 +212,6 @@ hipError_t launch_gram_wide(int Rpad, const CollapseArgs& a, hipStream_t s);
 // ldfull (the Gram kernel's outputs); launch_collapse_wide2 then streams the panel (partials of sum_t s_t: scol[b][tile])
 bool collapse_wide2_supported(int Rpad, int N);
 int collapse_wide2_tiles(int T);
-// Rp = 32, 17 <= r <= 20, 256 < N <= 1024 even, balanced: series split over the waves, weights in registers (collapse_ks.hip);
-// launch_collapse_wide2 / launch_wide_prep route to it themselves, callers only need the number of s_t partials per replicate
-bool collapse_ks_supported(int Rpad, int r, int N, bool missing);
-int collapse_ks_tiles(int T);
-hipError_t launch_collapse_ks(const CollapseArgs& a, const double* rinv, int npad, int num_cu, hipStream_t s);
 size_t collapse_wide2_ws_bytes(int B, int N, int Rpad);    // W [B][N][Rp] | 1 / R, log R [B][N padded to 32] | tile queue counters
 // r > 0: the caller's factor count (skips the W table when launch_collapse_wide2 will not read it); V: [B][N][32] lam / sqrt(R) for
 // launch_ct_miss_wide, or null

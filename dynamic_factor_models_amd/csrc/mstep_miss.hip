@@ -421,7 +421,7 @@ hipError_t launch_mm_slots(const MstepArgs& a, const double* V, double* OUT, dou
 
 hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
     note_kernel("mstep_miss_kernel");
-    static const int kp_want = [] { const char* v = route_env("DFM_MM_KP"); return v ? atoi(v) : 0; }();   // diagnostics: 8 | 16 | 32
+    static const int kp_want = [] { const char* v = diag_env("DFM_MM_KP"); return v ? atoi(v) : 0; }();   // diagnostics: 8 | 16 | 32
     static const int nbuf_want = [] { const char* v = diag_env("DFM_MM_NBUF"); return v ? atoi(v) : 0; }();  // diagnostics: 4 (with DFM_MM_KP=8)
     const MmGeo g = mm_geo(Rpad, r, kp_want, nbuf_want);
     const int tt16 = g.tt * 16, ntm16 = g.ntm * 16;

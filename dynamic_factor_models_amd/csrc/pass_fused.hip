@@ -1287,6 +1287,7 @@ hipError_t launch_pass_fused(const CollapseArgs& a, const FastArgs& fa, int nsw,
 // cov_wave_kernel: dfm_cov8.h's one-wave-per-replicate covariance recursion as a drop-in for cov_kernel (same global
 // outputs) -- DFM_COV_WAVE=1 on the separate-launch path; diagnostics and A/B of the recursion itself.
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef DFM_DIAG
 __global__ __launch_bounds__(256) void cov_wave_kernel(FastArgs a) {
     __shared__ __attribute__((aligned(16))) double wsm[4 * kCov8ScratchDoubles];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1305,6 +1306,7 @@ __global__ __launch_bounds__(256) void cov_wave_kernel(FastArgs a) {
     o.P0s = a.SP11 ? a.P0s + (size_t)b * 64 : nullptr;
     cov_wave8<scan_levels(8)>(a, b, Cel, a.ldfull[b], ws, o, lane);
 }
+#endif  // DFM_DIAG
 
 // ------------------------------------------------------------------------------------------------------------------
 // cov_grid_kernel: the same element-per-thread covariance recursion for states 9..16 / 17..32 wide -- a workgroup of
@@ -1360,9 +1362,14 @@ hipError_t launch_cov_grid(int Rpad, const FastArgs& a, hipStream_t s) {
 }
 
 hipError_t launch_cov_wave(const FastArgs& a, hipStream_t s) {
+#ifdef DFM_DIAG
     note_kernel("cov_wave_kernel");
     hipLaunchKernelGGL(cov_wave_kernel, dim3((a.B + 3) / 4), dim3(256), 0, s, a);
     return hipGetLastError();
+#else
+    (void)a; (void)s;
+    return hipErrorInvalidValue;                                  // (DFM_COV_WAVE is a switch of the diagnostics build)
+#endif
 }
 
 }  // namespace dfm

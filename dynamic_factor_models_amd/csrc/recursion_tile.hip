@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256, 1) void cov_tile_kernel(FastArgs a, int rstate
 }
 
 bool cov_tile_supported(int Rpad, const FastArgs& a, int rstate) {
-    static const bool off = [] { const char* v = route_env("DFM_NO_COV_TILE"); return v && atoi(v) != 0; }();
+    static const bool off = [] { const char* v = diag_env("DFM_NO_COV_TILE"); return v && atoi(v) != 0; }();
     return !off && Rpad == 32 && a.Lam == nullptr && rstate >= 1 && rstate <= 32 && a.T >= 1;
 }
 hipError_t launch_cov_tile(const FastArgs& a, int rstate, hipStream_t s) {
@@ -1033,7 +1033,7 @@ hipError_t launch_cov_tile(const FastArgs& a, int rstate, hipStream_t s) {
 // Rp = 32, information form, the plain factor model (loadings as wide as the state), 17 <= state width <= 31 (column 31 must
 // be padding).  DFM_NO_TILE=1: recursion_wave_kernel<32> instead (A/B, diagnostics).
 bool recursion_tile_supported(int Rpad, const RecursionArgs& a) {
-    static const bool off = [] { const char* v = route_env("DFM_NO_TILE"); return v && atoi(v) != 0; }();
+    static const bool off = [] { const char* v = diag_env("DFM_NO_TILE"); return v && atoi(v) != 0; }();
     if (off || Rpad != 32 || a.cov || a.Rc != 0 || a.rl != 0 || a.kdim != 0) return false;
     if (a.rstate < 17 || a.rstate > 31 || a.T < 1) return false;
     if (a.S11 && !a.A_out) return false;                       // (sums without the M-step: not a path the library takes)

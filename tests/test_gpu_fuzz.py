@@ -4,6 +4,8 @@ ragged T -- against the CPU oracle."""
 import numpy as np
 import pytest
 
+from conftest import diag_only
+
 from oracle import c_oracle as co
 from oracle import kalman_oracle as ko
 
@@ -128,6 +130,7 @@ def test_singular_Q_is_reported(ctx):
     assert e.value.code == -5
 
 
+@diag_only()
 @pytest.mark.parametrize("r", [3, 8])
 def test_lane_group_recursion_kernel_still_matches(r, monkeypatch):
     """DFM_NO_RECURSION_WAVE=1: the r-lanes-per-replicate recursion_kernel (what large batches and r > 8 use) on the

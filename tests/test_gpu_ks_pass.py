@@ -3,6 +3,8 @@ CPU oracle on the same seeded inputs.  fp64: tolerance 1e-9 relative (north_star
 import numpy as np
 import pytest
 
+from conftest import diag_only
+
 from oracle import c_oracle as co
 from oracle import kalman_oracle as ko
 
@@ -222,8 +224,11 @@ def test_balanced_fast_path_matches_oracle(ctx, B, N, T, r):
     _compare(_run_dev(ctx, panel, st, may_have_missing=False), ref, f"fast B={B} N={N} T={T} r={r}")
 
 
-@pytest.mark.parametrize("env", [dict(DFM_COLLAPSE_VARIANT=199), dict(DFM_COLLAPSE_VARIANT=198), dict(DFM_NO_FUSE_COV=1), dict(DFM_COLLAPSE_WPR=1), dict(DFM_COLLAPSE_WPR=3), dict(DFM_COLLAPSE_WPR=7),
-                                 dict(DFM_FORCE_GENERAL=1)])
+_D = lambda **env: pytest.param(env, marks=diag_only())           # (switches only the diagnostics build reads)
+
+
+@pytest.mark.parametrize("env", [_D(DFM_COLLAPSE_VARIANT=199), _D(DFM_COLLAPSE_VARIANT=198), _D(DFM_NO_FUSE_COV=1), _D(DFM_COLLAPSE_WPR=1),
+                                 _D(DFM_COLLAPSE_WPR=3), _D(DFM_COLLAPSE_WPR=7), dict(DFM_PASS_FUSED=0), dict(DFM_FORCE_GENERAL=1)])
 def test_balanced_kernel_choices_agree(env):
     """The VALU collapse, the wide collapse, the MFMA collapse with its covariance workgroups as separate launches,
     with 1/3/7 period segments per replicate, and the general
@@ -237,7 +242,7 @@ def test_balanced_kernel_choices_agree(env):
         c.close()
 
 
-@pytest.mark.parametrize("env", [dict(), dict(DFM_NO_CHUNK=1), dict(DFM_NO_CHUNK=1, DFM_NO_PAIR=1), dict(DFM_NO_CHUNK=1, DFM_PAIR_BMAX=3),
+@pytest.mark.parametrize("env", [dict(), dict(DFM_NO_CHUNK=1), dict(DFM_NO_CHUNK=1, DFM_NO_PAIR=1), _D(DFM_NO_CHUNK=1, DFM_PAIR_BMAX=3),
                                  dict(DFM_CHUNK_W=12), dict(DFM_CHUNK_W=2), dict(DFM_CHUNK_TOL=1e-30)])
 def test_sequential_kernel_choices_agree(env):
     """Panels with missing cells at Rp = 8: the time-chunked recursion (recursion_chunk.hip, the default since round 5; W = 12: a

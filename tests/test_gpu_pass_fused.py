@@ -4,6 +4,8 @@ against the CPU oracle, whatever the library's default path is: the contexts bel
 import numpy as np
 import pytest
 
+from conftest import diag_only
+
 from oracle import kalman_oracle as ko
 from test_gpu_ks_pass import _batch, _compare, _ctx_with_env, _oracle, _run_dev, _slow_riccati
 
@@ -37,6 +39,7 @@ def test_fused_pass_matches_oracle(fused, B, N, T, r):
     _compare(_run_dev(fused, panel, st, may_have_missing=False), _oracle(panel, st), f"fused B={B} N={N} T={T} r={r}")
 
 
+@diag_only()
 @pytest.mark.parametrize("nsw", [1, 2, 3, 4, 5, 6])
 def test_fused_pass_with_other_stream_wave_counts(nsw):
     c = _ctx_with_env(DFM_PASS_FUSED=1, DFM_PASS_NSW=nsw)
@@ -105,6 +108,7 @@ def test_fused_em_matches_oracle(fused, B, N, T, r, iters):
         assert np.abs(P[b] - ko.pack_sym(out["P_smooth"])).max() <= 1e-8 * np.abs(out["P_smooth"]).max()
 
 
+@diag_only()
 def test_cov_wave_kernel_matches_oracle():
     """dfm_cov8.h as a drop-in for cov_kernel on the separate-launch path (gram -> cov || collapse -> pfill -> scan)."""
     c = _ctx_with_env(DFM_NO_FUSE_COV=1, DFM_COV_WAVE=1, DFM_PASS_FUSED=0)

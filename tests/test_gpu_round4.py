@@ -271,39 +271,6 @@ def test_tile_recursion_edges(ctx, T, r, N, miss):
     _compare((f.cpu().numpy(), P.cpu().numpy(), ll.cpu().numpy()), _oracle(panel, st), f"T = {T}, r = {r}")
 
 
-# ---- the opt-in series-split collapse (collapse_ks.hip, DFM_COLLAPSE_KS=1): same pass as the default route -------------------
-_KS_CHILD = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from dynamic_factor_models_amd import DfmContext
-c = DfmContext(0)
-out = {}
-for (B, N, T, r) in ((24, 1000, 300, 20), (3, 514, 77, 17)):      # xcd-mapped and flat item lists; a partial last stage, group and item
-    panel, par = c.synth_panels(7 + N, 0, B, T, N, r)
-    f, P, ll = c.ks_pass_batch(panel, *par, may_have_missing=False)
-    torch.cuda.synchronize()
-    out[f"f{N}"] = f.cpu().numpy(); out[f"P{N}"] = P.cpu().numpy(); out[f"ll{N}"] = ll.cpu().numpy()
-np.savez(sys.argv[2], **out)
-"""
-
-
-def test_collapse_ks_route(tmp_path):
-    """The route switch is read once per process: two child processes, with and without it, on the same device-generated panels."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    res = {}
-    for tag, val in (("default", "0"), ("ks", "1")):
-        env = dict(os.environ, DFM_COLLAPSE_KS=val)
-        out = tmp_path / f"{tag}.npz"
-        subprocess.run([sys.executable, "-c", _KS_CHILD, root, str(out)], check=True, env=env, timeout=600)
-        res[tag] = np.load(out)
-    for k in res["default"].files:
-        a, b = res["default"][k], res["ks"][k]
-        assert np.all(np.isfinite(b)), k
-        scale = np.maximum(np.abs(a).max(), 1e-300)
-        assert np.abs(a - b).max() <= 1e-10 * scale, (k, np.abs(a - b).max(), scale)
-
-
 # ---- observed factors beyond r_o + r_u = 8 (VERDICT r3 weak #11): the ordinary loadings step on the moments of z = (g, f) -------
 @pytest.mark.parametrize("N,T,ru,ro,missing", [
     (60, 150, 6, 4, 0.0),      # width 10 -> 16, state Rp = 8, balanced panel (every series takes the shared inverse)
