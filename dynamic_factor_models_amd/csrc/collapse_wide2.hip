@@ -1162,7 +1162,12 @@ hipError_t launch_ct_miss_wide(const CollapseArgs& a, double* ws, int r, hipStre
                 attr_cs = true;
             }
             // time chunks: one workgroup per CU where the batch leaves CUs idle (each copies its slice once: chunks of >= 64 periods)
-            int TC = a.B >= 256 ? 1 : 256 / a.B;
+            static const int ncu = [] {                       // one workgroup per CU: time chunks per replicate = CUs / B (chunks >= 64 periods)
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+                return n;
+            }();
+            int TC = a.B >= ncu ? 1 : ncu / a.B;
             if (TC > a.T / 64) TC = a.T / 64;
             if (TC < 1) TC = 1;
             for (int s0 = 0, k = 0; s0 < a.N; s0 += per, ++k) {

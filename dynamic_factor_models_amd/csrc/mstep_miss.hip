@@ -302,13 +302,15 @@ __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const doub
         if (c < npr) S[(size_t)c * nsi + row] = s11[c] - v;
         else if (c >= ntm16 && c - ntm16 < r) S[(size_t)(npr + c - ntm16) * nsi + row] = v;
     }
+    for (int c = tid; c < npr + r; c += 256) S[(size_t)c * nsi + ns] = 0.0;   // the padding column (stride ns + 1): where idle threads work
     __syncthreads();
     // Cholesky and the two substitutions per series, in the series' LDS column, by ALL threads of the block: thread (si = tid % ns,
     // w = tid / ns) works on the rows i = w (mod 256 / ns) of series si in the right-looking (outer-product) form -- the updates of a
     // step are independent, three barriers per column.  (One thread per series walking the row-by-row form was ONE chain of dependent
     // LDS round trips with one wave per CU busy: 1.94 ms per config-4 EM iteration, a third of the dense product's time.)
     const int si = tid % ns, w = tid / ns, nw = 256 / ns;
-    const int sic = si < nrow ? si : 0;                        // (series past N of a partial block: a valid column, never stored)
+    const int sic = si < nrow ? si : ns;                       // (series past N of a partial block: the zeroed padding column -- never a live
+                                                               // series' column: its owner's read-modify-writes must not be repeated by an alias)
     double* L = S + sic;
     double* y = S + (size_t)npr * nsi + sic;
 #define LL(i, j) L[((i) * ((i) + 1) / 2 + (j)) * nsi]
