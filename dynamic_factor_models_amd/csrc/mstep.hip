@@ -85,9 +85,20 @@ __device__ __forceinline__ bool chol_solve_packed(const double (&S)[R * (R + 1) 
     return ok;
 }
 
-template <int R, int CPL, bool REGD>
-__global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
+// MX (round 6; R <= 8, N <= 256, register accumulators): the masked moment update D_i += m_it E_t -- 36 multiply-adds per lane and
+// period for a 0 / 1 weight, three quarters of what the kernel issued (~123 instructions per period and wave, bound by its issue rate:
+// 0.51 ms per 1024 replicates at the C2 shape) -- is a matrix product, D (series x entries) += M (series x periods) E (periods x
+// entries), and goes to the matrix pipe, which the kernel left idle: per block of 4 periods a wave issues 4 x ET `v_mfma_f64_16x16x4`
+// (its 64 series as 4 row tiles, the NP packed entries as ET = ceil(NP / 16) column tiles; 0 / 1 operands are exact in fp64, so the sums
+// are the same numbers in another order); the NP mod 16 entries beyond the full tiles stay with the VALU.  The A operands (the lanes' own NaN tests, as bytes) and the B operands (E_t, already in
+// the LDS tile) arrive by 4 + ET LDS reads per block.  The VALU keeps Sxf, Sxx and the counts.
+typedef double mx_v4 __attribute__((ext_vector_type(4)));
+template <int R, int CPL, bool REGD, bool MX = false>
+__global__ __launch_bounds__(256, (MX ? 2 : 1)) void mstep_lam_kernel(MstepArgs a) {
     constexpr int NP = R * (R + 1) / 2;
+    constexpr int ET = MX ? NP / 16 : 1;                      // FULL column tiles of 16 entries go to the matrix pipe; the NP % 16 entries left (R = 8: 32..35)
+    constexpr int NVX = MX ? NP - 16 * ET : 0;                // stay on the VALU -- the fp64 matrix peak of gfx950 equals its vector peak: a quarter-full tile would cost the pipe a full one
+    static_assert(!MX || (REGD && CPL == 1), "the matrix-pipe form keeps its sums in registers, one series per lane");
     const int b = blockIdx.x;
     if (a.active && !a.active[b]) return;
     const int tid = threadIdx.x;
@@ -123,6 +134,15 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
     constexpr int PER = R + NP;                               // moments per period
     constexpr int NLD = (UN * PER + 255) / 256;               // loads per thread and group
     __shared__ double mom[2][UN * PER];
+    __shared__ unsigned char mkS[MX ? UN * 256 : 1];          // MX: the group's NaN tests, [period][series]
+    __shared__ double Dl[MX ? 64 * (NP + 1) : 1];             // MX: a wave's sums on their way back to the lanes that own the series
+    static_assert(!MX || UN % 4 == 0, "blocks of 4 periods");
+    mx_v4 macc[MX ? 4 : 1][MX ? ET : 1];
+#pragma unroll
+    for (int st = 0; st < (MX ? 4 : 1); ++st)
+#pragma unroll
+        for (int et = 0; et < (MX ? ET : 1); ++et) macc[st][et] = mx_v4{0.0, 0.0, 0.0, 0.0};
+    const int mlane = tid & 63, mk4 = mlane >> 4, mc16 = mlane & 15, mwave = tid >> 6;
     const int ngroups = (T + UN - 1) / UN;
     double xn[UN][CPL], mn[NLD];
     auto issue = [&](int g) {
@@ -182,6 +202,32 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (MX) {
+            // the masked update of the group's UN periods on the matrix pipe (see the head of the kernel); periods past the sample: 0
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const double x = xv[u][0];
+                mkS[u * 256 + tid] = (t0 + u < T && tid < N && x != x) ? 1 : 0;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave reads back its own columns: LDS serves a wave in order)
+#pragma unroll
+            for (int blk = 0; blk < UN / 4; ++blk) {
+                const int u = 4 * blk + mk4;
+                double av[4], bv[ET];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) av[st] = (double)mkS[u * 256 + 64 * mwave + 16 * st + mc16];
+#pragma unroll
+                for (int et = 0; et < ET; ++et) {
+                    const int e = 16 * et + mc16;
+                    bv[et] = e < NP ? mb[UN * R + u * NP + e] : 0.0;
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int et = 0; et < ET; ++et)
+                        macc[st][et] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], bv[et], macc[st][et], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int t = t0 + u;
@@ -191,8 +237,8 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
             for (int k = 0; k < R; ++k) f[k] = mb[u * R + k];
             // E_t: REGD (accumulators in registers, R <= 8) reads the period's 36 entries in ONE batch in front of the update and
             // adds them by a multiply-add with the lane's 0 / 1 mask: no divergent region, no wait per LDS read
-            double ef[REGD ? NP : 1];
-            if constexpr (REGD) {
+            double ef[(REGD && !MX) ? NP : 1];
+            if constexpr (REGD && !MX) {
                 const double* pv = mb + UN * R + u * NP;
 #pragma unroll
                 for (int v = 0; v < NP; ++v) ef[v] = pv[v];
@@ -212,7 +258,14 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
 #pragma unroll
                 for (int k = 0; k < R; ++k) sxf[j][k] = fma(xz, f[k], sxf[j][k]);
             }
-            if constexpr (REGD) {
+            if constexpr (MX) {
+                if constexpr (NVX > 0) {                       // the entries beyond the full tiles: masked multiply-adds as before
+                    const double x = xv[u][0];
+                    const double mk = (tid < N && x != x) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int v = 0; v < NVX; ++v) dm[0][16 * ET + v] = fma(mk, mb[UN * R + u * NP + 16 * ET + v], dm[0][16 * ET + v]);
+                }
+            } else if constexpr (REGD) {
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
                     const int col = tid + 256 * j;
@@ -233,6 +286,28 @@ __global__ __launch_bounds__(256) void mstep_lam_kernel(MstepArgs a) {
                     }
                 }
             }
+        }
+    }
+
+    if constexpr (MX) {
+        // the sums leave the accumulator layout -- lane (K, j), register v of tile (st, et) = series 16 st + K + 4 v of the wave, entry
+        // 16 et + j -- for the lane that owns the series, one wave at a time through Dl
+        for (int w = 0; w < 4; ++w) {
+            if (mwave == w) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int et = 0; et < ET; ++et)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const int e = 16 * et + mc16;
+                            if (e < NP) Dl[(16 * st + mk4 + 4 * v) * (NP + 1) + e] = macc[st][et][v];
+                        }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int v = 0; v < 16 * ET; ++v) dm[0][v] = Dl[mlane * (NP + 1) + v];
+            }
+            __syncthreads();
         }
     }
 
@@ -304,6 +379,7 @@ static hipError_t launch_m(const MstepArgs& a, hipStream_t s) {
     constexpr bool small = (R <= 8);
     if (a.N <= 256) {
         if (a.Dmiss) hipLaunchKernelGGL((mstep_lam_kernel<R, 1, false>), dim3(a.B), dim3(256), 0, s, a);
+        else if constexpr (R == 8) hipLaunchKernelGGL((mstep_lam_kernel<R, 1, true, true>), dim3(a.B), dim3(256), 0, s, a);
         else if constexpr (small) hipLaunchKernelGGL((mstep_lam_kernel<R, 1, true>), dim3(a.B), dim3(256), 0, s, a);
         else return hipErrorInvalidValue;
     } else if (a.N <= 512) {
