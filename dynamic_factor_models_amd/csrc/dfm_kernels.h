@@ -188,6 +188,10 @@ hipError_t launch_collapse(int Rpad, const CollapseArgs& a, hipStream_t s);
 // the same contract on the LDS-DMA ring + matrix pipe (collapse_miss.hip): Rp = 8, the shapes of the MFMA collapse
 bool collapse_miss_supported(int Rpad, int N);
 hipError_t launch_collapse_miss(const CollapseArgs& a, int num_cu, hipStream_t s);
+// Rp = 16, covariance form, observation on the first <= 4 state components (VAR(p) factor dynamics): one wave per replicate on the
+// matrix pipe, rank-4 updates and the Bryson-Frazier smoother instead of 16 x 16 inversions (recursion_mbf16.hip)
+bool recursion_mbf16_supported(int Rpad, const RecursionArgs& a);
+hipError_t launch_recursion_mbf16(const RecursionArgs& a, hipStream_t s);
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a);
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad);
 // Rp = 8, information form, B <= ~1.5 x the SIMD count: the replicate split over a covariance wave and a mean wave (recursion_pair.hip)
