@@ -182,17 +182,21 @@ __device__ __forceinline__ bool update4(const double (&P)[4][4], const double (&
 
 }  // namespace
 
+template <int RC>
 __global__ __launch_bounds__(64) void recursion_mbf16_kernel(RecursionArgs a) {
     __shared__ double vmf[K16], vmp[K16], vr[K16], vs[K16], vy[K16];
     const int lane = threadIdx.x, b = blockIdx.x;
     const int k4 = lane >> 4, c = lane & 15;
     const int T = a.T, N = a.N;
-    const int Rc = a.Rc, NPc = Rc * (Rc + 1) / 2;
+    constexpr int Rc = RC, NPc = Rc * (Rc + 1) / 2;
+    // (wave-uniform, but deliberately VECTOR loads: scalar loads share the LDS counter, so every LDS exchange of a step would wait for
+    // the next period's prefetch -- measured 1.57 -> 2.17 ms per 1024 EM iterations with s_load)
     const double* bcol = a.bcol + (size_t)b * T * Rc;
     const double* scol = a.scol + (size_t)b * T;
     const int* nobs = a.nobs + (size_t)b * T;
     const double* ldrow = a.ldrow + (size_t)b * T;
-    const double* Ctb = a.Ct ? a.Ct + (size_t)b * T * NPc : nullptr;
+    const bool haveCt = a.Ct != nullptr;
+    const double* Ctb = (haveCt ? a.Ct : a.Cfull) + (haveCt ? (size_t)b * T * NPc : 0);   // (never read without a C_t array)
     const double ldfull = a.ldfull[b];
     double* slot0 = a.ZJtab + (size_t)b * (T + 1) * kSlot;
     const bool em = a.S11 != nullptr;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(64) void recursion_mbf16_kernel(RecursionArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) o.b[i] = i < Rc ? bcol[(size_t)t * Rc + i] : 0.0;
 #pragma unroll
-        for (int q = 0; q < 10; ++q) o.cp[q] = (Ctb != nullptr && q < NPc) ? Ctb[(size_t)t * NPc + q] : 0.0;
+        for (int q = 0; q < 10; ++q) o.cp[q] = (haveCt && q < NPc) ? Ctb[(size_t)t * NPc + q] : 0.0;
         return o;
     };
     ObsIn nxt = fetch_obs(0);
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(64) void recursion_mbf16_kernel(RecursionArgs a) {
         const ObsIn cur = nxt;
         nxt = fetch_obs(t + 1);
         const int nt = cur.nt;
-        const bool full = nt == N || Ctb == nullptr;
+        const bool full = nt == N || !haveCt;
         double C[4][4], bt[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -346,11 +350,12 @@ __global__ __launch_bounds__(64) void recursion_mbf16_kernel(RecursionArgs a) {
     auto fetch_slot = [&](int t) {
         SlotIn o;
         const double* sl = slot0 + (size_t)(t > 0 ? t : 0) * kSlot;
+        const double* su = sl;
         o.pp = *reinterpret_cast<const m16*>(sl + 4 * lane);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) o.W[q] = sl[kOffW + q];
+        for (int q = 0; q < 16; ++q) o.W[q] = su[kOffW + q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { o.u[q] = sl[kOffU + q]; o.mpr[q] = sl[kOffMp + k4 + 4 * q]; }
+        for (int q = 0; q < 4; ++q) { o.u[q] = su[kOffU + q]; o.mpr[q] = sl[kOffMp + k4 + 4 * q]; }
         o.ws = c < 4 ? sl[kOffW + 4 * c + k4] : 0.0;
         return o;
     };
@@ -610,7 +615,8 @@ bool recursion_mbf16_supported(int Rpad, const RecursionArgs& a) {
 
 hipError_t launch_recursion_mbf16(const RecursionArgs& a, hipStream_t s) {
     note_kernel("recursion_mbf16_kernel");
-    hipLaunchKernelGGL(recursion_mbf16_kernel, dim3(a.B), dim3(64), 0, s, a);
+    if (a.Rc == 4) hipLaunchKernelGGL(recursion_mbf16_kernel<4>, dim3(a.B), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(recursion_mbf16_kernel<2>, dim3(a.B), dim3(64), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.S11 == nullptr) return e;
     constexpr size_t RT = (size_t)16 * kTileStride<16>;
