@@ -130,6 +130,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t LamP, AP, QP, P0P, mu0P;                // padded parameters (only used when r != Rp)
     size_t bcol, scol, ldrow, nobs, Ct, Cfull, ldfull;
     size_t ZJ, wtab, status, ncov;
+    size_t ck_skip = (size_t)-1;                  // recursion_chunk.hip: replicates that failed their boundary check earlier in this EM run
     size_t ck_rows = (size_t)-1;                  // collapse_miss_kernel's rows + NaN masks (ct_build_kernel's input)
     size_t ck_scr = (size_t)-1, ck_obs = (size_t)-1, ck_cst = (size_t)-1, ck_term = (size_t)-1, ck_fail = (size_t)-1;   // recursion_chunk.hip (Rp = 8, general path)
     size_t Vwide = (size_t)-1;
@@ -222,6 +223,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
         p.ck_cst = take(off, (size_t)B * 320 * d);
         p.ck_term = take(off, (size_t)B * 96 * d);
         p.ck_fail = take(off, (size_t)B * sizeof(int));
+        p.ck_skip = take(off, (size_t)B * sizeof(int));
     }
     if (!fast && !p.cov && Rp == 32 && p.Rc == 0) {
         p.tk_bytes = recursion_tile_scratch_bytes(B, T);
@@ -702,6 +704,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ra.Cfull = ca.Cfull; ra.ldfull = ca.ldfull;
     ra.ZJtab = at<double>(h, p.ZJ); ra.wtab = at<double>(h, p.wtab); ra.eidx = nullptr;
     ra.chunk_scr = h->no_chunk ? nullptr : at<double>(h, p.ck_scr); ra.chunk_W = h->chunk_w; ra.chunk_tol = h->chunk_tol; ra.chunk_obs = at<double>(h, p.ck_obs); ra.chunk_cst = at<double>(h, p.ck_cst); ra.chunk_term = at<double>(h, p.ck_term); ra.chunk_fail = at<int>(h, p.ck_fail);
+    ra.chunk_skip = at<int>(h, p.ck_skip);
     ra.tile_scr = at<double>(h, p.tk_scr); ra.tile_scr_bytes = p.tk_bytes; ra.tile_nc = h->tile_nc; ra.tile_w = h->tile_w; ra.num_cu = h->num_cu;
     ra.f_smooth = f_smooth; ra.P_smooth = P_smooth; ra.loglik = loglik;
     ra.ncov = at<int>(h, p.ncov);

@@ -129,6 +129,8 @@ struct RecursionArgs {
     int chunk_obs_ready;  // 1: collapse_miss_kernel wrote the table itself (its table mode); 0: launch_recursion_chunk gathers the collapse
                           // kernels' per-period arrays
     int* chunk_fail;      // [B]       1: a chunk boundary did not agree to chunk_tol -- the replicate belongs to the sequential kernel
+    int* chunk_skip;      // [B] or null: persists between the iterations of an EM run (k = 0 clears it) -- consecutive failures of the replicate's
+                          // boundary check; from three on the chunked kernel leaves it to the sequential one at once (retried every 8th iteration)
     const int* only_if;   // [B] or null: the sequential kernels (recursion_wave / recursion_pair) run replicate b only if only_if[b] != 0
     int chunk_L, chunk_W;
     double chunk_tol;

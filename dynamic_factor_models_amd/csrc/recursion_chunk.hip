@@ -336,6 +336,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int r = a.r;
     const int rl = a.rl > 0 ? a.rl : R;
     const int npr = r * (r + 1) / 2;
+    // A replicate whose filter forgets too slowly for the warm-up fails its boundary check in EVERY iteration of an EM run (the real
+    // Stock-Watson window: all of them, whatever the warm-up up to 20 periods -- weakly loaded factors forget over tens of periods).  The
+    // count of CONSECUTIVE failures survives in the handle's workspace between the iterations of a run (k = 0 clears it; a first
+    // iteration from a rough start may fail where the later ones pass): after three in a row a replicate leaves at once and is the
+    // sequential kernel's, instead of spending 16 + 16 steps per lane on a result that is thrown away; every 8th iteration it is tried again.
+    if (a.chunk_skip) {
+        if (a.k == 0) { if (lane == 0) a.chunk_skip[b] = 0; }
+        else if (a.chunk_skip[b] >= 3 && (a.k & 7) != 0) { if (lane == 0) a.chunk_fail[b] = 1; return; }
+    }
 
     // LDS: the stage (64 x 368 bytes), then (EM) the accumulators [64 + 36][kAccSlots]
     // and two 8 x 8 tiles of the epilogue
@@ -485,6 +494,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     wave_mem_fence();                                               // the table, the warm-up states and the terminal state are read back below
     // boundary check, forward: the state lane + 1 started its chunk from against the state this lane leaves its own chunk with
     bool ok = lane + 1 > jtop || saved_state_close(sav_f, lane < 63 ? lane + 1 : 63, m, xi, tol);
+    if (!(__all(ok) != 0 && ll == ll)) {                           // (wave-uniform) a forward boundary is off: no backward sweep for nothing
+        if (lane == 0) { a.chunk_fail[b] = 1; if (a.chunk_skip) a.chunk_skip[b] = (a.k == 0 ? 0 : a.chunk_skip[b]) + 1; }
+        return;
+    }
 
     // =================================================== backward ==========================================================
     double P[NP], f[R];
@@ -541,7 +554,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     if (lane == 0 && (b == 0 || b == 777)) printf("CKCLK b=%d shader cycles %lld wall ticks %lld\n", b, clock64() - ck0, wall_clock64() - wk0);
 #endif
     const bool good = __all(ok) != 0 && ll == ll;                  // (a NaN log-likelihood also goes to the sequential kernel)
-    if (lane == 0) a.chunk_fail[b] = good ? 0 : 1;
+    if (lane == 0) { a.chunk_fail[b] = good ? 0 : 1; if (a.chunk_skip) a.chunk_skip[b] = good ? 0 : (a.k == 0 ? 0 : a.chunk_skip[b]) + 1; }
     if (!good) return;
     if (lane == 0) {
         a.loglik[b] = ll;
