@@ -159,3 +159,23 @@ def test_varp_and_ar_edge_cases(ctx):
     assert f.shape == (1, 2, r)
     assert abs(ll[0].item() - o["loglik"]) <= 1e-9 * abs(o["loglik"])
     _close(f[0].cpu().numpy(), o["f_smooth"][:, :r], 1e-9, "shortest AR panel")
+
+
+@pytest.mark.parametrize("N,T,r,p", [(20, 40, 1, 12), (16, 70, 1, 16), (30, 24, 2, 5)])
+def test_mbf16_edge_shapes(ctx, N, T, r, p):
+    """recursion_mbf16_kernel (round 6) at the edges of its domain: one factor with 12 / 16 lags (collapsed observations 2 wide, one of them
+    padding), periods without a single observed cell (C_t = 0: the rank-4 update must be the identity), a first and a last period among
+    them, and the pass without P_smooth."""
+    import torch
+    x, q = _batch(2, N, T, r, p, 0.15)
+    x[:, [0, 7, 8, T - 1], :] = np.nan
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    f, P, ll = ctx.ks_pass_varp_batch(t(x), *[t(q[k]) for k in KEYS])
+    torch.cuda.synchronize()
+    tri = np.tril_indices(r)
+    for b in range(2):
+        o = vo.kfs_pass_varp(x[b], p=p, **{k: q[k][b] for k in KEYS})
+        assert abs(ll[b].item() - o["loglik"]) <= 1e-9 * abs(o["loglik"])
+        _close(f[b].cpu().numpy(), o["f_smooth"][:, :r], 1e-9, "f_smooth")
+        _close(P[b].cpu().numpy(), o["P_smooth"][:, :r, :r][:, tri[0], tri[1]], 1e-9, "P_smooth")
