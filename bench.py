@@ -682,10 +682,10 @@ def f3_lines(torch, ctx, dev, cpu_seconds=2.0):
                           value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv,
                           whole_step=Bv * em_iteration_bytes(Nv, Tv, rv, rv * pv) / s_it / 1e9 / HBM_PEAK_GBS,
                           compulsory_bytes=Bv * em_iteration_bytes(Nv, Tv, rv, rv * pv),
-                          dominant="recursion_mbf16_kernel", matches_oracle=ok,
-                          note="16-wide companion state, singular Q: one wave per replicate on v_mfma_f64_16x16x4 tiles, rank-4 covariance-form update + "
-                               "modified Bryson-Frazier smoother (no 16 x 16 inversion; round 5: recursion_wave_kernel<16, COV>, 4.2 ms) -- a dependent chain "
-                               "per replicate, latency-bound",
+                          dominant="recursion_comp_kernel", matches_oracle=ok,
+                          note="16-wide companion state, singular Q: one wave per replicate on v_mfma_f64_16x16x4 tiles, information form as a block "
+                               "elimination with 4 x 4 pivots (no 16 x 16 inversion per period; round 5: recursion_wave_kernel<16, COV>, 4.2 ms) -- a "
+                               "dependent chain per replicate, latency-bound",
                           cpu_baseline=dict(value=1.0 / cpu_s, unit="EM iterations/s", cores=1, kind="port",
                                             sample=f"{n} iterations of oracle/varp_oracle.py em_step_varp (NumPy) in {cpu_seconds:.0f} s"),
                           seconds=round(time.perf_counter() - t_line, 2))
@@ -713,8 +713,10 @@ def f3_lines(torch, ctx, dev, cpu_seconds=2.0):
                         value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv,
                         whole_step=Bv * em_iteration_bytes(Nv, Tv, rv, rv * (qv + 1), qv) / s_it / 1e9 / HBM_PEAK_GBS,
                         compulsory_bytes=Bv * em_iteration_bytes(Nv, Tv, rv, rv * (qv + 1), qv),
-                        dominant="recursion_wave_kernel", matches_oracle=ok,
-                        note="quasi-differenced observation equation, 20-wide state padded to 32: one 1024-thread workgroup per replicate, latency-bound",
+                        dominant="collapse_kernel", matches_oracle=ok,
+                        note="quasi-differenced observation equation, 20-wide companion state padded to 32: recursion_comp_kernel<2> (one wave per replicate, 2 x 2 "
+                             "matrix-pipe tiles, 4 x 4 pivots; round 5: recursion_wave_kernel<32, COV>, 33.9 ms of the 43.5) -- what is left is the VALU collapse "
+                             "of the 32-wide loadings (5.6 ms) and the series CM-steps (4.3 ms)",
                         cpu_baseline=dict(value=1.0 / cpu_s, unit="EM iterations/s", cores=1, kind="port",
                                           sample=f"{n} iterations of oracle/ar_oracle.py em_step_ar (NumPy) in {cpu_seconds:.0f} s"),
                         seconds=round(time.perf_counter() - t_line, 2))
@@ -782,7 +784,7 @@ def c1_em_lines(torch, ctx, dev, cpu_seconds=2.0):
                      f"r={r}, factor VAR({lags}), {Bc} parametric-bootstrap replicates x {nit} EM iterations from the point estimate",
             value=Bc / s_job, unit="replicate estimations/s", ms_per_step=1e3 * s_job, batch=Bc, em_iterations=nit,
             whole_step=nb / s_job / 1e9 / HBM_PEAK_GBS, compulsory_bytes=nb,
-            dominant="recursion_chunk_kernel" if lags == 1 else "recursion_mbf16_kernel",
+            dominant="recursion_wave_kernel" if lags == 1 else "recursion_comp_kernel",
             matches_oracle=bool(err <= 1e-8), loglik_path_max_rel_err=err,
             cpu_baseline=dict(value=1.0 / cpu_s, unit="replicate estimations/s", cores=1, kind="port",
                               sample=f"{n} x {nit} EM iterations of oracle/{'varp_oracle.py em_varp' if lags > 1 else 'kalman_oracle.py em'} (NumPy) on replicate 0"),

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 SO = os.path.join(LIBDIR, "libdfmhip.so")
-SOURCES = ["collapse.hip", "collapse_miss.hip", "collapse_dma.hip", "collapse_mfma.hip", "collapse_wide.hip", "collapse_wide2.hip", "recursion.hip", "recursion_wave.hip", "recursion_pair.hip", "recursion_chunk.hip", "recursion_tile.hip", "recursion_mbf16.hip", "fastpath.hip", "scan_mfma32.hip", "em_update_grid.hip", "pass_fused.hip", "mstep.hip", "mstep_mfma.hip", "mstep_wide.hip", "mstep_ar.hip", "mstep_obs.hip", "mstep_miss.hip", "pca.hip", "gram_xx_wide.hip", "als.hip", "boot.hip", "breaks.hip", "synth.hip", "capi.hip", "multi.hip", "probe.hip"]
+SOURCES = ["collapse.hip", "collapse_miss.hip", "collapse_dma.hip", "collapse_mfma.hip", "collapse_wide.hip", "collapse_wide2.hip", "recursion.hip", "recursion_wave.hip", "recursion_pair.hip", "recursion_chunk.hip", "recursion_tile.hip", "recursion_mbf16.hip", "recursion_comp.hip", "fastpath.hip", "scan_mfma32.hip", "em_update_grid.hip", "pass_fused.hip", "mstep.hip", "mstep_mfma.hip", "mstep_wide.hip", "mstep_ar.hip", "mstep_obs.hip", "mstep_miss.hip", "pca.hip", "gram_xx_wide.hip", "als.hip", "boot.hip", "breaks.hip", "synth.hip", "capi.hip", "multi.hip", "probe.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 # per-file flags.  recursion_tile.hip: MFMA accumulators in VGPRs (gfx950 takes either file for srcC / vDst).  The default
 # allocation put the 16 x 16 tiles in AGPRs and bracketed every v_mfma with 8 + 8 v_accvgpr moves -- 16 of 129 instructions per

@@ -194,6 +194,11 @@ hipError_t launch_collapse_miss(const CollapseArgs& a, int num_cu, hipStream_t s
 // matrix pipe, rank-4 updates and the Bryson-Frazier smoother instead of 16 x 16 inversions (recursion_mbf16.hip)
 bool recursion_mbf16_supported(int Rpad, const RecursionArgs& a);
 hipError_t launch_recursion_mbf16(const RecursionArgs& a, hipStream_t s);
+hipError_t launch_cov_epilogue(int Rpad, const RecursionArgs& a, hipStream_t s);
+// companion states in blocks of 4 (VAR(p) factor dynamics at r = 4, AR idiosyncratic terms at r = 4): information form as a block
+// elimination, one wave per replicate on matrix-pipe tiles, 4 x 4 pivots only (recursion_comp.hip)
+bool recursion_comp_supported(int Rpad, const RecursionArgs& a);
+hipError_t launch_recursion_comp(int Rpad, const RecursionArgs& a, hipStream_t s);
 bool recursion_wave_supported(int Rpad, const RecursionArgs& a);
 hipError_t launch_recursion_wave(const RecursionArgs& a, hipStream_t s, int Rpad);
 // Rp = 8, information form, B <= ~1.5 x the SIMD count: the replicate split over a covariance wave and a mean wave (recursion_pair.hip)

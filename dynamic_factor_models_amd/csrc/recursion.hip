@@ -647,6 +647,7 @@ hipError_t launch_recursion(int Rpad, const RecursionArgs& a, hipStream_t s) {
         note_kernel("recursion_chunk_kernel");
         return e;
     }
+    if (a.wave && recursion_comp_supported(Rpad, a)) return launch_recursion_comp(Rpad, a, s);
     if (a.wave && recursion_mbf16_supported(Rpad, a)) return launch_recursion_mbf16(a, s);
     if (a.wave && recursion_tile_supported(Rpad, a)) return launch_recursion_tile(a, s);
     if (a.wave && recursion_wave_supported(Rpad, a)) return launch_recursion_wave(a, s, Rpad);

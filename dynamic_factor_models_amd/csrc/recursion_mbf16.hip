@@ -21,7 +21,7 @@
 // transpose of something just computed (no cross-lane transposition anywhere).  Rank-4 terms are ONE instruction (k = 4).
 // Vectors live in LDS (one wave: its DS operations are served in order, no barrier).
 // The EM epilogue (A, Q, mu0, P0, S11^-1, bookkeeping: companion constraints and all) is recursion_wave_kernel<16, COV>'s text with an
-// element per thread, as its own small launch on the sums this kernel leaves (cov16_epilogue_kernel below).
+// element per thread, as its own small launch on the sums this kernel leaves (cov_epilogue_kernel below).
 // Reference counterpart: none (dfm_functions.ipynb:21-23 declares `Parametric` only); oracle: oracle/varp_oracle.py, oracle/ar_oracle.py.
 #include <stdlib.h>
 
@@ -520,8 +520,10 @@ __global__ __launch_bounds__(64) void recursion_mbf16_kernel(RecursionArgs a) {
 // ---- the EM epilogue: recursion_wave_kernel<16, COV>'s, element (i, j) of every 16 x 16 matrix per thread, on the sums the pass left ------
 // EM bookkeeping (log-likelihood path, iteration counts, who keeps iterating), A = S10 S00^-1 with the companion constraints
 // (RecursionArgs::kdim / ka / kb), Q = sym(S11 - A S10') / T, mu0, P0, S11 / S11^-1 in the loadings step's layout.
-__global__ __launch_bounds__(256) void cov16_epilogue_kernel(RecursionArgs a) {
-    constexpr int R = 16, RR = 256, TS = kTileStride<R>, RT = R * TS;
+template <int R>
+__global__ __launch_bounds__(R * R) void cov_epilogue_kernel(RecursionArgs a) {
+    constexpr int RR = R * R, TS = kTileStride<R>, RT = R * TS;
+    constexpr int kSlotE = 2 * RR;
     extern __shared__ __attribute__((aligned(16))) double esm[];
     double* L0 = esm;
     double* L1 = L0 + RT;
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(256) void cov16_epilogue_kernel(RecursionArgs a) {
             a.active[b] = go ? 1 : 0;
         }
     }
-    const double S11 = a.ZJtab[(size_t)b * (T + 1) * kSlot + (size_t)T * kSlot + lane];
+    const double S11 = a.ZJtab[(size_t)b * (T + 1) * kSlotE + (size_t)T * kSlotE + lane];
     const double S10 = a.S10[o], S00 = a.S00[o], Ps = a.P0s[o];
     const double fs_r = a.f0s[(size_t)b * R + i];
     const bool narrow = a.rl > 0;
@@ -601,6 +603,18 @@ __global__ __launch_bounds__(256) void cov16_epilogue_kernel(RecursionArgs a) {
     }
 }
 
+template <int R>
+static hipError_t launch_cov_epilogue_r(const RecursionArgs& a, hipStream_t s) {
+    constexpr size_t RT = (size_t)R * kTileStride<R>;
+    const size_t lds = (2 * RT + kGridProw<R> + 2 * (R * R / 64) * R + 2 * RT) * sizeof(double);
+    hipLaunchKernelGGL(cov_epilogue_kernel<R>, dim3(a.B), dim3(R * R), lds, s, a);
+    return hipGetLastError();
+}
+// the sums of a pass (S11 in the last slot of ZJtab, S10 / S00 / P0s / f0s in their arrays, the log-likelihood) -> the M-step
+hipError_t launch_cov_epilogue(int Rpad, const RecursionArgs& a, hipStream_t s) {
+    return Rpad == 16 ? launch_cov_epilogue_r<16>(a, s) : Rpad == 32 ? launch_cov_epilogue_r<32>(a, s) : hipErrorInvalidValue;
+}
+
 // Rp = 16, covariance form, observation on the first rc <= 4 state components in the collapse kernels' narrow layout (VAR(p) factor
 // dynamics: dfm_*_varp_*); the EM epilogue is recursion_wave_kernel<16, COV>'s (RecursionArgs::sums_ready)
 bool recursion_mbf16_supported(int Rpad, const RecursionArgs& a) {
@@ -619,10 +633,7 @@ hipError_t launch_recursion_mbf16(const RecursionArgs& a, hipStream_t s) {
     else hipLaunchKernelGGL(recursion_mbf16_kernel<2>, dim3(a.B), dim3(64), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.S11 == nullptr) return e;
-    constexpr size_t RT = (size_t)16 * kTileStride<16>;
-    const size_t lds = (2 * RT + kGridProw<16> + 2 * (256 / 64) * 16 + 2 * RT) * sizeof(double);
-    hipLaunchKernelGGL(cov16_epilogue_kernel, dim3(a.B), dim3(256), lds, s, a);
-    return hipGetLastError();
+    return launch_cov_epilogue(16, a, s);
 }
 
 }  // namespace dfm
