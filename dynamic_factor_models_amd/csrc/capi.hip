@@ -694,6 +694,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     ca.ldrow = at<double>(h, p.ldrow); ca.Ct = at<double>(h, p.Ct); ca.Cfull = at<double>(h, p.Cfull);
     ca.ldfull = at<double>(h, p.ldfull); ca.status = h->status_dev;
     ca.obs_chunk = nullptr; ca.obs_table = nullptr; ca.obs_L = 0;
+    ca.kreal = (p.kdim > 0 && p.Rc == 0) ? p.kdim : 0;          // (companion state observed on every block: the AR idiosyncratic model)
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;

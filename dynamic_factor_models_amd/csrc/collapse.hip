@@ -19,7 +19,10 @@
 
 namespace dfm {
 
-template <int R, int CPL2, int RB>
+// KR <= R (round 6): the columns k >= KR of the loadings are zero padding (a 20-wide companion state in the 32-wide layout: the AR
+// idiosyncratic model) -- their sums are not formed (b_t: zeros; C_t: the packed entries of rows >= KR are zeros), which is 0.4 of the
+// multiply-adds and, more to the point, of the registers: the 32-wide instantiation holds 256 VGPRs + 210 AGPRs at one wave per SIMD
+template <int R, int CPL2, int RB, int KR = R>
 __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63;
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
     const double* __restrict__ L = a.Lam + (size_t)b * N * R;
     const double* __restrict__ Rv = a.Rv + (size_t)b * N;
 
-    double W[CPL2][2][R];
+    double W[CPL2][2][KR];
     double Ri[CPL2][2];
     bool own[CPL2][2];
 #pragma unroll
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
             const double ri = own[j][e] ? 1.0 / Rv[c] : 0.0;
             Ri[j][e] = ri;
 #pragma unroll
-            for (int k = 0; k < R; ++k) W[j][e][k] = own[j][e] ? L[(size_t)c * R + k] * ri : 0.0;
+            for (int k = 0; k < KR; ++k) W[j][e][k] = own[j][e] ? L[(size_t)c * R + k] * ri : 0.0;
         }
 
     // LDS tables for the rows with missing cells: loadings, 1/R, log R per series, the packed full-row C, its log det term
@@ -55,8 +58,25 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
     for (int q = threadIdx.x; q < N; q += 256) { const double rv = Rv[q]; rinvS[q] = 1.0 / rv; logRS[q] = log(rv); }
     __syncthreads();
     if (wave == 0) {  // per-replicate constants for the balanced rows
-        c_all<R, CPL2, 0, true>(W, L, own, lane, a.Cfull + (size_t)b * R * R);
-        c_all<R, CPL2, 0, false>(W, L, own, lane, CfS);
+        if constexpr (KR == R) {
+            c_all<R, CPL2, 0, true>(W, L, own, lane, a.Cfull + (size_t)b * R * R);
+            c_all<R, CPL2, 0, false>(W, L, own, lane, CfS);
+        } else {
+            // (the real columns only, from the LDS tables: a lane per packed entry, a loop over the series -- once per replicate)
+            double* cf = a.Cfull + (size_t)b * R * R;
+            for (int v = lane; v < NP; v += 64) {
+                int kk = 0;
+                while ((kk + 1) * (kk + 2) / 2 <= v) ++kk;
+                const int kp = v - kk * (kk + 1) / 2;
+                double s = 0.0;
+                if (kk < KR) {
+                    for (int c = 0; c < N; ++c) s = fma(LamS[(size_t)c * R + kk] * rinvS[c], LamS[(size_t)c * R + kp], s);
+                }
+                CfS[v] = s;
+                cf[kk * R + kp] = s;
+                cf[kp * R + kk] = s;
+            }
+        }
         double ld = 0.0;
 #pragma unroll
         for (int j = 0; j < CPL2; ++j)
@@ -68,22 +88,23 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
     }
     __syncthreads();
     // packed entries of C_t this lane produces on the slow path: v = lane + 64 q -> LDS offsets of lam_k, lam_k'
-    constexpr int EPL = (NP + 63) / 64;
+    constexpr int NPK = KR * (KR + 1) / 2;
+    constexpr int EPL = (NPK + 63) / 64;
     int ek[EPL], ekp[EPL];
 #pragma unroll
     for (int q = 0; q < EPL; ++q) {
         int v = lane + 64 * q;
-        v = v < NP ? v : NP - 1;
+        v = v < NPK ? v : NPK - 1;
         int k = 0;
         while ((k + 1) * (k + 2) / 2 <= v) ++k;
         ek[q] = k;
         ekp[q] = v - k * (k + 1) / 2;
     }
 
-    constexpr int NV = RB * (R + 1);
+    constexpr int NV = RB * (KR + 1);
     bool canon;
     const int myidx = reduce_index<NV>(lane, canon);
-    const int my_rr = myidx / (R + 1), my_k = myidx % (R + 1);
+    const int my_rr = myidx / (KR + 1), my_k = myidx % (KR + 1);
     const bool vec2 = (N & 1) == 0;
     const int nrb = (T + RB - 1) / RB;
 
@@ -143,12 +164,12 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
                 x0 = n0 ? 0.0 : x0;
                 x1 = n1 ? 0.0 : x1;
 #pragma unroll
-                for (int k = 0; k < R; ++k) {
-                    acc[rr * (R + 1) + k] = fma(W[j][0][k], x0, acc[rr * (R + 1) + k]);
-                    acc[rr * (R + 1) + k] = fma(W[j][1][k], x1, acc[rr * (R + 1) + k]);
+                for (int k = 0; k < KR; ++k) {
+                    acc[rr * (KR + 1) + k] = fma(W[j][0][k], x0, acc[rr * (KR + 1) + k]);
+                    acc[rr * (KR + 1) + k] = fma(W[j][1][k], x1, acc[rr * (KR + 1) + k]);
                 }
-                acc[rr * (R + 1) + R] = fma(x0 * Ri[j][0], x0, acc[rr * (R + 1) + R]);
-                acc[rr * (R + 1) + R] = fma(x1 * Ri[j][1], x1, acc[rr * (R + 1) + R]);
+                acc[rr * (KR + 1) + KR] = fma(x0 * Ri[j][0], x0, acc[rr * (KR + 1) + KR]);
+                acc[rr * (KR + 1) + KR] = fma(x1 * Ri[j][1], x1, acc[rr * (KR + 1) + KR]);
             }
             nanrow[rr] = anynan;
             nanbits[rr] = nb;
@@ -160,8 +181,12 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
         {
             const int t = t0 + my_rr;
             if (canon && t < T) {
-                if (my_k < R) a.bcol[((size_t)b * T + t) * R + my_k] = acc[0];
+                if (my_k < KR) a.bcol[((size_t)b * T + t) * R + my_k] = acc[0];
                 else {
+                    if constexpr (KR < R) {
+#pragma unroll
+                        for (int kk = KR; kk < R; ++kk) a.bcol[((size_t)b * T + t) * R + kk] = 0.0;
+                    }
                     a.scol[(size_t)b * T + t] = acc[0];
                     if (((nanmask >> my_rr) & 1u) == 0) a.nobs[(size_t)b * T + t] = N;
                 }
@@ -225,7 +250,10 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
 #pragma unroll
                 for (int q = 0; q < EPL; ++q) {
                     const int v = lane + 64 * q;
-                    if (v < NP) ct[v] = comp ? CfS[v] - cacc[q] : cacc[q];
+                    if (v < NPK) ct[v] = comp ? CfS[v] - cacc[q] : cacc[q];
+                }
+                if constexpr (KR < R) {
+                    for (int v = NPK + lane; v < NP; v += 64) ct[v] = 0.0;
                 }
             }
         }
@@ -233,18 +261,18 @@ __global__ __launch_bounds__(256) void collapse_kernel(CollapseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-template <int R, int CPL2, int RB>
+template <int R, int CPL2, int RB, int KR = R>
 static hipError_t launch_one(const CollapseArgs& a, hipStream_t s) {
     const size_t lds = ((size_t)a.N * R + 2 * (size_t)a.N + R * (R + 1) / 2 + 1) * sizeof(double);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static LdsOptIn attr_done;
     if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_kernel<R, CPL2, RB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&collapse_kernel<R, CPL2, RB, KR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((collapse_kernel<R, CPL2, RB>), dim3(a.B), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((collapse_kernel<R, CPL2, RB, KR>), dim3(a.B), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -252,6 +280,10 @@ template <int R>
 static hipError_t launch_r(const CollapseArgs& a, hipStream_t s) {
     // register budget: CPL2*2*R doubles of W + RB*(R+1) accumulators
     constexpr int RB = (R <= 4) ? 8 : (R <= 8) ? 4 : (R <= 16) ? 2 : 1;
+    if constexpr (R == 32) {                                     // a narrower real state in the 32-wide layout (CollapseArgs::kreal)
+        if (a.kreal > 0 && a.kreal <= 20) return a.N <= 128 ? launch_one<R, 1, RB, 20>(a, s) : a.N <= 256 ? launch_one<R, 2, RB, 20>(a, s) : hipErrorInvalidValue;
+        if (a.kreal > 0 && a.kreal <= 24) return a.N <= 128 ? launch_one<R, 1, RB, 24>(a, s) : a.N <= 256 ? launch_one<R, 2, RB, 24>(a, s) : hipErrorInvalidValue;
+    }
     if (a.N <= 128) return launch_one<R, 1, RB>(a, s);
     if (a.N <= 256) return launch_one<R, 2, RB>(a, s);
     if constexpr (R <= 16) {

@@ -74,6 +74,8 @@ struct CollapseArgs {
                           // 0 = the full Rp (Rp + 1) / 2 layout of the other recursion kernels
     double* obs_chunk;    // collapse_miss only (table mode): RecursionArgs::chunk_rows -- one 112-byte row per period: b_t (8), s_t,
                           // n_t log 2 pi + sum log R, the period's NaN bit mask (4 x 64 bits) -- written INSTEAD of bcol .. ldrow and C_t
+    int kreal;            // collapse_kernel<32>: > 0 = the loadings' columns kreal .. 31 are zero padding (companion states narrower than their
+                          // layout): their sums are written as zeros, not formed; 0 = all columns
     double* obs_table;    // ... and RecursionArgs::chunk_obs, the pass's observation table [B][obs_L][23][64] double2 (chunk-major, period
     int obs_L;            // t = obs_L lane + slot), which the workgroup fills from those rows when its stream is done (dfm_ctbuild.h)
 };
