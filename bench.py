@@ -713,10 +713,10 @@ def f3_lines(torch, ctx, dev, cpu_seconds=2.0):
                         value=Bv / s_it, unit="EM iterations/s", ms_per_step=1e3 * s_it, batch=Bv,
                         whole_step=Bv * em_iteration_bytes(Nv, Tv, rv, rv * (qv + 1), qv) / s_it / 1e9 / HBM_PEAK_GBS,
                         compulsory_bytes=Bv * em_iteration_bytes(Nv, Tv, rv, rv * (qv + 1), qv),
-                        dominant="collapse_kernel", matches_oracle=ok,
+                        dominant="mstep_ar_kernel", matches_oracle=ok,
                         note="quasi-differenced observation equation, 20-wide companion state padded to 32: recursion_comp_kernel<2> (one wave per replicate, 2 x 2 "
-                             "matrix-pipe tiles, 4 x 4 pivots; round 5: recursion_wave_kernel<32, COV>, 33.9 ms of the 43.5) -- what is left is the VALU collapse "
-                             "of the 32-wide loadings (5.6 ms) and the series CM-steps (4.3 ms)",
+                             "matrix-pipe tiles, 4 x 4 pivots; round 5: recursion_wave_kernel<32, COV>, 33.9 ms of the 43.5) and collapse_kernel<32,2,1,20> (the real state width as a template parameter: "
+                             "5.6 -> 1.1 ms) -- what is left is the series CM-steps (mstep_ar_kernel 4.3 ms of the 7.8)",
                         cpu_baseline=dict(value=1.0 / cpu_s, unit="EM iterations/s", cores=1, kind="port",
                                           sample=f"{n} iterations of oracle/ar_oracle.py em_step_ar (NumPy) in {cpu_seconds:.0f} s"),
                         seconds=round(time.perf_counter() - t_line, 2))

@@ -244,9 +244,15 @@ def estimate(m: DFMModel, method: EstimationMethod = None, *, max_em_iter: int =
             e = o["resid"]
             Qv = e.T @ e / (T - nlag); Qv = 0.5 * (Qv + Qv.T)
             P0v = Z.T @ Z / Z.shape[0]; P0v = 0.5 * (P0v + P0v.T)
-            params, path, iters, f, P = ctx.em_varp_batch_host(z[None], Lam[None], R[None], Avar[None], Qv[None],
-                                                               np.zeros((1, r * nlag)), P0v[None], max_iter=max_em_iter,
-                                                               tol=tol_em, may_have_missing=bool((~obs).any()))
+            from ._lib import DfmError
+            vargs = (z[None], Lam[None], R[None], Avar[None], Qv[None], np.zeros((1, r * nlag)), P0v[None])
+            vkw = dict(max_iter=max_em_iter, tol=tol_em, may_have_missing=bool((~obs).any()))
+            try:
+                params, path, iters, f, P = ctx.em_varp_batch_host(*vargs, **vkw)
+            except DfmError as err:                     # r = 4: recursion_comp.hip inverts the r x r block Q (as above)
+                if err.code != -5:
+                    raise
+                params, path, iters, f, P = ctx.em_varp_batch_host(*vargs, singular_q=True, **vkw)
             params = dict(params)
             params["A"] = params["Avar"]
     finally:

@@ -144,7 +144,7 @@ struct Plan {  // byte offsets into the workspace (all 256-byte aligned)
     size_t Wwide = (size_t)-1;                     // W = lam / R of the Rp = 32 collapse (collapse_wide2.hip)
     bool fast;
     // covariance-form recursion (DFM_F_SINGULAR_Q) and companion states (dfm_*_varp_*): see RecursionArgs
-    bool cov = false; int Rc = 0, rl = 0, kdim = 0, kb = 0, ka = 0;
+    bool cov = false; int Rc = 0, rl = 0, kdim = 0, kb = 0, ka = 0, qsing = 0;
     size_t total;
 };
 
@@ -698,7 +698,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     RecursionArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.B = B; ra.T = T; ra.N = N; ra.r = out_r;
-    ra.rstate = p.r; ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim; ra.kb = p.kb; ra.ka = p.ka; ra.wave = h->no_rec_wave ? 0 : 1;
+    ra.rstate = p.r; ra.cov = p.cov ? 1 : 0; ra.Rc = p.Rc; ra.rl = p.rl; ra.kdim = p.kdim; ra.kb = p.kb; ra.ka = p.ka; ra.qsing = p.qsing; ra.wave = h->no_rec_wave ? 0 : 1;
     ra.pair_bmax = h->pair_bmax >= 0 ? h->pair_bmax : 4 * h->num_cu;
     ra.A = pp.A; ra.Q = pp.Q; ra.mu0 = pp.mu0; ra.P0 = pp.P0;
     ra.bcol = ca.bcol; ra.scol = ca.scol; ra.nobs = ca.nobs; ra.ldrow = ca.ldrow; ra.Ct = ca.Ct;
@@ -941,7 +941,7 @@ int varp_run(dfm_handle* h, int B, int T, int N, int r, int nlag, const double* 
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
     HIP_TRY(h, hipSetDevice(h->device));
     Plan p = make_plan(B, T, N, k, flags | DFM_F_SINGULAR_Q, em, false);
-    p.Rc = pad_r(r); p.rl = r; p.kdim = k;
+    p.Rc = pad_r(r); p.rl = r; p.kdim = k; p.qsing = (flags & DFM_F_SINGULAR_Q) ? 1 : 0;
     if (int rc = ensure_ws(h, p.total)) return rc;
     const int Rk = p.Rp, Rc = p.Rc;
     double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
@@ -1029,6 +1029,8 @@ int ar_pass_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, cons
     HIP_TRY(h, hipSetDevice(h->device));
     const int Tq = T - q;
     Plan p = make_plan(B, Tq, N, k, flags | DFM_F_SINGULAR_Q, false, false);
+    p.kdim = k; p.kb = r; p.ka = r * nlag;                   // (the companion structure: recursion_comp.hip's route; collapse width)
+    p.qsing = (flags & DFM_F_SINGULAR_Q) ? 1 : 0;
     const size_t xoff = (p.total + 255) & ~(size_t)255;
     if (int rc = ensure_ws(h, xoff + (size_t)B * Tq * N * sizeof(double))) return rc;
     const int Rk = p.Rp;
@@ -1076,6 +1078,7 @@ int ar_em_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, const 
     HIP_TRY(h, hipSetDevice(h->device));
     const int Tq = T - q;
     Plan p = make_plan(B, Tq, N, k, flags | DFM_F_SINGULAR_Q, true, false);
+    p.qsing = (flags & DFM_F_SINGULAR_Q) ? 1 : 0;
     p.kdim = k; p.kb = r; p.ka = r * nlag;                   // companion constraints; the observation loads on q + 1 blocks (rl = 0)
     const size_t xoff = (p.total + 255) & ~(size_t)255;
     if (int rc = ensure_ws(h, xoff + (size_t)B * Tq * N * sizeof(double))) return rc;

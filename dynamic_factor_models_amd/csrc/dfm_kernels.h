@@ -118,6 +118,8 @@ struct RecursionArgs {
                           // (recursion_pair.hip); 0: never
     int ka;               // > 0 with kdim: only the first ka = r p columns of the transition rows are free (a VAR(p) inside a
                           // state that carries m > p lags); 0: all kdim columns
+    int qsing;            // 1 with kdim: the caller passed DFM_F_SINGULAR_Q -- the r x r innovation block itself may be rank deficient:
+                          // keep the kernels that never invert it (recursion_comp.hip inverts the block and is skipped)
     int ct_r;             // > 0: Ct holds the packed leading ct_r x ct_r block per period (see CollapseArgs::ct_r; recursion_tile only)
     int rstate;           // the model's state width before padding (0: unknown) -- recursion_tile.hip executes ceil(rstate / 4) of
                           // the 8 block pivots / k-steps of a 32-wide state and keeps the mean vectors in (padding) column 31

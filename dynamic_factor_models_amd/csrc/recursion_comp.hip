@@ -654,6 +654,7 @@ bool recursion_comp_supported(int Rpad, const RecursionArgs& a) {
     if (!var && !ar) return false;
     if (a.r > Rpad || a.ZJtab == nullptr) return false;
     if (a.S11 && !a.A_out) return false;
+    if (a.qsing) return false;                                    // the r x r innovation block is inverted here
     return true;
 }
 

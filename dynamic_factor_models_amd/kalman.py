@@ -408,15 +408,17 @@ class DfmContext:
 
     # ------------------------------------------------------------------ VAR(p) factor dynamics (companion form)
     def ks_pass_varp_batch(self, panel, Lam, R, Avar, Q, mu0, P0, want_P: bool = True,
-                           may_have_missing: Optional[bool] = None):
+                           may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """Smoother pass of x_t = Lam f_t + e_t, f_t = A_1 f_{t-1} + .. + A_p f_{t-p} + eta_t (device tensors).
-        Avar [B,r,r p] = [A_1 .. A_p], Q [B,r,r], mu0 [B,r p], P0 [B,r p,r p].  Returns (f_smooth, P_smooth, loglik)."""
+        Avar [B,r,r p] = [A_1 .. A_p], Q [B,r,r], mu0 [B,r p], P0 [B,r p,r p].  Returns (f_smooth, P_smooth, loglik).
+        singular_q (here and in the other VAR(p) / AR entry points): the r x r block Q itself may be rank deficient -- DFM_F_SINGULAR_Q,
+        the kernels that never invert it (include/dfm_hip.h)."""
         torch = self._torch
         B, T, N = panel.shape
         r = Lam.shape[2]
         k = Avar.shape[2]
         p = k // r
-        flags = self._flags(panel, may_have_missing)
+        flags = self._flags(panel, may_have_missing, singular_q)
         f = torch.empty((B, T, r), dtype=torch.float64, device=panel.device)
         P = torch.empty((B, T, r * (r + 1) // 2), dtype=torch.float64, device=panel.device) if want_P else None
         ll = torch.empty((B,), dtype=torch.float64, device=panel.device)
@@ -430,7 +432,7 @@ class DfmContext:
         return f, P, ll
 
     def em_varp_batch(self, panel, Lam, R, Avar, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
-                      want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None):
+                      want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """EM for the VAR(p) model, parameters (device tensors) updated in place.
         Returns (loglik_path [B,max_iter], iters [B] int32, f_smooth, P_smooth)."""
         torch = self._torch
@@ -438,7 +440,7 @@ class DfmContext:
         r = Lam.shape[2]
         k = Avar.shape[2]
         p = k // r
-        flags = self._flags(panel, may_have_missing)
+        flags = self._flags(panel, may_have_missing, singular_q)
         dev = panel.device
         path = torch.empty((B, max_iter), dtype=torch.float64, device=dev)
         iters = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -456,7 +458,7 @@ class DfmContext:
         return path, iters, f, P
 
     def em_varp_batch_host(self, panel, Lam, R, Avar, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
-                           may_have_missing: Optional[bool] = None):
+                           may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """Host-pointer entry (what Julia's ccall binds).  Returns (params dict, loglik_path, iters, f_smooth,
         P_smooth); inputs are not modified."""
         c = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
@@ -467,7 +469,7 @@ class DfmContext:
         p_lag = Avar.shape[2] // r
         if may_have_missing is None:
             may_have_missing = bool(np.isnan(panel).any())
-        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
         path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
         f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2))
         p = lambda a: ctypes.c_void_p(a.ctypes.data)
@@ -476,7 +478,7 @@ class DfmContext:
         _check(self._h, rc)
         return dict(Lam=Lam, R=R, Avar=Avar, Q=Q, mu0=mu0, P0=P0), path, iters, f, P
 
-    def ks_pass_varp_batch_host(self, panel, Lam, R, Avar, Q, mu0, P0, may_have_missing: Optional[bool] = None):
+    def ks_pass_varp_batch_host(self, panel, Lam, R, Avar, Q, mu0, P0, may_have_missing: Optional[bool] = None, singular_q: bool = False):
         c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         panel, Lam, R, Avar, Q, mu0, P0 = map(c, (panel, Lam, R, Avar, Q, mu0, P0))
         B, T, N = panel.shape
@@ -484,7 +486,7 @@ class DfmContext:
         p_lag = Avar.shape[2] // r
         if may_have_missing is None:
             may_have_missing = bool(np.isnan(panel).any())
-        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
         f = np.empty((B, T, r)); P = np.empty((B, T, r * (r + 1) // 2)); ll = np.empty(B)
         p = lambda a: ctypes.c_void_p(a.ctypes.data)
         rc = self._lib.dfm_ks_pass_varp_batch(self._h, B, T, N, r, p_lag, p(panel), p(Lam), p(R), p(Avar), p(Q), p(mu0),
@@ -494,7 +496,7 @@ class DfmContext:
 
     # ------------------------------------------------------------------ AR idiosyncratic terms (quasi-differencing)
     def ks_pass_ar_batch(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, want_P: bool = True,
-                         may_have_missing: Optional[bool] = None):
+                         may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """Smoother pass with AR(q) idiosyncratic terms (rho [B,N,q], sig2 [B,N]: the reference's uar_coef, uar_ser^2)
         and VAR(p) factors (Avar [B,r,r p]); mu0 [B,r m], P0 [B,r m,r m], m = max(p, q+1).  Device tensors.
         Returns (f_smooth [B,T-q,r], P_smooth or None, loglik [B]) for rows q+1..T."""
@@ -504,7 +506,7 @@ class DfmContext:
         p = Avar.shape[2] // r
         q = rho.shape[2]
         k = r * max(p, q + 1)
-        flags = self._flags(panel, may_have_missing)
+        flags = self._flags(panel, may_have_missing, singular_q)
         f = torch.empty((B, T - q, r), dtype=torch.float64, device=panel.device)
         P = torch.empty((B, T - q, r * (r + 1) // 2), dtype=torch.float64, device=panel.device) if want_P else None
         ll = torch.empty((B,), dtype=torch.float64, device=panel.device)
@@ -518,7 +520,7 @@ class DfmContext:
         _check(self._h, rc)
         return f, P, ll
 
-    def ks_pass_ar_batch_host(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, may_have_missing: Optional[bool] = None):
+    def ks_pass_ar_batch_host(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """Host-pointer entry (what Julia's ccall binds)."""
         c = lambda a: np.ascontiguousarray(a, dtype=np.float64)
         panel, Lam, sig2, rho, Avar, Q, mu0, P0 = map(c, (panel, Lam, sig2, rho, Avar, Q, mu0, P0))
@@ -528,7 +530,7 @@ class DfmContext:
         q = rho.shape[2]
         if may_have_missing is None:
             may_have_missing = bool(np.isnan(panel).any())
-        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
         f = np.empty((B, T - q, r)); P = np.empty((B, T - q, r * (r + 1) // 2)); ll = np.empty(B)
         p = lambda a: ctypes.c_void_p(a.ctypes.data) if a.size else None
         rc = self._lib.dfm_ks_pass_ar_batch(self._h, B, T, N, r, p_lag, q, p(panel), p(Lam), p(sig2), p(rho), p(Avar), p(Q),
@@ -537,7 +539,7 @@ class DfmContext:
         return f, P, ll
 
     def em_ar_batch(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
-                    want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None):
+                    want_smooth: bool = True, want_P: bool = True, may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """Joint ECM estimation with AR(q) idiosyncratic terms (include/dfm_hip.h: dfm_em_ar_batch_dev).  Device tensors;
         Lam [B,N,r], sig2 [B,N], rho [B,N,q], Avar [B,r,r p], Q, mu0 [B,r m], P0 [B,r m,r m] are UPDATED IN PLACE.
         Returns (loglik_path [B,max_iter], iters [B], f_smooth [B,T-q,r] or None, P_smooth or None)."""
@@ -547,7 +549,7 @@ class DfmContext:
         p = Avar.shape[2] // r
         q = rho.shape[2]
         k = r * max(p, q + 1)
-        flags = self._flags(panel, may_have_missing)
+        flags = self._flags(panel, may_have_missing, singular_q)
         dev = panel.device
         path = torch.empty((B, max_iter), dtype=torch.float64, device=dev)
         iters = torch.empty((B,), dtype=torch.int32, device=dev)
@@ -565,7 +567,7 @@ class DfmContext:
         return path, iters, f, P
 
     def em_ar_batch_host(self, panel, Lam, sig2, rho, Avar, Q, mu0, P0, max_iter: int = 10, tol: float = 0.0,
-                         may_have_missing: Optional[bool] = None):
+                         may_have_missing: Optional[bool] = None, singular_q: bool = False):
         """Host-pointer entry (what Julia's ccall binds).  Returns (params dict, loglik_path, iters, f_smooth, P_smooth);
         inputs are not modified."""
         c = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
@@ -577,7 +579,7 @@ class DfmContext:
         q = rho.shape[2]
         if may_have_missing is None:
             may_have_missing = bool(np.isnan(panel).any())
-        flags = _lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0
+        flags = (_lib.DFM_F_MAY_HAVE_MISSING if may_have_missing else 0) | (_lib.DFM_F_SINGULAR_Q if singular_q else 0)
         path = np.empty((B, max_iter)); iters = np.empty(B, dtype=np.int32)
         f = np.empty((B, T - q, r)); P = np.empty((B, T - q, r * (r + 1) // 2))
         p = lambda a: ctypes.c_void_p(a.ctypes.data) if a.size else None

@@ -220,6 +220,9 @@ int dfm_ks_pass_batch_multi(int ngpu, const int* device_ids, int B, int T, int N
  * z_t = (f_t, .., f_{t-p+1}), k = r p <= DFM_MAX_R, transition [A_1 .. A_p; I 0], innovation covariance [Q 0; 0 0]
  * (singular: covariance-form recursion, as with DFM_F_SINGULAR_Q).
  *   Avar [B][r][r p] = [A_1 .. A_p],  Q [B][r][r],  mu0 [B][r p], P0 [B][r p][r p] = moments of z_0 (P0 positive definite)
+ * Q itself (the r x r block) positive definite, or pass DFM_F_SINGULAR_Q: at r = 4 the companion recursion eliminates the state
+ * in 4 x 4 blocks and inverts that block (recursion_comp.hip; a block that is not positive definite gives a NaN log-likelihood =
+ * DFM_E_NUMERIC); with the flag the kernels that never invert it run instead (slower at r = 4).  Same for dfm_*_ar_*.
  * Outputs as dfm_ks_pass_batch / dfm_em_batch, for f_t = z_t[:r].  The M-step re-estimates Lam, R, [A_1..A_p], Q,
  * mu0, P0 and keeps the companion structure (oracle/varp_oracle.py).  p = 1 is dfm_em_batch's model. */
 int dfm_ks_pass_varp_batch_dev(dfm_handle* h, int B, int T, int N, int r, int p, const double* panel,

@@ -286,7 +286,8 @@ end
 
 "EM for VAR(p) factor dynamics in companion form (dfm_em_varp_batch; include/dfm_hip.h): p.Avar is r x (r p) =
 [A_1 .. A_p], p.mu0 / p.P0 the moments of z_0 = (f_0, .., f_{1-p})."
-function em_varp(h::Handle, z::Matrix{Float64}, p, nlag::Integer; max_iter::Integer = 50, tol::Real = 1e-6)
+function em_varp(h::Handle, z::Matrix{Float64}, p, nlag::Integer; max_iter::Integer = 50, tol::Real = 1e-6,
+                 singular_q::Bool = false)   # singular_q: the r x r block Q may be rank deficient (DFM_F_SINGULAR_Q)
     T, N = size(z); r = size(p.Lam, 2); k = r * nlag
     panel = to_c_panel(z)
     Lam = reshape(permutedims(p.Lam), r, N, 1); R = reshape(copy(p.R), N, 1)
@@ -294,7 +295,7 @@ function em_varp(h::Handle, z::Matrix{Float64}, p, nlag::Integer; max_iter::Inte
     mu0 = reshape(copy(p.mu0), k, 1); P0 = reshape(permutedims(p.P0), k, k, 1)
     path = Array{Float64}(undef, max_iter, 1); iters = Array{Cint}(undef, 1)
     f = Array{Float64}(undef, r, T, 1); np = div(r * (r + 1), 2); P = Array{Float64}(undef, np, T, 1)
-    flags = any(isnan, z) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    flags = (any(isnan, z) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)) | (singular_q ? DFM_F_SINGULAR_Q : Cuint(0))
     GC.@preserve panel Lam R Avar Q mu0 P0 path iters f P begin
         rc = ccall((:dfm_em_varp_batch, LIB), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
@@ -313,13 +314,14 @@ end
 deviations from its intercept), Lam N x r, sig2 = uar_ser.^2, rho = uar_coef (N x q), Avar r x (r p), Q r x r, mu0 / P0
 the moments of z_q, r max(p, q+1) wide.  Returns the smoothed factors of rows q+1..T and the conditional log-likelihood."
 function ks_pass_ar(h::Handle, x::Matrix{Float64}, Lam::Matrix{Float64}, sig2::Vector{Float64}, rho::Matrix{Float64},
-                    Avar::Matrix{Float64}, Q::Matrix{Float64}, mu0::Vector{Float64}, P0::Matrix{Float64})
+                    Avar::Matrix{Float64}, Q::Matrix{Float64}, mu0::Vector{Float64}, P0::Matrix{Float64};
+                    singular_q::Bool = false)
     T, N = size(x); r = size(Lam, 2); q = size(rho, 2); p = div(size(Avar, 2), r)
     panel = to_c_panel(x)
     LamC = permutedims(Lam); rhoC = permutedims(rho); AC = permutedims(Avar); QC = permutedims(Q); P0C = permutedims(P0)
     f = Array{Float64}(undef, r, T - q); np = div(r * (r + 1), 2); P = Array{Float64}(undef, np, T - q)
     ll = Array{Float64}(undef, 1)
-    flags = any(isnan, x) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    flags = (any(isnan, x) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)) | (singular_q ? DFM_F_SINGULAR_Q : Cuint(0))
     GC.@preserve panel LamC sig2 rhoC AC QC mu0 P0C f P ll begin
         rc = ccall((:dfm_ks_pass_ar_batch, LIB), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
@@ -336,14 +338,14 @@ Arguments as ks_pass_ar (the start: what `estimate!(m)` left in the model).  Ret
 log-likelihood path (conditional on the first q rows; non-decreasing) and the smoothed factors of rows q+1..T."
 function em_ar(h::Handle, x::Matrix{Float64}, Lam::Matrix{Float64}, sig2::Vector{Float64}, rho::Matrix{Float64},
                Avar::Matrix{Float64}, Q::Matrix{Float64}, mu0::Vector{Float64}, P0::Matrix{Float64};
-               max_iter::Integer = 20, tol::Real = 1e-6)
+               max_iter::Integer = 20, tol::Real = 1e-6, singular_q::Bool = false)
     T, N = size(x); r = size(Lam, 2); q = size(rho, 2); p = div(size(Avar, 2), r)
     panel = to_c_panel(x)
     LamC = permutedims(Lam); sig = copy(sig2); rhoC = permutedims(rho); AC = permutedims(Avar); QC = permutedims(Q)
     mu = copy(mu0); P0C = permutedims(P0)
     path = Array{Float64}(undef, max_iter); iters = Array{Cint}(undef, 1)
     f = Array{Float64}(undef, r, T - q); np = div(r * (r + 1), 2); P = Array{Float64}(undef, np, T - q)
-    flags = any(isnan, x) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)
+    flags = (any(isnan, x) ? DFM_F_MAY_HAVE_MISSING : Cuint(0)) | (singular_q ? DFM_F_SINGULAR_Q : Cuint(0))
     GC.@preserve panel LamC sig rhoC AC QC mu P0C path iters f P begin
         rc = ccall((:dfm_em_ar_batch, LIB), Cint,
                    (Ptr{Cvoid}, Cint, Cint, Cint, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},

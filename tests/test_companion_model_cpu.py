@@ -23,7 +23,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("N,T,r,p,miss", [(139, 222, 4, 4, 0.1), (30, 40, 3, 2, 0.3), (20, 50, 2, 3, 0.6), (40, 30, 4, 7, 0.05)])
+@pytest.mark.parametrize("N,T,r,p,miss", [(139, 222, 4, 4, 0.1), (30, 40, 3, 2, 0.3), (20, 50, 2, 3, 0.6), (40, 60, 4, 7, 0.05)])
 def test_block_elimination_reproduces_the_varp_oracle(N, T, r, p, miss):
     x = vo.synth_varp(5, N, T, r, p, missing=miss)
     q, _ = vo.varp_init(np.nan_to_num(x), r, p)

@@ -179,3 +179,30 @@ def test_mbf16_edge_shapes(ctx, N, T, r, p):
         assert abs(ll[b].item() - o["loglik"]) <= 1e-9 * abs(o["loglik"])
         _close(f[b].cpu().numpy(), o["f_smooth"][:, :r], 1e-9, "f_smooth")
         _close(P[b].cpu().numpy(), o["P_smooth"][:, :r, :r][:, tri[0], tri[1]], 1e-9, "P_smooth")
+
+
+def test_rank_deficient_innovation_block_at_r4(ctx):
+    """r = 4: recursion_comp_kernel eliminates the companion state in 4 x 4 blocks and inverts the r x r block Q.  A rank-deficient Q is
+    reported (NaN log-likelihood on the device entry, DFM_E_NUMERIC on the host entry) and DFM_F_SINGULAR_Q runs the kernels that never
+    invert it -- the oracle's covariance form has no such condition."""
+    import torch
+    from dynamic_factor_models_amd._lib import DfmError
+    r, p, N, T = 4, 3, 30, 60
+    x = vo.synth_varp(9, N, T, r, p, missing=0.1)
+    q, _ = vo.varp_init(np.nan_to_num(x), r, p)
+    G = np.linalg.cholesky(q["Q"])[:, :3]
+    q["Q"] = G @ G.T                                                        # rank 3
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = [t(q[k][None]) for k in KEYS]
+    _, _, ll = ctx.ks_pass_varp_batch(t(x[None]), *args)
+    assert not np.isfinite(ll[0].item())
+    with pytest.raises(DfmError) as e:
+        ctx.ks_pass_varp_batch_host(x[None], *[q[k][None] for k in KEYS])
+    assert e.value.code == -5
+    f, P, ll = ctx.ks_pass_varp_batch(t(x[None]), *args, singular_q=True)
+    o = vo.kfs_pass_varp(x, p=p, **q)
+    assert abs(ll[0].item() - o["loglik"]) <= 1e-9 * abs(o["loglik"])
+    _close(f[0].cpu().numpy(), o["f_smooth"][:, :r], 1e-9, "f_smooth, singular Q")
+    f2, _, ll2 = ctx.ks_pass_varp_batch_host(x[None], *[q[k][None] for k in KEYS], singular_q=True)
+    assert abs(ll2[0] - o["loglik"]) <= 1e-9 * abs(o["loglik"])
