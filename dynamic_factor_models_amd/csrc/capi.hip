@@ -744,7 +744,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
     }
     h->ck_fail_dev = nullptr; h->ck_fail_n = 0;
     if (ra.wave && recursion_chunk_supported(p.Rp, ra)) { h->ck_fail_dev = ra.chunk_fail; h->ck_fail_n = B; }
-    else if (ra.wave && recursion_tile_supported(p.Rp, ra) && recursion_tile_chunks(ra, nullptr, nullptr) > 1) { h->ck_fail_dev = ra.chunk_fail; h->ck_fail_n = B; }
+    else if (ra.wave && recursion_tile_supported(p.Rp, ra) && recursion_tile_writes_fail(ra)) { h->ck_fail_dev = ra.chunk_fail; h->ck_fail_n = B; }
     { ProfScope ps(h, K_RECURSION); HIP_TRY(h, launch_recursion(p.Rp, ra, h->stream)); }
     return 0;
 }

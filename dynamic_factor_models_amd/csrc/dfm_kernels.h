@@ -163,6 +163,7 @@ hipError_t launch_recursion_wave8_fallback(const RecursionArgs& a, hipStream_t s
 bool recursion_tile_supported(int Rpad, const RecursionArgs& a);
 hipError_t launch_recursion_tile(const RecursionArgs& a, hipStream_t s);
 int recursion_tile_chunks(const RecursionArgs& a, int* lc_out, int* w_out);   // chunks per replicate the launch will use (1: sequential)
+bool recursion_tile_writes_fail(const RecursionArgs& a);      // the launch checks chunk boundaries / writes chunk_fail (recursion_tile1_kernel or chunks > 1)
 size_t recursion_tile_scratch_bytes(int B, int T);            // tile_scr
 
 struct MstepArgs {

@@ -630,6 +630,678 @@ __global__ __launch_bounds__(256, CH ? 2 : 1) void recursion_tile_kernel(Recursi
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// recursion_tile1_kernel (round 6): the same recursion, the same chunks, the same scratch and tables -- ONE WAVE per (replicate,
+// chunk) that holds ALL FOUR tiles of every matrix (t[I][J]: 16 registers per lane).  What recursion_tile_kernel pays for its four
+// waves: nine 4-wave barriers and four LDS exchanges per period around 30 matrix instructions per wave -- 6.9 us per period of a
+// workgroup, a third of the matrix pipe busy with two workgroups per CU.  In one wave a D-layout matrix IS the B operand of a product
+// and the A operand of its transpose, tile by tile, as it stands: no exchange, no barrier; what is left in LDS is the pivot rows of the
+// block sweep (512 bytes per pivot, the wave's own in-order LDS queue) and three constant matrices that are only ever used
+// element-wise (Phi, Qi, Cfull).  120 matrix instructions per period and wave, 4 x as many independent chains per CU.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct M32 { v4d t[2][2]; };                       // t[I][J]: lane (q, c), register v = element (16 I + q + 4 v, 16 J + c)
+
+constexpr int kT1Praw = 0;                         // [32 columns][4 pivot rows]
+constexpr int kT1Phi = 128;                        // three matrices in the register-pair tile layout
+constexpr int kT1Qi = kT1Phi + 4 * kRtTile;
+constexpr int kT1Cf = kT1Qi + 4 * kRtTile;
+
+// the wave's own LDS writes are visible to its later reads (one in-order queue): only the compiler must not move them
+__device__ __forceinline__ void t1_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void t1_ld_g(const double* tab, int lane, M32& m) {
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) m.t[I][J] = ld_tile_g(tab, 2 * I + J, lane);
+}
+__device__ __forceinline__ void t1_st_g(double* tab, int lane, const M32& m) {
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) st_tile_g(tab, 2 * I + J, lane, m.t[I][J]);
+}
+__device__ __forceinline__ void t1_ld_s(const double* buf, int lane, M32& m) {
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) m.t[I][J] = ld_tile(buf, 2 * I + J, lane);
+}
+__device__ __forceinline__ void t1_st_s(double* buf, int lane, const M32& m) {
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J) st_tile(buf, 2 * I + J, lane, m.t[I][J]);
+}
+
+// out = init + Y'X over the first nks k-steps: tile (I, J) takes register s of Y's tile (kb, I) as the A operand and register s of
+// X's tile (kb, J) as the B operand -- the four accumulators are independent chains of the matrix pipe
+__device__ __forceinline__ void t1_mm(const M32& Y, const M32& X, int nks, const M32& init, M32& out) {
+    v4d a00 = init.t[0][0], a01 = init.t[0][1], a10 = init.t[1][0], a11 = init.t[1][1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][0][s], X.t[0][0][s], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][0][s], X.t[0][1][s], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][1][s], X.t[0][0][s], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][1][s], X.t[0][1][s], a11, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (4 + s < nks) {                                       // (wave-uniform)
+            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[1][0][s], X.t[1][0][s], a00, 0, 0, 0);
+            a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[1][0][s], X.t[1][1][s], a01, 0, 0, 0);
+            a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[1][1][s], X.t[1][0][s], a10, 0, 0, 0);
+            a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[1][1][s], X.t[1][1][s], a11, 0, 0, 0);
+        }
+    out.t[0][0] = a00; out.t[0][1] = a01; out.t[1][0] = a10; out.t[1][1] = a11;
+}
+
+// out = Y'X (accumulators start from the inline constant 0: no registers of zeros)
+__device__ __forceinline__ void t1_mm0(const M32& Y, const M32& X, int nks, M32& out) {
+    const v4d z = {0.0, 0.0, 0.0, 0.0};
+    v4d a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][0][0], X.t[0][0][0], z, 0, 0, 0);
+    v4d a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][0][0], X.t[0][1][0], z, 0, 0, 0);
+    v4d a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][1][0], X.t[0][0][0], z, 0, 0, 0);
+    v4d a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][1][0], X.t[0][1][0], z, 0, 0, 0);
+#pragma unroll
+    for (int s = 1; s < 4; ++s) {
+        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][0][s], X.t[0][0][s], a00, 0, 0, 0);
+        a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][0][s], X.t[0][1][s], a01, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][1][s], X.t[0][0][s], a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[0][1][s], X.t[0][1][s], a11, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (4 + s < nks) {                                       // (wave-uniform)
+            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[1][0][s], X.t[1][0][s], a00, 0, 0, 0);
+            a01 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[1][0][s], X.t[1][1][s], a01, 0, 0, 0);
+            a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[1][1][s], X.t[1][0][s], a10, 0, 0, 0);
+            a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(Y.t[1][1][s], X.t[1][1][s], a11, 0, 0, 0);
+        }
+    out.t[0][0] = a00; out.t[0][1] = a01; out.t[1][0] = a10; out.t[1][1] = a11;
+}
+
+__device__ __forceinline__ double t1_readlane(double x, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+
+// rt_sweep_inverse in one wave: the pivot block D comes out of the registers by v_readlane (the pivot is unrolled: constant lanes),
+// the four pivot rows of the lane's two columns through 512 bytes of LDS, the A operand is the lane's own published value
+// SIDE: k-step p of the product sacc += sY'sX rides behind pivot p's four matrix instructions -- it executes in the shadow of the NEXT
+// pivot's scalar chain (readlanes, LDL', LDS round trip), which waits for the pivot's own results only (npiv = number of k-steps)
+template <bool SIDE>
+__device__ __forceinline__ double t1_sweep_inverse(double* praw, M32& m, int npiv, int q, int c, const M32* sY = nullptr, const M32* sX = nullptr,
+                                                   M32* sacc = nullptr) {
+    double det = 1.0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p < npiv) {                                          // (wave-uniform)
+            const int Ik = p >> 2, vk = p & 3, ck = 4 * (p & 3);
+            const bool inblk = (c >= ck) && (c < ck + 4);        // (in tile column Ik)
+            double val[2];
+            val[0] = m.t[Ik][0][vk];
+            val[1] = m.t[Ik][1][vk];
+            const double vd = val[Ik];
+            const double D00 = t1_readlane(vd, ck), D10 = t1_readlane(vd, 16 + ck), D20 = t1_readlane(vd, 32 + ck), D30 = t1_readlane(vd, 48 + ck);
+            const double D11 = t1_readlane(vd, 16 + ck + 1), D21 = t1_readlane(vd, 32 + ck + 1), D31 = t1_readlane(vd, 48 + ck + 1);
+            const double D22 = t1_readlane(vd, 32 + ck + 2), D32 = t1_readlane(vd, 48 + ck + 2), D33 = t1_readlane(vd, 48 + ck + 3);
+            if (inblk) val[Ik] = (c - ck == q) ? -1.0 : 0.0;
+            praw[c * 4 + q] = val[0];
+            praw[(16 + c) * 4 + q] = val[1];
+            t1_lds_fence();
+            const double2* pr = reinterpret_cast<const double2*>(praw);
+            const double2 pa0 = pr[c * 2], pb0 = pr[c * 2 + 1], pa1 = pr[(16 + c) * 2], pb1 = pr[(16 + c) * 2 + 1];
+            const double i0 = fast_rcp3(D00);
+            const double l10 = D10 * i0, l20 = D20 * i0, l30 = D30 * i0;
+            const double e1 = fma(-l10, D10, D11);
+            const double i1 = fast_rcp3(e1);
+            const double u21 = fma(-l20, D10, D21), u31 = fma(-l30, D10, D31);
+            const double l21 = u21 * i1, l31 = u31 * i1;
+            const double e2 = fma(-l21, u21, fma(-l20, D20, D22));
+            const double i2 = fast_rcp3(e2);
+            const double u32 = fma(-l31, u21, fma(-l30, D20, D32));
+            const double l32 = u32 * i2;
+            const double e3 = fma(-l32, u32, fma(-l31, u31, fma(-l30, D30, D33)));
+            const double i3 = fast_rcp3(e3);
+            det *= (D00 * e1) * (e2 * e3);
+            double tq[2];
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                const double p0 = J ? pa1.x : pa0.x, p1 = J ? pa1.y : pa0.y, p2 = J ? pb1.x : pb0.x, p3 = J ? pb1.y : pb0.y;
+                const double y1 = fma(-l10, p0, p1);
+                const double y2 = fma(-l21, y1, fma(-l20, p0, p2));
+                const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, p0, p3)));
+                const double tq3 = y3 * i3;
+                const double tq2 = fma(-l32, tq3, y2 * i2);
+                const double tq1 = fma(-l31, tq3, fma(-l21, tq2, y1 * i1));
+                const double tq0 = fma(-l30, tq3, fma(-l20, tq2, fma(-l10, tq1, p0 * i0)));
+                tq[J] = -((q & 2) ? ((q & 1) ? tq3 : tq2) : ((q & 1) ? tq1 : tq0));
+            }
+            t1_lds_fence();                                      // (the rows are read before the next pivot publishes its own)
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J) {
+                    v4d acc = m.t[I][J];
+                    if (I == Ik) acc[vk] = 0.0;                  // pivot rows ...
+                    if (J == Ik && inblk) { acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0; }   // ... and pivot columns start from zero
+                    m.t[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[I], tq[J], acc, 0, 0, 0);
+                }
+            if constexpr (SIDE) {
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J)
+                        sacc->t[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(sY->t[Ik][I][vk], sX->t[Ik][J][vk], sacc->t[I][J], 0, 0, 0);
+            }
+        }
+    }
+    const int lim = 4 * npiv;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) m.t[I][J][v] = (16 * J + c < lim && 16 * I + q + 4 * v < lim) ? -m.t[I][J][v] : m.t[I][J][v];
+    return det;
+}
+}  // namespace
+
+namespace {
+using t1_lds_cptr = __attribute__((address_space(3))) char*;
+// One LDS-DMA instruction: lane l copies 16 bytes from gbase + voff to LDS byte lds_dst + 16 l -- nothing lands in a VGPR until the
+// arithmetic asks for it.  gbase, lds_dst wave-uniform.  t1_dma16: lanes 0 .. 15 only (a 256-byte row).
+__device__ __forceinline__ void t1_dma(const void* gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void t1_dma16(const void* gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    unsigned long long ex;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b64 %1, exec\n\ts_mov_b32 m0, %4\n\ts_mov_b64 exec, 0xffff\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
+}
+// a 16-KB table entry (16 rows of 1 KB) in one block: m0 and the offset step by 1 KB
+#define DFM_T1_DMA_ROW "s_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tv_add_u32 %1, 0x400, %1\n\ts_add_u32 m0, m0, 0x400\n\t"
+#define DFM_T1_DMA_ROW4 DFM_T1_DMA_ROW DFM_T1_DMA_ROW DFM_T1_DMA_ROW DFM_T1_DMA_ROW
+__device__ __forceinline__ void t1_dma_entry(const void* gbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\t" DFM_T1_DMA_ROW4 DFM_T1_DMA_ROW4 DFM_T1_DMA_ROW4 DFM_T1_DMA_ROW4 "s_mov_b32 m0, %0"
+                 : "=&s"(keep), "+v"(voff) : "s"(gbase), "s"(lds_dst) : "memory", "scc");
+}
+__device__ __forceinline__ void t1_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+constexpr int kT1QiC = kT1Qi;                      // Qi, plus Cfull where the lane's element lies outside the C_t block
+constexpr int kT1Stg = kT1Cf + 4 * kRtTile;        // forward: two stages of [C_t row, whole KBs of DMA | b_t row | a zero]
+// a stage: [rows area: a packed C_t / Z row in whole KBs of DMA | a 32-vector (b_t / w_t) | the zero, the one | 64 dump slots]
+constexpr int kT1StgB = 640, kT1StgZ = kT1StgB + 32, kT1StgOne = kT1StgZ + 1, kT1StgDump = kT1StgZ + 8, kT1StgLen = kT1StgDump + 64;
+constexpr int kT1Lds2 = kT1Stg + 2 * kT1StgLen;
+static_assert(kRt * (kRt + 1) / 2 <= kT1StgB, "a full packed C_t row fits its stage");
+}  // namespace
+
+// keeps the address arithmetic of a rarely taken branch inside the branch (hoisted out of the period loop it would sit in registers)
+template <typename P>
+__device__ __forceinline__ P* t1_here(P* p) { asm volatile("" : "+s"(p)); return p; }
+
+template <bool EM>
+__global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
+    constexpr int R = kRt, RR = R * R;
+    __shared__ __attribute__((aligned(16))) double sm[kT1Lds2];
+    const int lane = threadIdx.x, q = lane >> 4, c = lane & 15;
+    const int NC = a.tile_nc;
+    const int b = (int)blockIdx.x % a.B;
+    const int ck = (int)blockIdx.x / a.B;                     // this wave's chunk
+    const int T = a.T, N = a.N, r = a.r;
+    const bool first = ck == 0, lastc = ck == NC - 1;
+    const int Wk = a.tile_w;
+    const int s0 = ck * a.tile_lc;                             // (even: the stages go by the parity of the period)
+    const int e0 = lastc ? T : s0 + a.tile_lc;
+    const int tb = first ? 0 : s0 - Wk;
+    const int te = lastc ? T + 1 : e0 + Wk;
+    const int rs = a.rstate;
+    const int npiv = (rs + 3) >> 2, nks = npiv;
+    const bool c31 = (c == 15);                                // column 31 lives in the tiles (., 1) of these lanes
+    double* praw = sm + kT1Praw;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(t1_lds_cptr)(reinterpret_cast<char*>(sm)));
+    int zero_v;                                                // a zero the compiler cannot see through: per-lane (vector) loads of
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero_v));            // wave-uniform scalars -- their waits are vmcnt's, not the LDS queue's
+
+    const double* bcol = a.bcol + (size_t)b * T * R;
+    const double* scol = a.scol + (size_t)b * T;
+    const int* nobs = a.nobs + (size_t)b * T;
+    const double* ldrow = a.ldrow + (size_t)b * T;
+    double* ZJ = a.ZJtab + (size_t)b * (T + 1) * 2 * RR;
+    double* wtab = a.wtab + (size_t)b * T * R;
+    double* const slot = a.tile_scr + ((size_t)b * NC + ck) * tk_slot_doubles(Wk);
+    double* const xZJ = slot;
+    double* const xw = slot + (size_t)Wk * 2 * RR;
+    double* const bst = xw + (size_t)Wk * R;
+    double* const part = bst + 4 * kTkBst;
+    double* const sums = part + kTkPart;
+    auto tab_ent = [&](int t) -> double* { return t >= e0 ? xZJ + (size_t)(t - e0) * 2 * RR : ZJ + (size_t)t * 2 * RR; };
+    auto w_ent = [&](int t) -> double* { return t >= e0 ? xw + (size_t)(t - e0) * R : wtab + (size_t)t * R; };
+    auto put_state = [&](int k, const M32& M, const double (&vec)[2][4]) {
+        double* d = t1_here(bst + (size_t)k * kTkBst);
+        t1_st_g(d, lane, M);
+        if (c31) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) d[RR + 16 * I + q + 4 * v] = vec[I][v];
+        }
+    };
+    const int ctr = a.ct_r > 0 ? a.ct_r : R;
+    const int NPc = ctr * (ctr + 1) / 2;                       // (even for every ctr the library uses: rows are whole 16-byte units)
+    const unsigned rowB = (unsigned)NPc * 8u;
+    const int nC = (int)((rowB + 1023u) >> 10);                // DMA instructions per C_t row
+    int pkB[2][2][4];                                          // byte offset of the lane's element in a stage (the zero outside the block)
+    unsigned cinm = 0;                                         // bit 8 I + 4 J + v: the element lies inside the C_t block
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 16 * I + q + 4 * v, j = 16 * J + c;
+                const bool in = i < ctr && j < ctr;
+                if (in) cinm |= 1u << (8 * I + 4 * J + v);
+                pkB[I][J][v] = in ? 8 * ((i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i) : 8 * kT1StgZ;
+            }
+
+    // The table entry of a period is the PACKED lower triangle of the leading rb x rb block of Z (rb = 4 npiv: 210 doubles at r = 20 where
+    // the tile layout of (Z, J') took 2048) -- the rest of Z is the identity padding and J' = K Z is rebuilt by the backward step: an entry
+    // written and read back is 2 x 1.7 KB of HBM traffic instead of 2 x 16 KB (the kernel was bound by that traffic: 17 GB per pass).
+    const int rb = 4 * npiv;
+    const unsigned rowZB = (unsigned)(rb * (rb + 1) / 2) * 8u;
+    const int nZ = (int)((rowZB + 1023u) >> 10);
+    auto zoff = [&](int I, int J, int v, bool gather) -> int {
+        const int i = 16 * I + q + 4 * v, j = 16 * J + c;
+        const bool in = i < rb && j < rb;
+        if (gather) return in ? 8 * ((i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i) : 8 * (i == j ? kT1StgOne : kT1StgZ);
+        return (in && i >= j) ? 8 * (i * (i + 1) / 2 + j) : 8 * (kT1StgDump + lane);
+    };
+    // Z (tile layout) -> its packed row at `ent` (+ a 32-vector behind the rows when vec != nullptr), through the rows area of LDS stage `stg`
+    auto put_packed = [&](double* stg, double* ent, const M32& Zm) {
+        char* sb = reinterpret_cast<char*>(stg);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) *reinterpret_cast<double*>(sb + zoff(I, J, v, false)) = Zm.t[I][J][v];
+        t1_lds_fence();
+        for (int k = 0; k < nZ; ++k) {                           // (uniform)
+            const unsigned o = (unsigned)lane * 16u + ((unsigned)k << 10);
+            if (o < rowZB) *reinterpret_cast<double2*>(reinterpret_cast<char*>(ent) + o) = *reinterpret_cast<const double2*>(sb + o);
+        }
+        t1_lds_fence();
+    };
+    // the packed row of an entry (+ the 32-vector at vsrc) by LDS-DMA into stage (byte address dst)
+    auto dma_packed = [&](const double* ent, const double* vsrc, unsigned dst) {
+        for (int k = 0; k < nZ; ++k) {                           // (uniform)
+            unsigned vo = (unsigned)lane * 16u + ((unsigned)k << 10);
+            vo = vo < rowZB - 16u ? vo : rowZB - 16u;
+            t1_dma(ent, vo, dst + ((unsigned)k << 10));
+        }
+        t1_dma16(vsrc, (unsigned)(lane & 15) * 16u, dst + 8u * kT1StgB);
+    };
+    auto get_packed = [&](const double* stg, M32& Zm) {
+        const char* sb = reinterpret_cast<const char*>(stg);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Zm.t[I][J][v] = *reinterpret_cast<const double*>(sb + zoff(I, J, v, true));
+    };
+
+    // ---------------- prologue ---------------------------------------------------------------------------------------------
+    M32 Omf, Kt;
+    double xi[2][4];                                           // (column-31 lanes) xi_t
+    double qacc = 0.0;
+    double ldet0 = 0.0;                                        // log det P0 + T log det Q (the first chunk's part)
+    {
+        M32 Qi, Ael, Cf, Km, Phi;
+        double mu0v[2][4];
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const size_t o = (size_t)b * RR + (16 * I + q + 4 * v) * R + 16 * J + c;
+                    Qi.t[I][J][v] = a.Q[o]; Omf.t[I][J][v] = a.P0[o]; Ael.t[I][J][v] = a.A[o]; Cf.t[I][J][v] = a.Cfull[o];
+                }
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) mu0v[I][v] = a.mu0[(size_t)b * R + 16 * I + q + 4 * v];
+        double dets[2];
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {                            // Q^-1, then P0^-1: one copy of the sweep's code
+            M32 m = k ? Omf : Qi;
+            dets[k] = t1_sweep_inverse<false>(praw, m, npiv, q, c);
+            if (k) Omf = m; else Qi = m;
+        }
+        ldet0 = log(dets[1]) + (double)T * log(dets[0]);
+        t1_mm0(Ael, Qi, nks, Kt);                                // K' = A'Qi
+        t1_mm0(Qi, Ael, nks, Km);                                // K  = Qi A
+        t1_mm0(Km, Ael, nks, Phi);                               // Phi = K'A
+        t1_st_s(sm + kT1Phi, lane, Phi);
+        t1_st_s(sm + kT1Cf, lane, Cf);
+        if (first) {
+            M32 X = Kt, x0;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) X.t[I][1][v] = c31 ? mu0v[I][v] : Kt.t[I][1][v];
+            t1_mm0(Omf, X, 8, x0);                               // column 31: Om_f,0 mu0
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { xi[I][v] = x0.t[I][1][v]; qacc = fma(mu0v[I][v], x0.t[I][1][v], qacc); }
+        } else {                                                 // (uniform) a later chunk: the guess its warm-up periods forget
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Omf.t[I][J][v] = Qi.t[I][J][v] + Cf.t[I][J][v];
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xi[I][v] = 0.0;
+        }
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (!((cinm >> (8 * I + 4 * J + v)) & 1u)) Qi.t[I][J][v] += Cf.t[I][J][v];
+        t1_st_s(sm + kT1QiC, lane, Qi);
+        if (lane < 2) { sm[kT1Stg + kT1StgZ + lane] = (double)lane; sm[kT1Stg + kT1StgLen + kT1StgZ + lane] = (double)lane; }   // the zero, the one
+        t1_lds_fence();
+    }
+
+    // ---------------- forward sweep ----------------------------------------------------------------------------------------
+    // C_t and b_t of period t arrive by LDS-DMA in stage t & 1, issued two periods ahead right behind the reads of that stage; the
+    // three scalars of a period by per-lane loads a period ahead.
+    const double* Ctb = a.Ct ? a.Ct + (size_t)b * T * NPc : nullptr;
+    double cs_n, cl_n;
+    int cn_n;
+    auto issue_fwd = [&](int t) {
+        t = t < T ? t : T - 1;
+        const unsigned dst = lds0 + 8u * (unsigned)(kT1Stg + (t & 1) * kT1StgLen);
+        if (Ctb) {
+            const double* src = Ctb + (size_t)t * NPc;
+            for (int k = 0; k < nC; ++k) {                       // (uniform)
+                unsigned vo = (unsigned)lane * 16u + ((unsigned)k << 10);
+                vo = vo < rowB - 16u ? vo : rowB - 16u;
+                t1_dma(src, vo, dst + ((unsigned)k << 10));
+            }
+        }
+        t1_dma16(bcol + (size_t)t * R, (unsigned)(lane & 15) * 16u, dst + 8u * kT1StgB);
+    };
+    auto load_scal = [&](int t) {
+        t = t < T ? t : T - 1;
+        cs_n = scol[t + zero_v]; cn_n = nobs[t + zero_v]; cl_n = ldrow[t + zero_v];
+    };
+    double ssum = 0.0, nsum = 0.0, ldsum = 0.0;
+    LogProd detprod;
+    issue_fwd(tb);
+    issue_fwd(tb + 1);
+    load_scal(tb);
+#pragma unroll 1
+    for (int t = tb; t < te; ++t) {
+        const bool last = (t == T);
+        const bool own = t >= s0 && t < e0;
+        if (!first && t == s0) put_state(0, Omf, xi);
+        if (!lastc && t == e0) put_state(1, Omf, xi);
+        const double cs = cs_n, cl = cl_n;                       // (loaded a period ago)
+        const int cn = cn_n;
+        load_scal(t + 1);
+        M32 Z;
+        {
+            M32 Phi;
+            t1_ld_s(sm + kT1Phi, lane, Phi);
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Z.t[I][J][v] = last ? Omf.t[I][J][v] : Omf.t[I][J][v] + Phi.t[I][J][v];
+        }
+        const double dM = t1_sweep_inverse<false>(praw, Z, npiv, q, c);
+        M32 Jaug;
+        {
+            M32 X = Kt;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) X.t[I][1][v] = c31 ? xi[I][v] : Kt.t[I][1][v];
+            t1_mm0(Z, X, nks, Jaug);                             // [J | w] = Z'[K' | xi]
+        }
+        if (last) {                                              // the terminal step: P_T = Z, f_T = column 31 -- through the table's spare
+            double* ent = t1_here(ZJ + (size_t)T * 2 * RR);      // entry T (the backward sweep starts there; nothing live across the loop)
+            t1_wait_vm();                                        // (the stage's DMA has landed: its rows area is the packing buffer now)
+            put_packed(sm + kT1Stg + (t & 1) * kT1StgLen, ent, Z);
+            if (c31) {
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { ent[RR + 16 * I + q + 4 * v] = Jaug.t[I][1][v]; qacc = fma(-xi[I][v], Jaug.t[I][1][v], qacc); }
+            }
+            detprod.mul(dM);                                     // det Om_f,T
+        } else {
+            if (own) detprod.mul(dM);
+            M32 prod;
+            t1_mm0(Kt, Jaug, nks, prod);                         // K [J | w]
+            t1_wait_vm();                                        // stage t & 1 holds period t (issued two periods ago)
+            const bool full = (cn == N);
+            const double* stg = sm + kT1Stg + (t & 1) * kT1StgLen;
+            M32 QiL;
+            t1_ld_s(sm + kT1QiC, lane, QiL);
+            if (full || Ctb == nullptr) {                        // (uniform, rare) no missing cell: C_t = Cfull, and no row was written
+                M32 CfL;
+                t1_ld_s(sm + kT1Cf, lane, CfL);
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const bool in = (cinm >> (8 * I + 4 * J + v)) & 1u;
+                            const double omp = (J == 1 && c31) ? QiL.t[I][J][v] : QiL.t[I][J][v] - prod.t[I][J][v];
+                            Omf.t[I][J][v] = omp + (in ? CfL.t[I][J][v] : 0.0);
+                        }
+            } else {
+#pragma unroll
+                for (int I = 0; I < 2; ++I)
+#pragma unroll
+                    for (int J = 0; J < 2; ++J)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const double cv = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(stg) + pkB[I][J][v]);
+                            const double omp = (J == 1 && c31) ? QiL.t[I][J][v] : QiL.t[I][J][v] - prod.t[I][J][v];
+                            Omf.t[I][J][v] = omp + cv;
+                        }
+            }
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double bv = stg[kT1StgB + 16 * I + q + 4 * v];
+                    if (own) qacc = fma(-xi[I][v], Jaug.t[I][1][v], qacc);
+                    xi[I][v] = prod.t[I][1][v] + bv;
+                }
+            if (own) {
+                ssum += cs;
+                nsum += (double)cn;
+                ldsum += full ? a.ldfull[b] : cl;
+            }
+            t1_lds_fence();                                      // (the stage is read)
+            if (t >= s0) {                                       // (uniform; warm-up periods leave no entry) Z, packed, through the stage's rows area
+                put_packed(sm + kT1Stg + (t & 1) * kT1StgLen, tab_ent(t), Z);
+                if (c31) {
+                    double* we = w_ent(t);
+#pragma unroll
+                    for (int I = 0; I < 2; ++I)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) we[16 * I + q + 4 * v] = Jaug.t[I][1][v];
+                }
+            }
+            issue_fwd(t + 2);                                    // re-arm the stage
+        }
+    }
+
+    // ---------------- this chunk's part of the log-likelihood ---------------------------------------------------------------
+    {
+        double qd = c31 ? qacc : 0.0;
+        qd += __shfl_xor(qd, 16, 64);
+        qd += __shfl_xor(qd, 32, 64);                            // lanes c = 15: the sum over q
+        if (lane == 15) {
+            double LD = detprod.log_value();                     // (the last chunk's includes det Om_f,T)
+            if (first) LD += ldet0;
+            part[0] = nsum * kLog2PiT + ldsum + LD + ssum + qd;
+        }
+    }
+
+    // ---------------- backward sweep ---------------------------------------------------------------------------------------
+    // (Z, J') and w_t of step t arrive by LDS-DMA in stage t & 1, issued a step ahead; the smoothed moments a step leaves are stored at
+    // the start of the NEXT step, behind its wait: every wait finds only traffic a whole step old
+    const int npr = r * (r + 1) / 2;
+    int poff[2][2][4];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = 16 * I + q + 4 * v, j = 16 * J + c;
+                poff[I][J][v] = (i < r && j <= i) ? i * (i + 1) / 2 + j : -1;
+            }
+    double* const fsm = a.f_smooth + (size_t)b * T * r;
+    double* const Psm = a.P_smooth ? a.P_smooth + (size_t)b * T * npr : nullptr;
+    auto emit = [&](int trow, const M32& P, const double (&f)[2][4]) {
+        if (c31) {
+            double* fr = fsm + (size_t)trow * r;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (16 * I + q + 4 * v < r) fr[16 * I + q + 4 * v] = f[I][v];
+        }
+        if (Psm) {
+            double* pr = Psm + (size_t)trow * npr;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J <= I; ++J)                     // (tile (0, 1) lies above the diagonal)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (poff[I][J][v] >= 0) pr[poff[I][J][v]] = P.t[I][J][v];
+        }
+    };
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // (the wave reads back its own table and w_t stores: one CU, one write-through L1)
+    t1_lds_fence();
+    auto issue_bwd = [&](int t) {
+        t = t > s0 ? t : s0;
+        dma_packed(tab_ent(t), w_ent(t), lds0 + 8u * (unsigned)(kT1Stg + (t & 1) * kT1StgLen));
+    };
+    const int tl = lastc ? T - 1 : e0 + Wk - 1;                // backward steps tl .. s0
+    M32 Ps;
+    double fs[2][4];
+    {   // the start: (P_T, f_T) from entry T, or the guess the backward warm-up forgets: (Z, w) of the last extra period
+        const double* ent = lastc ? ZJ + (size_t)T * 2 * RR : xZJ + (size_t)(Wk - 1) * 2 * RR;
+        const double* fv = lastc ? ent + RR : xw + (size_t)(Wk - 1) * R;
+        const int sg = (tl + 1) & 1;                             // (the stage the first step does not use)
+        dma_packed(ent, fv, lds0 + 8u * (unsigned)(kT1Stg + sg * kT1StgLen));
+        issue_bwd(tl);
+        t1_wait_vm();
+        const double* stg = sm + kT1Stg + sg * kT1StgLen;
+        get_packed(stg, Ps);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) fs[I][v] = stg[kT1StgB + 16 * I + q + 4 * v];
+        t1_lds_fence();
+    }
+    M32 SP, SU;
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+        for (int J = 0; J < 2; ++J)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { SP.t[I][J][v] = (EM && lastc) ? Ps.t[I][J][v] : 0.0; SU.t[I][J][v] = 0.0; }
+    if (EM && lastc) t1_st_g(sums + 2 * RR, lane, Ps);         // P_T
+    int pend = lastc ? T - 1 : -1;                             // row the moments in (Ps, fs) belong to and still have to be stored; -1: none
+#pragma unroll 1
+    for (int t = tl; t >= s0; --t) {
+        const bool own = t < e0;
+        t1_wait_vm();                                            // stage t & 1 holds step t
+        t1_lds_fence();                                          // (the other stage's reads are done)
+        issue_bwd(t - 1);
+        if (pend >= 0) emit(pend, Ps, fs);
+        const double* stg = sm + kT1Stg + (t & 1) * kT1StgLen;
+        M32 zc, jt, U, Pn;
+        get_packed(stg, zc);
+        t1_mm0(Kt, zc, nks, jt);                                 // J' = K Z (the table holds Z only)
+        t1_mm0(Ps, jt, nks, U);                                  // U = P_s J' = Cov(f_t+1, f_t | X)
+        {
+            M32 Uaug = U;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Uaug.t[I][1][v] = c31 ? fs[I][v] : U.t[I][1][v];
+            t1_mm(jt, Uaug, nks, zc, Pn);                        // Z + J [U | f_t+1]   ((J')' = J: the same registers as the A operand)
+        }
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const double wv = stg[kT1StgB + 16 * I + q + 4 * v];
+                if (c31) {
+                    fs[I][v] = wv + (Pn.t[I][1][v] - zc.t[I][1][v]);
+                    Pn.t[I][1][v] = zc.t[I][1][v];
+                }
+            }
+        Ps = Pn;
+        if (EM && own) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int J = 0; J < 2; ++J)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) { SU.t[I][J][v] += U.t[I][J][v]; if (t > 0) SP.t[I][J][v] += Pn.t[I][J][v]; }
+        }
+        pend = (own && t > 0) ? t - 1 : -1;
+        if (!lastc && t == e0) put_state(2, Ps, fs);
+    }
+    if (pend >= 0) emit(pend, Ps, fs);
+    if (!first) put_state(3, Ps, fs);
+    if (!EM) return;
+    t1_st_g(sums, lane, SP);
+    t1_st_g(sums + RR, lane, SU);
+    if (first) {
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a.P0s[(size_t)b * RR + (16 * I + q + 4 * v) * R + 16 * J + c] = Ps.t[I][J][v];
+        if (c31) {
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) a.f0s[(size_t)b * R + 16 * I + q + 4 * v] = fs[I][v];
+        }
+    }
+}
+
 // The meeting point of a replicate's chunks: boundary checks (chunk_fail), the log-likelihood and the EM bookkeeping, the EM sums.
 __global__ __launch_bounds__(256) void tile_chunk_finish_kernel(RecursionArgs a, double tol) {
     constexpr int R = kRt, RR = R * R;
@@ -1066,16 +1738,66 @@ int recursion_tile_chunks(const RecursionArgs& a, int* lc_out, int* w_out) {
 // counts on small batches; nothing for batches that fill such a device with one workgroup per replicate (they run sequentially)
 size_t recursion_tile_scratch_bytes(int B, int T) {
     (void)T;
-    if (B > 512) return 0;
+    if (B > 1024) return 0;                                    // (recursion_tile1_kernel: one chunk per replicate up to 1024 replicates)
     const size_t slots = (size_t)B * kTkNCmax < 1024 ? (size_t)B * kTkNCmax : 1024;
     return slots * tk_slot_doubles(kTkWmax) * sizeof(double);
+}
+
+// recursion_tile1_kernel's plan: one wave per (replicate, chunk), as many chunks as put a wave on every SIMD (tile_nc = 0) or the forced
+// count; a single chunk is allowed (a batch that fills the SIMDs by itself).  0: not this kernel (no scratch, tile_nc = 1, DFM_NO_TILE1).
+static int tile1_chunks(const RecursionArgs& a, int* lc_out, int* w_out) {
+    static const bool off = [] { const char* v = diag_env("DFM_NO_TILE1"); return v && atoi(v) != 0; }();
+    if (off || a.tile_scr == nullptr || a.chunk_fail == nullptr || a.tile_nc == 1 || a.B < 1) return 0;
+    int W = a.tile_w > 0 ? a.tile_w : 16;
+    W = (W + 1) & ~1;
+    if (W > kTkWmax) W = kTkWmax;
+    *w_out = W;
+    const int cu = a.num_cu > 0 ? a.num_cu : 256;
+    int want = a.tile_nc > 1 ? a.tile_nc : (4 * cu + a.B - 1) / a.B;
+    if (want > kTkNCmax) want = kTkNCmax;
+    for (; want >= 1; --want) {
+        const int lc = want == 1 ? a.T : 2 * ((a.T + 2 * want - 1) / (2 * want));
+        const int lastlen = a.T - (want - 1) * lc;
+        if (want > 1 && (lc < 4 * W || lastlen < W + 2)) continue;
+        if ((size_t)a.B * want * tk_slot_doubles(W) * sizeof(double) > a.tile_scr_bytes) continue;
+        *lc_out = lc;
+        return want;
+    }
+    return 0;
+}
+
+// true: the launch goes through tile_chunk_finish_kernel, which writes chunk_fail[b] for every replicate (dfm_chunk_fallbacks counts them)
+bool recursion_tile_writes_fail(const RecursionArgs& a) {
+    int lc = 0, W = 0;
+    return tile1_chunks(a, &lc, &W) > 0 || recursion_tile_chunks(a, nullptr, nullptr) > 1;
 }
 
 hipError_t launch_recursion_tile(const RecursionArgs& a, hipStream_t s) {
     note_kernel("recursion_tile_kernel");
     int lc = a.T, W = 16;
-    const int nc = recursion_tile_chunks(a, &lc, &W);
     hipError_t e;
+    if (const int n1 = tile1_chunks(a, &lc, &W)) {
+        note_kernel("recursion_tile1_kernel");
+        RecursionArgs c = a;
+        c.tile_nc = n1; c.tile_lc = lc; c.tile_w = W;
+        if (a.S11) hipLaunchKernelGGL(recursion_tile1_kernel<true>, dim3((unsigned)(a.B * n1)), dim3(64), 0, s, c);
+        else hipLaunchKernelGGL(recursion_tile1_kernel<false>, dim3((unsigned)(a.B * n1)), dim3(64), 0, s, c);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        double ctol = a.chunk_tol > 0.0 ? a.chunk_tol : 1e-10;
+        if (a.S11 != nullptr && a.tol > 0.0 && 1e-2 * a.tol < ctol) ctol = 1e-2 * a.tol;
+        hipLaunchKernelGGL(tile_chunk_finish_kernel, dim3(a.B), dim3(256), 0, s, c, ctol);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (n1 > 1) {                                           // replicates with a boundary off (normally none: the blocks exit)
+            RecursionArgs f = a;
+            f.only_if = a.chunk_fail;
+            hipLaunchKernelGGL(recursion_tile_kernel<false>, dim3(a.B), dim3(256), 0, s, f);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess || !a.S11) return e;
+        hipLaunchKernelGGL(tile_mstep_kernel, dim3(a.B), dim3(1024), 0, s, a);
+        return hipGetLastError();
+    }
+    const int nc = recursion_tile_chunks(a, &lc, &W);
     if (nc > 1) {
         RecursionArgs c = a;
         c.tile_nc = nc; c.tile_lc = lc; c.tile_w = W;

@@ -31,12 +31,14 @@ def _num_cu():
 
 
 def _chunks(B, T, env, num_cu=256):
-    """recursion_tile_chunks() of recursion_tile.hip: the chunk count the launcher uses"""
+    """tile1_chunks() of recursion_tile.hip: the chunk count the launcher uses -- one wave per (replicate, chunk), a wave on every SIMD
+    (round 6: recursion_tile1_kernel); 0 = the sequential kernel (DFM_TILE_NC=1), 1 = one chunk per replicate (still through
+    tile_chunk_finish_kernel: every replicate counted, none redone)"""
     W = min((int(env.get("DFM_TILE_W", 16)) + 1) & ~1, 32)
     nc = int(env.get("DFM_TILE_NC", 0))
     if nc == 1:
-        return 1
-    want = min(nc if nc > 1 else (2 * num_cu) // B, 16)
+        return 0
+    want = min(nc if nc > 1 else (4 * num_cu + B - 1) // B, 16)
     while want > 1:
         lc = 2 * ((T + 2 * want - 1) // (2 * want))
         if lc >= 4 * W and T - (want - 1) * lc >= W + 2:
@@ -62,9 +64,11 @@ def test_chunked_and_sequential_tile_recursion_agree(env, expect_fail):
             panel, st = _batch(B, N, T, r, miss)
             _compare(_run_dev(c, panel, st, may_have_missing=True), _oracle(panel, st), f"{env} N={N} T={T} r={r} miss={miss}")
             nf, nt = c.chunk_fallbacks()
-            chunked = _chunks(B, T, env, _num_cu()) > 1
-            if not chunked:
+            cnt = _chunks(B, T, env, _num_cu())
+            if cnt == 0:
                 assert nt == 0, (env, T, nf, nt)
+            elif cnt == 1:
+                assert (nf, nt) == (0, B), (env, T, nf, nt)
             elif expect_fail == "some":
                 assert nt == B, (env, T, nf, nt)
                 redone += nf
@@ -145,7 +149,7 @@ def test_config4_small_batch_sixteen_chunks_per_replicate():
         f, P, ll = c.ks_pass_batch(panel, *par, may_have_missing=True)
         torch.cuda.synchronize()
         assert bool(torch.isfinite(ll).all())
-        assert c.chunk_fallbacks() == ((0, B) if _chunks(B, T, {}, _num_cu()) > 1 else (0, 0))
+        assert c.chunk_fallbacks() == ((0, B) if _chunks(B, T, {}, _num_cu()) >= 1 else (0, 0))
         ix = torch.tensor([0, 13, 31], device=panel.device)
         take = lambda t: t.index_select(0, ix).cpu().numpy()
         st = dict(zip(KEYS, [take(p) for p in par]))
