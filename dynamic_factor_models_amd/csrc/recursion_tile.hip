@@ -631,21 +631,32 @@ __global__ __launch_bounds__(256, CH ? 2 : 1) void recursion_tile_kernel(Recursi
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// recursion_tile1_kernel (round 6): the same recursion, the same chunks, the same scratch and tables -- ONE WAVE per (replicate,
-// chunk) that holds ALL FOUR tiles of every matrix (t[I][J]: 16 registers per lane).  What recursion_tile_kernel pays for its four
-// waves: nine 4-wave barriers and four LDS exchanges per period around 30 matrix instructions per wave -- 6.9 us per period of a
-// workgroup, a third of the matrix pipe busy with two workgroups per CU.  In one wave a D-layout matrix IS the B operand of a product
-// and the A operand of its transpose, tile by tile, as it stands: no exchange, no barrier; what is left in LDS is the pivot rows of the
-// block sweep (512 bytes per pivot, the wave's own in-order LDS queue) and three constant matrices that are only ever used
-// element-wise (Phi, Qi, Cfull).  120 matrix instructions per period and wave, 4 x as many independent chains per CU.
+// recursion_tile1_kernel (round 6): the same recursion, the same chunks, the same scratch -- ONE WAVE per (replicate, chunk) that holds
+// ALL FOUR tiles of every matrix (t[I][J]: 16 registers per lane).  What recursion_tile_kernel pays for its four waves: nine 4-wave
+// barriers and four LDS exchanges per period around 30 matrix instructions per wave -- 6.9 us per period of a workgroup, a third of the
+// matrix pipe busy with two workgroups per CU -- and a table of (Z, J') in the tile layout, 16 KB written and 16 KB read back per period:
+// 17 GB per config-4 pass.  Here:
+//   * a D-layout matrix IS the B operand of a product and the A operand of its transpose, tile by tile, as it stands: no exchange, no
+//     barrier.  What is left in LDS: the pivot rows of the block sweep (512 bytes per pivot, the wave's own in-order LDS queue; the pivot
+//     block itself comes out of the registers by v_readlane), two constant matrices that are only ever used element-wise (Phi, Qi) and one
+//     stage for the rows that arrive by LDS-DMA -- 19.8 KB per wave at r <= 20;
+//   * the table entry of a period is the PACKED lower triangle of the leading block of Z (210 doubles at r = 20); the backward step
+//     rebuilds J' = K Z (20 matrix instructions) and the padding is the identity: 2 x 1.7 KB of traffic per period instead of 2 x 16 KB;
+//   * C_t, b_t (forward) and Z, w_t (backward) are fetched a period ahead by LDS-DMA (no registers in flight), the smoothed moments of a
+//     step are stored at the start of the next one, the three scalars of a period by per-lane loads: every wait of the chain finds only
+//     traffic a period old.
+// 120 (forward 60, backward 60) matrix instructions per period and wave, four times as many independent chains per CU: 7.16 -> 4.8 ms per
+// 256 config-4 passes.  What bounds it now is the block sweep: 0.7 us per pivot block of ~170 dependent scalar-chain instructions
+// (LDL' of the 4 x 4 pivot, two substitutions) that one wave per SIMD cannot hide; a second wave per SIMD needs <= 256 registers and
+// spills (DFM_T1_OCC=2: measured slower).  Batches too small to put a wave on every SIMD keep recursion_tile_kernel.
 // ------------------------------------------------------------------------------------------------------------------
 namespace {
 struct M32 { v4d t[2][2]; };                       // t[I][J]: lane (q, c), register v = element (16 I + q + 4 v, 16 J + c)
 
 constexpr int kT1Praw = 0;                         // [32 columns][4 pivot rows]
-constexpr int kT1Phi = 128;                        // three matrices in the register-pair tile layout
+constexpr int kT1Phi = 128;                        // two matrices in the register-pair tile layout
 constexpr int kT1Qi = kT1Phi + 4 * kRtTile;
-constexpr int kT1Cf = kT1Qi + 4 * kRtTile;
+constexpr int kT1Cf = kT1Qi + 4 * kRtTile;         // (end of the constants: the stage starts here)
 
 // the wave's own LDS writes are visible to its later reads (one in-order queue): only the compiler must not move them
 __device__ __forceinline__ void t1_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -728,11 +739,7 @@ __device__ __forceinline__ double t1_readlane(double x, int l) {
 
 // rt_sweep_inverse in one wave: the pivot block D comes out of the registers by v_readlane (the pivot is unrolled: constant lanes),
 // the four pivot rows of the lane's two columns through 512 bytes of LDS, the A operand is the lane's own published value
-// SIDE: k-step p of the product sacc += sY'sX rides behind pivot p's four matrix instructions -- it executes in the shadow of the NEXT
-// pivot's scalar chain (readlanes, LDL', LDS round trip), which waits for the pivot's own results only (npiv = number of k-steps)
-template <bool SIDE>
-__device__ __forceinline__ double t1_sweep_inverse(double* praw, M32& m, int npiv, int q, int c, const M32* sY = nullptr, const M32* sX = nullptr,
-                                                   M32* sacc = nullptr) {
+__device__ __forceinline__ double t1_sweep_inverse(double* praw, M32& m, int npiv, int q, int c) {
     double det = 1.0;
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -779,22 +786,15 @@ __device__ __forceinline__ double t1_sweep_inverse(double* praw, M32& m, int npi
                 tq[J] = -((q & 2) ? ((q & 1) ? tq3 : tq2) : ((q & 1) ? tq1 : tq0));
             }
             t1_lds_fence();                                      // (the rows are read before the next pivot publishes its own)
+            m.t[Ik][0][vk] = 0.0;                                // pivot rows ...
+            m.t[Ik][1][vk] = 0.0;
+#pragma unroll
+            for (int I = 0; I < 2; ++I)
+                if (inblk) { m.t[I][Ik][0] = 0.0; m.t[I][Ik][1] = 0.0; m.t[I][Ik][2] = 0.0; m.t[I][Ik][3] = 0.0; }   // ... and pivot columns start from zero
 #pragma unroll
             for (int I = 0; I < 2; ++I)
 #pragma unroll
-                for (int J = 0; J < 2; ++J) {
-                    v4d acc = m.t[I][J];
-                    if (I == Ik) acc[vk] = 0.0;                  // pivot rows ...
-                    if (J == Ik && inblk) { acc[0] = 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0; }   // ... and pivot columns start from zero
-                    m.t[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[I], tq[J], acc, 0, 0, 0);
-                }
-            if constexpr (SIDE) {
-#pragma unroll
-                for (int I = 0; I < 2; ++I)
-#pragma unroll
-                    for (int J = 0; J < 2; ++J)
-                        sacc->t[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(sY->t[Ik][I][vk], sX->t[Ik][J][vk], sacc->t[I][J], 0, 0, 0);
-            }
+                for (int J = 0; J < 2; ++J) m.t[I][J] = __builtin_amdgcn_mfma_f64_16x16x4f64(val[I], tq[J], m.t[I][J], 0, 0, 0);
         }
     }
     const int lim = 4 * npiv;
@@ -824,32 +824,31 @@ __device__ __forceinline__ void t1_dma16(const void* gbase, unsigned voff, unsig
                  "s_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(gbase), "s"(lds_dst) : "memory");
 }
-// a 16-KB table entry (16 rows of 1 KB) in one block: m0 and the offset step by 1 KB
-#define DFM_T1_DMA_ROW "s_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tv_add_u32 %1, 0x400, %1\n\ts_add_u32 m0, m0, 0x400\n\t"
-#define DFM_T1_DMA_ROW4 DFM_T1_DMA_ROW DFM_T1_DMA_ROW DFM_T1_DMA_ROW DFM_T1_DMA_ROW
-__device__ __forceinline__ void t1_dma_entry(const void* gbase, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\t" DFM_T1_DMA_ROW4 DFM_T1_DMA_ROW4 DFM_T1_DMA_ROW4 DFM_T1_DMA_ROW4 "s_mov_b32 m0, %0"
-                 : "=&s"(keep), "+v"(voff) : "s"(gbase), "s"(lds_dst) : "memory", "scc");
-}
 __device__ __forceinline__ void t1_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 constexpr int kT1QiC = kT1Qi;                      // Qi, plus Cfull where the lane's element lies outside the C_t block
-constexpr int kT1Stg = kT1Cf + 4 * kRtTile;        // forward: two stages of [C_t row, whole KBs of DMA | b_t row | a zero]
-// a stage: [rows area: a packed C_t / Z row in whole KBs of DMA | a 32-vector (b_t / w_t) | the zero, the one | 64 dump slots]
-constexpr int kT1StgB = 640, kT1StgZ = kT1StgB + 32, kT1StgOne = kT1StgZ + 1, kT1StgDump = kT1StgZ + 8, kT1StgLen = kT1StgDump + 64;
-constexpr int kT1Lds2 = kT1Stg + 2 * kT1StgLen;
-static_assert(kRt * (kRt + 1) / 2 <= kT1StgB, "a full packed C_t row fits its stage");
+// LDS of a wave: the pivot rows, Phi, QiC, and ONE stage [rows area: a packed C_t / Z row in whole KBs of DMA (nR of them) | a 32-vector
+// (b_t / w_t) | the zero, the one] -- 19.8 KB at r <= 20: eight waves per CU, two per SIMD (the chain of a period is latency, not issue)
+constexpr int kT1Stg = kT1Cf;
+__host__ __device__ inline int t1_rows_kb(int ct_r, int rstate) {
+    const int ctr = ct_r > 0 ? ct_r : kRt, rb = 4 * ((rstate + 3) / 4);
+    const int nC = (ctr * (ctr + 1) / 2 * 8 + 1023) >> 10, nZ = (rb * (rb + 1) / 2 * 8 + 1023) >> 10;
+    return nC > nZ ? nC : nZ;
+}
+__host__ __device__ inline size_t t1_lds_bytes(int ct_r, int rstate) { return (size_t)(kT1Stg + t1_rows_kb(ct_r, rstate) * 128 + 32 + 8) * sizeof(double); }
 }  // namespace
 
 // keeps the address arithmetic of a rarely taken branch inside the branch (hoisted out of the period loop it would sit in registers)
 template <typename P>
 __device__ __forceinline__ P* t1_here(P* p) { asm volatile("" : "+s"(p)); return p; }
 
+#ifndef DFM_T1_OCC
+#define DFM_T1_OCC 1        // waves per SIMD the pass instantiation is compiled for (2: 256 registers -- measured slower: spills)
+#endif
 template <bool EM>
-__global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
+__global__ __launch_bounds__(64, (EM ? 1 : DFM_T1_OCC)) void recursion_tile1_kernel(RecursionArgs a) {
     constexpr int R = kRt, RR = R * R;
-    __shared__ __attribute__((aligned(16))) double sm[kT1Lds2];
+    extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x, q = lane >> 4, c = lane & 15;
     const int NC = a.tile_nc;
     const int b = (int)blockIdx.x % a.B;
@@ -857,13 +856,14 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
     const int T = a.T, N = a.N, r = a.r;
     const bool first = ck == 0, lastc = ck == NC - 1;
     const int Wk = a.tile_w;
-    const int s0 = ck * a.tile_lc;                             // (even: the stages go by the parity of the period)
+    const int s0 = ck * a.tile_lc;
     const int e0 = lastc ? T : s0 + a.tile_lc;
     const int tb = first ? 0 : s0 - Wk;
     const int te = lastc ? T + 1 : e0 + Wk;
     const int rs = a.rstate;
     const int npiv = (rs + 3) >> 2, nks = npiv;
     const bool c31 = (c == 15);                                // column 31 lives in the tiles (., 1) of these lanes
+    const int stgB = t1_rows_kb(a.ct_r, rs) * 128, stgZ = stgB + 32, stgOne = stgZ + 1;   // the stage: rows | 32-vector | zero, one
     double* praw = sm + kT1Praw;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(t1_lds_cptr)(reinterpret_cast<char*>(sm)));
     int zero_v;                                                // a zero the compiler cannot see through: per-lane (vector) loads of
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
                 const int i = 16 * I + q + 4 * v, j = 16 * J + c;
                 const bool in = i < ctr && j < ctr;
                 if (in) cinm |= 1u << (8 * I + 4 * J + v);
-                pkB[I][J][v] = in ? 8 * ((i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i) : 8 * kT1StgZ;
+                pkB[I][J][v] = in ? 8 * ((i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i) : 8 * stgZ;
             }
 
     // The table entry of a period is the PACKED lower triangle of the leading rb x rb block of Z (rb = 4 npiv: 210 doubles at r = 20 where
@@ -920,24 +920,21 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
     auto zoff = [&](int I, int J, int v, bool gather) -> int {
         const int i = 16 * I + q + 4 * v, j = 16 * J + c;
         const bool in = i < rb && j < rb;
-        if (gather) return in ? 8 * ((i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i) : 8 * (i == j ? kT1StgOne : kT1StgZ);
-        return (in && i >= j) ? 8 * (i * (i + 1) / 2 + j) : 8 * (kT1StgDump + lane);
+        (void)gather;
+        return in ? 8 * ((i >= j) ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i) : 8 * (i == j ? stgOne : stgZ);
     };
-    // Z (tile layout) -> its packed row at `ent` (+ a 32-vector behind the rows when vec != nullptr), through the rows area of LDS stage `stg`
-    auto put_packed = [&](double* stg, double* ent, const M32& Zm) {
-        char* sb = reinterpret_cast<char*>(stg);
+    // Z (tile layout) -> its packed row at `ent`: every lane stores the elements it holds of the block's lower triangle where they belong
+    // (12 scattered 8-byte stores; 1.7 KB per period -- and Z is dead right behind the product that uses it, not a period's update later)
+    auto put_packed = [&](double* ent, const M32& Zm) {
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
             for (int J = 0; J <= I; ++J)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) *reinterpret_cast<double*>(sb + zoff(I, J, v, false)) = Zm.t[I][J][v];
-        t1_lds_fence();
-        for (int k = 0; k < nZ; ++k) {                           // (uniform)
-            const unsigned o = (unsigned)lane * 16u + ((unsigned)k << 10);
-            if (o < rowZB) *reinterpret_cast<double2*>(reinterpret_cast<char*>(ent) + o) = *reinterpret_cast<const double2*>(sb + o);
-        }
-        t1_lds_fence();
+                for (int v = 0; v < 4; ++v) {
+                    const int i = 16 * I + q + 4 * v, j = 16 * J + c;
+                    if (i < rb && j <= i) ent[i * (i + 1) / 2 + j] = Zm.t[I][J][v];
+                }
     };
     // the packed row of an entry (+ the 32-vector at vsrc) by LDS-DMA into stage (byte address dst)
     auto dma_packed = [&](const double* ent, const double* vsrc, unsigned dst) {
@@ -946,7 +943,7 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
             vo = vo < rowZB - 16u ? vo : rowZB - 16u;
             t1_dma(ent, vo, dst + ((unsigned)k << 10));
         }
-        t1_dma16(vsrc, (unsigned)(lane & 15) * 16u, dst + 8u * kT1StgB);
+        t1_dma16(vsrc, (unsigned)(lane & 15) * 16u, dst + 8u * (unsigned)stgB);
     };
     auto get_packed = [&](const double* stg, M32& Zm) {
         const char* sb = reinterpret_cast<const char*>(stg);
@@ -983,7 +980,7 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
 #pragma unroll 1
         for (int k = 0; k < 2; ++k) {                            // Q^-1, then P0^-1: one copy of the sweep's code
             M32 m = k ? Omf : Qi;
-            dets[k] = t1_sweep_inverse<false>(praw, m, npiv, q, c);
+            dets[k] = t1_sweep_inverse(praw, m, npiv, q, c);
             if (k) Omf = m; else Qi = m;
         }
         ldet0 = log(dets[1]) + (double)T * log(dets[0]);
@@ -991,7 +988,6 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
         t1_mm0(Qi, Ael, nks, Km);                                // K  = Qi A
         t1_mm0(Km, Ael, nks, Phi);                               // Phi = K'A
         t1_st_s(sm + kT1Phi, lane, Phi);
-        t1_st_s(sm + kT1Cf, lane, Cf);
         if (first) {
             M32 X = Kt, x0;
 #pragma unroll
@@ -1023,19 +1019,19 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
                 for (int v = 0; v < 4; ++v)
                     if (!((cinm >> (8 * I + 4 * J + v)) & 1u)) Qi.t[I][J][v] += Cf.t[I][J][v];
         t1_st_s(sm + kT1QiC, lane, Qi);
-        if (lane < 2) { sm[kT1Stg + kT1StgZ + lane] = (double)lane; sm[kT1Stg + kT1StgLen + kT1StgZ + lane] = (double)lane; }   // the zero, the one
+        if (lane < 2) sm[kT1Stg + stgZ + lane] = (double)lane;   // the zero, the one
         t1_lds_fence();
     }
 
     // ---------------- forward sweep ----------------------------------------------------------------------------------------
-    // C_t and b_t of period t arrive by LDS-DMA in stage t & 1, issued two periods ahead right behind the reads of that stage; the
-    // three scalars of a period by per-lane loads a period ahead.
+    // C_t and b_t of period t arrive in the stage by LDS-DMA, issued a period ahead right behind the last use of the stage (the packing of
+    // Z); the three scalars of a period by per-lane loads a period ahead.
     const double* Ctb = a.Ct ? a.Ct + (size_t)b * T * NPc : nullptr;
     double cs_n, cl_n;
     int cn_n;
     auto issue_fwd = [&](int t) {
         t = t < T ? t : T - 1;
-        const unsigned dst = lds0 + 8u * (unsigned)(kT1Stg + (t & 1) * kT1StgLen);
+        const unsigned dst = lds0 + 8u * (unsigned)kT1Stg;
         if (Ctb) {
             const double* src = Ctb + (size_t)t * NPc;
             for (int k = 0; k < nC; ++k) {                       // (uniform)
@@ -1044,7 +1040,7 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
                 t1_dma(src, vo, dst + ((unsigned)k << 10));
             }
         }
-        t1_dma16(bcol + (size_t)t * R, (unsigned)(lane & 15) * 16u, dst + 8u * kT1StgB);
+        t1_dma16(bcol + (size_t)t * R, (unsigned)(lane & 15) * 16u, dst + 8u * (unsigned)stgB);
     };
     auto load_scal = [&](int t) {
         t = t < T ? t : T - 1;
@@ -1052,8 +1048,10 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
     };
     double ssum = 0.0, nsum = 0.0, ldsum = 0.0;
     LogProd detprod;
+    long long p_inv = 0, p_p1 = 0, p_p2 = 0, p_p3 = 0, q_w = 0, q_g = 0, q_u = 0, q_r = 0;
+    (void)p_inv; (void)p_p1; (void)p_p2; (void)p_p3; (void)q_w; (void)q_g; (void)q_u; (void)q_r;
+    const long long t_start = RT_NOW(); (void)t_start;
     issue_fwd(tb);
-    issue_fwd(tb + 1);
     load_scal(tb);
 #pragma unroll 1
     for (int t = tb; t < te; ++t) {
@@ -1075,7 +1073,10 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
 #pragma unroll
                     for (int v = 0; v < 4; ++v) Z.t[I][J][v] = last ? Omf.t[I][J][v] : Omf.t[I][J][v] + Phi.t[I][J][v];
         }
-        const double dM = t1_sweep_inverse<false>(praw, Z, npiv, q, c);
+        RT_TICK(p_inv);
+        const double dM = t1_sweep_inverse(praw, Z, npiv, q, c);
+        RT_TOCK(p_inv);
+        RT_TICK(p_p1);
         M32 Jaug;
         {
             M32 X = Kt;
@@ -1085,10 +1086,11 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
                 for (int v = 0; v < 4; ++v) X.t[I][1][v] = c31 ? xi[I][v] : Kt.t[I][1][v];
             t1_mm0(Z, X, nks, Jaug);                             // [J | w] = Z'[K' | xi]
         }
+        if (!last && t >= s0) put_packed(tab_ent(t), Z);         // (uniform; warm-up periods leave no entry)
+        if (last) RT_TOCK(p_p1);
         if (last) {                                              // the terminal step: P_T = Z, f_T = column 31 -- through the table's spare
             double* ent = t1_here(ZJ + (size_t)T * 2 * RR);      // entry T (the backward sweep starts there; nothing live across the loop)
-            t1_wait_vm();                                        // (the stage's DMA has landed: its rows area is the packing buffer now)
-            put_packed(sm + kT1Stg + (t & 1) * kT1StgLen, ent, Z);
+            put_packed(ent, Z);
             if (c31) {
 #pragma unroll
                 for (int I = 0; I < 2; ++I)
@@ -1100,14 +1102,15 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
             if (own) detprod.mul(dM);
             M32 prod;
             t1_mm0(Kt, Jaug, nks, prod);                         // K [J | w]
-            t1_wait_vm();                                        // stage t & 1 holds period t (issued two periods ago)
+            RT_TOCK(p_p1);
+            RT_TICK(p_p2);
+            t1_wait_vm();                                        // the stage holds period t (issued a period ago)
             const bool full = (cn == N);
-            const double* stg = sm + kT1Stg + (t & 1) * kT1StgLen;
+            const double* stg = sm + kT1Stg;
             M32 QiL;
             t1_ld_s(sm + kT1QiC, lane, QiL);
             if (full || Ctb == nullptr) {                        // (uniform, rare) no missing cell: C_t = Cfull, and no row was written
-                M32 CfL;
-                t1_ld_s(sm + kT1Cf, lane, CfL);
+                const double* Cfg = t1_here(a.Cfull + (size_t)b * RR);   // (from memory: a stall per such period, no LDS for the rare case)
 #pragma unroll
                 for (int I = 0; I < 2; ++I)
 #pragma unroll
@@ -1116,7 +1119,7 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
                         for (int v = 0; v < 4; ++v) {
                             const bool in = (cinm >> (8 * I + 4 * J + v)) & 1u;
                             const double omp = (J == 1 && c31) ? QiL.t[I][J][v] : QiL.t[I][J][v] - prod.t[I][J][v];
-                            Omf.t[I][J][v] = omp + (in ? CfL.t[I][J][v] : 0.0);
+                            Omf.t[I][J][v] = omp + (in ? Cfg[(16 * I + q + 4 * v) * R + 16 * J + c] : 0.0);
                         }
             } else {
 #pragma unroll
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
             for (int I = 0; I < 2; ++I)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const double bv = stg[kT1StgB + 16 * I + q + 4 * v];
+                    const double bv = stg[stgB + 16 * I + q + 4 * v];
                     if (own) qacc = fma(-xi[I][v], Jaug.t[I][1][v], qacc);
                     xi[I][v] = prod.t[I][1][v] + bv;
                 }
@@ -1144,8 +1147,9 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
                 ldsum += full ? a.ldfull[b] : cl;
             }
             t1_lds_fence();                                      // (the stage is read)
-            if (t >= s0) {                                       // (uniform; warm-up periods leave no entry) Z, packed, through the stage's rows area
-                put_packed(sm + kT1Stg + (t & 1) * kT1StgLen, tab_ent(t), Z);
+            RT_TOCK(p_p2);
+            RT_TICK(p_p3);
+            if (t >= s0) {                                       // (uniform; warm-up periods leave no entry)
                 if (c31) {
                     double* we = w_ent(t);
 #pragma unroll
@@ -1154,10 +1158,12 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
                         for (int v = 0; v < 4; ++v) we[16 * I + q + 4 * v] = Jaug.t[I][1][v];
                 }
             }
-            issue_fwd(t + 2);                                    // re-arm the stage
+            issue_fwd(t + 1);                                    // re-arm the stage
+            RT_TOCK(p_p3);
         }
     }
 
+    const long long t_fwd = RT_NOW(); (void)t_fwd;
     // ---------------- this chunk's part of the log-likelihood ---------------------------------------------------------------
     {
         double qd = c31 ? qacc : 0.0;
@@ -1171,8 +1177,8 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
     }
 
     // ---------------- backward sweep ---------------------------------------------------------------------------------------
-    // (Z, J') and w_t of step t arrive by LDS-DMA in stage t & 1, issued a step ahead; the smoothed moments a step leaves are stored at
-    // the start of the NEXT step, behind its wait: every wait finds only traffic a whole step old
+    // Z (packed) and w_t of step t arrive in the stage by LDS-DMA, issued a step ahead right behind the gather of the step before; the
+    // smoothed moments a step leaves are stored at the start of the NEXT step, behind its wait: every wait finds only traffic a step old
     const int npr = r * (r + 1) / 2;
     int poff[2][2][4];
 #pragma unroll
@@ -1210,7 +1216,7 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
     t1_lds_fence();
     auto issue_bwd = [&](int t) {
         t = t > s0 ? t : s0;
-        dma_packed(tab_ent(t), w_ent(t), lds0 + 8u * (unsigned)(kT1Stg + (t & 1) * kT1StgLen));
+        dma_packed(tab_ent(t), w_ent(t), lds0 + 8u * (unsigned)kT1Stg);
     };
     const int tl = lastc ? T - 1 : e0 + Wk - 1;                // backward steps tl .. s0
     M32 Ps;
@@ -1218,17 +1224,16 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
     {   // the start: (P_T, f_T) from entry T, or the guess the backward warm-up forgets: (Z, w) of the last extra period
         const double* ent = lastc ? ZJ + (size_t)T * 2 * RR : xZJ + (size_t)(Wk - 1) * 2 * RR;
         const double* fv = lastc ? ent + RR : xw + (size_t)(Wk - 1) * R;
-        const int sg = (tl + 1) & 1;                             // (the stage the first step does not use)
-        dma_packed(ent, fv, lds0 + 8u * (unsigned)(kT1Stg + sg * kT1StgLen));
-        issue_bwd(tl);
+        dma_packed(ent, fv, lds0 + 8u * (unsigned)kT1Stg);
         t1_wait_vm();
-        const double* stg = sm + kT1Stg + sg * kT1StgLen;
+        const double* stg = sm + kT1Stg;
         get_packed(stg, Ps);
 #pragma unroll
         for (int I = 0; I < 2; ++I)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) fs[I][v] = stg[kT1StgB + 16 * I + q + 4 * v];
+            for (int v = 0; v < 4; ++v) fs[I][v] = stg[stgB + 16 * I + q + 4 * v];
         t1_lds_fence();
+        issue_bwd(tl);
     }
     M32 SP, SU;
 #pragma unroll
@@ -1242,14 +1247,24 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
 #pragma unroll 1
     for (int t = tl; t >= s0; --t) {
         const bool own = t < e0;
-        t1_wait_vm();                                            // stage t & 1 holds step t
-        t1_lds_fence();                                          // (the other stage's reads are done)
+        RT_TICK(q_w);
+        t1_wait_vm();                                            // the stage holds step t
+        const double* stg = sm + kT1Stg;
+        M32 zc, jt, U, Pn;
+        double wv[2][4];
+        get_packed(stg, zc);
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) wv[I][v] = stg[stgB + 16 * I + q + 4 * v];
+        t1_lds_fence();                                          // (the stage is read: re-arm it)
         issue_bwd(t - 1);
         if (pend >= 0) emit(pend, Ps, fs);
-        const double* stg = sm + kT1Stg + (t & 1) * kT1StgLen;
-        M32 zc, jt, U, Pn;
-        get_packed(stg, zc);
+        RT_TOCK(q_w);
+        RT_TICK(q_g);
         t1_mm0(Kt, zc, nks, jt);                                 // J' = K Z (the table holds Z only)
+        RT_TOCK(q_g);
+        RT_TICK(q_u);
         t1_mm0(Ps, jt, nks, U);                                  // U = P_s J' = Cov(f_t+1, f_t | X)
         {
             M32 Uaug = U;
@@ -1263,13 +1278,13 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
         for (int I = 0; I < 2; ++I)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-                const double wv = stg[kT1StgB + 16 * I + q + 4 * v];
                 if (c31) {
-                    fs[I][v] = wv + (Pn.t[I][1][v] - zc.t[I][1][v]);
+                    fs[I][v] = wv[I][v] + (Pn.t[I][1][v] - zc.t[I][1][v]);
                     Pn.t[I][1][v] = zc.t[I][1][v];
                 }
             }
         Ps = Pn;
+        RT_TOCK(q_u);
         if (EM && own) {
 #pragma unroll
             for (int I = 0; I < 2; ++I)
@@ -1283,6 +1298,11 @@ __global__ __launch_bounds__(64) void recursion_tile1_kernel(RecursionArgs a) {
     }
     if (pend >= 0) emit(pend, Ps, fs);
     if (!first) put_state(3, Ps, fs);
+#ifdef DFM_TILE_PROF
+    if (b == 5 && ck == 1 && lane == 0)
+        printf("TILE1PROF steps %d (10 ns ticks): total %lld  forward %lld (inverse %lld, 2 products %lld, wait + update %lld, pack + store + issue %lld)  backward %lld (wait + issue + emit %lld, gather + J' %lld, U + P %lld)\n",
+               te - tb, RT_NOW() - t_start, t_fwd - t_start, p_inv, p_p1, p_p2, p_p3, RT_NOW() - t_fwd, q_w, q_g, q_u);
+#endif
     if (!EM) return;
     t1_st_g(sums, lane, SP);
     t1_st_g(sums + RR, lane, SU);
@@ -1739,7 +1759,7 @@ int recursion_tile_chunks(const RecursionArgs& a, int* lc_out, int* w_out) {
 size_t recursion_tile_scratch_bytes(int B, int T) {
     (void)T;
     if (B > 1024) return 0;                                    // (recursion_tile1_kernel: one chunk per replicate up to 1024 replicates)
-    const size_t slots = (size_t)B * kTkNCmax < 1024 ? (size_t)B * kTkNCmax : 1024;
+    const size_t slots = (size_t)B * kTkNCmax < 2048 ? (size_t)B * kTkNCmax : 2048;   // (two waves per SIMD of a 256-CU device)
     return slots * tk_slot_doubles(kTkWmax) * sizeof(double);
 }
 
@@ -1753,7 +1773,12 @@ static int tile1_chunks(const RecursionArgs& a, int* lc_out, int* w_out) {
     if (W > kTkWmax) W = kTkWmax;
     *w_out = W;
     const int cu = a.num_cu > 0 ? a.num_cu : 256;
-    int want = a.tile_nc > 1 ? a.tile_nc : (4 * cu + a.B - 1) / a.B;
+    // waves a CU holds: by LDS (160 KB), two per SIMD for the pass (256 registers), one with the EM sums
+    int wcu = (int)((size_t)160 * 1024 / t1_lds_bytes(a.ct_r, a.rstate));
+    const int wmax = a.S11 ? 4 : 4 * DFM_T1_OCC;
+    wcu = wcu > wmax ? wmax : (wcu < 1 ? 1 : wcu);
+    int want = a.tile_nc > 1 ? a.tile_nc : (wcu * cu + a.B - 1) / a.B;
+    if (a.tile_nc <= 0 && want > kTkNCmax) return 0;         // (a batch whose chunks cannot put a wave on every SIMD: four waves per chunk)
     if (want > kTkNCmax) want = kTkNCmax;
     for (; want >= 1; --want) {
         const int lc = want == 1 ? a.T : 2 * ((a.T + 2 * want - 1) / (2 * want));
@@ -1780,8 +1805,9 @@ hipError_t launch_recursion_tile(const RecursionArgs& a, hipStream_t s) {
         note_kernel("recursion_tile1_kernel");
         RecursionArgs c = a;
         c.tile_nc = n1; c.tile_lc = lc; c.tile_w = W;
-        if (a.S11) hipLaunchKernelGGL(recursion_tile1_kernel<true>, dim3((unsigned)(a.B * n1)), dim3(64), 0, s, c);
-        else hipLaunchKernelGGL(recursion_tile1_kernel<false>, dim3((unsigned)(a.B * n1)), dim3(64), 0, s, c);
+        const unsigned lds = (unsigned)t1_lds_bytes(a.ct_r, a.rstate);
+        if (a.S11) hipLaunchKernelGGL(recursion_tile1_kernel<true>, dim3((unsigned)(a.B * n1)), dim3(64), lds, s, c);
+        else hipLaunchKernelGGL(recursion_tile1_kernel<false>, dim3((unsigned)(a.B * n1)), dim3(64), lds, s, c);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         double ctol = a.chunk_tol > 0.0 ? a.chunk_tol : 1e-10;
         if (a.S11 != nullptr && a.tol > 0.0 && 1e-2 * a.tol < ctol) ctol = 1e-2 * a.tol;

@@ -31,20 +31,22 @@ def _num_cu():
 
 
 def _chunks(B, T, env, num_cu=256):
-    """tile1_chunks() of recursion_tile.hip: the chunk count the launcher uses -- one wave per (replicate, chunk), a wave on every SIMD
-    (round 6: recursion_tile1_kernel); 0 = the sequential kernel (DFM_TILE_NC=1), 1 = one chunk per replicate (still through
-    tile_chunk_finish_kernel: every replicate counted, none redone)"""
+    """The chunk plan of launch_recursion_tile (recursion_tile.hip).  Round 6: recursion_tile1_kernel -- one wave per (replicate, chunk), a
+    wave on every SIMD -- for batches whose chunks can fill the SIMDs (ceil(4 CUs / B) <= 16) and for every forced count; smaller batches
+    keep four waves per chunk (two workgroups per CU).  0 = the sequential kernel, no boundary bookkeeping (DFM_TILE_NC=1, or the
+    four-wave plan with one chunk); 1 = one chunk per replicate through tile_chunk_finish_kernel (every replicate counted, none redone)."""
     W = min((int(env.get("DFM_TILE_W", 16)) + 1) & ~1, 32)
     nc = int(env.get("DFM_TILE_NC", 0))
     if nc == 1:
         return 0
-    want = min(nc if nc > 1 else (4 * num_cu + B - 1) // B, 16)
+    one_wave = nc > 1 or (4 * num_cu + B - 1) // B <= 16
+    want = min(nc if nc > 1 else ((4 * num_cu + B - 1) // B if one_wave else (2 * num_cu) // B), 16)
     while want > 1:
         lc = 2 * ((T + 2 * want - 1) // (2 * want))
         if lc >= 4 * W and T - (want - 1) * lc >= W + 2:
             return want
         want -= 1
-    return 1
+    return 1 if one_wave else 0
 
 
 @pytest.mark.parametrize("env,expect_fail", [
