@@ -142,11 +142,259 @@ __global__ __launch_bounds__(256) void mmw_vec_kernel(MstepArgs a, double* __res
     }
 }
 
+
+// ---- the LIST form of D for panels with FEW missing cells --------------------------------------------------------------------
+// The dense product spends 14 of its 16 tiles (r = 20) multiplying V by a mask that is 90 % zeros.  Here the mask is never an
+// operand: a wave owns 16 series of the item's 128; per stage of 16 periods it takes the NaN pattern of its series as ballots
+// (lane = period x 4 series: four LDS reads give sixteen 16-bit masks in SGPRs) and, series by series, walks the SET bits only:
+// one row of V (vec(E_t), 1 680 bytes at r = 20) read from the LDS stage by the whole wave -- lane l holds columns 128 k + 2 l,
+// + 1 of the row in `ds_read_b128` number k -- and added into that series' accumulators (2 NR doubles per lane and series: 128
+// VGPRs at r = 20).  The accumulator index is static (the walk is unrolled over the 16 series), the loop over the bits scalar
+// (s_ff1 / s_and), the next row's read in flight under the current row's adds.  Sxf / Sxx / n stay a dense product on the
+// matrix pipe (A = the panel with NaN -> 0, B = f_t: NTF tiles), issued before the walk so that it runs under it.
+// Cost: one LDS row read per MISSING cell (LDS-bound: 16 clocks per cell and CU at r = 20) instead of 14 matrix instructions
+// per 64 cells: config 4 with 10 % missing 6.2 -> see DESIGN 8.9.  The time grows with the share of missing cells, the dense
+// form's does not: mm_share_kernel samples the panel (64 periods x 8 replicates) and BOTH kernels are launched -- each reads the
+// two counters and the one that is not chosen exits at once (no host round trip).
+constexpr int kMlKP = 16, kMlSer = 128, kMlMaxU = 4, kMlWaves = 16;
+
+typedef double mm_v2 __attribute__((ext_vector_type(2)));
+using lds_cv2_ptr_mm = const __attribute__((address_space(3))) mm_v2*;
+__device__ __forceinline__ mm_v2 lds_read128mm(unsigned a) { return *(lds_cv2_ptr_mm)(size_t)a; }
+
+__device__ __forceinline__ bool list_route(const unsigned* share, unsigned thr_pct) {
+    return (unsigned long long)share[0] * 100ull <= (unsigned long long)share[1] * (unsigned long long)thr_pct;
+}
+
+struct MlGeo {
+    int ntm16, tt16;                                     // column of f_t in a row of V / OUT, row length (doubles)
+    int nv;                                              // 1-KB DMAs per row of V
+    unsigned vrowB, vstride, pstride, panelB, stageB;
+    int U, nbuf;
+};
+
+// share[0] += NaN cells, share[1] += cells of the sample: block (x, y) = period x T / gridDim.x of replicate y B / gridDim.y
+__global__ __launch_bounds__(256) void mm_share_kernel(const double* __restrict__ panel, int B, int T, int N, unsigned* __restrict__ share) {
+    const int t = (int)(((long long)blockIdx.x * T) / gridDim.x), b = (int)(((long long)blockIdx.y * B) / gridDim.y);
+    const double* row = panel + ((size_t)b * T + t) * N;
+    unsigned c = 0;
+    for (int i = threadIdx.x; i < N; i += 256) { const double x = row[i]; c += (x != x) ? 1u : 0u; }
+    __shared__ unsigned red[4];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&share[0], red[0] + red[1] + red[2] + red[3]);
+        atomicAdd(&share[1], (unsigned)N);
+    }
+}
+
+template <int NR, int NTF>
+__global__ __launch_bounds__(64 * kMlWaves) void mstep_miss_list_kernel(MstepArgs a, const double* __restrict__ V, double* __restrict__ OUT,
+                                                                       double* __restrict__ sxx, double* __restrict__ cnt, MlGeo g, int nsb,
+                                                                       const unsigned* __restrict__ share, unsigned thr_pct) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (share && !list_route(share, thr_pct)) return;
+    constexpr int KP = kMlKP;
+    const int N = a.N, T = a.T, B = a.B;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k4 = lane >> 4, c16 = lane & 15;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char_ptr_mm)(smem));
+    const int nst = (T + KP - 1) / KP;
+    const int tt16 = g.tt16;
+    const int ND = KP * (1 + g.nv);
+    const int U = g.U, NBUF = g.nbuf;
+    const bool xmap = B >= 16;                                // (items as in mstep_miss_kernel: a replicate's blocks side by side on one L2)
+    const int xcd = xmap ? (int)blockIdx.x & 7 : 0, slot = xmap ? (int)blockIdx.x >> 3 : (int)blockIdx.x;
+    const int nslot = xmap ? (int)gridDim.x >> 3 : (int)gridDim.x, xstep = xmap ? 8 : 1;
+    const int nrep_x = xmap ? (B - xcd + 7) / 8 : B;
+    // the wave's DMAs of a stage (the same for every stage and item): LDS offset within the stage buffer | period << 16 | piece << 24
+    // (piece 0 = the panel row, k = the k-th KB of the row of V) -- worked out once (a division per DMA and stage otherwise)
+    unsigned cdU[kMlMaxU];
+#pragma unroll
+    for (int u = 0; u < kMlMaxU; ++u) {
+        int d = wave + kMlWaves * u;
+        d = d < ND ? d : ND - 1;                              // (a duplicate of the last DMA keeps the count equal)
+        const int per = d / (1 + g.nv), pc = d % (1 + g.nv);
+        const unsigned dst = pc == 0 ? (unsigned)per * g.pstride : g.panelB + (unsigned)per * g.vstride + 1024u * (unsigned)(pc - 1);
+        cdU[u] = __builtin_amdgcn_readfirstlane(dst | ((unsigned)per << 16) | ((unsigned)pc << 24));
+    }
+    const size_t rowXB = (size_t)N * 8;
+    // roles of the wave: the walk over series 8 wave .. + 7 of the item; of the dense part, periods 2 half .. + 1 (mod 4) of the
+    // 16 series of tile dt (two waves share a tile: their partial sums meet in LDS at the end of the item)
+    const int dt = wave >> 1, half = wave & 1;
+
+    for (int e = tid; e < (int)((NBUF * g.stageB + 1024u * NR) / 8); e += 64 * kMlWaves) reinterpret_cast<double*>(smem)[e] = 0.0;
+    __syncthreads();
+
+    for (int q = slot; q < nrep_x * nsb; q += nslot) {
+        const int b = xcd + xstep * (q / nsb), sb = q % nsb;
+        if (a.active && !a.active[b]) continue;
+        const int s0 = sb * kMlSer;
+        const char* Xl = reinterpret_cast<const char*>(a.panel + (size_t)b * T * N) + (size_t)(s0 + 2 * lane) * 8;
+        const char* Vl = reinterpret_cast<const char*>(V + (size_t)b * T * tt16) + 16 * lane;
+        const bool okP = s0 + 2 * lane < N;
+        auto issue_stage = [&](int st, int bsel) {
+            const unsigned sbase = lds0 + (unsigned)bsel * g.stageB;
+#pragma unroll
+            for (int u = 0; u < kMlMaxU; ++u) {
+                if (u < U) {
+                    int t = st * KP + (int)((cdU[u] >> 16) & 255u);
+                    t = t < T ? t : T - 1;
+                    const unsigned dst = sbase + (cdU[u] & 0xffffu);
+                    const unsigned pc = cdU[u] >> 24;
+                    if (pc == 0) {
+                        if (okP) dma16mm(Xl + (size_t)t * rowXB, dst);
+                    } else {
+                        const unsigned o = 1024u * (pc - 1u);
+                        if (o + 16u * (unsigned)lane < g.vrowB) dma16mm(Vl + ((size_t)t * g.vrowB + o), dst);
+                    }
+                }
+            }
+        };
+        mm_v2 acc[8][NR];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) acc[j][k] = mm_v2{0.0, 0.0};
+        mm_v4 accf[NTF];
+#pragma unroll
+        for (int x = 0; x < NTF; ++x) accf[x] = mm_v4{0.0, 0.0, 0.0, 0.0};
+        double qs = 0.0, nc = 0.0;
+        const int sw = s0 + 8 * wave;                         // the walk's first series
+        const int sd = s0 + 16 * dt;                          // the dense tile's first series
+        const bool ser_ok = sd + c16 < N;
+        const unsigned a_off = (unsigned)(8 * half + k4) * g.pstride + (unsigned)(16 * dt + c16) * 8u;
+        const unsigned b_off = g.panelB + (unsigned)(8 * half + k4) * g.vstride + (unsigned)(g.ntm16 + c16) * 8u;
+        const unsigned m_off = (unsigned)c16 * g.pstride + (unsigned)(8 * wave + k4) * 8u;   // masks: lane = (period c16, series k4 + 4 q)
+
+        for (int q0 = 0; q0 < NBUF - 1; ++q0)
+            if (q0 < nst) issue_stage(q0, q0);
+        int bsel = 0;
+        for (int st = 0; st < nst; ++st) {
+            {
+                const int younger = (nst - 1 - st < NBUF - 2) ? nst - 1 - st : NBUF - 2;
+                wait_vm_upto(younger * U);
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (st + NBUF - 1 < nst) issue_stage(st + NBUF - 1, bsel == 0 ? NBUF - 1 : bsel - 1);
+            const unsigned stg = lds0 + (unsigned)bsel * g.stageB;
+            // the stage's operands in flight together: the NaN patterns' cells, the dense part's two steps
+            double mx[2], xr[2], bvv[2][NTF];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) mx[qq] = lds_read64mm(stg + m_off + (unsigned)qq * 32u);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                xr[s] = lds_read64mm(stg + a_off + (unsigned)s * 4u * g.pstride);
+#pragma unroll
+                for (int x = 0; x < NTF; ++x) bvv[s][x] = lds_read64mm(stg + b_off + (unsigned)s * 4u * g.vstride + 128u * (unsigned)x);
+            }
+            // the NaN patterns of the wave's 8 series over the stage's 16 periods: bits 16 k4 + period of bal[q] = series 4 q + k4
+            unsigned long long bal[2];
+            {
+                const bool per_ok = st * KP + c16 < T;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) bal[qq] = __ballot((int)per_ok & (int)(sw + 4 * qq + k4 < N) & (int)(mx[qq] != mx[qq]));
+            }
+            // Sxf, Sxx, n: the dense part on the matrix pipe
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bool ok = (bool)((int)ser_ok & (int)(st * KP + 8 * half + 4 * s + k4 < T) & (int)(xr[s] == xr[s]));
+                const double xk = ok ? xr[s] : 0.0;
+                qs = fma(xk, xk, qs);
+                nc += ok ? 1.0 : 0.0;
+#pragma unroll
+                for (int x = 0; x < NTF; ++x) accf[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(xk, bvv[s][x], accf[x], 0, 0, 0);
+            }
+            // D: the rows of V at the missing cells, series by series (static accumulators), bit by bit (a scalar loop), the next
+            // row's read in flight under the current row's adds; the other waves of the SIMD cover the rest of the latency
+            const unsigned vb = stg + g.panelB + 16u * (unsigned)lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned m = (unsigned)(bal[j >> 2] >> (16 * (j & 3))) & 0xffffu;
+                if (m) {
+                    mm_v2 cur[NR];
+                    unsigned ad = vb + (unsigned)__builtin_ctz(m) * g.vstride;
+                    m &= m - 1u;
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) cur[k] = lds_read128mm(ad + 1024u * (unsigned)k);
+                    while (m) {
+                        mm_v2 nx[NR];
+                        ad = vb + (unsigned)__builtin_ctz(m) * g.vstride;
+                        m &= m - 1u;
+#pragma unroll
+                        for (int k = 0; k < NR; ++k) nx[k] = lds_read128mm(ad + 1024u * (unsigned)k);
+#pragma unroll
+                        for (int k = 0; k < NR; ++k) { acc[j][k] += cur[k]; cur[k] = nx[k]; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) acc[j][k] += cur[k];
+                }
+            }
+            bsel = bsel == NBUF - 1 ? 0 : bsel + 1;
+        }
+        // D: lane l holds columns 128 k + 2 l, + 1 of series sw + j
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (sw + j < N) {
+                double* orow = OUT + ((size_t)b * N + sw + j) * tt16;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int col = 128 * k + 2 * lane;
+                    if (col < g.ntm16) *reinterpret_cast<mm_v2*>(orow + col) = acc[j][k];
+                }
+            }
+        }
+        // the dense part: the odd wave's partial sums to the even wave through LDS (the stage buffers are free behind the barrier)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        double* xch = reinterpret_cast<double*>(smem) + (size_t)dt * (4 * NTF + 2) * 64 + lane;
+        if (half == 1) {
+#pragma unroll
+            for (int x = 0; x < NTF; ++x)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xch[(4 * x + v) * 64] = accf[x][v];
+            xch[4 * NTF * 64] = qs;
+            xch[(4 * NTF + 1) * 64] = nc;
+        }
+        __syncthreads();
+        if (half == 0) {
+#pragma unroll
+            for (int x = 0; x < NTF; ++x)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) accf[x][v] += xch[(4 * x + v) * 64];
+            qs += xch[4 * NTF * 64];
+            nc += xch[(4 * NTF + 1) * 64];
+            // Sxf: 16x16x4 D[(l / 16) + 4 v][l % 16] -> series k4 + 4 v, column c16 of the tile
+            double* out = OUT + ((size_t)b * N + sd) * tt16 + g.ntm16 + c16;
+#pragma unroll
+            for (int x = 0; x < NTF; ++x) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = k4 + 4 * v;
+                    if (sd + row < N) out[(size_t)row * tt16 + 16 * x] = accf[x][v];
+                }
+            }
+            qs += __shfl_xor(qs, 16, 64); qs += __shfl_xor(qs, 32, 64);
+            nc += __shfl_xor(nc, 16, 64); nc += __shfl_xor(nc, 32, 64);
+            if (k4 == 0 && ser_ok) {
+                sxx[(size_t)b * N + sd + c16] = qs;
+                cnt[(size_t)b * N + sd + c16] = nc;
+            }
+        }
+        __syncthreads();                                      // the exchange area is read before the next item's DMAs land on it
+    }
+}
+
 // OUT[b][series][16 tt]: D (16 ntm columns) then Sxf (16 ntf columns); sxx, cnt [b][series]
 template <int TPW, int KP, int NBUF>
 __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, const double* __restrict__ V, double* __restrict__ OUT,
-                                                                  double* __restrict__ sxx, double* __restrict__ cnt, MmGeo g, int nsb) {
+                                                                  double* __restrict__ sxx, double* __restrict__ cnt, MmGeo g, int nsb,
+                                                                  const unsigned* __restrict__ share, unsigned thr_pct) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (share && list_route(share, thr_pct)) return;      // (few missing cells: mstep_miss_list_kernel has done this launch's work)
     const int N = a.N, T = a.T, B = a.B;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -389,12 +637,13 @@ bool mstep_miss_supported(int Rpad, int r, int N) {
 // V [B][T][16 tt] | OUT [B][N][16 tt] | sxx [B][N] | cnt [B][N]
 size_t mstep_miss_workspace(int B, int T, int N, int Rpad, int r) {
     const MmGeo g = mm_geo(Rpad, r);
-    return ((size_t)B * T * g.tt * 16 + (size_t)B * N * g.tt * 16 + 2 * (size_t)B * N) * sizeof(double) + 256;
+    return ((size_t)B * T * g.tt * 16 + (size_t)B * N * g.tt * 16 + 2 * (size_t)B * N) * sizeof(double) + 512;   // (+ the two counters of mm_share_kernel)
 }
 
 namespace {
 template <int TPW, int KP, int NBUF>
-hipError_t launch_mm(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MmGeo& g, int G, hipStream_t s) {
+hipError_t launch_mm(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MmGeo& g, int G, hipStream_t s,
+                     const unsigned* share, unsigned thr) {
     static LdsOptIn attr_done;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_miss_kernel<TPW, KP, NBUF>),
@@ -404,20 +653,54 @@ hipError_t launch_mm(const MstepArgs& a, const double* V, double* OUT, double* s
     }
     const int nsb = (a.N + g.ser - 1) / g.ser;
     hipLaunchKernelGGL((mstep_miss_kernel<TPW, KP, NBUF>), dim3((unsigned)G), dim3(64 * kMmWaves), (size_t)NBUF * g.stageB, s, a, V, OUT,
-                       sxx, cnt, g, nsb);
+                       sxx, cnt, g, nsb, share, thr);
     return hipGetLastError();
 }
 // tile slots per wave: the next instantiation at or above the geometry's (at most 3 idle slots)
 template <int KP, int NBUF>
-hipError_t launch_mm_slots(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MmGeo& g, int G, hipStream_t s) {
-    if (g.tpw <= 4) return launch_mm<4, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);              // Rp = 8
-    if (g.tpw <= 7) return launch_mm<7, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);
-    if (g.tpw <= 10) return launch_mm<10, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);            // r = 16
-    if (g.tpw <= 13) return launch_mm<13, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);
-    if (g.tpw <= 16) return launch_mm<16, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);            // r = 20 (config 4)
-    if (g.tpw <= 18) return launch_mm<18, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);            // r = 32: two column groups
-    if (g.tpw <= 21) return launch_mm<21, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s);            // r = 24
+hipError_t launch_mm_slots(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MmGeo& g, int G, hipStream_t s,
+                           const unsigned* share, unsigned thr) {
+    if (g.tpw <= 4) return launch_mm<4, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s, share, thr);              // Rp = 8
+    if (g.tpw <= 7) return launch_mm<7, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
+    if (g.tpw <= 10) return launch_mm<10, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s, share, thr);            // r = 16
+    if (g.tpw <= 13) return launch_mm<13, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
+    if (g.tpw <= 16) return launch_mm<16, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s, share, thr);            // r = 20 (config 4)
+    if (g.tpw <= 18) return launch_mm<18, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s, share, thr);            // r = 32: two column groups
+    if (g.tpw <= 21) return launch_mm<21, KP, NBUF>(a, V, OUT, sxx, cnt, g, G, s, share, thr);            // r = 24
     return hipErrorInvalidValue;
+}
+
+// the list form's geometry over the SAME V / OUT layout as the dense product (mm_geo): false = not supported (NR > 2: the 16 series'
+// accumulators would not fit the registers; a stage of 16 periods that does not fit the LDS twice)
+bool ml_geo(const MmGeo& d, MlGeo* g, int* NR) {
+    *NR = (d.npr + 127) / 128;
+    if (*NR > 2) return false;                              // (r <= 22)
+    g->ntm16 = d.ntm * 16; g->tt16 = d.tt * 16;
+    g->vrowB = d.vrowB; g->nv = d.nv; g->vstride = d.vstride;
+    g->pstride = (unsigned)kMlSer * 8u + 128u;
+    g->panelB = (unsigned)kMlKP * g->pstride;
+    g->stageB = g->panelB + (unsigned)kMlKP * g->vstride;
+    g->U = (kMlKP * (1 + g->nv) + kMlWaves - 1) / kMlWaves;
+    const unsigned slack = 1024u * (unsigned)*NR;          // (the walk reads NR KB from a row's start whatever the row's length)
+    g->nbuf = 3u * g->stageB + slack <= kMmLdsMax + 2048u ? 3 : 2;
+    if (g->U > kMlMaxU) return false;
+    if (g->nbuf == 3 && g->U > 6) g->nbuf = 2;            // (wait_vm_upto's cases)
+    return (unsigned)g->nbuf * g->stageB + slack <= kMmLdsMax + 2048u;
+}
+template <int NR, int NTF>
+hipError_t launch_ml(const MstepArgs& a, const double* V, double* OUT, double* sxx, double* cnt, const MlGeo& g, int G, hipStream_t s,
+                     const unsigned* share, unsigned thr) {
+    static LdsOptIn attr_done;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mstep_miss_list_kernel<NR, NTF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    const int nsb = (a.N + kMlSer - 1) / kMlSer;
+    hipLaunchKernelGGL((mstep_miss_list_kernel<NR, NTF>), dim3((unsigned)G), dim3(64 * kMlWaves), (size_t)g.nbuf * g.stageB + 1024u * NR, s,
+                       a, V, OUT, sxx, cnt, g, nsb, share, thr);
+    return hipGetLastError();
 }
 }  // namespace
 
@@ -449,10 +732,40 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     G = (G / 8) * 8;
     if (G < 8) G = 8;
     if (g.nbuf >= 3 && g.U > 6) return hipErrorInvalidValue;
-    if (g.kp == 32) e = launch_mm_slots<32, 2>(a, V, OUT, sxx, cnt, g, G, s);
-    else if (g.kp == 16) e = launch_mm_slots<16, 2>(a, V, OUT, sxx, cnt, g, G, s);
-    else if (g.nbuf == 4) e = launch_mm_slots<8, 4>(a, V, OUT, sxx, cnt, g, G, s);
-    else e = launch_mm_slots<8, 3>(a, V, OUT, sxx, cnt, g, G, s);
+    // few missing cells: the list form (mstep_miss_list_kernel).  DFM_MSTEP_LIST: 0 = never, 1 = by the sampled share of missing cells
+    // (default; both kernels are launched, one exits), 2 = always where its geometry exists
+    static const int list_mode = [] { const char* v = route_env("DFM_MSTEP_LIST"); return v ? atoi(v) : 1; }();
+    static const int list_pct = [] { const char* v = diag_env("DFM_MM_LIST_PCT"); return v ? atoi(v) : 30; }();
+    const unsigned* share = nullptr;
+    const unsigned thr = (unsigned)list_pct;
+    MlGeo lg; int NR = 0;
+    bool list_done = false;
+    if (list_mode != 0 && ml_geo(g, &lg, &NR)) {
+        unsigned* sh = reinterpret_cast<unsigned*>(cnt + (size_t)a.B * a.N);
+        if (list_mode == 1) {
+            e = hipMemsetAsync(sh, 0, 2 * sizeof(unsigned), s);
+            if (e != hipSuccess) return e;
+            const int np = a.T < 64 ? a.T : 64, nr = a.B < 8 ? a.B : 8;
+            hipLaunchKernelGGL(mm_share_kernel, dim3(np, nr), dim3(256), 0, s, a.panel, a.B, a.T, a.N, sh);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            share = sh;
+        }
+        int Gl = ((num_cu > 0 ? num_cu : 256) / 8) * 8;
+        if (Gl < 8) Gl = 8;
+        const int ntf = g.ntf;
+        if (NR == 1 && ntf == 1) e = launch_ml<1, 1>(a, V, OUT, sxx, cnt, lg, Gl, s, share, thr);
+        else if (NR == 2 && ntf == 1) e = launch_ml<2, 1>(a, V, OUT, sxx, cnt, lg, Gl, s, share, thr);
+        else if (NR == 2 && ntf == 2) e = launch_ml<2, 2>(a, V, OUT, sxx, cnt, lg, Gl, s, share, thr);
+        else e = hipErrorInvalidValue;
+        if (e != hipSuccess) return e;
+        list_done = list_mode != 1;
+    }
+    if (list_done) { /* DFM_MSTEP_LIST=2: the list form has done the step */ }
+    else if (g.kp == 32) e = launch_mm_slots<32, 2>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
+    else if (g.kp == 16) e = launch_mm_slots<16, 2>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
+    else if (g.nbuf == 4) e = launch_mm_slots<8, 4>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
+    else e = launch_mm_slots<8, 3>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
     if (e != hipSuccess) return e;
     const int npr = r * (r + 1) / 2;
     // series per block: 64 where two blocks' packed matrices share a CU's LDS, else 32 (r = 20: 60 KB per block; one block per CU with
