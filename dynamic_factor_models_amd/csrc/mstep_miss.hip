@@ -735,7 +735,7 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     // few missing cells: the list form (mstep_miss_list_kernel).  DFM_MSTEP_LIST: 0 = never, 1 = by the sampled share of missing cells
     // (default; both kernels are launched, one exits), 2 = always where its geometry exists
     static const int list_mode = [] { const char* v = route_env("DFM_MSTEP_LIST"); return v ? atoi(v) : 1; }();
-    static const int list_pct = [] { const char* v = diag_env("DFM_MM_LIST_PCT"); return v ? atoi(v) : 30; }();
+    static const int list_pct = [] { const char* v = diag_env("DFM_MM_LIST_PCT"); return v ? atoi(v) : 40; }();
     const unsigned* share = nullptr;
     const unsigned thr = (unsigned)list_pct;
     MlGeo lg; int NR = 0;

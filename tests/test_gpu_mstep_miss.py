@@ -15,14 +15,16 @@ RTOL = 1e-8
 KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
 
 
-def _ctx(mode, kp=None):
+def _ctx(mode, kp=None, lst=None):
     import torch
     assert torch.cuda.is_available()
     from dynamic_factor_models_amd import DfmContext
-    old = {k: os.environ.get(k) for k in ("DFM_MSTEP_MISS", "DFM_MM_KP")}
+    old = {k: os.environ.get(k) for k in ("DFM_MSTEP_MISS", "DFM_MM_KP", "DFM_MSTEP_LIST")}
     os.environ["DFM_MSTEP_MISS"] = str(mode)
     if kp:
         os.environ["DFM_MM_KP"] = str(kp)
+    if lst is not None:
+        os.environ["DFM_MSTEP_LIST"] = str(lst)
     try:
         return DfmContext()
     finally:
@@ -59,9 +61,10 @@ def _dev(ctx, a):
     (2, 70, 92, 27, 0.1),       # two column groups (24 + 2 tiles, 13 per wave), 64 series per item
     (2, 66, 107, 32, 0.05),     # 33 + 2 tiles, 18 slots per wave, every factor column in use
 ])
-def test_loadings_step_with_missing_cells_matches_the_oracle(B, N, T, r, missing):
+@pytest.mark.parametrize("lst", [None, 0])     # the default route (the list form where it exists and few cells are missing) | the dense product
+def test_loadings_step_with_missing_cells_matches_the_oracle(B, N, T, r, missing, lst):
     import torch
-    ctx = _ctx(2)
+    ctx = _ctx(2, lst=lst)
     try:
         panel, st = _start(B, N, T, r, missing)
         dev = {k: _dev(ctx, st[k]) for k in KEYS}
@@ -79,6 +82,62 @@ def test_loadings_step_with_missing_cells_matches_the_oracle(B, N, T, r, missing
         ctx.close()
 
 
+@pytest.mark.parametrize("lst", [0, 2])
+@pytest.mark.parametrize("B,N,T,r,missing", [
+    (2, 30, 50, 5, 0.15),       # Rp = 8: one 1-KB read per row of V, one partial series block, last stage of 2 periods
+    (17, 130, 65, 8, 0.1),      # two series blocks (the second of 2 series), XCD-ordered items
+    (2, 48, 57, 16, 0.1),       # Rp = 16, r = 16: two reads per row, one tile of f
+    (2, 300, 60, 20, 0.1),      # config 4's class: two reads per row, two tiles of f, three series blocks (the last of 44)
+    (2, 140, 45, 22, 0.02),     # the widest row of the list form (253 columns, stages in two buffers), hardly a missing cell
+    (2, 300, 120, 20, 0.6),     # most cells missing: walks of ten rows per series and stage
+])
+def test_list_form_and_dense_product_both_match_the_oracle(B, N, T, r, missing, lst):
+    """DFM_MSTEP_LIST = 0: the dense product (mstep_miss_kernel) everywhere; 2: the walk over the missing cells
+    (mstep_miss_list_kernel) wherever its geometry exists -- the default decides between them on the device from a sampled share
+    of missing cells, so each is pinned here on its own."""
+    import torch
+    ctx = _ctx(2, lst=lst)
+    try:
+        panel, st = _start(B, N, T, r, missing)
+        dev = {k: _dev(ctx, st[k]) for k in KEYS}
+        path, its, f, P = ctx.em_batch(_dev(ctx, panel), *[dev[k] for k in KEYS], max_iter=2, tol=0.0)
+        torch.cuda.synchronize()
+        path = path.cpu().numpy()
+        for b in range(B):
+            p, opath, _ = ko.em(panel[b], {k: st[k][b] for k in KEYS}, max_iter=2, tol=0.0)
+            np.testing.assert_allclose(path[b], opath, rtol=RTOL, err_msg=f"loglik path b={b}")
+            for k in KEYS:
+                got = dev[k][b].cpu().numpy()
+                assert np.abs(got - p[k]).max() <= RTOL * max(1.0, np.abs(p[k]).max()), (k, b, np.abs(got - p[k]).max())
+    finally:
+        ctx.close()
+
+
+def test_route_follows_the_share_of_missing_cells():
+    """The default route: 10 % missing -> the list form, 60 % -> the dense product (the kernel that is not chosen exits at once, so
+    the library's kernel log shows both launches; the RESULT must be the oracle's either way -- checked above -- and the two
+    routes' results differ by rounding only)."""
+    import torch
+    B, N, T, r = 2, 300, 120, 20
+    for missing in (0.1, 0.6):
+        panel, st = _start(B, N, T, r, missing)
+        outs = []
+        for lst in (None, 0, 2):
+            ctx = _ctx(2, lst=lst)
+            try:
+                dev = {kk: _dev(ctx, st[kk]) for kk in KEYS}
+                ctx.em_batch(_dev(ctx, panel), *[dev[kk] for kk in KEYS], max_iter=1, tol=0.0)
+                torch.cuda.synchronize()
+                outs.append({kk: dev[kk].cpu().numpy() for kk in ("Lam", "R")})
+            finally:
+                ctx.close()
+        want = 2 if missing < 0.4 else 1                  # index into outs of the route the default must have taken
+        other = 3 - want
+        for kk in ("Lam", "R"):
+            assert np.array_equal(outs[0][kk], outs[want][kk]), (missing, kk)       # bit-identical to the chosen route
+            assert np.abs(outs[0][kk] - outs[other][kk]).max() <= 1e-11 * max(1.0, np.abs(outs[0][kk]).max()), (missing, kk)
+
+
 @pytest.mark.parametrize("kp", [8, 16, 32])
 def test_stage_depths_agree(kp):
     """The same EM step through every stage depth that fits (8 periods x 3 buffers, 16 x 2, 32 x 2): identical to rounding."""
@@ -87,7 +146,7 @@ def test_stage_depths_agree(kp):
     panel, st = _start(B, N, T, r, 0.12)
     outs = []
     for k in (None, kp):
-        ctx = _ctx(2, k)
+        ctx = _ctx(2, k, lst=0)
         try:
             dev = {kk: _dev(ctx, st[kk]) for kk in KEYS}
             ctx.em_batch(_dev(ctx, panel), *[dev[kk] for kk in KEYS], max_iter=1, tol=0.0)
