@@ -18,7 +18,7 @@
 //   * the item streams through LDS in stages of 8 periods, three stage buffers, all by `global_load_lds_dwordx4` with a
 //     counted `s_waitcnt vmcnt` (every wave issues the same number of DMAs per stage); rows 128 bytes (mod 256) apart;
 //   * the mask costs nothing extra: it is the A operand (1.0 | 0.0) of the D tiles, as xz is the A operand of the Sxf tiles.
-// mmw_finish_kernel (thread = series, its packed Sff in a conflict-free LDS column) then solves by Cholesky.
+// mmw_solve_kernel (a lane per row of a series' normal matrix, 64 / r series per wave) then solves by symmetric elimination.
 // Flops at config 4: 2 x 256 x 1000 x 2000 x 256 = 2.6e11 = 3.3 ms at the fp64 matrix peak.
 #include <stdlib.h>
 
@@ -520,6 +520,7 @@ __global__ __launch_bounds__(64 * kMmWaves) void mstep_miss_kernel(MstepArgs a, 
     }
 }
 
+#ifdef DFM_DIAG   // (the LDS-column solve: diagnostics library only, DFM_MM_FINISH=1)
 // thread = series: packed Sff_i = S11 - D_i in the thread's own LDS column, Cholesky in place, lam_i, R_i.  256 threads load
 // the block's rows (one contiguous piece of OUT); the first ns of them solve (ns = series per block = the LDS column count)
 __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const double* __restrict__ OUT, const double* __restrict__ sxx,
@@ -626,6 +627,107 @@ __global__ __launch_bounds__(256) void mmw_finish_kernel(MstepArgs a, const doub
     a.R_out[(size_t)b * N + col] = (sxx[(size_t)b * N + col] - yy) / nobs_i;
     double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
     for (int k = 0; k < Rp; ++k) lo[k] = k < r ? y[k * nsi] : 0.0;
+}
+
+#endif
+
+// mmw_solve_kernel -- the same solve with a LANE per ROW: the r lanes of a group hold the rows of one series' normal matrix
+// Sff_i = S11 - D_i (row i in the registers of lane i, static indices throughout), 64 / r series per wave.  Symmetric elimination
+// without pivoting (LDL' by rows: for pivot j every later row takes its multiple of row j, broadcast by `ds_bpermute`) leaves row i of
+// the upper factor in lane i; the back-substitution needs exactly that row and the solved components broadcast one by one -- no
+// transpose, no LDS matrix, no barrier (mmw_finish_kernel: 140 workgroup barriers around dependent LDS read-modify-writes per block
+// of 32 series: 1.02 ms per config-4 iteration).  The wave's rows of OUT pass through LDS once (coalesced in, gathered out).
+template <int RMAX>
+__global__ __launch_bounds__(256, 4) void mmw_solve_kernel(MstepArgs a, const double* __restrict__ OUT, const double* __restrict__ sxx,
+                                                        const double* __restrict__ cnt, int r, int Rp, int ntm16, int tt16) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (a.active && !a.active[b]) return;
+    const int N = a.N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int spw = 64 / r;                                   // series per wave
+    const int g = lane / r, i = lane - g * r;                 // group of the lane, its row
+    const bool lane_ok = g < spw;
+    const int base = g * r;
+    const int s_first = ((int)blockIdx.y * 4 + wave) * spw;   // the wave's first series
+    double* s11 = reinterpret_cast<double*>(smem);             // [Rp][Rp]: the replicate's S11 (every lane gathers 2 r entries of it)
+    for (int e = threadIdx.x; e < Rp * Rp; e += 256) s11[e] = a.S11[(size_t)b * Rp * Rp + e];
+    __syncthreads();
+    if (s_first >= N) return;
+    const int ns = (N - s_first < spw) ? N - s_first : spw;
+    double* rows = s11 + Rp * Rp + (size_t)wave * spw * tt16;
+    {
+        const double2* src = reinterpret_cast<const double2*>(OUT + ((size_t)b * N + s_first) * tt16);
+        double2* dst = reinterpret_cast<double2*>(rows);
+        const int n2 = ns * tt16 / 2;
+        for (int e = lane; e < n2; e += 64) dst[e] = src[e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the wave's own LDS stores are visible to its loads)
+    const bool live = lane_ok && g < ns;
+    const int gs = live ? g : 0;                               // (idle lanes work on a copy of group 0's rows; they never store)
+    const int ii = i < r ? i : 0;
+    const double* row = rows + (size_t)gs * tt16;
+    double A[RMAX];
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k) {
+        A[k] = 0.0;
+        if (k < r) {
+            const int hi = ii > k ? ii : k, lo = ii > k ? k : ii;
+            A[k] = 0.5 * (s11[ii * Rp + k] + s11[k * Rp + ii]) - row[hi * (hi + 1) / 2 + lo];
+        }
+    }
+    const double sxf = row[ntm16 + ii];
+    double bb = sxf, rdiag = 1.0;                              // rdiag: 1 / U[i][i], kept by lane i at its own pivot step
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+        if (j < r) {                                           // (wave-uniform)
+            const int src = base + j;
+            const double d = __shfl(A[j], src, 64);            // the pivot
+            ok = ok && (d > 0.0);
+            const double rinv = 1.0 / (d > 0.0 ? d : 1.0);
+            if (ii == j) rdiag = rinv;
+            const double m = (ii > j) ? A[j] * rinv : 0.0;
+            const double bj = __shfl(bb, src, 64);
+            bb = fma(-m, bj, bb);
+#pragma unroll
+            for (int k = j + 1; k < RMAX; ++k) {
+                if (k < r) {
+                    const double pk = __shfl(A[k], src, 64);
+                    A[k] = fma(-m, pk, A[k]);
+                }
+            }
+        }
+    }
+    // U x = y from the last row up: lane j holds U[j][j .. r); x_j from lane j, every earlier row takes its term
+    double lam = 0.0;
+#pragma unroll
+    for (int j = RMAX - 1; j >= 0; --j) {
+        if (j < r) {
+            const double xj = __shfl(bb * rdiag, base + j, 64);
+            if (ii == j) lam = xj;
+            if (ii < j) bb = fma(-A[j], xj, bb);
+        }
+    }
+    // lam' Sxf over the group
+    const double part = lam * sxf;
+    double yy = 0.0;
+#pragma unroll
+    for (int k = 0; k < RMAX; ++k)
+        if (k < r) yy += __shfl(part, base + k, 64);
+    if (!live) return;
+    const int col = s_first + g;
+    const double nobs_i = cnt[(size_t)b * N + col];
+    // a series without a single observed cell keeps its parameters; so does one with fewer cells than the caller's minimum, or whose
+    // normal matrix is not positive definite (mmw_finish_kernel's rules)
+    if (!ok || nobs_i < (double)(a.min_cells > 1 ? a.min_cells : 1)) return;
+    double* lo = a.Lam_out + ((size_t)b * N + col) * a.lam_stride;
+    lo[i] = lam;
+    if (i == 0) {
+        a.R_out[(size_t)b * N + col] = (sxx[(size_t)b * N + col] - yy) / nobs_i;
+        for (int k = r; k < Rp; ++k) lo[k] = 0.0;
+    }
 }
 
 // Rp = 8 | 16 | 32 (r <= Rp the caller's factor count), even N (16-byte aligned series pairs)
@@ -767,20 +869,35 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     else if (g.nbuf == 4) e = launch_mm_slots<8, 4>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
     else e = launch_mm_slots<8, 3>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
     if (e != hipSuccess) return e;
-    const int npr = r * (r + 1) / 2;
-    // series per block: 64 where two blocks' packed matrices share a CU's LDS, else 32 (r = 20: 60 KB per block; one block per CU with
-    // 64 series was 1.5 ms of a config-4 iteration's loadings step against 1.0 ms)
-    const int nthr = ((size_t)(npr + r) * 65 + npr) * sizeof(double) <= 72 * 1024 ? 64 : 32;
-    const size_t lds = ((size_t)(npr + r) * (nthr + 1) + npr) * sizeof(double);
-    static LdsOptIn fin_done;
-    if (!fin_done) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmw_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        fin_done = true;
+#ifdef DFM_DIAG
+    static const int fin_old = [] { const char* v = diag_env("DFM_MM_FINISH"); return v ? atoi(v) : 0; }();
+    if (fin_old) {
+        const int npr = r * (r + 1) / 2;
+        // series per block: 64 where two blocks' packed matrices share a CU's LDS, else 32 (r = 20: 60 KB per block; one block per CU with
+        // 64 series was 1.5 ms of a config-4 iteration's loadings step against 1.0 ms)
+        const int nthr = ((size_t)(npr + r) * 65 + npr) * sizeof(double) <= 72 * 1024 ? 64 : 32;
+        const size_t lds = ((size_t)(npr + r) * (nthr + 1) + npr) * sizeof(double);
+        static LdsOptIn fin_done;
+        if (!fin_done) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mmw_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            fin_done = true;
+        }
+        hipLaunchKernelGGL(mmw_finish_kernel, dim3(a.B, (a.N + nthr - 1) / nthr), dim3(256), lds, s, a, (const double*)OUT, (const double*)sxx,
+                           (const double*)cnt, r, Rpad, ntm16, tt16, nthr);
+        return hipGetLastError();
     }
-    hipLaunchKernelGGL(mmw_finish_kernel, dim3(a.B, (a.N + nthr - 1) / nthr), dim3(256), lds, s, a, (const double*)OUT, (const double*)sxx,
-                       (const double*)cnt, r, Rpad, ntm16, tt16, nthr);
-    return hipGetLastError();
+#endif
+    // the per-series solves: a lane per row (mmw_solve_kernel); DFM_MM_FINISH=1 (diagnostics) keeps the LDS-column kernel
+    {
+        const int spw = 64 / r;
+        const size_t lds = ((size_t)4 * spw * tt16 + (size_t)Rpad * Rpad) * sizeof(double);
+        const dim3 grid(a.B, (a.N + 4 * spw - 1) / (4 * spw));
+        // (the 16-wide instantiation sends the register allocator into 4 000 spills; Rp = 16 takes the 32-wide one with 16 live columns)
+        if (Rpad == 8) hipLaunchKernelGGL(mmw_solve_kernel<8>, grid, dim3(256), lds, s, a, (const double*)OUT, (const double*)sxx, (const double*)cnt, r, Rpad, ntm16, tt16);
+        else hipLaunchKernelGGL(mmw_solve_kernel<32>, grid, dim3(256), lds, s, a, (const double*)OUT, (const double*)sxx, (const double*)cnt, r, Rpad, ntm16, tt16);
+        return hipGetLastError();
+    }
 }
 
 }  // namespace dfm
