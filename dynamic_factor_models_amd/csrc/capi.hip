@@ -1081,10 +1081,11 @@ int ar_em_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, const 
     p.qsing = (flags & DFM_F_SINGULAR_Q) ? 1 : 0;
     p.kdim = k; p.kb = r; p.ka = r * nlag;                   // companion constraints; the observation loads on q + 1 blocks (rl = 0)
     const size_t xoff = (p.total + 255) & ~(size_t)255;
-    if (int rc = ensure_ws(h, xoff + (size_t)B * Tq * N * sizeof(double))) return rc;
     const int Rk = p.Rp;
+    const size_t moff = (xoff + (size_t)B * Tq * N * sizeof(double) + 255) & ~(size_t)255;   // the series CM-steps' moments (mstep_ar.hip)
+    if (int rc = ensure_ws(h, moff + mstep_ar_workspace(B, T, N, r, q, Rk))) return rc;
     double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),
-           *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P), *xq = at<double>(h, xoff);
+           *mu0P = at<double>(h, p.mu0P), *P0P = at<double>(h, p.P0P), *xq = at<double>(h, xoff), *mws = at<double>(h, moff);
     {
         const size_t nm = (size_t)B * Rk * Rk;
         hipLaunchKernelGGL(companion_pad_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, h->stream, B, N, r, k,
@@ -1122,7 +1123,7 @@ int ar_em_run(dfm_handle* h, int B, int T, int N, int r, int nlag, int q, const 
         ArMstepArgs ma;
         ma.B = B; ma.T = T; ma.N = N; ma.r = r; ma.q = q; ma.Rk = Rk;
         ma.panel = panel; ma.zsm = fsm; ma.Psm = Psm; ma.active = active; ma.Lam = Lam; ma.rho = rho; ma.sig2 = sig2;
-        { ProfScope ps(h, K_MSTEP_STATS); HIP_TRY(h, launch_mstep_ar(ma, h->stream)); }
+        { ProfScope ps(h, K_MSTEP_STATS); HIP_TRY(h, launch_mstep_ar(ma, mws, h->stream)); }
         if (tol > 0.0 && it + 1 < max_iter) {
             act_host.resize(B);
             HIP_TRY(h, hipMemcpyAsync(act_host.data(), active, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, h->stream));

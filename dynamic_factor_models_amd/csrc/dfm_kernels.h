@@ -262,7 +262,12 @@ struct ArMstepArgs {
     double* sig2;               // [B][N]      in / out
 };
 bool mstep_ar_supported(int r, int q);
-hipError_t launch_mstep_ar(const ArMstepArgs& a, hipStream_t s);
+size_t mstep_ar_workspace(int B, int T, int N, int r, int q, int Rk);
+// ws: mstep_ar_workspace bytes (the moment form: ar_moments_kernel + ar_solve_kernel), or null (mstep_ar_kernel)
+hipError_t launch_mstep_ar(const ArMstepArgs& a, double* ws, hipStream_t s);
+// V[b][t][tt16] = [vec(E f f' + P) of the leading r states (packed lower), zeros to ntm16 | f_t (Rp columns), zeros] (mstep_miss.hip)
+hipError_t launch_mmw_vec(const double* fsm, const double* Psm, const int* active, int B, int T, int r, int Rp, int ntm16, int tt16,
+                          double* V, hipStream_t s);
 
 // Parametric model with OBSERVED factors (mstep_obs.hip): x_it = lam_o,i' g_t + lam_u,i' f_t + e_it with g_t
 // known regressors.  E-step on the residual panel y = x - Lam_o g; loadings by one joint regression per series on z = (g, f).

@@ -806,6 +806,14 @@ hipError_t launch_ml(const MstepArgs& a, const double* V, double* OUT, double* s
 }
 }  // namespace
 
+hipError_t launch_mmw_vec(const double* fsm, const double* Psm, const int* active, int B, int T, int r, int Rp, int ntm16, int tt16,
+                          double* V, hipStream_t s) {
+    MstepArgs a{};
+    a.B = B; a.T = T; a.fsm = fsm; a.Psm = Psm; a.active = active;
+    hipLaunchKernelGGL(mmw_vec_kernel, dim3(B, (T + 15) / 16), dim3(256), 0, s, a, V, r, Rp, ntm16, tt16);
+    return hipGetLastError();
+}
+
 hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, int num_cu, hipStream_t s) {
     note_kernel("mstep_miss_kernel");
     static const int kp_want = [] { const char* v = diag_env("DFM_MM_KP"); return v ? atoi(v) : 0; }();   // diagnostics: 8 | 16 | 32
