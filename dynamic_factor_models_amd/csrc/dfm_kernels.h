@@ -263,7 +263,7 @@ struct ArMstepArgs {
 };
 bool mstep_ar_supported(int r, int q);
 size_t mstep_ar_workspace(int B, int T, int N, int r, int q, int Rk);
-// ws: mstep_ar_workspace bytes (the moment form: ar_moments_kernel + ar_solve_kernel), or null (mstep_ar_kernel)
+// ws: mstep_ar_workspace bytes (ar_moments_kernel + ar_solve_kernel)
 hipError_t launch_mstep_ar(const ArMstepArgs& a, double* ws, hipStream_t s);
 // V[b][t][tt16] = [vec(E f f' + P) of the leading r states (packed lower), zeros to ntm16 | f_t (Rp columns), zeros] (mstep_miss.hip)
 hipError_t launch_mmw_vec(const double* fsm, const double* Psm, const int* active, int B, int T, int r, int Rp, int ntm16, int tt16,

@@ -12,8 +12,9 @@
 //   (3) rho given the NEW loadings: u_itl = x_i,t-l - lam_i' f_{t-l},  U_i = sum_t E[u_it u_it'],
 //                             rho_i = U_i[1:,1:]^-1 U_i[1:,0];
 //   (4) sig2_i = a_i' U_i a_i / n_i.
-// One thread per series, two sweeps over the periods (the second needs the first one's loadings).  The smoothed moments of
-// a period are the same for every series: their addresses are wave-uniform, so they travel through the scalar unit.
+// Round 6: all three steps from per-series moments that do not depend on the series' parameters, the moments as products on the
+// f64 matrix pipe (ar_moments_kernel), then four lanes per series for the solves (ar_solve_kernel); the two-sweep kernel with a
+// thread per series (mstep_ar_kernel: 4.3 ms per 1024 replicates at the Stock-Watson shape) is kept in the diagnostics library.
 // The reference has no counterpart of the joint estimation (dfm_functions.ipynb:21-23 declares `Parametric` only).
 #include "dfm_kernels.h"
 
@@ -72,6 +73,7 @@ __device__ __forceinline__ bool chol_solve_reg(double (&M)[NMAX][NMAX], double (
 
 }  // namespace
 
+#ifdef DFM_DIAG   // (the two-sweep kernel: diagnostics library only, DFM_AR_MSTEP_OLD=1)
 // R = the model's number of factors (exact), Q1 = q + 1.
 template <int R, int Q1>
 __global__ __launch_bounds__(256) void mstep_ar_kernel(ArMstepArgs a) {
@@ -234,6 +236,8 @@ __global__ __launch_bounds__(256) void mstep_ar_kernel(ArMstepArgs a) {
     for (int c = 0; c < R; ++c) a.Lam[((size_t)b * N + i) * R + c] = lam[c];
     a.sig2[(size_t)b * N + i] = sig / (double)n;
 }
+
+#endif
 
 // ---- round 6: the same CM-steps from per-series MOMENTS, the moments as matrix products ----------------------------------------
 // Both sweeps of mstep_ar_kernel re-derive, per series and period, sums that do not depend on the series' parameters:
@@ -534,11 +538,14 @@ static hipError_t launch_ar_rq(const ArMstepArgs& a, double* ws, hipStream_t s) 
     if constexpr (R * Q1 > 32) {
         return hipErrorInvalidValue;
     } else {
-        static const bool old_form = [] { const char* v = route_env("DFM_AR_MSTEP_OLD"); return v && atoi(v) != 0; }();
-        if (ws == nullptr || old_form) {
+#ifdef DFM_DIAG
+        static const bool old_form = [] { const char* v = diag_env("DFM_AR_MSTEP_OLD"); return v && atoi(v) != 0; }();
+        if (old_form) {
             hipLaunchKernelGGL((mstep_ar_kernel<R, Q1>), dim3((a.N + 255) / 256, a.B), dim3(256), 0, s, a);
             return hipGetLastError();
         }
+#endif
+        if (ws == nullptr) return hipErrorInvalidValue;
         using G = ArGeo<R, Q1>;
         size_t nV = 0, nOUT = 0;
         int VW = 0, ntm16 = 0, Ns = 0, TT = 0;
@@ -566,7 +573,7 @@ static hipError_t launch_ar_r(const ArMstepArgs& a, double* ws, hipStream_t s) {
     }
 }
 bool mstep_ar_supported(int r, int q) { return r >= 1 && r <= 8 && q >= 0 && q <= 4 && r * (q + 1) <= 32; }
-// ws: mstep_ar_workspace bytes (the moment form), or null (mstep_ar_kernel: a thread per series, two sweeps over the periods)
+// ws: mstep_ar_workspace bytes
 hipError_t launch_mstep_ar(const ArMstepArgs& a, double* ws, hipStream_t s) {
     note_kernel("mstep_ar_kernel");
     switch (a.r) {
