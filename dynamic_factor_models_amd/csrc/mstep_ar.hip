@@ -539,7 +539,8 @@ static hipError_t launch_ar_rq(const ArMstepArgs& a, double* ws, hipStream_t s) 
         return hipErrorInvalidValue;
     } else {
 #ifdef DFM_DIAG
-        static const bool old_form = [] { const char* v = diag_env("DFM_AR_MSTEP_OLD"); return v && atoi(v) != 0; }();
+        const char* ov = diag_env("DFM_AR_MSTEP_OLD");        // (read per launch: the A/B test switches it inside one process)
+        const bool old_form = ov && atoi(ov) != 0;
         if (old_form) {
             hipLaunchKernelGGL((mstep_ar_kernel<R, Q1>), dim3((a.N + 255) / 256, a.B), dim3(256), 0, s, a);
             return hipGetLastError();

@@ -878,7 +878,8 @@ hipError_t launch_mstep_miss(const MstepArgs& a, double* ws, int Rpad, int r, in
     else e = launch_mm_slots<8, 3>(a, V, OUT, sxx, cnt, g, G, s, share, thr);
     if (e != hipSuccess) return e;
 #ifdef DFM_DIAG
-    static const int fin_old = [] { const char* v = diag_env("DFM_MM_FINISH"); return v ? atoi(v) : 0; }();
+    const char* fv = diag_env("DFM_MM_FINISH");                // (read per launch: the A/B test switches it inside one process)
+    const int fin_old = fv ? atoi(fv) : 0;
     if (fin_old) {
         const int npr = r * (r + 1) / 2;
         // series per block: 64 where two blocks' packed matrices share a CU's LDS, else 32 (r = 20: 60 KB per block; one block per CU with

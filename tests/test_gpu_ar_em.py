@@ -46,6 +46,47 @@ def test_em_ar_matches_oracle(ctx, B, N, T, r, p, q, missing, iters):
     assert np.all(its == iters)
 
 
+@pytest.mark.parametrize("B,N,T,r,p,q,missing", [
+    (2, 50, 150, 4, 4, 4, 0.05),       # three series blocks of 48 / 2 series, two staged chunks of the panel (128 + 18 periods)
+    (2, 33, 40, 2, 1, 0, 0.1),         # q = 0: one lag, a single tile product for the lanes to share
+    (2, 17, 45, 5, 1, 3, 0.1),         # r = 5, q = 3: 20 states, odd N, one partial series block
+])
+def test_em_ar_moment_form_shapes(ctx, B, N, T, r, p, q, missing):
+    """ar_moments_kernel / ar_solve_kernel beyond the shapes above: several series blocks and staged chunks, q = 0, odd widths."""
+    panel, st = _stack(B, N, T, r, p, q, missing)
+    est, path, its, f, P = ctx.em_ar_batch_host(panel, *[st[k] for k in KEYS], max_iter=2)
+    for b in range(B):
+        ref, opath, out = ao.em_ar(panel[b], {k: st[k][b] for k in KEYS}, max_iter=2)
+        np.testing.assert_allclose(path[b], opath, rtol=1e-8, err_msg=f"loglik path b={b}")
+        for k in KEYS:
+            if ref[k].size == 0:                                  # (rho at q = 0)
+                continue
+            tol = 1e-7 * max(1.0, np.abs(ref[k]).max())
+            assert np.abs(est[k][b] - ref[k]).max() <= tol, (k, b, np.abs(est[k][b] - ref[k]).max())
+
+
+def test_two_sweep_kernel_agrees_with_the_moment_form():
+    """Diagnostics build only (DFM_AR_MSTEP_OLD=1: mstep_ar_kernel, a thread per series, two sweeps): the same estimates to rounding."""
+    import os
+    from conftest import diag_only  # noqa: F401
+    if os.environ.get("DFM_LIB") != "diag":
+        pytest.skip("switch of the diagnostics build: run with DFM_LIB=diag")
+    from dynamic_factor_models_amd import DfmContext
+    panel, st = _stack(2, 30, 80, 4, 4, 4, 0.05)
+    outs = []
+    for old in ("0", "1"):
+        os.environ["DFM_AR_MSTEP_OLD"] = old
+        try:
+            c = DfmContext(0)
+            est, path, _, _, _ = c.em_ar_batch_host(panel, *[st[k] for k in KEYS], max_iter=2)
+            outs.append((est, path))
+            c.close()
+        finally:
+            os.environ.pop("DFM_AR_MSTEP_OLD", None)
+    for k in KEYS:
+        assert np.abs(outs[0][0][k] - outs[1][0][k]).max() <= 1e-10 * max(1.0, np.abs(outs[0][0][k]).max()), k
+
+
 def test_em_ar_likelihood_monotone_and_tol(ctx):
     panel, st = _stack(4, 18, 120, 2, 1, 1, 0.0)
     est, path, its, _, _ = ctx.em_ar_batch_host(panel, *[st[k] for k in KEYS], max_iter=25, tol=1e-5)

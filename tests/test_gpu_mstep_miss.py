@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+from conftest import diag_only
 from oracle import kalman_oracle as ko
 
 pytestmark = pytest.mark.gpu
@@ -138,6 +139,30 @@ def test_route_follows_the_share_of_missing_cells():
             assert np.abs(outs[0][kk] - outs[other][kk]).max() <= 1e-11 * max(1.0, np.abs(outs[0][kk]).max()), (missing, kk)
 
 
+@diag_only()
+def test_lds_column_solve_agrees_with_the_row_per_lane_solve():
+    """Diagnostics build only (DFM_MM_FINISH=1: mmw_finish_kernel): the same loadings to rounding as mmw_solve_kernel."""
+    import torch
+    B, N, T, r = 3, 140, 75, 20
+    panel, st = _start(B, N, T, r, 0.12)
+    outs = []
+    for fin in (None, "1"):
+        if fin:
+            os.environ["DFM_MM_FINISH"] = fin
+        try:
+            ctx = _ctx(2)
+            dev = {kk: _dev(ctx, st[kk]) for kk in KEYS}
+            ctx.em_batch(_dev(ctx, panel), *[dev[kk] for kk in KEYS], max_iter=1, tol=0.0)
+            torch.cuda.synchronize()
+            outs.append({kk: dev[kk].cpu().numpy() for kk in ("Lam", "R")})
+            ctx.close()
+        finally:
+            os.environ.pop("DFM_MM_FINISH", None)
+    for kk in ("Lam", "R"):
+        assert np.abs(outs[0][kk] - outs[1][kk]).max() <= 1e-11 * max(1.0, np.abs(outs[0][kk]).max()), kk
+
+
+@diag_only()
 @pytest.mark.parametrize("kp", [8, 16, 32])
 def test_stage_depths_agree(kp):
     """The same EM step through every stage depth that fits (8 periods x 3 buffers, 16 x 2, 32 x 2): identical to rounding."""
