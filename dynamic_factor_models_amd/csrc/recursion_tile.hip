@@ -206,6 +206,39 @@ __host__ __device__ inline size_t tk_slot_doubles(int W) {
 
 // sum_t f_t f_t', sum_t f_t f_t-1', sum_t f_t-1 f_t-1' (periods 1 .. T; f_0 in f0sh) as products over time: k = 4 periods per
 // MFMA, operands straight from f_smooth (agent-scope loads: in the sequential kernel this CU wrote the rows itself)
+// the same three products for a kernel that runs AFTER the one that wrote F (tile_chunk_finish_kernel): plain loads, the operands of
+// four steps in flight together (one step at a time every step waited for its own trip to L2: 0.34 ms per config-4 EM iteration with
+// one workgroup per replicate).  The matrix instructions keep their order: the sums are the same numbers.
+__device__ __forceinline__ void tile_gsums_ahead(const double* __restrict__ F, const double* f0sh, int T, int r, int I, int J, int q, int c,
+                                                 v4d& G11, v4d& G10, v4d& G00) {
+    const int ci = 16 * I + c, cj = 16 * J + c;
+    const bool oki = ci < r, okj = cj < r;
+    const double f0i = f0sh[ci], f0j = f0sh[cj];
+    constexpr int U = 4;
+    for (int k0 = 0; k0 < T; k0 += 4 * U) {
+        double fi[U], fj[U], pi[U], pj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = k0 + 4 * u + q;
+            const bool in = t < T;
+            fi[u] = (in && oki) ? F[(size_t)t * r + ci] : 0.0;
+            fj[u] = (in && okj) ? F[(size_t)t * r + cj] : 0.0;
+            pi[u] = 0.0; pj[u] = 0.0;
+            if (in) {
+                pi[u] = t == 0 ? f0i : (oki ? F[(size_t)(t - 1) * r + ci] : 0.0);
+                pj[u] = t == 0 ? f0j : (okj ? F[(size_t)(t - 1) * r + cj] : 0.0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (k0 + 4 * u < T) {
+                G11 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[u], fj[u], G11, 0, 0, 0);
+                G10 = __builtin_amdgcn_mfma_f64_16x16x4f64(fi[u], pj[u], G10, 0, 0, 0);
+                G00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pi[u], pj[u], G00, 0, 0, 0);
+            }
+        }
+    }
+}
 __device__ __forceinline__ void tile_gsums(const double* F, const double* f0sh, int T, int r, int I, int J, int q, int c,
                                            v4d& G11, v4d& G10, v4d& G00) {
     const int ci = 16 * I + c, cj = 16 * J + c;                  // this lane's column of F as A operand (I) and as B operand (J)
@@ -1402,7 +1435,7 @@ __global__ __launch_bounds__(256) void tile_chunk_finish_kernel(RecursionArgs a,
         for (int v = 0; v < 4; ++v) { SP[v] += p[v]; SU[v] += u[v]; }
     }
     const v4d PT = ld_tile_g(bst(NC - 1, 0) + 4 * kTkBst + kTkPart + 2 * RR, w, lane);
-    tile_gsums(a.f_smooth + (size_t)b * T * r, f0sh, T, r, I, J, q, c, G11, G10, G00);
+    tile_gsums_ahead(a.f_smooth + (size_t)b * T * r, f0sh, T, r, I, J, q, c, G11, G10, G00);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const size_t o = (size_t)b * RR + (16 * I + q + 4 * v) * R + 16 * J + c;
