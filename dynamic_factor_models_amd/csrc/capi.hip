@@ -55,6 +55,7 @@ struct dfm_handle {
     int pass_nsw = 0;                      // DFM_PASS_NSW: stream waves per workgroup of that launch (0 = automatic)
     bool wide_old = false;                 // DFM_WIDE_OLD=1: Rp = 32 balanced collapse by collapse_wide_kernel + gram_wide_kernel
     bool collapse_miss_old = false;        // DFM_COLLAPSE_MISS_OLD=1: register-streamed collapse_kernel for panels with missing cells
+    bool narrow_tab_off = false;           // DFM_NARROW_TAB=0 (diagnostics build): r <= 4 on the 8-wide state through collapse_kernel<4> + chunk_bridge_kernel
     bool gram_xx_valu = false;             // DFM_GRAM_XX_VALU=1: X'X of the PCA start on the VALU kernel (diagnostics)
     int pass_ncov = 0;                     // DFM_PASS_NCOV: covariance waves per workgroup of that launch (0 = automatic)
     bool cov_wave = false;                 // DFM_COV_WAVE=1: one-wave-per-replicate covariance recursion on the separate-launch path
@@ -219,7 +220,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
     if (!fast && !p.cov && Rp == 8) {
         p.ck_scr = take(off, recursion_chunk_scratch_bytes(B, T));
         p.ck_obs = take(off, recursion_chunk_obs_bytes(B, T));
-        if (p.Rc == 0 && collapse_miss_supported(8, N)) p.ck_rows = take(off, recursion_chunk_rows_bytes(B, T));
+        if (collapse_miss_supported(8, N)) p.ck_rows = take(off, recursion_chunk_rows_bytes(B, T));   // (also r <= 4 on the 8-wide state: CollapseArgs::lam_w)
         p.ck_cst = take(off, (size_t)B * 320 * d);
         p.ck_term = take(off, (size_t)B * 96 * d);
         p.ck_fail = take(off, (size_t)B * sizeof(int));
@@ -417,8 +418,15 @@ bool fast_eligible(const dfm_handle* h, int N, int r, unsigned flags) {
     return collapse_dma_supported(pad_r(r), N) || collapse_wide_supported(pad_r(r), N);
 }
 
-bool needs_odd_pad(bool fast, int N, int r) {
+bool g_odd_pad8 = true;                  // DFM_ODD_PAD8=0 (diagnostics build): odd N at states up to 8 wide stays on collapse_kernel
+bool needs_odd_pad(bool fast, int N, int r, unsigned flags = 0, int B = 0) {
     if (fast) return false;
+    // states up to 8 wide, panels with missing cells: collapse_miss_kernel's rows are moved 16 bytes at a time (even N).  With the
+    // appended series the pass takes its table mode (+ recursion_chunk_kernel) instead of collapse_kernel + chunk_bridge_kernel:
+    // the Stock-Watson window (N = 139) is such a panel.  (r <= 4 beyond 1536 replicates stays on the 4-wide lane-group kernels.)
+    if (g_odd_pad8 && pad_r(r) <= 8 && (N & 1) && (flags & DFM_F_MAY_HAVE_MISSING) && !(flags & DFM_F_SINGULAR_Q) && collapse_miss_supported(8, N + 1) &&
+        (pad_r(r) == 8 || (g_widen_small_r && B <= 1536)))
+        return true;
     return pad_r(r) == 32 && (N & 1) && N > collapse_max_n(32) && collapse_wide2_supported(32, N + 1);
 }
 
@@ -726,8 +734,13 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
         const int Rcol = p.Rc ? p.Rc : p.Rp;
         // the time-chunked recursion reads one table row per period (C_t, b_t, s_t, n_t log 2 pi + log det R_t): at Rp = 8 with loadings as
         // wide as the state collapse_miss_kernel writes it directly
-        const bool table = ra.wave && !h->collapse_miss_old && p.Rc == 0 && recursion_chunk_supported(p.Rp, ra);
-        if (table && p.ck_rows != (size_t)-1 && collapse_miss_supported(Rcol, N)) {
+        // (r <= 4 widened to the 8-wide state, Plan::Rc = 2 / 4: the kernel pads the loadings with zero columns in its LDS tables --
+        // CollapseArgs::lam_w -- and the table is the 8-wide one the chunks read anyway; collapse_kernel<4> + chunk_bridge_kernel took
+        // 0.25 ms per 1024 replicates of the Stock-Watson window where this takes 0.1)
+        const bool narrow_tab = p.Rc > 0 && p.Rc < 8 && p.kdim == 0 && p.rl == p.Rc && !h->narrow_tab_off;
+        const bool table = ra.wave && !h->collapse_miss_old && (p.Rc == 0 || narrow_tab) && recursion_chunk_supported(p.Rp, ra);
+        if (table && p.ck_rows != (size_t)-1 && collapse_miss_supported(8, N) && (p.Rc == 0 ? Rcol == 8 : true)) {
+            ca.lam_w = p.Rc;
             ca.obs_chunk = at<double>(h, p.ck_rows);
             ca.obs_table = ra.chunk_obs; ca.obs_L = recursion_chunk_len(T);
             ra.chunk_obs_ready = 1;
@@ -824,7 +837,7 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
     if (!panel || !Lam || !R || !A || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
     HIP_TRY(h, hipSetDevice(h->device));
-    if (needs_odd_pad(fast_eligible(h, N, r, flags) && !h->em_general, N, r)) {   // odd N beyond the tilings: one all-missing series appended
+    if (needs_odd_pad(fast_eligible(h, N, r, flags) && !h->em_general, N, r, flags, B)) {   // odd N beyond the tilings: one all-missing series appended
         OddPad o;
         if (int rc = odd_pad(h, B, T, N, r, panel, Lam, R, &o, k_first > 0)) return rc;
         // (the appended series is missing in EVERY period: the padded problem has missing cells whatever the caller said about N)
@@ -1303,6 +1316,8 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = diag_env("DFM_PASS_NCOV")) h->pass_ncov = atoi(v);
     if (const char* v = diag_env("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
     if (const char* v = diag_env("DFM_COLLAPSE_MISS_OLD")) h->collapse_miss_old = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_NARROW_TAB")) h->narrow_tab_off = atoi(v) == 0;
+    if (const char* v = diag_env("DFM_ODD_PAD8")) g_odd_pad8 = atoi(v) != 0;
     if (const char* v = route_env("DFM_NO_CHUNK")) h->no_chunk = atoi(v) != 0;
     if (const char* v = route_env("DFM_CHUNK_W")) h->chunk_w = atoi(v) > 0 ? atoi(v) : 0;
     if (const char* v = route_env("DFM_CHUNK_TOL")) h->chunk_tol = atof(v) > 0.0 ? atof(v) : 0.0;
@@ -1454,7 +1469,7 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
     if (!fast_eligible(h, N, r, flags))
         if (int rc = check_general_n(h, N, r, true)) return rc;
     HIP_TRY(h, hipSetDevice(h->device));
-    if (needs_odd_pad(fast_eligible(h, N, r, flags), N, r)) {  // odd N beyond the tilings: one all-missing series appended
+    if (needs_odd_pad(fast_eligible(h, N, r, flags), N, r, flags, B)) {  // odd N beyond the tilings: one all-missing series appended
         OddPad o;
         if (int rc = odd_pad(h, B, T, N, r, panel, Lam, R, &o)) return rc;
         // (the appended series is missing in EVERY period: the padded problem has missing cells whatever the caller said about N)

@@ -162,11 +162,12 @@ __global__ __launch_bounds__(256, 2) void collapse_miss_kernel(CollapseArgs a, u
     }
 
     // ---- tables of the replicate in LDS: W = lam / R, R (lam = W R); row N is a zero row (padding of the index lists) ------
-    const double* __restrict__ Lg = a.Lam + (size_t)b * N * R;
+    const int lw = a.lam_w > 0 ? a.lam_w : R;                   // (narrow loadings: r <= 4 on the 8-wide state)
+    const double* __restrict__ Lg = a.Lam + (size_t)b * N * lw;
     const double* __restrict__ Rg = a.Rv + (size_t)b * N;
     for (int e = threadIdx.x; e < (N + 1) * R; e += 256) {
-        const int c = e >> 3;
-        Wt[e] = c < N ? Lg[e] / Rg[c] : 0.0;
+        const int c = e >> 3, f = e & 7;
+        Wt[e] = (c < N && f < lw) ? Lg[c * lw + f] / Rg[c] : 0.0;
     }
     for (int c = threadIdx.x; c <= N; c += 256) Rt[c] = c < N ? Rg[c] : 1.0;
     double rown[NQ][2], lr[NQ][2];

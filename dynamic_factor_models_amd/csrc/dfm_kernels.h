@@ -78,6 +78,8 @@ struct CollapseArgs {
                           // layout): their sums are written as zeros, not formed; 0 = all columns
     double* obs_table;    // ... and RecursionArgs::chunk_obs, the pass's observation table [B][obs_L][23][64] double2 (chunk-major, period
     int obs_L;            // t = obs_L lane + slot), which the workgroup fills from those rows when its stream is done (dfm_ctbuild.h)
+    int lam_w;            // collapse_miss only: > 0 = Lam is [B][N][lam_w], lam_w < 8 (r <= 4 on the 8-wide state: columns lam_w .. 7 of the
+                          // kernel's tables are zeros -- b_t, C_t come out 8 wide with a zero padding block); 0 = 8
 };
 
 struct RecursionArgs {

@@ -281,9 +281,13 @@ __global__ __launch_bounds__(64) void chunk_bridge_kernel(RecursionArgs a) {
 // (collapse_miss_kernel's table mode): bcol, scol, C_t of every period; nobs = 0 and ldrow = n_t log 2 pi + sum log R make the sequential kernels'
 // "n log 2 pi + sum of log R" come out right without n_t (they read C_t / ldrow of every period whose nobs differs from N).
 // Without a C_t array (the caller promised a balanced panel) the periods are all alike: nobs = N, Cfull and ldfull from period 0.
+// RC: width of the per-period arrays the sequential kernel reads (RecursionArgs::Rc: 2 / 4 when the loadings are narrower than the
+// 8-wide state -- the leading RC x RC block of the packed C_t is its first RC (RC + 1) / 2 entries; the padding block is zero)
+template <int RC>
 __global__ __launch_bounds__(64) void chunk_unbridge_kernel(RecursionArgs a, double* bcol, double* scol, int* nobs, double* ldrow, double* Ct,
                                                           double* Cfull, double* ldfull) {
     using namespace chunk;
+    constexpr int NPC = RC * (RC + 1) / 2;
     const int T = a.T, L = a.chunk_L;
     const int b = blockIdx.x / L, slot = blockIdx.x - b * L, lane = threadIdx.x;
     if (a.chunk_fail[b] == 0) return;
@@ -295,21 +299,21 @@ __global__ __launch_bounds__(64) void chunk_unbridge_kernel(RecursionArgs a, dou
 #pragma unroll
     for (int k = 0; k < kObsRows; ++k) { const double2 u = src[k * 64]; v[2 * k] = u.x; v[2 * k + 1] = u.y; }
 #pragma unroll
-    for (int i = 0; i < R; ++i) bcol[bt * R + i] = v[NP + i];
+    for (int i = 0; i < RC; ++i) bcol[bt * RC + i] = v[NP + i];
     scol[bt] = v[NP + R];
     if (Ct) {
         nobs[bt] = 0;                                          // (never equal to N >= 1: the period reads its own C_t / ldrow; adds 0 to the n-sum)
         ldrow[bt] = v[NP + R + 1];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) Ct[bt * NP + k] = v[k];
+        for (int k = 0; k < NPC; ++k) Ct[bt * NPC + k] = v[k];
     } else {
         nobs[bt] = a.N;
         if (t == 0) {
             ldfull[b] = v[NP + R + 1] - (double)a.N * kLog2PiC;
 #pragma unroll
-            for (int i = 0; i < R; ++i)
+            for (int i = 0; i < RC; ++i)
 #pragma unroll
-                for (int j = 0; j < R; ++j) Cfull[(size_t)b * R * R + i * R + j] = v[pidx(i, j)];
+                for (int j = 0; j < RC; ++j) Cfull[(size_t)b * RC * RC + i * RC + j] = v[pidx(i, j)];
         }
     }
 }
@@ -723,9 +727,16 @@ hipError_t launch_recursion_chunk(const RecursionArgs& a0, hipStream_t s) {
 hipError_t launch_chunk_unbridge(const RecursionArgs& a0, hipStream_t s) {
     RecursionArgs a = a0;
     a.chunk_L = recursion_chunk_len(a.T);
-    hipLaunchKernelGGL(chunk_unbridge_kernel, dim3((unsigned)a.B * (unsigned)a.chunk_L), dim3(64), 0, s, a, const_cast<double*>(a.bcol),
-                       const_cast<double*>(a.scol), const_cast<int*>(a.nobs), const_cast<double*>(a.ldrow), const_cast<double*>(a.Ct),
-                       const_cast<double*>(a.Cfull), const_cast<double*>(a.ldfull));
+    const int Rc = a.Rc > 0 ? a.Rc : 8;
+    const dim3 grid((unsigned)a.B * (unsigned)a.chunk_L);
+#define DFM_UNBRIDGE(RC_)                                                                                                                   \
+    hipLaunchKernelGGL(chunk_unbridge_kernel<RC_>, grid, dim3(64), 0, s, a, const_cast<double*>(a.bcol), const_cast<double*>(a.scol),      \
+                       const_cast<int*>(a.nobs), const_cast<double*>(a.ldrow), const_cast<double*>(a.Ct), const_cast<double*>(a.Cfull),     \
+                       const_cast<double*>(a.ldfull))
+    if (Rc == 8) DFM_UNBRIDGE(8);
+    else if (Rc == 4) DFM_UNBRIDGE(4);
+    else DFM_UNBRIDGE(2);
+#undef DFM_UNBRIDGE
     return hipGetLastError();
 }
 

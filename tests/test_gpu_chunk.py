@@ -263,3 +263,55 @@ def test_a_boundary_within_tol_means_a_result_within_tol(tol):
     finally:
         c.close()
     assert kept > 0 and worst > 1e-3 * tol, (kept, worst)
+
+
+def test_narrow_state_replicates_on_both_kernels(ctx):
+    """r = 4 on the 8-wide state through collapse_miss_kernel's table (CollapseArgs::lam_w) with every other replicate handed back:
+    chunk_unbridge_kernel<4> writes the sequential kernel's 4-wide rows from the 8-wide table.  Odd N: one all-missing series appended."""
+    B, T, r, NN = 6, 240, 4, 141
+    panels, sts = [], []
+    for b in range(B):
+        N = 7 if b % 2 == 0 else NN
+        x, p = ko.synth_replicate(100 + b, N, T, r, missing=0.1)
+        xx = np.full((T, NN), np.nan); xx[:, :N] = x
+        Lam = np.zeros((NN, r)); Lam[:N] = p["Lam"]
+        R = np.ones(NN); R[:N] = p["R"]
+        panels.append(xx); sts.append(dict(p, Lam=Lam, R=R))
+    panel = np.stack(panels)
+    st = {k: np.stack([s[k] for s in sts]) for k in KEYS}
+    ref = co.ks_pass_batch(panel, *[st[k] for k in KEYS])
+    got = _pass(ctx, panel, st)
+    nf, nt = ctx.chunk_fallbacks()
+    assert nt == B and 3 <= nf < B, (nf, nt)
+    _compare(got, ref, "narrow mixed batch")
+
+
+@pytest.mark.parametrize("B,N,T,r,missing,iters", [
+    (3, 101, 160, 8, 0.1, 3),             # odd N at Rp = 8: the appended series has no observed cell in any period
+    (3, 77, 130, 3, 0.1, 3),              # r = 3 -> collapsed observations 4 wide, odd N
+    (2, 51, 120, 2, 0.05, 2),
+])
+def test_em_odd_n_through_the_table(ctx, B, N, T, r, missing, iters):
+    import torch
+    panels, starts = [], []
+    for b in range(B):
+        x, _ = ko.synth_replicate(60 + b, N, T, r, missing=missing)
+        p0, _ = ko.pca_init(np.nan_to_num(x), r)
+        panels.append(x); starts.append(p0)
+    panel = np.stack(panels)
+    st = {k: np.stack([s[k] for s in starts]) for k in KEYS}
+    ref = co.ks_pass_batch(panel, *[st[k] for k in KEYS])
+    _compare(_pass(ctx, panel, st), ref, f"pass N={N} r={r}")
+    dev = {k: _dev(ctx, st[k]) for k in KEYS}
+    path, its, f, P = ctx.em_batch(_dev(ctx, panel), *[dev[k] for k in KEYS], max_iter=iters, tol=0.0)
+    torch.cuda.synchronize()
+    nf, nt = ctx.chunk_fallbacks()
+    assert nt == B, (nf, nt)
+    path = path.cpu().numpy(); f = f.cpu().numpy()
+    for b in range(B):
+        p, opath, out = ko.em(panel[b], {k: st[k][b] for k in KEYS}, max_iter=iters, tol=0.0)
+        np.testing.assert_allclose(path[b], opath, rtol=1e-8, err_msg=f"loglik path b={b}")
+        for k in KEYS:
+            got = dev[k][b].cpu().numpy()
+            assert np.abs(got - p[k]).max() <= 1e-8 * max(1.0, np.abs(p[k]).max()), (k, b, np.abs(got - p[k]).max())
+        assert np.abs(f[b] - out["f_smooth"]).max() <= 1e-8 * np.abs(out["f_smooth"]).max()
