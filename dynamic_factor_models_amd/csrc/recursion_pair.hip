@@ -51,6 +51,7 @@ __global__ __launch_bounds__(128, 2) void recursion_pair_kernel(RecursionArgs a)
     G.l = lane; G.i = i; G.j = j;
     const int T = a.T, N = a.N, r = a.r;
     const int b = blockIdx.x;
+    if (a.only_if && a.only_if[b] == 0) return;              // (block-uniform) the replicate was done by recursion_chunk_kernel
     const bool diag = (i == j);
 
     const int Rc = a.Rc > 0 ? a.Rc : R;
