@@ -739,6 +739,22 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
         // 0.25 ms per 1024 replicates of the Stock-Watson window where this takes 0.1)
         const bool narrow_tab = p.Rc > 0 && p.Rc < 8 && p.kdim == 0 && p.rl == p.Rc && !h->narrow_tab_off;
         const bool table = ra.wave && !h->collapse_miss_old && (p.Rc == 0 || narrow_tab) && recursion_chunk_supported(p.Rp, ra);
+        // companion states (VAR(p) factor dynamics) with loadings up to 4 wide: the same table, then EVERY replicate's rows written
+        // back in the layout the sequential kernels read (chunk_unbridge_kernel<Rc>: b_t, s_t, C_t of every period, nobs = 0) --
+        // collapse_kernel<4> took 0.235 ms per 1024 replicates of the Stock-Watson window where these two take 0.12
+        const bool comp_table = p.kdim > 0 && p.kb == 0 && p.Rc > 0 && p.Rc < 8 && p.ck_rows != (size_t)-1 && p.ck_obs != (size_t)-1 &&
+                                p.ck_fail != (size_t)-1 && collapse_miss_supported(8, N);
+        if (comp_table) {
+            ca.lam_w = p.Rc;
+            ca.obs_chunk = at<double>(h, p.ck_rows);
+            ca.obs_table = at<double>(h, p.ck_obs); ca.obs_L = recursion_chunk_len(T);
+            { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream)); }
+            RecursionArgs ua = ra;
+            ua.chunk_obs = at<double>(h, p.ck_obs);
+            ua.chunk_fail = at<int>(h, p.ck_fail);
+            HIP_TRY(h, hipMemsetAsync(ua.chunk_fail, 1, (size_t)B * sizeof(int), h->stream));   // (non-zero: every replicate)
+            HIP_TRY(h, launch_chunk_unbridge(ua, h->stream));
+        } else
         if (table && p.ck_rows != (size_t)-1 && collapse_miss_supported(8, N) && (p.Rc == 0 ? Rcol == 8 : true)) {
             ca.lam_w = p.Rc;
             ca.obs_chunk = at<double>(h, p.ck_rows);
@@ -953,8 +969,31 @@ int varp_run(dfm_handle* h, int B, int T, int N, int r, int nlag, const double* 
     if (!panel || !Lam || !R || !Avar || !Q || !mu0 || !P0) return fail(h, DFM_E_NULL, "required pointer is NULL%s");
     if (max_iter < 1) return fail(h, DFM_E_DIMS, "max_iter must be >= 1%s");
     HIP_TRY(h, hipSetDevice(h->device));
+    // panels with missing cells, loadings up to 4 wide: the collapse on collapse_miss_kernel's table mode (comp_table below); odd N
+    // gets one all-missing series appended for it, as in em_run (the Stock-Watson window has 139 series)
+    const bool comp_tab_ok = g_odd_pad8 && !h->narrow_tab_off && !h->collapse_miss_old && pad_r(r) < 8 && (flags & DFM_F_MAY_HAVE_MISSING);
+    if (comp_tab_ok && (N & 1) && collapse_miss_supported(8, N + 1)) {
+        OddPad o;
+        if (int rc = odd_pad(h, B, T, N, r, panel, Lam, R, &o)) return rc;
+        if (int rc = varp_run(h, B, T, N + 1, r, nlag, o.panel, o.Lam, o.R, Avar, Q, mu0, P0, max_iter, tol, loglik_path, iters, loglik_single,
+                              f_smooth, P_smooth, flags, em)) return rc;
+        if (em) {
+            const size_t n_lam = (size_t)B * N * r, n_R = (size_t)B * N;
+            hipLaunchKernelGGL(copy_series_rows_kernel, dim3((unsigned)((n_lam + 255) / 256)), dim3(256), 0, h->stream, (size_t)B, N + 1, N, r, 0.0, o.Lam, Lam);
+            hipLaunchKernelGGL(copy_series_rows_kernel, dim3((unsigned)((n_R + 255) / 256)), dim3(256), 0, h->stream, (size_t)B, N + 1, N, 1, 0.0, o.R, R);
+            HIP_TRY(h, hipGetLastError());
+        }
+        return 0;
+    }
     Plan p = make_plan(B, T, N, k, flags | DFM_F_SINGULAR_Q, em, false);
     p.Rc = pad_r(r); p.rl = r; p.kdim = k; p.qsing = (flags & DFM_F_SINGULAR_Q) ? 1 : 0;
+    if (comp_tab_ok && collapse_miss_supported(8, N) && (size_t)B * recursion_chunk_len(T) <= 0x7fffffffu) {
+        size_t off = p.total;                                 // rows + masks, the chunk-major table, "every replicate" flags (comp_table)
+        p.ck_rows = take(off, recursion_chunk_rows_bytes(B, T));
+        p.ck_obs = take(off, recursion_chunk_obs_bytes(B, T));
+        p.ck_fail = take(off, (size_t)B * sizeof(int));
+        p.total = off;
+    }
     if (int rc = ensure_ws(h, p.total)) return rc;
     const int Rk = p.Rp, Rc = p.Rc;
     double *LamP = at<double>(h, p.LamP), *AP = at<double>(h, p.AP), *QP = at<double>(h, p.QP),

@@ -40,7 +40,9 @@ def _close(got, want, tol, what):
                                              # round 6 (recursion_mbf16_kernel: 9 <= r p <= 16, r <= 4): collapsed observations 2 wide,
                                              # a state narrower than its padding, most cells missing, a batch beyond one wave per SIMD
                                              (3, 30, 50, 2, 6, 0.1), (2, 36, 64, 3, 4, 0.2), (2, 40, 33, 4, 3, 0.0), (2, 20, 90, 2, 8, 0.6),
-                                             (1100, 12, 40, 3, 3, 0.1)])
+                                             (1100, 12, 40, 3, 3, 0.1),
+                                             # the collapse on collapse_miss_kernel's table (loadings <= 4 wide, missing cells; odd N padded)
+                                             (2, 51, 60, 1, 4, 0.1), (3, 33, 70, 2, 3, 0.3), (2, 201, 64, 4, 2, 0.05)])
 def test_varp_pass(ctx, B, N, T, r, p, miss):
     import torch
     x, q = _batch(B, N, T, r, p, miss)
@@ -58,7 +60,8 @@ def test_varp_pass(ctx, B, N, T, r, p, miss):
 
 @pytest.mark.parametrize("B,N,T,r,p,miss", [(3, 30, 60, 2, 2, 0.0), (2, 40, 80, 4, 4, 0.0), (2, 25, 50, 3, 2, 0.15),
                                              (2, 50, 70, 4, 4, 0.1), (2, 24, 40, 3, 1, 0.1),
-                                             (2, 30, 50, 2, 6, 0.1), (2, 36, 64, 3, 4, 0.2), (2, 40, 45, 4, 3, 0.0)])
+                                             (2, 30, 50, 2, 6, 0.1), (2, 36, 64, 3, 4, 0.2), (2, 40, 45, 4, 3, 0.0),
+                                             (2, 33, 70, 2, 3, 0.3), (2, 51, 60, 1, 4, 0.1)])
 def test_varp_em(ctx, B, N, T, r, p, miss):
     import torch
     x, q = _batch(B, N, T, r, p, miss)
