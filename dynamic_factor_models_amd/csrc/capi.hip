@@ -31,6 +31,8 @@ struct dfm_handle {
     int num_cu = 256;
     int scan_abl = 0;
     bool no_side = false;                  // DFM_NO_SIDE=1: gram/cov on the main stream (diagnostics)
+    bool no_pipe = false;                  // DFM_PIPE=0 (diagnostics build): large batches with missing cells as ONE batch on one stream (pipe_eligible)
+    bool in_pipe = false;                  // inside a sub-batch of pipe_run: no nesting
     // The handle's status word: its own 256-byte allocation, zeroed at creation and again by whoever READS a non-zero value
     // (status_check).  It is sticky between checks -- no memset per call: that was a 5 us fill kernel in front of every pass,
     // 2 % of the headline's step.  Device-pointer callers that never check see nothing; dfm_synchronize / dfm_check_status and
@@ -437,6 +439,56 @@ int check_em_n(dfm_handle* h, int N, int r, unsigned flags) {
         return 0;
     }
     return check_general_n(h, N, r, true);
+}
+
+// ---- large batches of panels with missing cells (states 8 wide): sub-batches on two streams, two workspace slots ------------------
+// The general path's workspace is 0.9 MB per replicate (table entries of every period): 7.4 GB at B = 8192, 59 GB at B = 65536, beside
+// 0.8 MB of panel per replicate.  From 16 replicates per CU on, the batch runs as sub-batches of 8 per CU that alternate between the
+// caller's stream and h->post, each stream with its own workspace slot: the workspace stops growing (3.7 GB), and the kernels of
+// neighbouring sub-batches overlap.  What the overlap is worth, measured (B = 8192, C2 shape, 10 % missing; profiles/r06/README.md):
+// nothing for the pass (3.80 ms as one batch; 4.13 / 4.01 / 3.79 / 3.84 ms with sub-batches of 512 / 1024 / 2048 / 4096 -- the collapse
+// beside the recursion takes 0.43-0.57 ms per 1024 replicates instead of 0.25, the recursion 0.37-0.45 instead of 0.24: one wave of each
+// on a SIMD compete for its VALU issue slots), 3 % for the EM iteration (7.86 -> 7.56-7.64 ms).  Replicates are independent: the results
+// are bit for bit those of the one-batch call (tests/test_gpu_pipe.py).
+// body(b0, bn): enqueue everything for replicates [b0, b0 + bn) on h->stream with h->ws as its workspace.
+int pipe_sub(const dfm_handle* h) { return 8 * h->num_cu; }
+bool pipe_eligible(const dfm_handle* h, int B, int N, int r, unsigned flags) {
+    if (h->no_pipe || h->in_pipe || !h->post) return false;
+    if (pad_r(r) != 8 || !(flags & DFM_F_MAY_HAVE_MISSING) || (flags & DFM_F_SINGULAR_Q)) return false;
+    return B >= 2 * pipe_sub(h) && collapse_miss_supported(8, N) && !h->collapse_miss_old && !h->no_chunk;
+}
+template <class Body>
+int pipe_run(dfm_handle* h, int B, size_t slot_bytes, Body body) {
+    const int Bs = pipe_sub(h), S = (B + Bs - 1) / Bs;
+    const size_t slot = (slot_bytes + 255) & ~(size_t)255;
+    if (int rc = ensure_ws(h, 2 * slot + (size_t)B * sizeof(int))) return rc;
+    char* base = static_cast<char*>(h->ws);
+    int* agg = reinterpret_cast<int*>(base + 2 * slot);       // chunk_fail of every replicate (dfm_chunk_fallbacks)
+    hipStream_t main = h->stream;
+    HIP_TRY(h, hipEventRecord(h->ev_fork, main));
+    HIP_TRY(h, hipStreamWaitEvent(h->post, h->ev_fork, 0));
+    int rc = 0;
+    bool have_fail = true;
+    h->in_pipe = true;
+    for (int s_ = 0; s_ < S && rc == 0; ++s_) {
+        const int b0 = s_ * Bs, bn = (B - b0 < Bs) ? B - b0 : Bs;
+        h->ws = base + (size_t)(s_ & 1) * slot;
+        h->stream = (s_ & 1) ? h->post : main;
+        rc = body(b0, bn);
+        if (rc == 0) {
+            if (h->ck_fail_dev && h->ck_fail_n == bn) {
+                const hipError_t e = hipMemcpyAsync(agg + b0, h->ck_fail_dev, (size_t)bn * sizeof(int), hipMemcpyDeviceToDevice, h->stream);
+                if (e != hipSuccess) rc = hip_fail(h, e, "hipMemcpyAsync(chunk_fail)");
+            } else have_fail = false;
+        }
+    }
+    h->in_pipe = false;
+    h->ws = base; h->stream = main;
+    (void)hipEventRecord(h->ev_post, h->post);
+    (void)hipStreamWaitEvent(main, h->ev_post, 0);              // join (also after a failure: the slots are in use until then)
+    h->ck_fail_dev = (rc == 0 && have_fail) ? agg : nullptr;
+    h->ck_fail_n = (rc == 0 && have_fail) ? B : 0;
+    return rc;
 }
 
 // gram + cov on the side stream, beside the streaming collapse on the main stream; the batch is cut
@@ -864,6 +916,17 @@ int em_run(dfm_handle* h, int B, int T, int N, int r, const double* panel, doubl
         hipLaunchKernelGGL(copy_series_rows_kernel, dim3((unsigned)((n_R + 255) / 256)), dim3(256), 0, h->stream, (size_t)B, N + 1, N, 1, 0.0, o.R, R);
         HIP_TRY(h, hipGetLastError());
         return 0;
+    }
+    if (pipe_eligible(h, B, N, r, flags)) {     // sub-batches as EM runs of their own on two streams (pipe_run)
+        const Plan ps = make_plan(pipe_sub(h), T, N, r, flags, true, false);
+        const size_t rr = (size_t)r * r, np = (size_t)r * (r + 1) / 2;
+        return pipe_run(h, B, ps.total, [&](int b0, int bn) -> int {
+            return em_run(h, bn, T, N, r, panel + (size_t)b0 * T * N, Lam + (size_t)b0 * N * r, R + (size_t)b0 * N, A + b0 * rr, Q + b0 * rr,
+                          mu0 + (size_t)b0 * r, P0 + b0 * rr, max_iter, tol, loglik_path ? loglik_path + (size_t)b0 * max_iter : nullptr,
+                          iters ? iters + b0 : nullptr, loglik_single ? loglik_single + b0 : nullptr,
+                          f_smooth ? f_smooth + (size_t)b0 * T * r : nullptr, P_smooth ? P_smooth + (size_t)b0 * T * np : nullptr, flags,
+                          k_first, k_count, active_ext ? active_ext + b0 : nullptr);
+        });
     }
     // balanced panels: E-step on the fast path (collapse on the matrix pipe, time-parallel scan), transition
     // M-step by em_update_kernel; panels with missing cells: recursion_kernel does both
@@ -1336,6 +1399,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) h->num_cu = prop.multiProcessorCount; }
     if (const char* v = route_env("DFM_NUM_CU")) { if (atoi(v) > 0) h->num_cu = atoi(v); }   // diagnostics: persistent grids sized for fewer CUs
     if (const char* v = diag_env("DFM_NO_SIDE")) h->no_side = atoi(v) != 0;
+    if (const char* v = diag_env("DFM_PIPE")) h->no_pipe = atoi(v) == 0;
     if (const char* v = diag_env("DFM_NO_RECURSION_WAVE")) h->no_rec_wave = atoi(v) != 0;
     if (const char* v = diag_env("DFM_PAIR_BMAX")) h->pair_bmax = atoi(v) > 0 ? atoi(v) : 0;
     if (const char* v = route_env("DFM_NO_PAIR")) { if (atoi(v) != 0) h->pair_bmax = 0; }
@@ -1514,6 +1578,16 @@ int dfm_ks_pass_batch_dev(dfm_handle* h, int B, int T, int N, int r, const doubl
         // (the appended series is missing in EVERY period: the padded problem has missing cells whatever the caller said about N)
         return dfm_ks_pass_batch_dev(h, B, T, N + 1, r, o.panel, o.Lam, o.R, A, Q, mu0, P0, f_smooth, P_smooth, loglik,
                                      flags | DFM_F_MAY_HAVE_MISSING);
+    }
+    if (pipe_eligible(h, B, N, r, flags)) {
+        const Plan ps = make_plan(pipe_sub(h), T, N, r, flags, false, false);
+        const size_t rr = (size_t)r * r, np = (size_t)r * (r + 1) / 2;
+        return pipe_run(h, B, ps.total, [&](int b0, int bn) -> int {
+            PaddedParams pp;
+            if (int rc = pad_params(h, ps, bn, N, r, Lam + (size_t)b0 * N * r, A + b0 * rr, Q + b0 * rr, mu0 + (size_t)b0 * r, P0 + b0 * rr, &pp)) return rc;
+            return enqueue_pass(h, ps, bn, T, N, r, panel + (size_t)b0 * T * N, pp, R + (size_t)b0 * N, f_smooth + (size_t)b0 * T * r,
+                                P_smooth ? P_smooth + (size_t)b0 * T * np : nullptr, loglik + b0, nullptr);
+        });
     }
     const Plan p = make_plan(B, T, N, r, flags, false, fast_eligible(h, N, r, flags));
     if (int rc = ensure_ws(h, p.total)) return rc;

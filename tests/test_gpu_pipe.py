@@ -1,0 +1,77 @@
+"""Large batches of panels with missing cells (states 8 wide; from 16 replicates per CU on) run as sub-batches of 8 replicates per CU
+on two streams with two workspace slots (capi.hip pipe_run): the results must be those of the sub-batches run one call at a time, whatever the batch does not
+divide into (to rounding: which sequential kernel takes the replicates that fail the chunk boundary check depends on the size of the
+launch -- the wave pair up to one replicate per SIMD, one wave beyond), and equal to the oracle's."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from oracle import kalman_oracle as ko
+
+pytestmark = pytest.mark.gpu
+KEYS = ("Lam", "R", "A", "Q", "mu0", "P0")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from dynamic_factor_models_amd import DfmContext
+    c = DfmContext()
+    yield c
+    c.close()
+
+
+def _synth(ctx, B, N, T, r, missing, seed=11):
+    panel, par = ctx.synth_panels(seed, 0, B, T, N, r, missing_prob=missing)
+    return panel, par
+
+
+@pytest.mark.parametrize("B,N,T,r,missing", [(4200, 40, 64, 8, 0.1), (4096, 36, 50, 6, 0.2), (6145, 24, 40, 8, 0.05)])
+def test_piped_pass_equals_its_sub_batches(ctx, B, N, T, r, missing):
+    import torch
+    panel, par = _synth(ctx, B, N, T, r, missing)
+    f, P, ll = ctx.ks_pass_batch(panel, *par, may_have_missing=True)
+    torch.cuda.synchronize()
+    nf, nt = ctx.chunk_fallbacks()
+    assert nt == B, (nf, nt)
+    Bs = 2000                                                     # (below two sub-batches: one batch, one stream)
+    for b0 in range(0, B, Bs):
+        sl = slice(b0, min(B, b0 + Bs))
+        f1, P1, ll1 = ctx.ks_pass_batch(panel[sl].contiguous(), *[p[sl].contiguous() for p in par], may_have_missing=True)
+        torch.cuda.synchronize()
+        for a, c, what in ((ll[sl], ll1, "loglik"), (f[sl], f1, "f_smooth"), (P[sl], P1, "P_smooth")):
+            assert (a - c).abs().max().item() <= 1e-11 * c.abs().max().item(), f"{what} of the sub-batch at {b0}"
+    for b in (0, 2047, 2048, B - 1):
+        st = [p[b:b + 1].cpu().numpy() for p in par]
+        fo, Po, llo = co.ks_pass_batch(panel[b:b + 1].cpu().numpy(), *st)
+        np.testing.assert_allclose(ll[b:b + 1].cpu().numpy(), llo, rtol=1e-9)
+        assert np.abs(f[b:b + 1].cpu().numpy() - fo).max() <= 1e-9 * np.abs(fo).max()
+        assert np.abs(P[b:b + 1].cpu().numpy() - Po).max() <= 1e-9 * np.abs(Po).max()
+
+
+@pytest.mark.parametrize("tol", [0.0, 1e-4])
+def test_piped_em_equals_its_sub_batches(ctx, tol):
+    import torch
+    B, N, T, r, iters = 4200, 40, 64, 8, 4
+    panel, par = _synth(ctx, B, N, T, r, 0.1, seed=5)
+    start = [p.clone() for p in par]
+    path, its, f, P = ctx.em_batch(panel, *par, max_iter=iters, tol=tol)
+    torch.cuda.synchronize()
+    Bs = 2000
+    for b0 in range(0, B, Bs):
+        sl = slice(b0, min(B, b0 + Bs))
+        sub = [p[sl].clone() for p in start]
+        path1, its1, f1, P1 = ctx.em_batch(panel[sl].contiguous(), *sub, max_iter=iters, tol=tol)
+        torch.cuda.synchronize()
+        assert torch.equal(its[sl], its1), f"iteration counts at {b0}"
+        pa, pb = torch.nan_to_num(path[sl]), torch.nan_to_num(path1)
+        assert (pa - pb).abs().max().item() <= 1e-9 * pb.abs().max().item(), f"loglik path at {b0}"
+        for a, c in zip(par, sub):
+            assert (a[sl] - c).abs().max().item() <= 1e-8 * max(1.0, c.abs().max().item()), f"parameters at {b0}"
+        assert (f[sl] - f1).abs().max().item() <= 1e-8 * f1.abs().max().item()
+    b = 2500
+    p0 = {k: start[i][b].cpu().numpy() for i, k in enumerate(KEYS)}
+    po, opath, out = ko.em(panel[b].cpu().numpy(), p0, max_iter=iters, tol=tol)
+    got = path[b].cpu().numpy()
+    np.testing.assert_allclose(got[:len(opath)], opath, rtol=1e-8)
