@@ -160,6 +160,9 @@ size_t take(size_t& off, size_t bytes) {
 // Sequential path with r <= 4: the state is padded to 8 so that the one-wave-per-replicate recursion (recursion_wave.hip)
 // applies; collapse, loadings and the loadings M-step stay pad_r(r) wide (Plan::Rc).  DFM_NO_RECURSION_WAVE=1 turns it off.
 bool g_widen_small_r = true;
+// DFM_NO_CHUNK=1 (route switch; process-wide like g_widen_small_r: follows the most recently created handle): no chunk scratch /
+// observation table in the plans (184 KB per replicate at T = 500 that the sequential kernels never touch)
+bool g_plan_chunk = true;
 // Loadings step with missing cells on the matrix pipe (mstep_miss.hip).  DFM_MSTEP_MISS: 0 = never (mstep_lam_kernel),
 // 1 = where mstep_lam_kernel keeps its per-series accumulators in global memory (Rp > 8 or N > 256; default), 2 = wherever supported.
 int g_mstep_miss_mode = 1;
@@ -219,7 +222,7 @@ Plan make_plan(int B, int T, int N, int r, unsigned flags, bool em, bool fast = 
     // (fast path, Rp >= 16: the mean scan on the matrix pipe keeps the steady part of w_t in a second, chunk-major region behind the
     // T natural rows -- scan_mfma32.hip)
     p.wtab = take(off, (size_t)B * wtab_rows(fast, Rp, T) * Rp * d);
-    if (!fast && !p.cov && Rp == 8) {
+    if (!fast && !p.cov && Rp == 8 && g_plan_chunk) {
         p.ck_scr = take(off, recursion_chunk_scratch_bytes(B, T));
         p.ck_obs = take(off, recursion_chunk_obs_bytes(B, T));
         if (collapse_miss_supported(8, N)) p.ck_rows = take(off, recursion_chunk_rows_bytes(B, T));   // (also r <= 4 on the 8-wide state: CollapseArgs::lam_w)
@@ -1422,6 +1425,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = diag_env("DFM_NARROW_TAB")) h->narrow_tab_off = atoi(v) == 0;
     if (const char* v = diag_env("DFM_ODD_PAD8")) g_odd_pad8 = atoi(v) != 0;
     if (const char* v = route_env("DFM_NO_CHUNK")) h->no_chunk = atoi(v) != 0;
+    g_plan_chunk = !h->no_chunk;
     if (const char* v = route_env("DFM_CHUNK_W")) h->chunk_w = atoi(v) > 0 ? atoi(v) : 0;
     if (const char* v = route_env("DFM_CHUNK_TOL")) h->chunk_tol = atof(v) > 0.0 ? atof(v) : 0.0;
     if (const char* v = route_env("DFM_TILE_NC")) h->tile_nc = atoi(v) > 0 ? atoi(v) : 0;

@@ -75,3 +75,46 @@ def test_piped_em_equals_its_sub_batches(ctx, tol):
     po, opath, out = ko.em(panel[b].cpu().numpy(), p0, max_iter=iters, tol=tol)
     got = path[b].cpu().numpy()
     np.testing.assert_allclose(got[:len(opath)], opath, rtol=1e-8)
+
+
+def _fresh_ctx(env):
+    import os
+    from dynamic_factor_models_amd import DfmContext
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return DfmContext()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_route_switches_of_this_file_agree():
+    """Diagnostics build only: DFM_PIPE=0 (one batch, one stream), DFM_NARROW_TAB=0 / DFM_ODD_PAD8=0 (r <= 4 and odd N through
+    collapse_kernel + chunk_bridge_kernel) give the default routes' results to rounding."""
+    import os
+    import torch
+    if os.environ.get("DFM_LIB") != "diag":
+        pytest.skip("switches of the diagnostics build: run with DFM_LIB=diag")
+    base = _fresh_ctx({})
+    try:
+        panel, par = base.synth_panels(3, 0, 4200, 40, 36, 8, missing_prob=0.1)
+        pn, parn = base.synth_panels(4, 0, 6, 120, 77, 4, missing_prob=0.1)
+        ref = base.ks_pass_batch(panel, *par, may_have_missing=True)
+        refn = base.ks_pass_batch(pn, *parn, may_have_missing=True)
+        torch.cuda.synchronize()
+    finally:
+        pass
+    for env, (x, p, want) in (({"DFM_PIPE": "0"}, (panel, par, ref)), ({"DFM_NARROW_TAB": "0", "DFM_ODD_PAD8": "0"}, (pn, parn, refn))):
+        c = _fresh_ctx(env)
+        try:
+            got = c.ks_pass_batch(x, *p, may_have_missing=True)
+            torch.cuda.synchronize()
+            for a, b_ in zip(got, want):
+                assert (a - b_).abs().max().item() <= 1e-10 * b_.abs().max().item(), env
+        finally:
+            c.close()
+    base.close()
