@@ -1423,6 +1423,7 @@ int dfm_create(dfm_handle** out, int device_id, void* stream) {
     if (const char* v = diag_env("DFM_GRAM_XX_VALU")) h->gram_xx_valu = atoi(v) != 0;
     if (const char* v = diag_env("DFM_COLLAPSE_MISS_OLD")) h->collapse_miss_old = atoi(v) != 0;
     if (const char* v = diag_env("DFM_NARROW_TAB")) h->narrow_tab_off = atoi(v) == 0;
+    g_odd_pad8 = true;                       // (process-wide like g_widen_small_r: follows the most recently created handle)
     if (const char* v = diag_env("DFM_ODD_PAD8")) g_odd_pad8 = atoi(v) != 0;
     if (const char* v = route_env("DFM_NO_CHUNK")) h->no_chunk = atoi(v) != 0;
     g_plan_chunk = !h->no_chunk;
