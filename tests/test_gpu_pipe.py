@@ -118,3 +118,26 @@ def test_route_switches_of_this_file_agree():
         finally:
             c.close()
     base.close()
+
+
+def test_piped_em_iterate_equals_em_batch(ctx):
+    """dfm_em_iterate_batch_dev (the unit the multi-GPU drivers step; the caller owns path / iters / active) over a sub-batched batch:
+    the per-replicate state a handle keeps between the calls (the chunk kernel's count of consecutive boundary failures) lives in a
+    workspace slot that other sub-batches overwrite -- it only steers which kernel computes a replicate, never what comes out."""
+    import torch
+    B, N, T, r, iters = 4200, 40, 64, 8, 4
+    panel, par = _synth(ctx, B, N, T, r, 0.1, seed=9)
+    a = [p.clone() for p in par]
+    b = [p.clone() for p in par]
+    path, its, f, P = ctx.em_batch(panel, *a, max_iter=iters, tol=0.0, may_have_missing=True)
+    dev = panel.device
+    path2 = torch.empty((B, iters), dtype=torch.float64, device=dev)
+    its2 = torch.empty((B,), dtype=torch.int32, device=dev)
+    act2 = torch.empty((B,), dtype=torch.int32, device=dev)
+    for k in range(iters):
+        ctx.em_iterate_batch(panel, *b, k, iters, 0.0, path2, its2, act2, may_have_missing=True)
+    torch.cuda.synchronize()
+    assert torch.equal(its, its2)
+    assert (path - path2).abs().max().item() <= 1e-9 * path.abs().max().item()
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() <= 1e-8 * max(1.0, x.abs().max().item())
