@@ -47,10 +47,15 @@ __device__ __forceinline__ double crd(double v, int lane) {
 }
 __device__ __forceinline__ double crow16(double v) { v += xor_lane<1>(v); v += xor_lane<2>(v); v += xor_lane<4>(v); v += xor_lane<8>(v); return v; }
 __device__ __forceinline__ double ccol4(double v) { v += xor_lane<16>(v); v += xor_lane<32>(v); return v; }
-__device__ __forceinline__ double cpick(const double (&x)[4], int q) { return q == 0 ? x[0] : q == 1 ? x[1] : q == 2 ? x[2] : x[3]; }
+// (the operands are PRVALUES -- unary plus: `q == 0 ? x[0] : x[1]` on lvalues is an lvalue, clang emits a select of ADDRESSES and one load,
+// the array then stays in scratch memory behind a dynamic offset, and every pick is a scratch round trip behind an s_waitcnt vmcnt(0))
+__device__ __forceinline__ double cpick(const double (&x)[4], int q) {
+    const double a0 = +x[0], a1 = +x[1], a2 = +x[2], a3 = +x[3];
+    return q == 0 ? +a0 : q == 1 ? +a1 : q == 2 ? +a2 : +a3;
+}
 __device__ __forceinline__ double cpick44(const double (&W)[4][4], int i, int j) {   // W[i][j], i and j run-time (selects, no indexing)
     const double r0 = cpick(W[0], j), r1 = cpick(W[1], j), r2 = cpick(W[2], j), r3 = cpick(W[3], j);
-    return i == 0 ? r0 : i == 1 ? r1 : i == 2 ? r2 : r3;
+    return i == 0 ? +r0 : i == 1 ? +r1 : i == 2 ? +r2 : +r3;
 }
 __device__ __forceinline__ void csqrt(double x, double& s, double& r) {   // sqrt and 1 / sqrt of a positive normal x (recursion_mbf16.hip)
     r = __builtin_amdgcn_rsq(x);
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
     // M_dd^-1 [c][k4] in the lanes of the first four columns (the A operand of "M_dd^-1 padded")
     auto wsel = [&](const double (&W)[4][4]) -> double {
         const double r0 = cpick(W[0], k4), r1 = cpick(W[1], k4), r2 = cpick(W[2], k4), r3 = cpick(W[3], k4);
-        const double x = c == 0 ? r0 : c == 1 ? r1 : c == 2 ? r2 : r3;
+        const double x = c == 0 ? +r0 : c == 1 ? +r1 : c == 2 ? +r2 : +r3;
         return c < 4 ? x : 0.0;
     };
 
@@ -331,6 +336,14 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
                     Mdd[i][j] = pv; Mdd[j][i] = pv;
                 }
         }
+#ifdef DFM_DIAG
+        if (a.tile_nc & 2) {                                       // DFM_COMP_ABL bit 1 (timing only, WRONG results): no 4 x 4 inversion
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Mdi[i][j] = i == j ? 1.0 / Mdd[i][i] : 0.0;
+        } else
+#endif
         detM.mul(inv4(Mdd, Mdi, okall));
 #pragma unroll
         for (int q = 0; q < 4; ++q) xd[q] = xi[4 * db + q];
@@ -444,6 +457,9 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");        // the slots are read back by this wave (other lanes)
 
+#ifdef DFM_DIAG
+    if (a.tile_nc & 1) return;                                     // DFM_COMP_ABL bit 0 (timing only): the forward sweep alone
+#endif
     // =================================================== backward ==========================================================
     const int r = a.r, rl = a.rl > 0 ? a.rl : R, npr = r * (r + 1) / 2;
     c16 S11[NT][NT], S10[NT][NT], VT[NT][NT];
@@ -553,7 +569,7 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
             }
 #pragma unroll
             for (int qp = 0; qp < 4; ++qp) {
-                const double mdi = k4 == 0 ? sc.Mdi[qp] : k4 == 1 ? sc.Mdi[4 + qp] : k4 == 2 ? sc.Mdi[8 + qp] : sc.Mdi[12 + qp];
+                const double mdi = k4 == 0 ? +sc.Mdi[qp] : k4 == 1 ? +sc.Mdi[4 + qp] : k4 == 2 ? +sc.Mdi[8 + qp] : +sc.Mdi[12 + qp];
                 vdd[qp] = crow16(part[qp]) + mdi;
             }
         }
@@ -658,8 +674,11 @@ bool recursion_comp_supported(int Rpad, const RecursionArgs& a) {
     return true;
 }
 
-hipError_t launch_recursion_comp(int Rpad, const RecursionArgs& a, hipStream_t s) {
+hipError_t launch_recursion_comp(int Rpad, const RecursionArgs& a0, hipStream_t s) {
     note_kernel("recursion_comp_kernel");
+    RecursionArgs a = a0;
+    static const int abl = [] { const char* v = diag_env("DFM_COMP_ABL"); return v ? atoi(v) : 0; }();   // diagnostics build: timing ablations
+    a.tile_nc = abl;
     const bool var = a.Rc == 4;
     if (Rpad == 16) {
         if (var) hipLaunchKernelGGL((recursion_comp_kernel<1, true>), dim3(a.B), dim3(64), 0, s, a);

@@ -67,7 +67,12 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& r) 
     s = x * r;
     s = fma(0.5 * r, fma(-s, s, x), s);
 }
-__device__ __forceinline__ double pick4(const double (&x)[4], int q) { return q == 0 ? x[0] : q == 1 ? x[1] : q == 2 ? x[2] : x[3]; }
+// (PRVALUE operands -- unary plus: a conditional on array lvalues is an lvalue, i.e. a select of addresses + one load: the array stays in
+// scratch memory and every pick is a scratch round trip behind s_waitcnt vmcnt(0); recursion_comp.hip cpick)
+__device__ __forceinline__ double pick4(const double (&x)[4], int q) {
+    const double a0 = +x[0], a1 = +x[1], a2 = +x[2], a3 = +x[3];
+    return q == 0 ? +a0 : q == 1 ? +a1 : q == 2 ? +a2 : +a3;
+}
 
 // the wave-uniform 4 x 4 algebra of one period (see the head of the file).  In: P11 (symmetric, full), C (symmetric, full), e0 = b - C mp1.
 // Out: W (symmetric, full), u, det G.  false: a pivot was not positive (P11 is not positive definite to working precision).
@@ -384,11 +389,11 @@ __global__ __launch_bounds__(64) void recursion_mbf16_kernel(RecursionArgs a) {
             for (int q = 0; q < 4; ++q) zq[q] = rdlane(z, 16 * q);
             double corr = 0.0;
             if (c < 4) {
-                const double w0 = c == 0 ? W[0][0] : c == 1 ? W[1][0] : c == 2 ? W[2][0] : W[3][0];
-                const double w1 = c == 0 ? W[0][1] : c == 1 ? W[1][1] : c == 2 ? W[2][1] : W[3][1];
-                const double w2 = c == 0 ? W[0][2] : c == 1 ? W[1][2] : c == 2 ? W[2][2] : W[3][2];
-                const double w3 = c == 0 ? W[0][3] : c == 1 ? W[1][3] : c == 2 ? W[2][3] : W[3][3];
-                corr = (c == 0 ? u[0] : c == 1 ? u[1] : c == 2 ? u[2] : u[3]) - (w0 * zq[0] + w1 * zq[1] + w2 * zq[2] + w3 * zq[3]);
+                const double w0 = c == 0 ? +W[0][0] : c == 1 ? +W[1][0] : c == 2 ? +W[2][0] : +W[3][0];
+                const double w1 = c == 0 ? +W[0][1] : c == 1 ? +W[1][1] : c == 2 ? +W[2][1] : +W[3][1];
+                const double w2 = c == 0 ? +W[0][2] : c == 1 ? +W[1][2] : c == 2 ? +W[2][2] : +W[3][2];
+                const double w3 = c == 0 ? +W[0][3] : c == 1 ? +W[1][3] : c == 2 ? +W[2][3] : +W[3][3];
+                corr = (c == 0 ? +u[0] : c == 1 ? +u[1] : c == 2 ? +u[2] : +u[3]) - (w0 * zq[0] + w1 * zq[1] + w2 * zq[2] + w3 * zq[3]);
             }
             wave_lds_sync();                                       // (every lane has read the old r)
             if (k4 == 0) vr[c] = y + corr;
