@@ -494,11 +494,15 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) mrow[ti][v] = m[ri(ti, v)];
         }
+        // (VAR(p): the outputs are the first block, r <= 4 -- row i = k4 of tile row 0, register 0; the other registers' rows start at 4)
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
+        for (int ti = 0; ti < (RCN ? 1 : NT); ++ti)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
+            for (int v = 0; v < (RCN ? 1 : 4); ++v) {
                 const int i = ri(ti, v);
+#ifdef DFM_DIAG
+                if (a.tile_nc & 4) continue;                       // DFM_COMP_ABL bit 2 (timing only): no output stores
+#endif
                 if (i < r) {
                     if (c == 0) a.f_smooth[((size_t)b * T + t) * r + i] = (i < rl && i < k) ? mrow[ti][v] : 0.0;
                     if (a.P_smooth) {
