@@ -542,7 +542,10 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) gcs[tk][s] = c < 4 ? sG[c * 32 + 16 * tk + 4 * s + k4] : 0.0;
+            for (int s = 0; s < 4; ++s) {                          // (unconditional read of a valid row, then the select: no branch around the load)
+                const double gx = sG[(c & 3) * 32 + 16 * tk + 4 * s + k4];
+                gcs[tk][s] = c < 4 ? gx : 0.0;
+            }
         // GV (row strip): gv[tj] = (G V)[k4][16 tj + c]
         double gv[NT];
 #pragma unroll
@@ -582,6 +585,17 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
         for (int tj = 0; tj < NT; ++tj) sGV[k4 * 32 + cj(tj)] = gv[tj];
         wave_lds_sync();
         const int qp_l = (c >> 2) == vd ? (c & 3) : -1;            // this lane's column within block column db (tile column td), or none
+        // (what does not depend on the register index, outside the register loop; LDS reads unconditional at a valid address, then selected:
+        // a read under a lane-divergent condition is a branch region of its own -- the loop was bound by what it issues)
+        const double* gvrow = sGV + (c & 3) * 32;
+        const double md_l = cpick(md, c & 3);
+        double mprev_t[NT];
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+            const int j = cj(tj);
+            const double mj4 = m[j + 4 < 32 ? j + 4 : 31];
+            mprev_t[tj] = j < ka ? mj4 : ((tj == td && qp_l >= 0) ? md_l : 0.0);
+        }
         // S10 += Cov(s_t, s_{t-1} | X) + m_t m_{t-1}',  Cov = [V[:, 4:], V G']
         // new state: V moved one block up-left, block row / column db from GV, block (db, db) = Vdd;  m' = (m[4:], md)
         c16 Vn[NT][NT];
@@ -603,12 +617,13 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
                     const double b0s = dpp_mov<kDppShl4>(b0), b1s = tj + 1 < NT ? dpp_mov<kDppShr12>(b1) : 0.0;
                     const double vul = c < 12 ? b0s : b1s;
                     const bool incol = tj == td && qp_l >= 0;      // column j = ka + q' of the new block
-                    const double cs0 = (incol && i < k) ? sGV[qp_l * 32 + i] : 0.0;
-                    const double cs1 = (incol && i < ka) ? sGV[qp_l * 32 + i + 4] : 0.0;
+                    const double g0x = gvrow[i], g1x = gvrow[i + 4 < 32 ? i + 4 : 31];
+                    const double cs0 = (incol && i < k) ? g0x : 0.0;
+                    const double cs1 = (incol && i < ka) ? g1x : 0.0;
                     if (em) {
                         const double cov = j < ka ? vl : (incol ? cs0 : 0.0);
-                        const double mprev = j < ka ? m[j + 4 < 32 ? j + 4 : 31] : (incol ? cpick(md, qp_l) : 0.0);
-                        if (i < k && j < k) S10[ti][tj][v] += fma(mrow[ti][v], mprev, cov);
+                        const double add = fma(mrow[ti][v], mprev_t[tj], cov);
+                        S10[ti][tj][v] += (i < k && j < k) ? add : 0.0;
                     }
                     double nv = (i < ka && j < ka) ? vul : 0.0;
                     if (i < ka && incol) nv = cs1;                 // block column db
@@ -634,7 +649,11 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
             for (int tj = 0; tj < NT; ++tj) V[ti][tj] = Vn[ti][tj];
-        if (lane < 32) mn[lane] = lane < ka ? m[lane + 4 < 32 ? lane + 4 : 31] : (lane < k ? cpick(md, (lane - ka) & 3) : 0.0);
+        {
+            const double ml4 = m[(lane & 31) + 4 < 32 ? (lane & 31) + 4 : 31];
+            const double mdl = cpick(md, (lane - ka) & 3);
+            if (lane < 32) mn[lane] = lane < ka ? ml4 : (lane < k ? mdl : 0.0);
+        }
         mc ^= 1;
         wave_lds_sync();
     }
