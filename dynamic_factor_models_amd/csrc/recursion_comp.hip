@@ -617,17 +617,15 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
                     const double b0s = dpp_mov<kDppShl4>(b0), b1s = tj + 1 < NT ? dpp_mov<kDppShr12>(b1) : 0.0;
                     const double vul = c < 12 ? b0s : b1s;
                     const bool incol = tj == td && qp_l >= 0;      // column j = ka + q' of the new block
+                    // V, G V and m are EXACT zeros outside the k x k state (every one of them is built by selects with a literal 0.0), so
+                    // V[i][j + 4], V[i + 4][j + 4] vanish by themselves where j + 4 >= k or i + 4 >= k -- in particular in the lanes of block
+                    // column db -- and the tests `i < k && j < k`, `j < ka`, `i < ka && j < ka` of the first version only repeated that:
+                    // Cov = V[:, 4:] + (G V)' placed in block column db, the new V likewise
                     const double g0x = gvrow[i], g1x = gvrow[i + 4 < 32 ? i + 4 : 31];
-                    const double cs0 = (incol && i < k) ? g0x : 0.0;
-                    const double cs1 = (incol && i < ka) ? g1x : 0.0;
-                    if (em) {
-                        const double cov = j < ka ? vl : (incol ? cs0 : 0.0);
-                        const double add = fma(mrow[ti][v], mprev_t[tj], cov);
-                        S10[ti][tj][v] += (i < k && j < k) ? add : 0.0;
-                    }
-                    double nv = (i < ka && j < ka) ? vul : 0.0;
-                    if (i < ka && incol) nv = cs1;                 // block column db
-                    Vn[ti][tj][v] = nv;
+                    const double cs0 = incol ? g0x : 0.0;          // (G V)[q'][i]: 0 for i >= k by itself
+                    const double cs1 = (incol && i < ka) ? g1x : 0.0;   // (G V)[q'][i + 4]: the row ends at 16 NT, the test stays
+                    if (em) S10[ti][tj][v] += fma(mrow[ti][v], mprev_t[tj], vl + cs0);
+                    Vn[ti][tj][v] = vul + cs1;
                 }
             }
         // block row db: Vn[4 db + k4][j] = GV[k4][j + 4] (j < ka), Vdd in the block itself
