@@ -468,14 +468,14 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) { S11[ti][tj] = zero; S10[ti][tj] = zero; VT[ti][tj] = zero; }
     double mTrow[NT][4], mTcol[NT];
-    struct SlotIn { double g[NT], Mdi[16], z[4]; };
+    struct SlotIn { double g[NT], mdr[4], z[4]; };                // (row k4 of M_dd^-1: the only one this lane uses -- 9 values a period, not 21)
     auto fetch_slot = [&](int t) {
         SlotIn o;
         const double* sl = slot0 + (size_t)(t > 0 ? t : 0) * kSlot;
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj) o.g[tj] = sl[64 * tj + lane];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) o.Mdi[q] = sl[128 + q];
+        for (int q = 0; q < 4; ++q) o.mdr[q] = sl[128 + 4 * k4 + q];
 #pragma unroll
         for (int q = 0; q < 4; ++q) o.z[q] = sl[144 + q];
         return o;
@@ -576,8 +576,7 @@ __global__ __launch_bounds__(64) void recursion_comp_kernel(RecursionArgs a) {
             }
 #pragma unroll
             for (int qp = 0; qp < 4; ++qp) {
-                const double mdi = k4 == 0 ? +sc.Mdi[qp] : k4 == 1 ? +sc.Mdi[4 + qp] : k4 == 2 ? +sc.Mdi[8 + qp] : +sc.Mdi[12 + qp];
-                vdd[qp] = crow16(part[qp]) + mdi;
+                vdd[qp] = crow16(part[qp]) + sc.mdr[qp];
             }
         }
         // ---- GV in column form (LDS transposition): cs0[ti][v] = GV[q'][i], cs1 = GV[q'][i + 4], q' = c - 4 vd, in the lanes of block column db
