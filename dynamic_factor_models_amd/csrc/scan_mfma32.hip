@@ -145,9 +145,15 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
     double* fout = a.f_smooth + (size_t)b * T * r;
     const int npr = r * (r + 1) / 2;
     const bool fpair = (r & 1) == 0 && (reinterpret_cast<size_t>(fout) & 15) == 0;   // f_t rows can be stored as 16-byte pairs
-    unsigned long long stamps[10];                            // DFM_SCAN_ABL & 256: phase stamps of workgroup 0 (diagnostics)
+    // DFM_SCAN_ABL & 256: phase stamps of workgroup 0 -- diagnostics build only (the dynamically indexed array is 96 bytes of scratch and
+    // the printf a hostcall buffer in every launch of the production kernel otherwise)
+#ifdef DFM_DIAG
+    unsigned long long stamps[10];
     int nstamp = 0;
     auto stamp = [&]() { if ((a.abl & 256) && blockIdx.x == 0 && tid == 0 && nstamp < 10) stamps[nstamp++] = __builtin_amdgcn_s_memrealtime(); };
+#else
+    auto stamp = [] {};
+#endif
     stamp();
 
     constexpr int NW = kS3Threads / 64;
@@ -434,12 +440,14 @@ __global__ __launch_bounds__(S3Geo<R>::NT, (R == 16 ? 4 : 1)) void meanscan_mfma
         if (ts == 0 && wave == 0 && cg == 0 && a.f0s) a.f0s[(size_t)b * R + i32] = s_vec[3 * R + i32];
     }
 
+#ifdef DFM_DIAG
     if ((a.abl & 256) && blockIdx.x == 0 && tid == 0) {
         const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         printf("S3STAMP ts=%d L=%d :", ts, L);
         for (int k = 1; k < nstamp; ++k) printf(" %llu", stamps[k] - stamps[0]);
         printf(" end %llu\n", t1 - stamps[0]);
     }
+#endif
     // ---- log-likelihood ---------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, kWave);
