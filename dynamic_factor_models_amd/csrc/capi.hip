@@ -798,7 +798,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
         // back in the layout the sequential kernels read (chunk_unbridge_kernel<Rc>: b_t, s_t, C_t of every period, nobs = 0) --
         // collapse_kernel<4> took 0.235 ms per 1024 replicates of the Stock-Watson window where these two take 0.12
         const bool comp_table = p.kdim > 0 && p.kb == 0 && p.Rc > 0 && p.Rc < 8 && p.ck_rows != (size_t)-1 && p.ck_obs != (size_t)-1 &&
-                                p.ck_fail != (size_t)-1 && collapse_miss_supported(8, N);
+                                collapse_miss_supported(8, N);
         if (comp_table) {
             ca.lam_w = p.Rc;
             ca.obs_chunk = at<double>(h, p.ck_rows);
@@ -806,8 +806,7 @@ int enqueue_pass(dfm_handle* h, const Plan& p, int B, int T, int N, int out_r, c
             { ProfScope ps(h, K_COLLAPSE); HIP_TRY(h, launch_collapse_miss(ca, h->num_cu, h->stream)); }
             RecursionArgs ua = ra;
             ua.chunk_obs = at<double>(h, p.ck_obs);
-            ua.chunk_fail = at<int>(h, p.ck_fail);
-            HIP_TRY(h, hipMemsetAsync(ua.chunk_fail, 1, (size_t)B * sizeof(int), h->stream));   // (non-zero: every replicate)
+            ua.chunk_fail = nullptr;                              // (no flags: every replicate)
             HIP_TRY(h, launch_chunk_unbridge(ua, h->stream));
         } else
         if (table && p.ck_rows != (size_t)-1 && collapse_miss_supported(8, N) && (p.Rc == 0 ? Rcol == 8 : true)) {
@@ -1054,10 +1053,9 @@ int varp_run(dfm_handle* h, int B, int T, int N, int r, int nlag, const double* 
     Plan p = make_plan(B, T, N, k, flags | DFM_F_SINGULAR_Q, em, false);
     p.Rc = pad_r(r); p.rl = r; p.kdim = k; p.qsing = (flags & DFM_F_SINGULAR_Q) ? 1 : 0;
     if (comp_tab_ok && collapse_miss_supported(8, N) && (size_t)B * recursion_chunk_len(T) <= 0x7fffffffu) {
-        size_t off = p.total;                                 // rows + masks, the chunk-major table, "every replicate" flags (comp_table)
+        size_t off = p.total;                                 // rows + masks, the chunk-major table (comp_table)
         p.ck_rows = take(off, recursion_chunk_rows_bytes(B, T));
         p.ck_obs = take(off, recursion_chunk_obs_bytes(B, T));
-        p.ck_fail = take(off, (size_t)B * sizeof(int));
         p.total = off;
     }
     if (int rc = ensure_ws(h, p.total)) return rc;

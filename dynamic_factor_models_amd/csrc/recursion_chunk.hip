@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64) void chunk_unbridge_kernel(RecursionArgs a, dou
     constexpr int NPC = RC * (RC + 1) / 2;
     const int T = a.T, L = a.chunk_L;
     const int b = blockIdx.x / L, slot = blockIdx.x - b * L, lane = threadIdx.x;
-    if (a.chunk_fail[b] == 0) return;
+    if (a.chunk_fail && a.chunk_fail[b] == 0) return;          // (no flags: every replicate -- the companion models' collapse, capi.hip comp_table)
     const int t = L * lane + slot;
     if (t >= T) return;
     const size_t bt = (size_t)b * T + t;
